@@ -1,0 +1,151 @@
+"""Deterministic synthetic HDL-64E-like scans (KITTI data is not in the
+reference tree nor in this image, so every BASELINE.json config is restated on these generators).
+
+A scan is ray-cast from a sensor pose into a closed-form street scene (ground plane, building
+boxes with seeded setbacks on both sides, cross walls, parked-car boxes, pole cylinders) and
+returned in the SENSOR frame as (n, 4) float32 [x, y, z, intensity(w)=1].
+"""
+import numpy as np
+
+SENSOR_HEIGHT = 1.73
+
+
+class Scene:
+    def __init__(self, seed: int = 1, length: float = 260.0):
+        rng = np.random.RandomState(seed)
+        boxes = []
+        # buildings: both sides of the street, varying setback / length / height, small gaps
+        for side in (-1.0, 1.0):
+            x = -60.0
+            while x < length:
+                ln = rng.uniform(8.0, 22.0)
+                setback = 12.0 + rng.choice([0.0, 0.0, 1.5, 3.0, 4.5])
+                h = rng.uniform(5.0, 11.0)
+                y0, y1 = (setback, setback + 15.0) if side > 0 else (-setback - 15.0, -setback)
+                boxes.append([x, x + ln, y0, y1, -SENSOR_HEIGHT, -SENSOR_HEIGHT + h])
+                x += ln + rng.choice([0.0, 0.0, 2.0, 5.0])
+        # cross walls closing the street
+        boxes.append([-62.0, -60.0, -30.0, 30.0, -SENSOR_HEIGHT, 8.0])
+        boxes.append([length, length + 2.0, -30.0, 30.0, -SENSOR_HEIGHT, 8.0])
+        # parked cars 4 x 1.8 x 1.5
+        n_cars = int(12 * (length + 60.0) / 100.0)
+        for _ in range(n_cars):
+            cx = rng.uniform(-50.0, length - 10.0)
+            cy = rng.choice([-1.0, 1.0]) * rng.uniform(5.0, 9.5)
+            boxes.append([cx - 2.0, cx + 2.0, cy - 0.9, cy + 0.9, -SENSOR_HEIGHT, -SENSOR_HEIGHT + 1.5])
+        self.boxes = np.asarray(boxes, dtype=np.float64)
+        n_poles = int(8 * (length + 60.0) / 100.0)
+        px = rng.uniform(-50.0, length - 10.0, n_poles)
+        py = rng.choice([-1.0, 1.0], n_poles) * rng.uniform(10.0, 11.5, n_poles)
+        self.poles = np.stack([px, py], axis=1)
+        self.pole_r = 0.3
+        self.pole_top = -SENSOR_HEIGHT + 6.0
+
+    def cast(self, origin, dirs, max_range):
+        """origin (3,), dirs (n,3) unit -> range t (n,), inf where nothing is hit."""
+        n = dirs.shape[0]
+        t = np.full(n, np.inf)
+        # ground plane z = -SENSOR_HEIGHT
+        dz = dirs[:, 2]
+        with np.errstate(divide="ignore", invalid="ignore"):
+            tg = (-SENSOR_HEIGHT - origin[2]) / dz
+        tg[~(tg > 0)] = np.inf
+        t = np.minimum(t, tg)
+        # boxes (slab method)
+        with np.errstate(divide="ignore", invalid="ignore"):
+            inv = 1.0 / dirs
+        for b in self.boxes:
+            t0 = (b[0::2][None, :] - origin[None, :]) * inv
+            t1 = (b[1::2][None, :] - origin[None, :]) * inv
+            tmin = np.nanmax(np.minimum(t0, t1), axis=1)
+            tmax = np.nanmin(np.maximum(t0, t1), axis=1)
+            hit = (tmax >= tmin) & (tmax > 0)
+            tb = np.where(tmin > 0, tmin, tmax)
+            tb[~hit] = np.inf
+            t = np.minimum(t, tb)
+        # poles: vertical cylinders
+        dxy = dirs[:, :2]
+        a = (dxy ** 2).sum(1)
+        for c in self.poles:
+            oc = origin[:2] - c
+            bq = 2.0 * (dxy @ oc)
+            cq = oc @ oc - self.pole_r ** 2
+            disc = bq * bq - 4.0 * a * cq
+            ok = disc > 0
+            with np.errstate(divide="ignore", invalid="ignore"):
+                tp = (-bq - np.sqrt(np.where(ok, disc, 0.0))) / (2.0 * a)
+            z = origin[2] + tp * dz
+            ok &= (tp > 0) & (z <= self.pole_top) & (z >= -SENSOR_HEIGHT)
+            tp[~ok] = np.inf
+            t = np.minimum(t, tp)
+        t[t > max_range] = np.inf
+        return t
+
+
+def pose_matrix(x=0.0, y=0.0, z=0.0, roll=0.0, pitch=0.0, yaw=0.0):
+    """world<-sensor 4x4 (float64), R = Rx(roll) Ry(pitch) Rz(yaw) like the reference's pose chart."""
+    cx, sx, cy, sy, cz, sz = np.cos(roll), np.sin(roll), np.cos(pitch), np.sin(pitch), np.cos(yaw), np.sin(yaw)
+    Rx = np.array([[1, 0, 0], [0, cx, -sx], [0, sx, cx]])
+    Ry = np.array([[cy, 0, sy], [0, 1, 0], [-sy, 0, cy]])
+    Rz = np.array([[cz, -sz, 0], [sz, cz, 0], [0, 0, 1]])
+    T = np.eye(4)
+    T[:3, :3] = Rx @ Ry @ Rz
+    T[:3, 3] = [x, y, z]
+    return T
+
+
+def gen_scan(scene: Scene, T_world_sensor, seed: int, beams: int = 64, az_steps: int = 2083,
+             max_range: float = 80.0, noise: float = 0.02, clamp: bool = False):
+    """One spinning-lidar scan. beams x az_steps rays, elevation -24.8..+2.0 deg linear.
+    clamp=False: drop returns beyond max_range (HDL-64E config); clamp=True: keep every ray,
+    clamped to max_range (cfg5, exactly beams*az_steps points)."""
+    rng = np.random.RandomState(seed)
+    elev = np.deg2rad(np.linspace(-24.8, 2.0, beams))
+    az = np.arange(az_steps) * (2.0 * np.pi / az_steps)
+    ce, se = np.cos(elev), np.sin(elev)
+    # firing order: azimuth-major (a column of `beams` shots per azimuth step), as a spinning unit reports
+    d_s = np.stack([np.outer(np.cos(az), ce), np.outer(np.sin(az), ce), np.outer(np.ones_like(az), se)], axis=2).reshape(-1, 3)
+    R = T_world_sensor[:3, :3]
+    o = T_world_sensor[:3, 3]
+    d_w = d_s @ R.T
+    t = scene.cast(o, d_w, max_range if not clamp else np.inf)
+    if clamp:
+        t = np.minimum(t, max_range)
+        keep = np.ones(t.shape, dtype=bool)
+    else:
+        keep = np.isfinite(t)
+    t = t[keep] + rng.normal(0.0, noise, int(keep.sum()))
+    pts = d_s[keep] * t[:, None]
+    out = np.empty((pts.shape[0], 4), dtype=np.float32)
+    out[:, :3] = pts.astype(np.float32)
+    out[:, 3] = 1.0
+    return out
+
+
+def trajectory(n: int = 30, step: float = 1.0, yaw_rate: float = 0.004):
+    """cfg2: n poses, `step` m apart along +x with a gentle yaw."""
+    poses = []
+    x = y = yaw = 0.0
+    for i in range(n):
+        poses.append(pose_matrix(x, y, 0.0, 0.002 * np.sin(0.3 * i), -0.003 * np.cos(0.2 * i), yaw))
+        yaw += yaw_rate
+        x += step * np.cos(yaw)
+        y += step * np.sin(yaw)
+    return poses
+
+
+def to_xyzi32(xyzw):
+    """(n,4) float32 -> (n,8) float32 in pcl::PointXYZI layout (32 B per point)."""
+    xyzw = np.asarray(xyzw, dtype=np.float32)
+    out = np.zeros((xyzw.shape[0], 8), dtype=np.float32)
+    out[:, :3] = xyzw[:, :3]
+    out[:, 3] = 1.0
+    out[:, 4] = xyzw[:, 3] if xyzw.shape[1] > 3 else 1.0
+    return out
+
+
+def transform_points(T, xyzw):
+    out = np.array(xyzw, dtype=np.float32, copy=True)
+    T32 = np.asarray(T, dtype=np.float32)
+    out[:, :3] = xyzw[:, :3] @ T32[:3, :3].T + T32[:3, 3]
+    return out

@@ -1,0 +1,176 @@
+/*
+ * icp_oracle.c — CPU ORACLE (TEST INFRASTRUCTURE ONLY; see lsa_oracle.h header).
+ *
+ * Restates ICPRegistrationManual (point-to-point Gauss-Newton, all f32):
+ *   S/models/registration/icp_registration_manual.cpp:45-60 (ScanMatch), :125-178 (calculateTrans)
+ * Third-party pieces it calls and that are absent from /root/reference (pins: CMake only,
+ * lidar_localization/cmake/PCL.cmake:1; sophus via "sophus/se3.hpp", no version):
+ *   pcl::KdTreeFLANN::nearestKSearch(k=1)  -> exact 1-NN, SQUARED L2 distance in f32
+ *   Sophus::SO3f::hat / exp                -> textbook hat; exp via unit quaternion
+ *   Eigen 6x6 f32 determinant / inverse    -> partial-pivot LU in f32
+ * Quirk kept (:147): the SQUARED NN distance is compared with the un-squared threshold.
+ * PARITY STATUS: UNPINNED (f32 summation order inside Eigen/FLANN is not reproducible from text;
+ * tests compare with a float tolerance, see tests/test_icp_*.py).
+ */
+#include "lsa_oracle.h"
+
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+
+typedef struct {
+  float cell;
+  int lo[3], dim[3];
+  int *start; /* dim0*dim1*dim2 + 1 */
+  int *idx;   /* point ids sorted by cell */
+  const void *pts; size_t stride; size_t n;
+} nn_grid;
+
+static inline const float *P(const void *pts, size_t stride, size_t i) { return (const float *)((const char *)pts + i * stride); }
+
+static nn_grid *nn_build(const void *pts, size_t n, size_t stride, float cell) {
+  nn_grid *g = (nn_grid *)calloc(1, sizeof(nn_grid));
+  g->cell = cell; g->pts = pts; g->stride = stride; g->n = n;
+  int mn[3] = {2147483647, 2147483647, 2147483647}, mx[3] = {-2147483647, -2147483647, -2147483647};
+  for (size_t i = 0; i < n; i++) {
+    const float *p = P(pts, stride, i);
+    for (int a = 0; a < 3; a++) { int c = (int)floorf(p[a] / cell); if (c < mn[a]) mn[a] = c; if (c > mx[a]) mx[a] = c; }
+  }
+  for (int a = 0; a < 3; a++) { g->lo[a] = mn[a]; g->dim[a] = mx[a] - mn[a] + 1; }
+  size_t nc = (size_t)g->dim[0] * g->dim[1] * g->dim[2];
+  g->start = (int *)calloc(nc + 1, sizeof(int));
+  g->idx = (int *)malloc(n * sizeof(int));
+  int *cid = (int *)malloc(n * sizeof(int));
+  for (size_t i = 0; i < n; i++) {
+    const float *p = P(pts, stride, i);
+    int c[3];
+    for (int a = 0; a < 3; a++) c[a] = (int)floorf(p[a] / cell) - g->lo[a];
+    cid[i] = c[0] + c[1] * g->dim[0] + c[2] * g->dim[0] * g->dim[1];
+    g->start[cid[i] + 1]++;
+  }
+  for (size_t c = 0; c < nc; c++) g->start[c + 1] += g->start[c];
+  int *fill = (int *)calloc(nc, sizeof(int));
+  for (size_t i = 0; i < n; i++) g->idx[g->start[cid[i]] + fill[cid[i]]++] = (int)i;
+  free(fill); free(cid);
+  return g;
+}
+
+static void nn_free(nn_grid *g) { if (g) { free(g->start); free(g->idx); free(g); } }
+
+/* exact 1-NN restricted to squared distance <= gate (cell >= sqrt(gate)); returns -1 if none */
+static int nn_query(const nn_grid *g, const float q[3], float gate, float *sqd_out) {
+  int c[3];
+  for (int a = 0; a < 3; a++) c[a] = (int)floorf(q[a] / g->cell) - g->lo[a];
+  int best = -1; float bd = INFINITY;
+  for (int dz = -1; dz <= 1; dz++) for (int dy = -1; dy <= 1; dy++) for (int dx = -1; dx <= 1; dx++) {
+    int x = c[0] + dx, y = c[1] + dy, z = c[2] + dz;
+    if (x < 0 || y < 0 || z < 0 || x >= g->dim[0] || y >= g->dim[1] || z >= g->dim[2]) continue;
+    int ci = x + y * g->dim[0] + z * g->dim[0] * g->dim[1];
+    for (int k = g->start[ci]; k < g->start[ci + 1]; k++) {
+      int id = g->idx[k];
+      const float *p = P(g->pts, g->stride, (size_t)id);
+      float ex = q[0] - p[0], ey = q[1] - p[1], ez = q[2] - p[2];
+      float d = ex * ex + ey * ey + ez * ez;
+      if (d < bd || (d == bd && id < best)) { bd = d; best = id; }
+    }
+  }
+  if (best < 0 || bd > gate) return -1;
+  *sqd_out = bd;
+  return best;
+}
+
+/* f32 partial-pivot LU: returns det, writes inverse */
+static float lu6_inverse(const float A[36], float inv[36]) {
+  float M[6][12];
+  for (int r = 0; r < 6; r++) for (int c = 0; c < 6; c++) { M[r][c] = A[r * 6 + c]; M[r][6 + c] = (r == c) ? 1.0f : 0.0f; }
+  float det = 1.0f;
+  for (int k = 0; k < 6; k++) {
+    int piv = k; float mv = fabsf(M[k][k]);
+    for (int r = k + 1; r < 6; r++) if (fabsf(M[r][k]) > mv) { mv = fabsf(M[r][k]); piv = r; }
+    if (mv == 0.0f) return 0.0f;
+    if (piv != k) { for (int c = 0; c < 12; c++) { float t = M[k][c]; M[k][c] = M[piv][c]; M[piv][c] = t; } det = -det; }
+    det *= M[k][k];
+    float ip = 1.0f / M[k][k];
+    for (int c = 0; c < 12; c++) M[k][c] *= ip;
+    for (int r = 0; r < 6; r++) if (r != k) {
+      float f = M[r][k];
+      if (f != 0.0f) for (int c = 0; c < 12; c++) M[r][c] -= f * M[k][c];
+    }
+  }
+  for (int r = 0; r < 6; r++) for (int c = 0; c < 6; c++) inv[r * 6 + c] = M[r][6 + c];
+  return det;
+}
+
+static void so3_exp_f32(const float w[3], float R[9]) {
+  /* Sophus SO3::exp via unit quaternion, then Eigen Quaternion::toRotationMatrix */
+  float theta_sq = w[0] * w[0] + w[1] * w[1] + w[2] * w[2];
+  float imag, real;
+  if (theta_sq < 1e-10f) {
+    float theta_po4 = theta_sq * theta_sq;
+    imag = 0.5f - (1.0f / 48.0f) * theta_sq + (1.0f / 3840.0f) * theta_po4;
+    real = 1.0f - (1.0f / 8.0f) * theta_sq + (1.0f / 384.0f) * theta_po4;
+  } else {
+    float theta = sqrtf(theta_sq), half = 0.5f * theta;
+    imag = sinf(half) / theta; real = cosf(half);
+  }
+  float qw = real, qx = imag * w[0], qy = imag * w[1], qz = imag * w[2];
+  float tx = 2.0f * qx, ty = 2.0f * qy, tz = 2.0f * qz;
+  float twx = tx * qw, twy = ty * qw, twz = tz * qw;
+  float txx = tx * qx, txy = ty * qx, txz = tz * qx;
+  float tyy = ty * qy, tyz = tz * qy, tzz = tz * qz;
+  R[0] = 1.0f - (tyy + tzz); R[1] = txy - twz; R[2] = txz + twy;
+  R[3] = txy + twz; R[4] = 1.0f - (txx + tzz); R[5] = tyz - twx;
+  R[6] = txz - twy; R[7] = tyz + twx; R[8] = 1.0f - (txx + tyy);
+}
+
+int orc_icp_manual(const void *tgt, size_t nt, size_t tstride, const void *src, size_t ns, size_t sstride,
+                   float max_correspond_dis, int max_iter, const float guess[16], float out_pose[16]) {
+  float T[16];
+  memcpy(T, guess, sizeof(T));
+  float R[9], t[3];
+  for (int r = 0; r < 3; r++) { for (int c = 0; c < 3; c++) R[r * 3 + c] = T[c * 4 + r]; t[r] = T[12 + r]; }
+  float cell = sqrtf(max_correspond_dis);
+  if (!(cell > 0.05f)) cell = 0.05f;
+  nn_grid *g = nt ? nn_build(tgt, nt, tstride, cell) : NULL;
+  for (int it = 0; it < max_iter; it++) {
+    float H[36], B[6];
+    memset(H, 0, sizeof(H)); memset(B, 0, sizeof(B));
+    for (size_t i = 0; i < ns; i++) {
+      const float *p = P(src, sstride, i);
+      if (!isfinite(p[0]) || !isfinite(p[1]) || !isfinite(p[2])) continue;
+      float q[3];
+      orc_transform_point(T, p, q); /* pcl::transformPointCloud, :132 */
+      float sqd;
+      int id = g ? nn_query(g, q, max_correspond_dis, &sqd) : -1;
+      if (id < 0) continue; /* distances[0] > max_correspond_distance_ (:147, squared vs un-squared, sic) */
+      const float *c = P(tgt, tstride, (size_t)id);
+      float e[3] = {q[0] - c[0], q[1] - c[1], q[2] - c[2]};
+      float J[3][6];
+      memset(J, 0, sizeof(J));
+      J[0][0] = J[1][1] = J[2][2] = 1.0f;
+      float hat[9] = {0, -p[2], p[1], p[2], 0, -p[0], -p[1], p[0], 0};
+      for (int r = 0; r < 3; r++)
+        for (int cc = 0; cc < 3; cc++)
+          J[r][3 + cc] = ((-R[r * 3 + 0]) * hat[0 * 3 + cc] + (-R[r * 3 + 1]) * hat[1 * 3 + cc]) + (-R[r * 3 + 2]) * hat[2 * 3 + cc];
+      for (int a = 0; a < 6; a++) {
+        for (int b = 0; b < 6; b++) H[a * 6 + b] += (J[0][a] * J[0][b] + J[1][a] * J[1][b]) + J[2][a] * J[2][b];
+        B[a] += (-J[0][a]) * e[0] + (-J[1][a]) * e[1] + (-J[2][a]) * e[2];
+      }
+    }
+    float Hi[36];
+    float det = lu6_inverse(H, Hi);
+    if (det == 0.0f) continue; /* :165 */
+    float d[6];
+    for (int a = 0; a < 6; a++) { float s = 0; for (int b = 0; b < 6; b++) s += Hi[a * 6 + b] * B[b]; d[a] = s; }
+    t[0] += d[0]; t[1] += d[1]; t[2] += d[2];
+    float dR[9], Rn[9];
+    so3_exp_f32(d + 3, dR);
+    for (int r = 0; r < 3; r++) for (int c = 0; c < 3; c++)
+      Rn[r * 3 + c] = (R[r * 3 + 0] * dR[0 * 3 + c] + R[r * 3 + 1] * dR[1 * 3 + c]) + R[r * 3 + 2] * dR[2 * 3 + c];
+    memcpy(R, Rn, sizeof(R));
+    for (int r = 0; r < 3; r++) { for (int c = 0; c < 3; c++) T[c * 4 + r] = R[r * 3 + c]; T[12 + r] = t[r]; }
+  }
+  nn_free(g);
+  memcpy(out_pose, T, sizeof(T));
+  return 0;
+}

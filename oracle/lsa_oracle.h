@@ -1,0 +1,136 @@
+/*
+ * lsa_oracle.h — CPU ORACLE (TEST INFRASTRUCTURE ONLY).
+ *
+ * A plain-C restatement of the reference's scan-matching hot path
+ * (VoxelFilter -> NDT / ICP scan-to-local-map).  Nothing under oracle/ is part
+ * of the product: only tests/, __graft_entry__.smoke() and bench.py's
+ * cpu_baseline leg may load it, and only as the checker / the timed CPU
+ * baseline.  The product library (lidar-slam_amd/csrc) never links, loads or
+ * calls anything in this directory.
+ *
+ * PARITY STATUS: "parity partially pinned".
+ *   - The reference holds NO tests, golden vectors or fixtures for this path
+ *     (SURVEY.md section 4 / 8c), and its in-tree NDT sources need PCL / boost /
+ *     ROS headers that this image lacks, so they are unbuildable here under the
+ *     no-stand-in rule (DESIGN.md section "Oracle").
+ *   - What IS pinned against real reference code: the 3x3 symmetric
+ *     eigen-solver (reference header SymmetricEigenSolver.h, compiled in place)
+ *     and the vendored-Eigen building blocks the path calls (Matrix3d::inverse,
+ *     JacobiSVD<6x6>::solve, eulerAngles(0,1,2), Translation*AngleAxis^3) — see
+ *     oracle/_ref (built by oracle/Makefile) and tests/golden/eigen_blocks.json.
+ *   - Everything else (grid build loops, radius search, derivative loops,
+ *     More-Thuente control flow, PCL VoxelGrid, ICP) is restated from the
+ *     reference text / published PCL 1.7 algorithm and is UNPINNED.
+ *
+ * Citations use SURVEY.md's abbreviations:
+ *   NS/ = lidar_localization/src/models/registration/ndt_registration_manual/
+ *   NI/ = lidar_localization/include/lidar_localization/models/registration/ndt_registration_manual/
+ *   S/  = lidar_localization/src/
+ */
+#ifndef LSA_ORACLE_H_
+#define LSA_ORACLE_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- small building blocks (pinned against oracle/_ref) ---------------- */
+
+/* NI/SymmetricEigenSolver.h:55-273 incl. its two transcription quirks.
+ * a: 3x3 row-major (only the upper triangle is read). evecs: row-major, eigenvectors in COLUMNS. */
+void orc_eig3(const double a[9], double evals[3], double evecs[9]);
+/* Eigen 3.2.92 LU/InverseImpl.h:124-169 cofactor inverse, row-major in/out. */
+void orc_inv3(const double m[9], double out[9]);
+/* x = V S^-1 U^T b with Eigen's rank rule (SVD/SVDBase.h:130-140,260-272); H row-major. returns rank. */
+int orc_svd6_solve(const double H[36], const double b[6], double x[6]);
+/* Translation(p0..2) * AngleAxis(p3,X) * AngleAxis(p4,Y) * AngleAxis(p5,Z) in f32
+ * (NS/NormalDistributionsTransform.cpp:691-694). T: column-major 4x4. */
+void orc_pose_to_matrix(const double p[6], float T[16]);
+/* p = (translation, rotation.eulerAngles(0,1,2)) in f32 then widened (NS/...:331-337). */
+void orc_matrix_to_pose(const float T[16], double p[6]);
+/* pcl::transformPointCloud f32 semantics (PCL 1.7 common/impl/transforms.hpp). xyz only. */
+void orc_transform_point(const float T[16], const float in[3], float out[3]);
+
+/* Eigen fixed-size-3 dot / mat-vec association (a0 + (a1 + a2)), pinned by oracle/_ref */
+double orc_dot3(const double a[3], const double b[3]);
+void orc_mv3(const double m[9], const double v[3], double out[3]);
+/* NS/VoxelGrid.cpp:286,293-294 covariance expression and :317 eigen-floor rebuild */
+void orc_cov_expr(const double tmp_cov[9], const double pt_sum[3], double n, double cov[9]);
+void orc_cov_floor_rebuild(const double evecs[9], const double evals[3], double cov[9]);
+
+/* ---- NDT voxel grid (NS/VoxelGrid.cpp) --------------------------------- */
+
+typedef struct orc_grid orc_grid;
+
+orc_grid *orc_grid_build(const void *pts, size_t n, size_t stride, size_t w_off, float leaf);
+void orc_grid_free(orc_grid *g);
+/* info[0..2]=vgrid dims, [3..5]=min_b, [6..8]=real_min, [9..11]=real_max, [12]=voxel_num */
+void orc_grid_info(const orc_grid *g, int info[13]);
+/* number of cells with >=1 point, and with points_per_voxel >= 6 (valid for NDT) */
+void orc_grid_counts(const orc_grid *g, int *occupied, int *valid);
+/* dense accessors by reference voxel id (idx-min_b + ...), VoxelGrid.cpp:237-242 */
+int orc_grid_cell(const orc_grid *g, int vid, int *npts, int *ppv, double centroid[3], double icov[9], double *weight);
+/* VoxelGrid.cpp:432-480; returns count, ids in the reference's x->y->z order */
+int orc_grid_radius_search(const orc_grid *g, const float p[3], float radius, int *ids, int cap);
+/* dump of all occupied cells in ascending (ix + iy*dx + iz*dx*dy over REAL bounds) order:
+ * for each: ix,iy,iz (absolute voxel coords), npts, ppv -> ints[5*k..]; centroid(3) icov(9) weight(1) -> dbl[13*k..] */
+int orc_grid_dump(const orc_grid *g, int *ints, double *dbls, int cap);
+
+/* ---- NDT registration (NS/NormalDistributionsTransform.cpp) ------------ */
+
+typedef struct orc_ndt orc_ndt;
+
+typedef struct {
+  int iterations;      /* nr_iterations_ (NS/...:383) */
+  int ls_iterations;   /* real_iterations_ increment for this align (:753) */
+  int passes;          /* derivative / hessian passes over the source */
+  int converged;
+  double score;        /* last score */
+  double trans_probability;
+  double pairs_per_pass; /* mean (point,voxel) pairs = K-bar * M */
+  double final_p[6];
+} orc_ndt_stats;
+
+/* parameters arrive as float exactly as NDTRegistrationManual's ctor passes them
+ * (S/models/registration/ndt_registration_manual.cpp:14-22) */
+orc_ndt *orc_ndt_create(float res, float step_size, float trans_eps, int max_iter, float outlier_ratio);
+void orc_ndt_free(orc_ndt *h);
+int orc_ndt_set_target(orc_ndt *h, const void *pts, size_t n, size_t stride, size_t w_off);
+const orc_grid *orc_ndt_grid(const orc_ndt *h);
+void orc_ndt_gauss(const orc_ndt *h, double *d1, double *d2);
+/* one computeDerivatives pass (NS/...:391-445) at f32 transform T and f64 pose p.
+ * g[6], H[36] row-major; returns score. pairs (may be NULL) receives #(point,voxel) pairs. */
+double orc_ndt_derivatives(orc_ndt *h, const void *src, size_t n, size_t stride, const float T[16],
+                           const double p[6], int compute_hessian, double g[6], double H[36], long *pairs);
+/* computeHessian pass (NS/...:901-936) */
+void orc_ndt_hessian(orc_ndt *h, const void *src, size_t n, size_t stride, const float T[16],
+                     const double p[6], double H[36]);
+/* Registration::align + computeTransformation (NS/Registration.cpp:76-95, NS/Normal...:310-389) */
+int orc_ndt_align(orc_ndt *h, const void *src, size_t n, size_t stride, const float guess[16],
+                  float out_pose[16], orc_ndt_stats *stats);
+/* optional per-pass trace: rows of [p(6), score, step_len, kind] appended; kind 0=deriv+H,1=deriv,2=hessian */
+void orc_ndt_set_trace(orc_ndt *h, double *buf, int cap_rows, int *n_rows);
+/* getFitnessScore (NS/...:940-965) with the octree-bounded nearest-voxel search */
+double orc_ndt_fitness(orc_ndt *h, const void *src, size_t n, size_t stride, const float T[16]);
+
+/* ---- generic GN/More-Thuente driver with caller-supplied evaluator ----- */
+/* evaluator: given x_t (6) and f32 T, kind (0 = score+g+H, 1 = score+g, 2 = H only) fill out28:
+ * [score, g0..g5, H upper-tri 21 (row-major i<=j)]  — used by the world_size-2 gloo tests */
+typedef int (*orc_eval_fn)(void *user, const double p[6], const float T[16], int kind, double out28[28]);
+
+/* ---- PCL VoxelGrid filter (PCL 1.7 filters/impl/voxel_grid.hpp) -------- */
+/* returns 0 ok, 1 = "leaf size too small" (output = copy of input), <0 error. out is n_out x 4 floats (x,y,z,intensity) */
+int orc_voxel_filter(const void *pts, size_t n, size_t stride, size_t w_off, float lx, float ly, float lz,
+                     float *out_xyzi, size_t cap, size_t *n_out);
+
+/* ---- ICP (S/models/registration/icp_registration_manual.cpp:125-178) --- */
+int orc_icp_manual(const void *tgt, size_t nt, size_t tstride, const void *src, size_t ns, size_t sstride,
+                   float max_correspond_dis, int max_iter, const float guess[16], float out_pose[16]);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

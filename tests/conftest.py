@@ -1,0 +1,54 @@
+import importlib.util
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "oracle"))
+
+
+def _load_pkg():
+    """The package directory is `lidar-slam_amd/` (hyphen); register it as `lidar_slam_amd`."""
+    if "lidar_slam_amd" in sys.modules:
+        return sys.modules["lidar_slam_amd"]
+    pkg_dir = os.path.join(ROOT, "lidar-slam_amd")
+    spec = importlib.util.spec_from_file_location("lidar_slam_amd", os.path.join(pkg_dir, "__init__.py"),
+                                                  submodule_search_locations=[pkg_dir])
+    mod = importlib.util.module_from_spec(spec)
+    sys.modules["lidar_slam_amd"] = mod
+    spec.loader.exec_module(mod)
+    return mod
+
+
+_load_pkg()
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def oracle():
+    import oracle_py
+    oracle_py.build(ref=False)
+    return oracle_py.Oracle()
+
+
+@pytest.fixture(scope="session")
+def scene():
+    from lidar_slam_amd import synth
+    return synth.Scene(seed=1)
+
+
+@pytest.fixture(scope="session")
+def scan_pair(scene):
+    """cfg1 pair: same scene from T0 = I and T1 = (1.0, 0.05, 0.01, 0.002, -0.003, 0.02)."""
+    from lidar_slam_amd import synth
+    T0 = synth.pose_matrix()
+    T1 = synth.pose_matrix(1.0, 0.05, 0.01, 0.002, -0.003, 0.02)
+    s0 = synth.gen_scan(scene, T0, seed=10)
+    s1 = synth.gen_scan(scene, T1, seed=11)
+    return s0, s1, T0, T1
