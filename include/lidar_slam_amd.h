@@ -1,0 +1,201 @@
+/*
+ * lidar_slam_amd.h — C-ABI of the MI355X-native scan-matching front end.
+ *
+ * Drop-in boundary for ONE hot path of FISH1129/Lidar-SLAM: the lidar_localization front_end
+ * per-scan pipeline  VoxelFilter downsample -> NDT / ICP scan-to-local-map.  Every entry point
+ * below names the reference interface it replaces (paths relative to the reference root):
+ *
+ *   CloudFilterInterface::Filter        lidar_localization/include/lidar_localization/models/cloud_filter/cloud_filter_interface.hpp:13-18
+ *     VoxelFilter (pcl::VoxelGrid)      lidar_localization/src/models/cloud_filter/voxel_filter.cpp:12-41
+ *   RegistrationInterface               lidar_localization/include/lidar_localization/models/registration/registration_interface.hpp:14-24
+ *     NDTRegistrationManual             lidar_localization/src/models/registration/ndt_registration_manual.cpp:12-78
+ *     ICPRegistrationManual             lidar_localization/src/models/registration/icp_registration_manual.cpp:12-179
+ *   CloudData::POINT = pcl::PointXYZI   lidar_localization/include/lidar_localization/sensor_data/cloud_data.hpp:33-38
+ *
+ * The library is plain C at the boundary: opaque handles, raw pointers + sizes, no PCL / Eigen /
+ * boost / yaml / torch types.  Host clouds are passed as (pointer, count, stride, intensity offset) so a
+ * `cloud->points.data()` of pcl::PointXYZI (stride 32, xyz at 0, intensity at 16) can be handed
+ * over as is; 4x4 poses are 16 floats COLUMN-major (Eigen::Matrix4f::data()).
+ * `intensity` carries the reference's per-point static weight (front_end.cpp:303-327).
+ *
+ * Every function returns LSA_OK (0) or a negative lsa_status; nothing throws across the ABI.  There
+ * is NO CPU fallback: without a usable gfx950 device every compute entry point fails with
+ * LSA_ERR_NO_DEVICE.  The reference's plugins return `true` unconditionally; INTEGRATION.md shows the
+ * adaptor mapping non-zero -> false + LOG(ERROR).
+ *
+ * Threading: like the reference (single-threaded callers, front_end_node.cpp:27-34) a handle is
+ * not re-entrant; different handles may be used from different threads.
+ */
+#ifndef LIDAR_SLAM_AMD_H_
+#define LIDAR_SLAM_AMD_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define LSA_VERSION_MAJOR 0
+#define LSA_VERSION_MINOR 1
+
+typedef enum {
+  LSA_OK = 0,
+  LSA_ERR_INVALID = -1,    /* bad argument (null pointer, zero size where one is required, ...) */
+  LSA_ERR_NO_DEVICE = -2,  /* no gfx950 device / HIP runtime cannot initialise — there is no CPU path */
+  LSA_ERR_HIP = -3,        /* a HIP call failed; lsa_last_error() has the text */
+  LSA_ERR_NO_TARGET = -4,  /* ScanMatch / GetFitnessScore before SetInputTarget */
+  LSA_ERR_CAPACITY = -5,   /* caller-provided output buffer too small */
+  LSA_ERR_COLLECTIVE = -6, /* the all-reduce callback reported failure */
+  LSA_ERR_RANGE = -7       /* voxel index would overflow int32 (PCL: "Leaf size is too small") */
+} lsa_status;
+
+/* pcl::PointXYZI layout constants (cloud_data.hpp:35) */
+#define LSA_POINTXYZI_STRIDE 32
+#define LSA_POINTXYZI_W_OFF 16
+
+/* ---------------------------------------------------------------------------------------------
+ * Context: one per process per GPU (one process per GPU; see INTEGRATION.md for the multi-GPU layout)
+ * ------------------------------------------------------------------------------------------- */
+typedef struct lsa_context lsa_context;
+
+/* device: HIP ordinal. hip_stream: a hipStream_t to enqueue on, or NULL to create a private stream. */
+int lsa_context_create(lsa_context **out, int device, void *hip_stream);
+void lsa_context_destroy(lsa_context *ctx);
+/* text of the last failure on this context (valid until the next call on it); never NULL */
+const char *lsa_last_error(const lsa_context *ctx);
+/* text of the last failure of a *_create call that returned no handle (thread-local) */
+const char *lsa_last_global_error(void);
+void *lsa_context_stream(lsa_context *ctx);
+int lsa_context_synchronize(lsa_context *ctx);
+int lsa_version(void);
+
+/* ---------------------------------------------------------------------------------------------
+ * VoxelFilter  — replaces VoxelFilter::Filter (voxel_filter.cpp:36-41 -> pcl::VoxelGrid::filter)
+ * Semantics (PCL 1.7 VoxelGrid, downsample_all_data = true, min_points_per_voxel = 0):
+ * one output point per occupied voxel = mean of x,y,z,intensity of its members, outputs ordered by
+ * ascending linear voxel index i + j*dx + k*dx*dy.
+ * ------------------------------------------------------------------------------------------- */
+typedef struct lsa_voxel_filter lsa_voxel_filter;
+
+/* VoxelFilter::VoxelFilter(float leaf_size_x, y, z)  (voxel_filter.cpp:20-22) */
+int lsa_voxel_filter_create(lsa_voxel_filter **out, lsa_context *ctx, float leaf_x, float leaf_y, float leaf_z);
+void lsa_voxel_filter_destroy(lsa_voxel_filter *f);
+
+/* Filter(input_cloud_ptr, filtered_cloud_ptr): host AoS in, host AoS out.
+ * out may alias in (viewer.cpp:207 calls Filter with in == out); out_cap in points (n is always
+ * enough).  Output points get data[3] = 1.0f like a default-constructed PointXYZI when out_stride >= 16.
+ * Returns LSA_ERR_RANGE (and copies the input through, as PCL does) if dx*dy*dz > INT32_MAX. */
+int lsa_voxel_filter_apply(lsa_voxel_filter *f, const void *in_pts, size_t n, size_t in_stride, size_t in_w_off,
+                           void *out_pts, size_t out_cap, size_t out_stride, size_t out_w_off, size_t *n_out);
+
+/* Device-resident variant: d_in / d_out are device pointers to packed float4 {x,y,z,intensity}
+ * (16 B / point, 16-B aligned).  d_out must hold n points.  *n_out is written on the host (one sync). */
+int lsa_voxel_filter_apply_device(lsa_voxel_filter *f, const float *d_in_xyzw, size_t n, float *d_out_xyzw, size_t *n_out);
+
+/* ---------------------------------------------------------------------------------------------
+ * NDT registration — replaces NDTRegistrationManual (ndt_registration_manual.cpp) and, behind it,
+ * lidar_localization::NormalDistributionsTransform / VoxelGrid (ndt_registration_manual/ *.cpp)
+ * ------------------------------------------------------------------------------------------- */
+typedef struct lsa_ndt lsa_ndt;
+
+typedef struct {
+  int32_t iterations;       /* Newton iterations (nr_iterations_, NormalDistributionsTransform.cpp:383) */
+  int32_t ls_iterations;    /* More-Thuente trial steps taken in this call (:746) */
+  int32_t passes;           /* derivative / Hessian passes over the source cloud */
+  int32_t converged;        /* hasConverged() */
+  double score;             /* last NDT score */
+  double trans_probability; /* getTransformationProbability(), score / #source points (:386-388) */
+  double pairs_per_pass;    /* mean number of (source point, target voxel) pairs per pass = K-bar * M */
+  double final_p[6];        /* final (x,y,z,roll,pitch,yaw) in the reference's Euler chart */
+  double gpu_ms;            /* device time of the passes (HIP events on the context's stream) */
+} lsa_ndt_stats;
+
+/* NDTRegistrationManual(float res, float step_size, float trans_eps, int max_iter, float outlier_ratio)
+ * (ndt_registration_manual.cpp:25-29); YAML defaults config/mapping/front_end.yaml:24-29 */
+int lsa_ndt_create(lsa_ndt **out, lsa_context *ctx, float res, float step_size, float trans_eps, int max_iter,
+                   float outlier_ratio);
+void lsa_ndt_destroy(lsa_ndt *ndt);
+
+/* SetInputTarget(input_target) (ndt_registration_manual.cpp:48-54 -> NormalDistributionsTransform::setInputTarget
+ * -> VoxelGrid::setInput, VoxelGrid.cpp:326-358).  The target is copied to the device; the caller's
+ * buffer is not retained. */
+int lsa_ndt_set_input_target(lsa_ndt *ndt, const void *pts, size_t n, size_t stride, size_t w_off);
+int lsa_ndt_set_input_target_device(lsa_ndt *ndt, const float *d_xyzw, size_t n);
+
+/* ScanMatch(input_source, predict_pose, result_cloud_ptr, result_pose) (ndt_registration_manual.cpp:57-68).
+ * result_cloud_ptr is never written by the reference plugin (Registration.cpp:92-95) and no caller reads
+ * it, so it has no counterpart here.  stats may be NULL. */
+int lsa_ndt_scan_match(lsa_ndt *ndt, const void *src, size_t n, size_t stride, const float predict_pose[16],
+                       float result_pose[16], lsa_ndt_stats *stats);
+int lsa_ndt_scan_match_device(lsa_ndt *ndt, const float *d_src_xyzw, size_t n, const float predict_pose[16],
+                              float result_pose[16], lsa_ndt_stats *stats);
+
+/* GetFitnessScore() (ndt_registration_manual.cpp:71-77 -> NormalDistributionsTransform::getFitnessScore,
+ * :940-965): mean distance from each transformed source point of the LAST ScanMatch to the nearest
+ * target-voxel centroid, searched the way the reference's octree does. */
+int lsa_ndt_get_fitness_score(lsa_ndt *ndt, float *score);
+
+/* ---- introspection used by the parity tests and bench.py ----------------------------------- */
+
+/* info[0..2] = occupied-bounds dims (real_max - real_min + 1), [3..5] = real_min, [6] = occupied cells,
+ * [7] = valid cells (>= 6 points and accepted eigenvalues, VoxelGrid.cpp:292-306), [8] = target points */
+int lsa_ndt_grid_info(lsa_ndt *ndt, int64_t info[9]);
+/* all occupied cells in ascending linear index (x fastest over the occupied bounds):
+ * cell_ijk: 3 ints (absolute voxel coords) + npts + valid flag -> 5 ints per cell;
+ * rec: centroid(3) icov sym (xx,xy,xz,yy,yz,zz) weight(1) -> 10 doubles per cell. cap in cells. */
+int lsa_ndt_grid_dump(lsa_ndt *ndt, int32_t *cell_ints, double *cell_rec, size_t cap, size_t *n_cells);
+
+/* One derivative pass of computeDerivatives / computeHessian (NormalDistributionsTransform.cpp:391-445,
+ * :901-936) at rigid transform T (f32, column-major) and pose p (f64, for the angle derivatives).
+ * kind 0: score + gradient + Hessian, 1: score + gradient, 2: Hessian only.
+ * out32 = [score, g(6), H upper triangle row-major (21), #pairs, #points, 0, 0].
+ * The source must have been uploaded with lsa_ndt_set_source[_device]. */
+int lsa_ndt_set_source(lsa_ndt *ndt, const void *src, size_t n, size_t stride);
+int lsa_ndt_set_source_device(lsa_ndt *ndt, const float *d_src_xyzw, size_t n);
+int lsa_ndt_derivatives(lsa_ndt *ndt, const float T[16], const double p[6], int kind, double out32[32]);
+/* Enqueue `repeat` identical passes back to back and return the mean device time per pass (HIP events
+ * on the context's stream): the roofline measurement of bench.py. */
+int lsa_ndt_derivatives_timed(lsa_ndt *ndt, const float T[16], const double p[6], int kind, int repeat,
+                              double out32[32], double *ms_per_pass);
+
+/* ---- multi-GPU: source cloud sharded over ranks, target replicated ------------------------- */
+/* Called once per pass with a DEVICE buffer of n doubles (32) that must be summed in place over all
+ * ranks (RCCL all-reduce over xGMI), enqueued on hip_stream; return 0 on success. */
+typedef int (*lsa_allreduce_fn)(void *user, void *device_buf, size_t n_doubles, void *hip_stream);
+int lsa_ndt_set_allreduce(lsa_ndt *ndt, lsa_allreduce_fn fn, void *user);
+
+/* ---- host-side Newton / More-Thuente driver with a caller-supplied pass evaluator ---------- */
+/* The same driver lsa_ndt_scan_match runs, exposed so the multi-process path can be exercised
+ * without a GPU (tests: world_size-2 gloo).  eval must fill out32 as lsa_ndt_derivatives does,
+ * already summed over ranks. */
+typedef int (*lsa_pass_eval_fn)(void *user, const float T[16], const double p[6], int kind, double out32[32]);
+int lsa_gn_solve(lsa_pass_eval_fn eval, void *user, float res, float step_size, float trans_eps, int max_iter,
+                 float outlier_ratio, const float predict_pose[16], float result_pose[16], lsa_ndt_stats *stats);
+/* pose helpers of that driver (f32 rigid transform <-> the reference's (t, Euler XYZ) chart) */
+void lsa_pose_to_matrix(const double p[6], float T[16]);
+void lsa_matrix_to_pose(const float T[16], double p[6]);
+void lsa_ndt_gauss_constants(float res, float outlier_ratio, double *d1, double *d2);
+
+/* ---------------------------------------------------------------------------------------------
+ * ICP registration — replaces ICPRegistrationManual (icp_registration_manual.cpp:12-179):
+ * point-to-point Gauss-Newton, fixed max_iter iterations, exact 1-NN correspondences gated by
+ * squared-distance <= max_correspond_dis (sic, :147).  mode 1 = point-to-plane extension
+ * (normals from the target's NDT voxel covariances; not in the reference, BASELINE.json config 3).
+ * ------------------------------------------------------------------------------------------- */
+typedef struct lsa_icp lsa_icp;
+int lsa_icp_create(lsa_icp **out, lsa_context *ctx, float max_correspond_dis, int max_iter, int mode);
+void lsa_icp_destroy(lsa_icp *icp);
+int lsa_icp_set_input_target(lsa_icp *icp, const void *pts, size_t n, size_t stride);
+int lsa_icp_set_input_target_device(lsa_icp *icp, const float *d_xyzw, size_t n);
+int lsa_icp_scan_match(lsa_icp *icp, const void *src, size_t n, size_t stride, const float predict_pose[16],
+                       float result_pose[16]);
+int lsa_icp_scan_match_device(lsa_icp *icp, const float *d_src_xyzw, size_t n, const float predict_pose[16],
+                              float result_pose[16]);
+/* GetFitnessScore(): unimplemented in the reference, returns 0 (:62-67) */
+int lsa_icp_get_fitness_score(lsa_icp *icp, float *score);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LIDAR_SLAM_AMD_H_ */

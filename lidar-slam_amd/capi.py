@@ -1,0 +1,170 @@
+"""ctypes binding of the C-ABI declared in include/lidar_slam_amd.h.
+
+The shared library is built in-tree (lidar-slam_amd/liblidar_slam_amd.so) by
+__graft_entry__.build() / `make -C lidar-slam_amd/csrc`.  There is no fallback: if the
+library is missing, or no gfx950 device is usable, the calls raise LsaError.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "liblidar_slam_amd.so")
+HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "lidar_slam_amd.h")
+
+LSA_OK = 0
+LSA_ERR_INVALID, LSA_ERR_NO_DEVICE, LSA_ERR_HIP, LSA_ERR_NO_TARGET, LSA_ERR_CAPACITY, LSA_ERR_COLLECTIVE, LSA_ERR_RANGE = -1, -2, -3, -4, -5, -6, -7
+POINT_STRIDE = 32
+W_OFF = 16
+
+
+class LsaError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("lidar_slam_amd error %d: %s" % (code, msg))
+        self.code = code
+
+
+class NdtStats(C.Structure):
+    _fields_ = [
+        ("iterations", C.c_int32),
+        ("ls_iterations", C.c_int32),
+        ("passes", C.c_int32),
+        ("converged", C.c_int32),
+        ("score", C.c_double),
+        ("trans_probability", C.c_double),
+        ("pairs_per_pass", C.c_double),
+        ("final_p", C.c_double * 6),
+        ("gpu_ms", C.c_double),
+    ]
+
+    def as_dict(self):
+        return dict(iterations=self.iterations, ls_iterations=self.ls_iterations, passes=self.passes, converged=self.converged,
+                    score=self.score, trans_probability=self.trans_probability, pairs_per_pass=self.pairs_per_pass,
+                    final_p=np.array(self.final_p[:]), gpu_ms=self.gpu_ms)
+
+
+ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p)
+PASS_EVAL_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_double), C.c_int, C.POINTER(C.c_double))
+
+_lib = None
+
+
+def lib():
+    """Load the product library; raises if it has not been built (no silent fallback)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise LsaError(LSA_ERR_NO_DEVICE, "%s not built; run __graft_entry__.build()" % LIB_PATH)
+    L = C.CDLL(LIB_PATH)
+    vp, sz, f, i = C.c_void_p, C.c_size_t, C.c_float, C.c_int
+    PF, PD, PSZ = C.POINTER(C.c_float), C.POINTER(C.c_double), C.POINTER(C.c_size_t)
+    PVP = C.POINTER(C.c_void_p)
+    L.lsa_version.restype = i
+    L.lsa_context_create.argtypes = [PVP, i, vp]
+    L.lsa_context_destroy.argtypes = [vp]
+    L.lsa_context_destroy.restype = None
+    L.lsa_last_error.argtypes = [vp]
+    L.lsa_last_error.restype = C.c_char_p
+    L.lsa_last_global_error.restype = C.c_char_p
+    L.lsa_context_stream.argtypes = [vp]
+    L.lsa_context_stream.restype = vp
+    L.lsa_context_synchronize.argtypes = [vp]
+    L.lsa_voxel_filter_create.argtypes = [PVP, vp, f, f, f]
+    L.lsa_voxel_filter_destroy.argtypes = [vp]
+    L.lsa_voxel_filter_destroy.restype = None
+    L.lsa_voxel_filter_apply.argtypes = [vp, vp, sz, sz, sz, vp, sz, sz, sz, PSZ]
+    L.lsa_voxel_filter_apply_device.argtypes = [vp, vp, sz, vp, PSZ]
+    L.lsa_ndt_create.argtypes = [PVP, vp, f, f, f, i, f]
+    L.lsa_ndt_destroy.argtypes = [vp]
+    L.lsa_ndt_destroy.restype = None
+    L.lsa_ndt_set_input_target.argtypes = [vp, vp, sz, sz, sz]
+    L.lsa_ndt_set_input_target_device.argtypes = [vp, vp, sz]
+    L.lsa_ndt_scan_match.argtypes = [vp, vp, sz, sz, PF, PF, C.POINTER(NdtStats)]
+    L.lsa_ndt_scan_match_device.argtypes = [vp, vp, sz, PF, PF, C.POINTER(NdtStats)]
+    L.lsa_ndt_get_fitness_score.argtypes = [vp, PF]
+    L.lsa_ndt_grid_info.argtypes = [vp, C.POINTER(C.c_int64)]
+    L.lsa_ndt_grid_dump.argtypes = [vp, C.POINTER(C.c_int32), PD, sz, PSZ]
+    L.lsa_ndt_set_source.argtypes = [vp, vp, sz, sz]
+    L.lsa_ndt_set_source_device.argtypes = [vp, vp, sz]
+    L.lsa_ndt_derivatives.argtypes = [vp, PF, PD, i, PD]
+    L.lsa_ndt_derivatives_timed.argtypes = [vp, PF, PD, i, i, PD, PD]
+    L.lsa_ndt_set_allreduce.argtypes = [vp, ALLREDUCE_FN, vp]
+    L.lsa_gn_solve.argtypes = [PASS_EVAL_FN, vp, f, f, f, i, f, PF, PF, C.POINTER(NdtStats)]
+    L.lsa_pose_to_matrix.argtypes = [PD, PF]
+    L.lsa_pose_to_matrix.restype = None
+    L.lsa_matrix_to_pose.argtypes = [PF, PD]
+    L.lsa_matrix_to_pose.restype = None
+    L.lsa_ndt_gauss_constants.argtypes = [f, f, PD, PD]
+    L.lsa_ndt_gauss_constants.restype = None
+    L.lsa_icp_create.argtypes = [PVP, vp, f, i, i]
+    L.lsa_icp_destroy.argtypes = [vp]
+    L.lsa_icp_destroy.restype = None
+    L.lsa_icp_set_input_target.argtypes = [vp, vp, sz, sz]
+    L.lsa_icp_set_input_target_device.argtypes = [vp, vp, sz]
+    L.lsa_icp_scan_match.argtypes = [vp, vp, sz, sz, PF, PF]
+    L.lsa_icp_scan_match_device.argtypes = [vp, vp, sz, PF, PF]
+    L.lsa_icp_get_fitness_score.argtypes = [vp, PF]
+    _lib = L
+    return L
+
+
+def declared_symbols():
+    """Every function name declared in include/lidar_slam_amd.h (for the export test)."""
+    import re
+    txt = open(HEADER_PATH).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    names = re.findall(r"\b(lsa_[a-z0-9_]+)\s*\(", txt)
+    skip = {"lsa_allreduce_fn", "lsa_pass_eval_fn"}
+    return sorted(set(n for n in names if n not in skip))
+
+
+def colmajor(T):
+    """4x4 (row-major numpy) -> 16 floats column-major, as Eigen::Matrix4f::data()."""
+    return np.ascontiguousarray(np.asarray(T, dtype=np.float32).T).reshape(16)
+
+
+def from_colmajor(buf):
+    return np.asarray(buf, dtype=np.float32).reshape(4, 4).T.copy()
+
+
+def fptr(a):
+    return a.ctypes.data_as(C.POINTER(C.c_float))
+
+
+def dptr(a):
+    return a.ctypes.data_as(C.POINTER(C.c_double))
+
+
+class Context:
+    def __init__(self, device=0, stream=None):
+        L = lib()
+        h = C.c_void_p()
+        rc = L.lsa_context_create(C.byref(h), device, stream)
+        if rc != LSA_OK:
+            raise LsaError(rc, L.lsa_last_global_error().decode())
+        self.h = h
+        self.device = device
+
+    def check(self, rc):
+        if rc != LSA_OK:
+            raise LsaError(rc, lib().lsa_last_error(self.h).decode())
+
+    def synchronize(self):
+        self.check(lib().lsa_context_synchronize(self.h))
+
+    @property
+    def stream(self):
+        return lib().lsa_context_stream(self.h)
+
+    def close(self):
+        if self.h:
+            lib().lsa_context_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -1,0 +1,73 @@
+"""Host-side mirror of the reference's cloud_filter plugin layer over the C-ABI.
+
+Reference: lidar_localization/include/lidar_localization/models/cloud_filter/cloud_filter_interface.hpp:13-18
+(CloudFilterInterface::Filter), .../voxel_filter.hpp + src/models/cloud_filter/voxel_filter.cpp:12-41 (VoxelFilter),
+src/models/cloud_filter/no_filter.cpp:13-16 (NoFilter).  Same names, argument meaning and (non-)error behaviour:
+Filter returns True; a cloud is an (n, 8) float32 array in pcl::PointXYZI layout (x y z 1 | intensity 0 0 0).
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import capi
+
+
+class CloudFilterInterface:
+    def Filter(self, input_cloud, filtered_cloud=None):  # noqa: N802 (reference naming)
+        raise NotImplementedError
+
+
+class NoFilter(CloudFilterInterface):
+    """no_filter.cpp:13-16: deep copy."""
+
+    def Filter(self, input_cloud, filtered_cloud=None):  # noqa: N802
+        return True, np.array(input_cloud, copy=True)
+
+
+class VoxelFilterHip(CloudFilterInterface):
+    """VoxelFilter(leaf_size_x, leaf_size_y, leaf_size_z) or VoxelFilter(node) with node['leaf_size'] = [x, y, z]."""
+
+    def __init__(self, ctx, leaf_x=None, leaf_y=None, leaf_z=None, node=None):
+        if node is not None:
+            leaf_x, leaf_y, leaf_z = (float(v) for v in node["leaf_size"])
+        self.ctx = ctx
+        self.leaf = (float(leaf_x), float(leaf_y), float(leaf_z))
+        h = C.c_void_p()
+        ctx.check(capi.lib().lsa_voxel_filter_create(C.byref(h), ctx.h, *self.leaf))
+        self.h = h
+
+    def Filter(self, input_cloud, filtered_cloud=None):  # noqa: N802
+        """Host path. Returns (True, filtered (m, 8) float32). `filtered_cloud` may be the input (viewer.cpp:207)."""
+        pts = np.ascontiguousarray(input_cloud, dtype=np.float32)
+        n = pts.shape[0]
+        stride = pts.strides[0]
+        w_off = capi.W_OFF if pts.shape[1] >= 5 else 12
+        out = np.zeros((max(n, 1), 8), dtype=np.float32)
+        n_out = C.c_size_t(0)
+        rc = capi.lib().lsa_voxel_filter_apply(self.h, pts.ctypes.data, n, stride, w_off, out.ctypes.data, n, capi.POINT_STRIDE, capi.W_OFF, C.byref(n_out))
+        if rc == capi.LSA_ERR_RANGE:
+            return True, out[: n_out.value]  # PCL warns and passes the input through; the plugin still returns true
+        self.ctx.check(rc)
+        return True, out[: n_out.value]
+
+    def filter_device(self, d_in, d_out=None):
+        """Device path: d_in a CUDA float32 tensor (n, 4) {x,y,z,intensity}; returns a view of d_out[:m]."""
+        import torch
+        assert d_in.is_cuda and d_in.dtype == torch.float32 and d_in.is_contiguous() and d_in.shape[1] == 4
+        n = d_in.shape[0]
+        if d_out is None:
+            d_out = torch.empty((max(n, 1), 4), dtype=torch.float32, device=d_in.device)
+        n_out = C.c_size_t(0)
+        self.ctx.check(capi.lib().lsa_voxel_filter_apply_device(self.h, d_in.data_ptr(), n, d_out.data_ptr(), C.byref(n_out)))
+        return d_out[: n_out.value]
+
+    def close(self):
+        if self.h:
+            capi.lib().lsa_voxel_filter_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -1,0 +1,80 @@
+// lsa_common.h — internal: context, grow-only device buffers, error plumbing.
+#ifndef LSA_COMMON_H_
+#define LSA_COMMON_H_
+
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <string>
+
+#include "lidar_slam_amd.h"
+
+struct lsa_context {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  bool own_stream = false;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  int num_cus = 256;
+  std::string err;
+};
+
+void lsa_set_global_error(const char *fmt, ...);
+int lsa_fail(lsa_context *ctx, int code, const char *fmt, ...);
+
+#define LSA_HIP(ctx, call)                                                                          \
+  do {                                                                                              \
+    hipError_t e__ = (call);                                                                        \
+    if (e__ != hipSuccess)                                                                          \
+      return lsa_fail((ctx), (e__ == hipErrorNoDevice || e__ == hipErrorInvalidDevice) ? LSA_ERR_NO_DEVICE : LSA_ERR_HIP, \
+                      "%s failed: %s (%s:%d)", #call, hipGetErrorString(e__), __FILE__, __LINE__); \
+  } while (0)
+
+// grow-only device allocation
+template <typename T>
+struct DevBuf {
+  T *p = nullptr;
+  size_t cap = 0;  // elements
+  int reserve(lsa_context *ctx, size_t n, double headroom = 1.0) {
+    if (n <= cap) return LSA_OK;
+    size_t want = (size_t)((double)n * headroom);
+    if (want < n) want = n;
+    if (p) { (void)hipFree(p); p = nullptr; cap = 0; }
+    hipError_t e = hipMalloc((void **)&p, want * sizeof(T));
+    if (e != hipSuccess) return lsa_fail(ctx, LSA_ERR_HIP, "hipMalloc(%zu B) failed: %s", want * sizeof(T), hipGetErrorString(e));
+    cap = want;
+    return LSA_OK;
+  }
+  void release() {
+    if (p) (void)hipFree(p);
+    p = nullptr; cap = 0;
+  }
+};
+
+template <typename T>
+struct PinnedBuf {
+  T *p = nullptr;
+  size_t cap = 0;
+  int reserve(lsa_context *ctx, size_t n) {
+    if (n <= cap) return LSA_OK;
+    if (p) { (void)hipHostFree(p); p = nullptr; cap = 0; }
+    size_t want = n + n / 4;
+    hipError_t e = hipHostMalloc((void **)&p, want * sizeof(T), hipHostMallocDefault);
+    if (e != hipSuccess) return lsa_fail(ctx, LSA_ERR_HIP, "hipHostMalloc(%zu B) failed: %s", want * sizeof(T), hipGetErrorString(e));
+    cap = want;
+    return LSA_OK;
+  }
+  void release() {
+    if (p) (void)hipHostFree(p);
+    p = nullptr; cap = 0;
+  }
+};
+
+// host AoS (pcl::PointXYZI-like) -> packed float4 {x,y,z,w}; w_off == SIZE_MAX -> w = 1
+void lsa_pack_xyzw(const void *pts, size_t n, size_t stride, size_t w_off, float *out4);
+
+static inline unsigned lsa_div_up(size_t a, size_t b) { return (unsigned)((a + b - 1) / b); }
+
+#endif

@@ -1,0 +1,111 @@
+// lsa_context.hip — context lifecycle, error text, host-side packing helpers.
+#include "lsa_common.h"
+
+#include <cstdlib>
+
+static thread_local std::string g_global_err;
+
+void lsa_set_global_error(const char *fmt, ...) {
+  char buf[512];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof(buf), fmt, ap);
+  va_end(ap);
+  g_global_err = buf;
+}
+
+int lsa_fail(lsa_context *ctx, int code, const char *fmt, ...) {
+  char buf[768];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof(buf), fmt, ap);
+  va_end(ap);
+  if (ctx) ctx->err = buf;
+  g_global_err = buf;
+  return code;
+}
+
+void lsa_pack_xyzw(const void *pts, size_t n, size_t stride, size_t w_off, float *out4) {
+  const char *p = (const char *)pts;
+  if (w_off != SIZE_MAX) {
+    for (size_t i = 0; i < n; i++, p += stride) {
+      const float *q = (const float *)p;
+      out4[4 * i] = q[0]; out4[4 * i + 1] = q[1]; out4[4 * i + 2] = q[2];
+      out4[4 * i + 3] = *(const float *)(p + w_off);
+    }
+  } else {
+    for (size_t i = 0; i < n; i++, p += stride) {
+      const float *q = (const float *)p;
+      out4[4 * i] = q[0]; out4[4 * i + 1] = q[1]; out4[4 * i + 2] = q[2];
+      out4[4 * i + 3] = 1.0f;
+    }
+  }
+}
+
+extern "C" int lsa_version(void) { return LSA_VERSION_MAJOR * 100 + LSA_VERSION_MINOR; }
+
+extern "C" const char *lsa_last_global_error(void) { return g_global_err.c_str(); }
+
+extern "C" const char *lsa_last_error(const lsa_context *ctx) { return ctx ? ctx->err.c_str() : g_global_err.c_str(); }
+
+extern "C" int lsa_context_create(lsa_context **out, int device, void *hip_stream) {
+  if (!out) { lsa_set_global_error("lsa_context_create: out is null"); return LSA_ERR_INVALID; }
+  *out = nullptr;
+  int count = 0;
+  hipError_t e = hipGetDeviceCount(&count);
+  if (e != hipSuccess || count <= 0) {
+    lsa_set_global_error("lsa_context_create: no HIP device available (%s); this library has no CPU path",
+                         e == hipSuccess ? "device count is 0" : hipGetErrorString(e));
+    return LSA_ERR_NO_DEVICE;
+  }
+  if (device < 0 || device >= count) {
+    lsa_set_global_error("lsa_context_create: device %d out of range (have %d)", device, count);
+    return LSA_ERR_NO_DEVICE;
+  }
+  e = hipSetDevice(device);
+  if (e != hipSuccess) { lsa_set_global_error("hipSetDevice(%d): %s", device, hipGetErrorString(e)); return LSA_ERR_NO_DEVICE; }
+  hipDeviceProp_t prop;
+  e = hipGetDeviceProperties(&prop, device);
+  if (e != hipSuccess) { lsa_set_global_error("hipGetDeviceProperties: %s", hipGetErrorString(e)); return LSA_ERR_HIP; }
+  if (strncmp(prop.gcnArchName, "gfx950", 6) != 0 && !getenv("LSA_ALLOW_ANY_ARCH")) {
+    lsa_set_global_error("lsa_context_create: device %d is %s; this library ships gfx950 (MI355X) code objects only", device, prop.gcnArchName);
+    return LSA_ERR_NO_DEVICE;
+  }
+  lsa_context *ctx = new lsa_context();
+  ctx->device = device;
+  ctx->num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+  if (hip_stream) {
+    ctx->stream = (hipStream_t)hip_stream;
+    ctx->own_stream = false;
+  } else {
+    e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
+    if (e != hipSuccess) { lsa_set_global_error("hipStreamCreate: %s", hipGetErrorString(e)); delete ctx; return LSA_ERR_HIP; }
+    ctx->own_stream = true;
+  }
+  if (hipEventCreate(&ctx->ev0) != hipSuccess || hipEventCreate(&ctx->ev1) != hipSuccess) {
+    lsa_set_global_error("hipEventCreate failed");
+    delete ctx;
+    return LSA_ERR_HIP;
+  }
+  *out = ctx;
+  return LSA_OK;
+}
+
+extern "C" void lsa_context_destroy(lsa_context *ctx) {
+  if (!ctx) return;
+  (void)hipSetDevice(ctx->device);
+  (void)hipStreamSynchronize(ctx->stream);
+  if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
+  if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
+  if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
+  delete ctx;
+}
+
+extern "C" void *lsa_context_stream(lsa_context *ctx) { return ctx ? (void *)ctx->stream : nullptr; }
+
+extern "C" int lsa_context_synchronize(lsa_context *ctx) {
+  if (!ctx) return LSA_ERR_INVALID;
+  LSA_HIP(ctx, hipSetDevice(ctx->device));
+  LSA_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return LSA_OK;
+}

@@ -1,0 +1,231 @@
+// ndt_api.hip — lsa_ndt_*: the RegistrationInterface replacement for NDT
+// (reference: lidar_localization/src/models/registration/ndt_registration_manual.cpp:12-78).
+#include "ndt_internal.h"
+#include "ndt_pass.h"
+
+#include <vector>
+
+int ndt_fitness(lsa_ndt *h, float *score);  // ndt_fitness.hip
+
+namespace {
+
+int upload_points(lsa_ndt *h, const void *pts, size_t n, size_t stride, size_t w_off, DevBuf<float4> &dst) {
+  lsa_context *ctx = h->ctx;
+  int rc;
+  if ((rc = h->h_stage.reserve(ctx, n * 4))) return rc;
+  if ((rc = dst.reserve(ctx, n, 1.25))) return rc;
+  // the staging buffer may still be feeding an earlier async copy
+  LSA_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  lsa_pack_xyzw(pts, n, stride, w_off, h->h_stage.p);
+  LSA_HIP(ctx, hipMemcpyAsync(dst.p, h->h_stage.p, n * sizeof(float4), hipMemcpyHostToDevice, ctx->stream));
+  return LSA_OK;
+}
+
+// one pass, synchronous: kernel(s) -> [all-reduce] -> D2H of 32 doubles
+int run_pass(lsa_ndt *h, const float T[16], const double p[6], int kind, double out32[32]) {
+  lsa_context *ctx = h->ctx;
+  PassParams P;
+  ndt_make_pass_params(h, T, p, &P);
+  int rc = ndt_enqueue_pass(h, P, kind);
+  if (rc) return rc;
+  if (h->allreduce) {
+    int crc = h->allreduce(h->allreduce_user, h->d_out.p, kOutDoubles, (void *)ctx->stream);
+    if (crc) return lsa_fail(ctx, LSA_ERR_COLLECTIVE, "all-reduce callback returned %d", crc);
+  }
+  if ((rc = h->h_out.reserve(ctx, kOutDoubles))) return rc;
+  LSA_HIP(ctx, hipMemcpyAsync(h->h_out.p, h->d_out.p, kOutDoubles * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+  LSA_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  memcpy(out32, h->h_out.p, kOutDoubles * sizeof(double));
+  return LSA_OK;
+}
+
+int eval_trampoline(void *user, const float T[16], const double p[6], int kind, double out32[32]) {
+  return run_pass((lsa_ndt *)user, T, p, kind, out32);
+}
+
+int check(lsa_ndt *h) {
+  if (!h) return LSA_ERR_INVALID;
+  hipError_t e = hipSetDevice(h->ctx->device);
+  if (e != hipSuccess) return lsa_fail(h->ctx, LSA_ERR_NO_DEVICE, "hipSetDevice(%d): %s", h->ctx->device, hipGetErrorString(e));
+  return LSA_OK;
+}
+
+int scan_match_common(lsa_ndt *h, const float predict_pose[16], float result_pose[16], lsa_ndt_stats *stats) {
+  lsa_context *ctx = h->ctx;
+  if (!h->has_target) return lsa_fail(ctx, LSA_ERR_NO_TARGET, "ScanMatch before SetInputTarget");
+  lsa_ndt_gauss_constants(h->resolution, h->outlier_ratio, &h->d1, &h->d2);
+  lsa_ndt_stats st;
+  memset(&st, 0, sizeof(st));
+  int rc = lsa_gn_solve(eval_trampoline, h, h->resolution, h->step_size, h->trans_eps, h->max_iter, h->outlier_ratio, predict_pose, result_pose, &st);
+  if (rc) return rc;
+  memcpy(h->last_T, result_pose, sizeof(h->last_T));
+  h->has_result = true;
+  if (stats) *stats = st;
+  return LSA_OK;
+}
+
+}  // namespace
+
+extern "C" int lsa_ndt_create(lsa_ndt **out, lsa_context *ctx, float res, float step_size, float trans_eps, int max_iter, float outlier_ratio) {
+  if (!out || !ctx) { lsa_set_global_error("lsa_ndt_create: null argument"); return LSA_ERR_INVALID; }
+  if (!(res > 0)) return lsa_fail(ctx, LSA_ERR_INVALID, "lsa_ndt_create: res must be > 0");
+  lsa_ndt *h = new lsa_ndt();
+  h->ctx = ctx;
+  h->resolution = res; h->step_size = step_size; h->trans_eps = trans_eps; h->max_iter = max_iter; h->outlier_ratio = outlier_ratio;
+  lsa_ndt_gauss_constants(res, outlier_ratio, &h->d1, &h->d2);
+  *out = h;
+  return LSA_OK;
+}
+
+extern "C" void lsa_ndt_destroy(lsa_ndt *h) {
+  if (!h) return;
+  (void)hipSetDevice(h->ctx->device);
+  (void)hipStreamSynchronize(h->ctx->stream);
+  h->vi.release(); h->d_target.release(); h->rec.release(); h->state.release(); h->vbits.release(); h->words.release(); h->d_small.release();
+  h->d_source_own.release(); h->h_stage.release(); h->partials.release(); h->d_out.release(); h->h_out.release();
+  delete h;
+}
+
+extern "C" int lsa_ndt_set_input_target_device(lsa_ndt *h, const float *d_xyzw, size_t n) {
+  int rc = check(h);
+  if (rc) return rc;
+  if (n == 0) return LSA_OK;  // setInputTarget ignores an empty cloud (NormalDistributionsTransform.cpp:94)
+  if (!d_xyzw) return lsa_fail(h->ctx, LSA_ERR_INVALID, "set_input_target: null points");
+  return ndt_build_grid(h, (const float4 *)d_xyzw, n);
+}
+
+extern "C" int lsa_ndt_set_input_target(lsa_ndt *h, const void *pts, size_t n, size_t stride, size_t w_off) {
+  int rc = check(h);
+  if (rc) return rc;
+  if (n == 0) return LSA_OK;
+  if (!pts || stride < 12) return lsa_fail(h->ctx, LSA_ERR_INVALID, "set_input_target: bad points / stride");
+  if ((rc = upload_points(h, pts, n, stride, w_off, h->d_target))) return rc;
+  return ndt_build_grid(h, h->d_target.p, n);
+}
+
+extern "C" int lsa_ndt_set_source_device(lsa_ndt *h, const float *d_xyzw, size_t n) {
+  int rc = check(h);
+  if (rc) return rc;
+  if (n && !d_xyzw) return lsa_fail(h->ctx, LSA_ERR_INVALID, "set_source: null points");
+  h->d_source = (const float4 *)d_xyzw;
+  h->n_source = n;
+  return LSA_OK;
+}
+
+extern "C" int lsa_ndt_set_source(lsa_ndt *h, const void *src, size_t n, size_t stride) {
+  int rc = check(h);
+  if (rc) return rc;
+  if (n && (!src || stride < 12)) return lsa_fail(h->ctx, LSA_ERR_INVALID, "set_source: bad points / stride");
+  if (n) {
+    if ((rc = upload_points(h, src, n, stride, SIZE_MAX, h->d_source_own))) return rc;
+  }
+  h->d_source = h->d_source_own.p;
+  h->n_source = n;
+  return LSA_OK;
+}
+
+extern "C" int lsa_ndt_derivatives(lsa_ndt *h, const float T[16], const double p[6], int kind, double out32[32]) {
+  int rc = check(h);
+  if (rc) return rc;
+  if (!T || !p || !out32 || kind < 0 || kind > 2) return lsa_fail(h->ctx, LSA_ERR_INVALID, "lsa_ndt_derivatives: bad argument");
+  if (!h->has_target) return lsa_fail(h->ctx, LSA_ERR_NO_TARGET, "derivatives before SetInputTarget");
+  lsa_ndt_gauss_constants(h->resolution, h->outlier_ratio, &h->d1, &h->d2);
+  return run_pass(h, T, p, kind, out32);
+}
+
+extern "C" int lsa_ndt_derivatives_timed(lsa_ndt *h, const float T[16], const double p[6], int kind, int repeat, double out32[32], double *ms_per_pass) {
+  int rc = check(h);
+  if (rc) return rc;
+  lsa_context *ctx = h->ctx;
+  if (!T || !p || !out32 || !ms_per_pass || kind < 0 || kind > 2 || repeat < 1) return lsa_fail(ctx, LSA_ERR_INVALID, "lsa_ndt_derivatives_timed: bad argument");
+  if (!h->has_target) return lsa_fail(ctx, LSA_ERR_NO_TARGET, "derivatives before SetInputTarget");
+  lsa_ndt_gauss_constants(h->resolution, h->outlier_ratio, &h->d1, &h->d2);
+  PassParams P;
+  ndt_make_pass_params(h, T, p, &P);
+  if ((rc = ndt_enqueue_pass(h, P, kind))) return rc;  // warm-up + buffer sizing
+  LSA_HIP(ctx, hipEventRecord(ctx->ev0, ctx->stream));
+  for (int i = 0; i < repeat; i++)
+    if ((rc = ndt_enqueue_pass(h, P, kind))) return rc;
+  LSA_HIP(ctx, hipEventRecord(ctx->ev1, ctx->stream));
+  if ((rc = h->h_out.reserve(ctx, kOutDoubles))) return rc;
+  LSA_HIP(ctx, hipMemcpyAsync(h->h_out.p, h->d_out.p, kOutDoubles * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+  LSA_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  float ms = 0;
+  LSA_HIP(ctx, hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1));
+  *ms_per_pass = (double)ms / repeat;
+  memcpy(out32, h->h_out.p, kOutDoubles * sizeof(double));
+  return LSA_OK;
+}
+
+extern "C" int lsa_ndt_scan_match_device(lsa_ndt *h, const float *d_src_xyzw, size_t n, const float predict_pose[16], float result_pose[16],
+                                         lsa_ndt_stats *stats) {
+  int rc = lsa_ndt_set_source_device(h, d_src_xyzw, n);
+  if (rc) return rc;
+  if (!predict_pose || !result_pose) return lsa_fail(h->ctx, LSA_ERR_INVALID, "ScanMatch: null pose");
+  return scan_match_common(h, predict_pose, result_pose, stats);
+}
+
+extern "C" int lsa_ndt_scan_match(lsa_ndt *h, const void *src, size_t n, size_t stride, const float predict_pose[16], float result_pose[16],
+                                  lsa_ndt_stats *stats) {
+  int rc = lsa_ndt_set_source(h, src, n, stride);
+  if (rc) return rc;
+  if (!predict_pose || !result_pose) return lsa_fail(h->ctx, LSA_ERR_INVALID, "ScanMatch: null pose");
+  return scan_match_common(h, predict_pose, result_pose, stats);
+}
+
+extern "C" int lsa_ndt_get_fitness_score(lsa_ndt *h, float *score) {
+  int rc = check(h);
+  if (rc) return rc;
+  if (!score) return lsa_fail(h->ctx, LSA_ERR_INVALID, "GetFitnessScore: null output");
+  if (!h->has_target || !h->has_result) return lsa_fail(h->ctx, LSA_ERR_NO_TARGET, "GetFitnessScore before SetInputTarget + ScanMatch");
+  return ndt_fitness(h, score);
+}
+
+extern "C" int lsa_ndt_set_allreduce(lsa_ndt *h, lsa_allreduce_fn fn, void *user) {
+  if (!h) return LSA_ERR_INVALID;
+  h->allreduce = fn;
+  h->allreduce_user = user;
+  return LSA_OK;
+}
+
+extern "C" int lsa_ndt_grid_info(lsa_ndt *h, int64_t info[9]) {
+  int rc = check(h);
+  if (rc) return rc;
+  if (!info) return lsa_fail(h->ctx, LSA_ERR_INVALID, "grid_info: null output");
+  if (!h->has_target) return lsa_fail(h->ctx, LSA_ERR_NO_TARGET, "grid_info before SetInputTarget");
+  for (int a = 0; a < 3; a++) { info[a] = h->vi.map.dim[a]; info[3 + a] = h->vi.map.min_b[a]; }
+  info[6] = (int64_t)h->vi.nocc;
+  info[7] = (int64_t)h->n_valid;
+  info[8] = (int64_t)h->n_target;
+  return LSA_OK;
+}
+
+extern "C" int lsa_ndt_grid_dump(lsa_ndt *h, int32_t *cell_ints, double *cell_rec, size_t cap, size_t *n_cells) {
+  int rc = check(h);
+  if (rc) return rc;
+  lsa_context *ctx = h->ctx;
+  if (!n_cells) return lsa_fail(ctx, LSA_ERR_INVALID, "grid_dump: null output");
+  if (!h->has_target) return lsa_fail(ctx, LSA_ERR_NO_TARGET, "grid_dump before SetInputTarget");
+  size_t V = h->vi.nocc;
+  *n_cells = V;
+  if (!cell_ints && !cell_rec) return LSA_OK;
+  if (cap < V) return lsa_fail(ctx, LSA_ERR_CAPACITY, "grid_dump: cap %zu < %zu cells", cap, V);
+  std::vector<int32_t> cor(V), cnt(V), st(V);
+  LSA_HIP(ctx, hipMemcpyAsync(cor.data(), h->vi.cell_of_rank.p, V * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
+  LSA_HIP(ctx, hipMemcpyAsync(cnt.data(), h->vi.cnt.p, V * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
+  LSA_HIP(ctx, hipMemcpyAsync(st.data(), h->state.p, V * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
+  if (cell_rec) LSA_HIP(ctx, hipMemcpyAsync(cell_rec, h->rec.p, V * kRecDoubles * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+  LSA_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  if (cell_ints) {
+    const CellMap &m = h->vi.map;
+    for (size_t r = 0; r < V; r++) {
+      int cell = cor[r];
+      int k = cell / (m.dim[0] * m.dim[1]);
+      int rem = cell - k * (m.dim[0] * m.dim[1]);
+      int j = rem / m.dim[0], i = rem - j * m.dim[0];
+      cell_ints[5 * r] = i + m.min_b[0]; cell_ints[5 * r + 1] = j + m.min_b[1]; cell_ints[5 * r + 2] = k + m.min_b[2];
+      cell_ints[5 * r + 3] = cnt[r]; cell_ints[5 * r + 4] = st[r];
+    }
+  }
+  return LSA_OK;
+}

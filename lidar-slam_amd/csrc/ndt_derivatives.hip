@@ -1,0 +1,229 @@
+// ndt_derivatives.hip — the hot loop: one NDT derivative pass over the source cloud.
+//
+// Replaces NormalDistributionsTransform::computeDerivatives / computeHessian and what they call per point
+// (reference: lidar_localization/src/models/registration/ndt_registration_manual/NormalDistributionsTransform.cpp
+//  :391-445 computeDerivatives, :448-482 computePointDerivatives, :485-520 updateDerivatives, :875-899 updateHessian,
+//  :901-936 computeHessian; VoxelGrid.cpp:432-480 radiusSearch; pcl::transformPointCloud, f32).
+//
+// One lane per source point: f32 rigid transform (bit-identical to PCL's, no FMA contraction), probe of the <= 3x3x3
+// cell neighbourhood through the {occupancy, valid, prefix} words, gather of the 80-byte voxel record, f64 pair math
+// exploiting the symmetry of C^-1 (21 unique Hessian entries + 6 gradient + score = 28 values), wave shuffle
+// reduction -> LDS -> one 32-double partial per workgroup, then a fixed-order second-stage reduction (no atomics:
+// bitwise reproducible run to run).  No MFMA: the largest contraction is 6x6.
+//
+// Algorithmic bytes per pass (SURVEY.md 8d formula C, with this implementation's record size):
+//   16*M (points) + 27*16*M (cell words, worst case) + 80*Kbar*M (records); the word table and the records are
+//   L2 / Infinity-Cache resident at every BASELINE.json size, so the pass is latency / f64-issue bound, not HBM bound.
+#include "ndt_internal.h"
+#include "ndt_pass.h"
+
+namespace {
+
+constexpr int kBlockD = 128;
+
+template <int KIND>
+__device__ __forceinline__ void pair_update(const PassParams &P, const double *__restrict__ R, float tx, float ty, float tz,
+                                            const double pg[8], const double ph[15], double acc[28], unsigned &pairs) {
+  // R: centroid(3), C = icov (xx,xy,xz,yy,yz,zz), w
+  double cx = R[0] - (double)tx, cy = R[1] - (double)ty, cz = R[2] - (double)tz;
+  double dist = sqrt(cx * cx + cy * cy + cz * cz);
+  if (!(dist < (double)P.res)) return;  // VoxelGrid.cpp:470-472
+  pairs++;
+  double d0 = -cx, d1 = -cy, d2 = -cz;  // x_trans - centroid (:434)
+  double C00 = R[3], C01 = R[4], C02 = R[5], C11 = R[6], C12 = R[7], C22 = R[8];
+  double u0 = C00 * d0 + C01 * d1 + C02 * d2;
+  double u1 = C01 * d0 + C11 * d1 + C12 * d2;
+  double u2 = C02 * d0 + C12 * d1 + C22 * d2;
+  double q = d0 * u0 + d1 * u1 + d2 * u2;
+  double e = exp(-P.d2 * q / 2);  // :494
+  double f = P.d2 * e;
+  if (f > 1 || f < 0 || f != f) return;  // :499-501 / :884-886
+  if (KIND != 2) acc[0] += R[9] * (-P.d1 * e);  // static weight multiplies the score only (:440-441)
+  f *= P.d1;
+  // J columns 3..5: J3 = (0, pg0, pg1), J4 = (pg2, pg3, pg4), J5 = (pg5, pg6, pg7)   (:453-460)
+  double uJ3 = u1 * pg[0] + u2 * pg[1];
+  double uJ4 = u0 * pg[2] + u1 * pg[3] + u2 * pg[4];
+  double uJ5 = u0 * pg[5] + u1 * pg[6] + u2 * pg[7];
+  if (KIND != 2) {
+    acc[1] += f * u0; acc[2] += f * u1; acc[3] += f * u2;
+    acc[4] += f * uJ3; acc[5] += f * uJ4; acc[6] += f * uJ5;
+  }
+  if (KIND != 1) {
+    double nd2 = -P.d2;
+    // C * J_j for j = 3..5
+    double a3x = C01 * pg[0] + C02 * pg[1], a3y = C11 * pg[0] + C12 * pg[1], a3z = C12 * pg[0] + C22 * pg[1];
+    double a4x = C00 * pg[2] + C01 * pg[3] + C02 * pg[4], a4y = C01 * pg[2] + C11 * pg[3] + C12 * pg[4], a4z = C02 * pg[2] + C12 * pg[3] + C22 * pg[4];
+    double a5x = C00 * pg[5] + C01 * pg[6] + C02 * pg[7], a5y = C01 * pg[5] + C11 * pg[6] + C12 * pg[7], a5z = C02 * pg[5] + C12 * pg[6] + C22 * pg[7];
+    // rows 0..2 (translation)
+    acc[7] += f * (nd2 * u0 * u0 + C00);
+    acc[8] += f * (nd2 * u0 * u1 + C01);
+    acc[9] += f * (nd2 * u0 * u2 + C02);
+    acc[10] += f * (nd2 * u0 * uJ3 + a3x);
+    acc[11] += f * (nd2 * u0 * uJ4 + a4x);
+    acc[12] += f * (nd2 * u0 * uJ5 + a5x);
+    acc[13] += f * (nd2 * u1 * u1 + C11);
+    acc[14] += f * (nd2 * u1 * u2 + C12);
+    acc[15] += f * (nd2 * u1 * uJ3 + a3y);
+    acc[16] += f * (nd2 * u1 * uJ4 + a4y);
+    acc[17] += f * (nd2 * u1 * uJ5 + a5y);
+    acc[18] += f * (nd2 * u2 * u2 + C22);
+    acc[19] += f * (nd2 * u2 * uJ3 + a3z);
+    acc[20] += f * (nd2 * u2 * uJ4 + a4z);
+    acc[21] += f * (nd2 * u2 * uJ5 + a5z);
+    // rows 3..5 (rotation): u . H_E block + J_j . (C J_i)   (:465-480, :512-514)
+    // blocks: (3,3)=a=(0,ph0,ph1) (3,4)=b=(0,ph2,ph3) (3,5)=c=(0,ph4,ph5) (4,4)=d=(ph6..8) (4,5)=e=(ph9..11) (5,5)=f=(ph12..14)
+    acc[22] += f * (nd2 * uJ3 * uJ3 + (u1 * ph[0] + u2 * ph[1]) + (pg[0] * a3y + pg[1] * a3z));
+    acc[23] += f * (nd2 * uJ3 * uJ4 + (u1 * ph[2] + u2 * ph[3]) + (pg[2] * a3x + pg[3] * a3y + pg[4] * a3z));
+    acc[24] += f * (nd2 * uJ3 * uJ5 + (u1 * ph[4] + u2 * ph[5]) + (pg[5] * a3x + pg[6] * a3y + pg[7] * a3z));
+    acc[25] += f * (nd2 * uJ4 * uJ4 + (u0 * ph[6] + u1 * ph[7] + u2 * ph[8]) + (pg[2] * a4x + pg[3] * a4y + pg[4] * a4z));
+    acc[26] += f * (nd2 * uJ4 * uJ5 + (u0 * ph[9] + u1 * ph[10] + u2 * ph[11]) + (pg[5] * a4x + pg[6] * a4y + pg[7] * a4z));
+    acc[27] += f * (nd2 * uJ5 * uJ5 + (u0 * ph[12] + u1 * ph[13] + u2 * ph[14]) + (pg[5] * a5x + pg[6] * a5y + pg[7] * a5z));
+  }
+}
+
+template <int KIND>
+__global__ __launch_bounds__(kBlockD) void k_ndt_pass(const float4 *__restrict__ src, size_t n, PassParams P, const uint4 *__restrict__ words,
+                                                      const double *__restrict__ rec, double *__restrict__ partials) {
+  double acc[28];
+#pragma unroll
+  for (int k = 0; k < 28; k++) acc[k] = 0.0;
+  unsigned pairs = 0, npts = 0;
+  const int dimx = P.dim[0], dimxy = P.dim[0] * P.dim[1];
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    float4 s = src[i];
+    npts++;
+    // pcl::transformPointCloud: x' = m00*x + m01*y + m02*z + m03, f32, left to right, no FMA
+    float tx = __fadd_rn(__fadd_rn(__fadd_rn(__fmul_rn(P.T[0], s.x), __fmul_rn(P.T[1], s.y)), __fmul_rn(P.T[2], s.z)), P.T[3]);
+    float ty = __fadd_rn(__fadd_rn(__fadd_rn(__fmul_rn(P.T[4], s.x), __fmul_rn(P.T[5], s.y)), __fmul_rn(P.T[6], s.z)), P.T[7]);
+    float tz = __fadd_rn(__fadd_rn(__fadd_rn(__fmul_rn(P.T[8], s.x), __fmul_rn(P.T[9], s.y)), __fmul_rn(P.T[10], s.z)), P.T[11]);
+    if (!lsa_finite3(tx, ty, tz)) continue;
+    // radiusSearch cell box (VoxelGrid.cpp:438-455), relative to real_min
+    float r = P.res;
+    int hx = (int)floorf(__fdiv_rn(__fadd_rn(tx, r), r)) - P.min_b[0], lx = (int)floorf(__fdiv_rn(__fsub_rn(tx, r), r)) - P.min_b[0];
+    int hy = (int)floorf(__fdiv_rn(__fadd_rn(ty, r), r)) - P.min_b[1], ly = (int)floorf(__fdiv_rn(__fsub_rn(ty, r), r)) - P.min_b[1];
+    int hz = (int)floorf(__fdiv_rn(__fadd_rn(tz, r), r)) - P.min_b[2], lz = (int)floorf(__fdiv_rn(__fsub_rn(tz, r), r)) - P.min_b[2];
+    hx = min(hx, P.dim[0] - 1); hy = min(hy, P.dim[1] - 1); hz = min(hz, P.dim[2] - 1);
+    lx = max(lx, 0); ly = max(ly, 0); lz = max(lz, 0);
+    if (lx > hx || ly > hy || lz > hz) continue;
+    // point derivative terms depend on the point only (the reference recomputes them per pair)
+    double x = s.x, y = s.y, z = s.z;
+    double pg[8], ph[15];
+#pragma unroll
+    for (int k = 0; k < 8; k++) pg[k] = x * P.ja[k][0] + y * P.ja[k][1] + z * P.ja[k][2];
+    if (KIND != 1) {
+#pragma unroll
+      for (int k = 0; k < 15; k++) ph[k] = x * P.ha[k][0] + y * P.ha[k][1] + z * P.ha[k][2];
+    }
+    for (int iz = lz; iz <= hz; iz++)
+      for (int iy = ly; iy <= hy; iy++) {
+        int base = iy * dimx + iz * dimxy;
+        for (int ix = lx; ix <= hx; ix++) {
+          int cell = base + ix;
+          uint4 w = words[cell >> 5];
+          uint32_t bit = 1u << (cell & 31);
+          if (!(w.y & bit)) continue;  // points_per_voxel >= min_points_per_voxel_ and accepted (:465)
+          unsigned rank = w.z + __popc(w.x & (bit - 1u));
+          pair_update<KIND>(P, rec + (size_t)rank * kRecDoubles, tx, ty, tz, pg, ph, acc, pairs);
+        }
+      }
+  }
+  // wave reduction (fixed tree), then across the block's waves through LDS
+  __shared__ double sm[kBlockD / 64][kOutDoubles];
+  int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int k = 0; k < 28; k++) {
+    double v = lsa_wave_sum(acc[k]);
+    if (lane == 0) sm[wave][k] = v;
+  }
+  {
+    double vp = lsa_wave_sum((double)pairs), vn = lsa_wave_sum((double)npts);
+    if (lane == 0) { sm[wave][28] = vp; sm[wave][29] = vn; sm[wave][30] = 0.0; sm[wave][31] = 0.0; }
+  }
+  __syncthreads();
+  if (threadIdx.x < kOutDoubles) {
+    double v = 0.0;
+#pragma unroll
+    for (int w = 0; w < kBlockD / 64; w++) v += sm[w][threadIdx.x];
+    partials[(size_t)blockIdx.x * kOutDoubles + threadIdx.x] = v;
+  }
+}
+
+// second stage: out[c] = sum_b partials[b][c], fixed order -> deterministic. 1024 threads = 32 columns x 32 row lanes.
+__global__ __launch_bounds__(1024) void k_reduce_partials(const double *__restrict__ partials, int nb, double *__restrict__ out) {
+  int col = threadIdx.x & 31, rl = threadIdx.x >> 5;
+  double v = 0.0;
+  for (int b = rl; b < nb; b += 32) v += partials[(size_t)b * kOutDoubles + col];
+  __shared__ double sm[32][33];
+  sm[rl][col] = v;
+  __syncthreads();
+  for (int st = 16; st > 0; st >>= 1) {
+    if (rl < st) sm[rl][col] += sm[rl + st][col];
+    __syncthreads();
+  }
+  if (rl == 0) out[col] = sm[0][col];
+}
+
+}  // namespace
+
+void ndt_make_pass_params(const lsa_ndt *h, const float T[16], const double p[6], PassParams *P) {
+  for (int r = 0; r < 3; r++)
+    for (int c = 0; c < 4; c++) P->T[r * 4 + c] = T[c * 4 + r];
+  // computeAngleDerivatives (:523-645), including the |angle| < 10e-5 snap
+  double cx, cy, cz, sx, sy, sz;
+  if (std::fabs(p[3]) < 10e-5) { cx = 1.0; sx = 0.0; } else { cx = std::cos(p[3]); sx = std::sin(p[3]); }
+  if (std::fabs(p[4]) < 10e-5) { cy = 1.0; sy = 0.0; } else { cy = std::cos(p[4]); sy = std::sin(p[4]); }
+  if (std::fabs(p[5]) < 10e-5) { cz = 1.0; sz = 0.0; } else { cz = std::cos(p[5]); sz = std::sin(p[5]); }
+  double (*j)[3] = P->ja;
+  j[0][0] = -sx * sz + cx * sy * cz; j[0][1] = -sx * cz - cx * sy * sz; j[0][2] = -cx * cy;
+  j[1][0] = cx * sz + sx * sy * cz;  j[1][1] = cx * cz - sx * sy * sz;  j[1][2] = -sx * cy;
+  j[2][0] = -sy * cz;                j[2][1] = sy * sz;                 j[2][2] = cy;
+  j[3][0] = sx * cy * cz;            j[3][1] = -sx * cy * sz;           j[3][2] = sx * sy;
+  j[4][0] = -cx * cy * cz;           j[4][1] = cx * cy * sz;            j[4][2] = -cx * sy;
+  j[5][0] = -cy * sz;                j[5][1] = -cy * cz;                j[5][2] = 0;
+  j[6][0] = cx * cz - sx * sy * sz;  j[6][1] = -cx * sz - sx * sy * cz; j[6][2] = 0;
+  j[7][0] = sx * cz + cx * sy * sz;  j[7][1] = cx * sy * cz - sx * sz;  j[7][2] = 0;
+  double (*q)[3] = P->ha;
+  q[0][0] = -cx * sz - sx * sy * cz;  q[0][1] = -cx * cz + sx * sy * sz;  q[0][2] = sx * cy;
+  q[1][0] = -sx * sz + cx * sy * cz;  q[1][1] = -cx * sy * sz - sx * cz;  q[1][2] = -cx * cy;
+  q[2][0] = cx * cy * cz;             q[2][1] = -cx * cy * sz;            q[2][2] = cx * sy;
+  q[3][0] = sx * cy * cz;             q[3][1] = -sx * cy * sz;            q[3][2] = sx * sy;
+  q[4][0] = -sx * cz - cx * sy * sz;  q[4][1] = sx * sz - cx * sy * cz;   q[4][2] = 0;
+  q[5][0] = cx * cz - sx * sy * sz;   q[5][1] = -sx * sy * cz - cx * sz;  q[5][2] = 0;
+  q[6][0] = -cy * cz;                 q[6][1] = cy * sz;                  q[6][2] = sy;
+  q[7][0] = -sx * sy * cz;            q[7][1] = sx * sy * sz;             q[7][2] = sx * cy;
+  q[8][0] = cx * sy * cz;             q[8][1] = -cx * sy * sz;            q[8][2] = -cx * cy;
+  q[9][0] = sy * sz;                  q[9][1] = sy * cz;                  q[9][2] = 0;
+  q[10][0] = -sx * cy * sz;           q[10][1] = -sx * cy * cz;           q[10][2] = 0;
+  q[11][0] = cx * cy * sz;            q[11][1] = cx * cy * cz;            q[11][2] = 0;
+  q[12][0] = -cy * cz;                q[12][1] = cy * sz;                 q[12][2] = 0;
+  q[13][0] = -cx * sz - sx * sy * cz; q[13][1] = -cx * cz + sx * sy * sz; q[13][2] = 0;
+  q[14][0] = -sx * sz + cx * sy * cz; q[14][1] = -cx * sy * sz - sx * cz; q[14][2] = 0;
+  P->d1 = h->d1; P->d2 = h->d2;
+  P->res = h->resolution;
+  for (int a = 0; a < 3; a++) { P->min_b[a] = h->vi.map.min_b[a]; P->dim[a] = h->vi.map.dim[a]; }
+}
+
+unsigned ndt_pass_grid(const lsa_ndt *h, size_t n) {
+  size_t blocks = (n + kBlockD - 1) / kBlockD;
+  size_t cap = (size_t)h->ctx->num_cus * 8;
+  if (blocks > cap) blocks = cap;
+  if (blocks < 1) blocks = 1;
+  return (unsigned)blocks;
+}
+
+// enqueue one pass: partial kernel + second-stage reduction into h->d_out (device). No sync.
+int ndt_enqueue_pass(lsa_ndt *h, const PassParams &P, int kind) {
+  lsa_context *ctx = h->ctx;
+  unsigned g = ndt_pass_grid(h, h->n_source);
+  int rc;
+  if ((rc = h->partials.reserve(ctx, (size_t)g * kOutDoubles, 1.0))) return rc;
+  if ((rc = h->d_out.reserve(ctx, kOutDoubles))) return rc;
+  const uint4 *words = h->words.p;
+  const double *rec = h->rec.p;
+  if (kind == 0) hipLaunchKernelGGL(k_ndt_pass<0>, dim3(g), dim3(kBlockD), 0, ctx->stream, h->d_source, h->n_source, P, words, rec, h->partials.p);
+  else if (kind == 1) hipLaunchKernelGGL(k_ndt_pass<1>, dim3(g), dim3(kBlockD), 0, ctx->stream, h->d_source, h->n_source, P, words, rec, h->partials.p);
+  else hipLaunchKernelGGL(k_ndt_pass<2>, dim3(g), dim3(kBlockD), 0, ctx->stream, h->d_source, h->n_source, P, words, rec, h->partials.p);
+  hipLaunchKernelGGL(k_reduce_partials, dim3(1), dim3(1024), 0, ctx->stream, h->partials.p, (int)g, h->d_out.p);
+  LSA_HIP(ctx, hipGetLastError());
+  return LSA_OK;
+}

@@ -1,0 +1,53 @@
+// ndt_internal.h — internal state of an lsa_ndt handle.
+#ifndef LSA_NDT_INTERNAL_H_
+#define LSA_NDT_INTERNAL_H_
+
+#include "voxel_index_dev.h"
+
+// per occupied cell: centroid(3), inverse covariance symmetric (xx,xy,xz,yy,yz,zz), mean static weight
+constexpr int kRecDoubles = 10;
+// per-pass result: [score, g(6), H upper triangle (21), #pairs, #points, 0, 0]
+constexpr int kOutDoubles = 32;
+
+struct lsa_ndt {
+  lsa_context *ctx = nullptr;
+  float resolution = 1.0f;
+  float step_size = 0.1f, trans_eps = 0.01f, outlier_ratio = 0.55f;
+  int max_iter = 30;
+  double d1 = 0, d2 = 0;
+
+  // target
+  VoxelIndex vi;
+  DevBuf<float4> d_target;      // only when set from host
+  DevBuf<double> rec;           // [nocc][kRecDoubles]
+  DevBuf<int32_t> state;        // [nocc] 0 / 1 / -1
+  DevBuf<uint32_t> vbits;       // valid bitmap
+  DevBuf<uint4> words;          // {occ bits, valid bits, prefix, 0} per 32 cells
+  DevBuf<double> d_small;
+  bool has_target = false;
+  size_t n_target = 0, n_valid = 0;
+
+  // source
+  DevBuf<float4> d_source_own;
+  const float4 *d_source = nullptr;
+  size_t n_source = 0;
+  PinnedBuf<float> h_stage;
+
+  // per-pass buffers
+  DevBuf<double> partials;      // [grid][kOutDoubles]
+  DevBuf<double> d_out;         // kOutDoubles
+  PinnedBuf<double> h_out;
+
+  // multi-GPU
+  lsa_allreduce_fn allreduce = nullptr;
+  void *allreduce_user = nullptr;
+
+  // last result (for GetFitnessScore)
+  float last_T[16];
+  bool has_result = false;
+  double pass_ms = 0;
+};
+
+int ndt_build_grid(lsa_ndt *h, const float4 *d_pts, size_t n);
+
+#endif

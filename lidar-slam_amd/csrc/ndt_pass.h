@@ -1,0 +1,21 @@
+// ndt_pass.h — internal: kernel argument block of one derivative pass.
+#ifndef LSA_NDT_PASS_H_
+#define LSA_NDT_PASS_H_
+
+struct lsa_ndt;
+
+struct PassParams {
+  float T[12];       // rigid transform, row-major 3x4, f32 as the reference builds it
+  double ja[8][3];   // j_ang_a .. j_ang_h   (NormalDistributionsTransform.cpp:551-581)
+  double ha[15][3];  // h_ang_a2,a3,b2,b3,c2,c3,d1,d2,d3,e1,e2,e3,f1,f2,f3 (:584-642)
+  double d1, d2;     // gauss_d1_, gauss_d2_
+  float res;         // resolution_ = search radius = leaf
+  int min_b[3];      // real_min_b*
+  int dim[3];        // real_max_b* - real_min_b* + 1
+};
+
+void ndt_make_pass_params(const lsa_ndt *h, const float T[16], const double p[6], PassParams *P);
+unsigned ndt_pass_grid(const lsa_ndt *h, size_t n);
+int ndt_enqueue_pass(lsa_ndt *h, const PassParams &P, int kind);
+
+#endif

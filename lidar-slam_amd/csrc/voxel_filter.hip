@@ -1,0 +1,137 @@
+// voxel_filter.hip — lsa_voxel_filter_*: the CloudFilterInterface::Filter replacement
+// (reference: lidar_localization/src/models/cloud_filter/voxel_filter.cpp:36-41 -> pcl::VoxelGrid::filter).
+//
+// Pipeline on the device (no sort: ranks of the occupancy bitmap are already in PCL's output order):
+//   bbox reduce -> [host: PCL min_b/div_b rules] -> mark bitmap -> popcount scan -> fixed-point accumulate
+//   -> finalize (mean of x,y,z,intensity per voxel).
+// Algorithmic HBM bytes (SURVEY.md 8d formula A): 16*N read + 16*V written; this implementation re-reads
+// the points once per streaming pass (bbox, mark, accumulate: 3 x 16*N + 2 x 4*N cell ids).
+#include "voxel_index_dev.h"
+
+struct lsa_voxel_filter {
+  lsa_context *ctx = nullptr;
+  float leaf[3] = {0, 0, 0};
+  VoxelIndex vi;
+  DevBuf<float4> d_in, d_out;
+  PinnedBuf<float> h_stage;
+};
+
+namespace {
+constexpr int kBlock = 256;
+
+__global__ __launch_bounds__(kBlock) void k_filter_finalize(const long long *__restrict__ acc, const int32_t *__restrict__ cnt,
+                                                            const int32_t *__restrict__ cell_of_rank, size_t nocc, CellMap m, FixScales fs,
+                                                            float4 *__restrict__ out) {
+  size_t r = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= nocc) return;
+  const long long *a = acc + r * 4;
+  double n = (double)cnt[r];
+  double o[3];
+  lsa_cell_origin(m, cell_of_rank[r], o);
+  float4 v;
+  v.x = (float)(o[0] + ((double)a[0] * fs.inv_s1) / n);
+  v.y = (float)(o[1] + ((double)a[1] * fs.inv_s1) / n);
+  v.z = (float)(o[2] + ((double)a[2] * fs.inv_s1) / n);
+  v.w = (float)(((double)a[3] * fs.inv_sw) / n);
+  out[r] = v;
+}
+
+int filter_device(lsa_voxel_filter *f, const float4 *d_in, size_t n, float4 *d_out, size_t *n_out) {
+  lsa_context *ctx = f->ctx;
+  *n_out = 0;
+  if (n == 0) return LSA_OK;
+  float mn[3], mx[3];
+  size_t nfin = 0;
+  int rc = vi_bbox(ctx, f->vi, d_in, n, mn, mx, &nfin);
+  if (rc) return rc;
+  if (nfin == 0) return LSA_OK;
+  rc = vi_make_map_pcl(mn, mx, f->leaf, &f->vi.map);
+  if (rc == LSA_ERR_RANGE) return lsa_fail(ctx, LSA_ERR_RANGE, "voxel filter: leaf size too small for the input dataset, integer indices would overflow");
+  vi_make_scales(f->vi.map, nfin, &f->vi.fs);
+  if ((rc = vi_build(ctx, f->vi, d_in, n))) return rc;
+  if ((rc = vi_accumulate(ctx, f->vi, d_in, n, 4))) return rc;
+  size_t V = f->vi.nocc;
+  if (V) {
+    hipLaunchKernelGGL(k_filter_finalize, dim3(lsa_div_up(V, kBlock)), dim3(kBlock), 0, ctx->stream, f->vi.acc.p, f->vi.cnt.p,
+                       f->vi.cell_of_rank.p, V, f->vi.map, f->vi.fs, d_out);
+    LSA_HIP(ctx, hipGetLastError());
+  }
+  *n_out = V;
+  return LSA_OK;
+}
+}  // namespace
+
+extern "C" int lsa_voxel_filter_create(lsa_voxel_filter **out, lsa_context *ctx, float lx, float ly, float lz) {
+  if (!out || !ctx) { lsa_set_global_error("lsa_voxel_filter_create: null argument"); return LSA_ERR_INVALID; }
+  if (!(lx > 0) || !(ly > 0) || !(lz > 0)) return lsa_fail(ctx, LSA_ERR_INVALID, "lsa_voxel_filter_create: leaf sizes must be > 0");
+  lsa_voxel_filter *f = new lsa_voxel_filter();
+  f->ctx = ctx;
+  f->leaf[0] = lx; f->leaf[1] = ly; f->leaf[2] = lz;
+  *out = f;
+  return LSA_OK;
+}
+
+extern "C" void lsa_voxel_filter_destroy(lsa_voxel_filter *f) {
+  if (!f) return;
+  (void)hipSetDevice(f->ctx->device);
+  f->vi.release(); f->d_in.release(); f->d_out.release(); f->h_stage.release();
+  delete f;
+}
+
+extern "C" int lsa_voxel_filter_apply_device(lsa_voxel_filter *f, const float *d_in_xyzw, size_t n, float *d_out_xyzw, size_t *n_out) {
+  if (!f || !n_out || (n && (!d_in_xyzw || !d_out_xyzw))) return f ? lsa_fail(f->ctx, LSA_ERR_INVALID, "lsa_voxel_filter_apply_device: null argument") : LSA_ERR_INVALID;
+  LSA_HIP(f->ctx, hipSetDevice(f->ctx->device));
+  int rc = filter_device(f, (const float4 *)d_in_xyzw, n, (float4 *)d_out_xyzw, n_out);
+  if (rc) return rc;
+  LSA_HIP(f->ctx, hipStreamSynchronize(f->ctx->stream));
+  return LSA_OK;
+}
+
+extern "C" int lsa_voxel_filter_apply(lsa_voxel_filter *f, const void *in_pts, size_t n, size_t in_stride, size_t in_w_off, void *out_pts,
+                                      size_t out_cap, size_t out_stride, size_t out_w_off, size_t *n_out) {
+  if (!f || !n_out || (n && (!in_pts || !out_pts))) return f ? lsa_fail(f->ctx, LSA_ERR_INVALID, "lsa_voxel_filter_apply: null argument") : LSA_ERR_INVALID;
+  lsa_context *ctx = f->ctx;
+  *n_out = 0;
+  if (n == 0) return LSA_OK;
+  if (in_stride < 12 || out_stride < 12) return lsa_fail(ctx, LSA_ERR_INVALID, "lsa_voxel_filter_apply: stride < 12");
+  LSA_HIP(ctx, hipSetDevice(ctx->device));
+  int rc;
+  if ((rc = f->h_stage.reserve(ctx, n * 4))) return rc;
+  if ((rc = f->d_in.reserve(ctx, n, 1.25))) return rc;
+  if ((rc = f->d_out.reserve(ctx, n, 1.25))) return rc;
+  lsa_pack_xyzw(in_pts, n, in_stride, in_w_off, f->h_stage.p);
+  LSA_HIP(ctx, hipMemcpyAsync(f->d_in.p, f->h_stage.p, n * sizeof(float4), hipMemcpyHostToDevice, ctx->stream));
+  size_t V = 0;
+  rc = filter_device(f, f->d_in.p, n, f->d_out.p, &V);
+  if (rc == LSA_ERR_RANGE) {
+    // PCL: warns and sets output = *input_
+    if (out_pts != in_pts) {
+      if (out_cap < n) return lsa_fail(ctx, LSA_ERR_CAPACITY, "lsa_voxel_filter_apply: out_cap %zu < %zu", out_cap, n);
+      for (size_t i = 0; i < n; i++) {
+        const float *p = f->h_stage.p + 4 * i;
+        char *o = (char *)out_pts + i * out_stride;
+        memcpy(o, p, 12);
+        if (out_stride >= 16 && out_w_off != 12) ((float *)o)[3] = 1.0f;
+        if (out_w_off != SIZE_MAX && out_w_off + 4 <= out_stride) memcpy(o + out_w_off, p + 3, 4);
+      }
+    }
+    *n_out = n;
+    return LSA_ERR_RANGE;
+  }
+  if (rc) return rc;
+  if (V > out_cap) return lsa_fail(ctx, LSA_ERR_CAPACITY, "lsa_voxel_filter_apply: out_cap %zu < %zu voxels", out_cap, V);
+  if (V) {
+    // the staging buffer is free again (input already consumed on the stream once we synchronise)
+    LSA_HIP(ctx, hipMemcpyAsync(f->h_stage.p, f->d_out.p, V * sizeof(float4), hipMemcpyDeviceToHost, ctx->stream));
+  }
+  LSA_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  for (size_t i = 0; i < V; i++) {
+    const float *p = f->h_stage.p + 4 * i;
+    char *o = (char *)out_pts + i * out_stride;
+    memcpy(o, p, 12);
+    if (out_stride >= 16 && out_w_off != 12) ((float *)o)[3] = 1.0f;
+    if (out_w_off != SIZE_MAX && out_w_off + 4 <= out_stride) memcpy(o + out_w_off, p + 3, 4);
+  }
+  *n_out = V;
+  return LSA_OK;
+}

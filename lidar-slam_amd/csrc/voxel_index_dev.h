@@ -1,0 +1,57 @@
+// voxel_index_dev.h — internal device helpers shared by the .hip translation units.
+#ifndef LSA_VOXEL_INDEX_DEV_H_
+#define LSA_VOXEL_INDEX_DEV_H_
+
+#include "voxel_index.h"
+
+__device__ __forceinline__ bool lsa_finite3(float x, float y, float z) {
+  return isfinite(x) && isfinite(y) && isfinite(z);
+}
+
+// integer cell coordinates (relative to min_b) of a point.
+//  mode 0: PCL voxel_grid.hpp: ijk = (int)(floor(x * inverse_leaf) - (float)min_b)
+//  mode 1: reference VoxelGrid.cpp:218-222: floor(p.x / voxel_x_) - min_b   (f32 division, correctly rounded)
+__device__ __forceinline__ void lsa_cell_ijk(const CellMap &m, float x, float y, float z, int ijk[3]) {
+  if (m.mode == 0) {
+    ijk[0] = (int)(floorf(__fmul_rn(x, m.inv[0])) - (float)m.min_b[0]);
+    ijk[1] = (int)(floorf(__fmul_rn(y, m.inv[1])) - (float)m.min_b[1]);
+    ijk[2] = (int)(floorf(__fmul_rn(z, m.inv[2])) - (float)m.min_b[2]);
+  } else {
+    ijk[0] = (int)floorf(__fdiv_rn(x, m.leaf[0])) - m.min_b[0];
+    ijk[1] = (int)floorf(__fdiv_rn(y, m.leaf[1])) - m.min_b[1];
+    ijk[2] = (int)floorf(__fdiv_rn(z, m.leaf[2])) - m.min_b[2];
+  }
+}
+
+__device__ __forceinline__ int lsa_cell_linear(const CellMap &m, const int ijk[3]) {
+  if ((unsigned)ijk[0] >= (unsigned)m.dim[0] || (unsigned)ijk[1] >= (unsigned)m.dim[1] || (unsigned)ijk[2] >= (unsigned)m.dim[2]) return -1;
+  return ijk[0] + ijk[1] * m.dim[0] + ijk[2] * m.dim[0] * m.dim[1];
+}
+
+// reference corner of a cell, the offset all fixed-point sums are taken against (any fixed value works;
+// the corner keeps |d| <= ~leaf so the sums stay far from int64 overflow)
+__device__ __forceinline__ void lsa_cell_origin(const CellMap &m, int cell, double o[3]) {
+  int k = cell / (m.dim[0] * m.dim[1]);
+  int r = cell - k * (m.dim[0] * m.dim[1]);
+  int j = r / m.dim[0];
+  int i = r - j * m.dim[0];
+  o[0] = (double)(i + m.min_b[0]) * (double)m.leaf[0];
+  o[1] = (double)(j + m.min_b[1]) * (double)m.leaf[1];
+  o[2] = (double)(k + m.min_b[2]) * (double)m.leaf[2];
+}
+
+__device__ __forceinline__ void lsa_cell_unravel(const CellMap &m, int cell, int ijk_abs[3]) {
+  int k = cell / (m.dim[0] * m.dim[1]);
+  int r = cell - k * (m.dim[0] * m.dim[1]);
+  int j = r / m.dim[0];
+  int i = r - j * m.dim[0];
+  ijk_abs[0] = i + m.min_b[0]; ijk_abs[1] = j + m.min_b[1]; ijk_abs[2] = k + m.min_b[2];
+}
+
+__device__ __forceinline__ double lsa_wave_sum(double v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+  return v;
+}
+
+#endif

@@ -1,0 +1,190 @@
+"""Host-side mirror of the reference's registration plugin layer over the C-ABI.
+
+Reference: lidar_localization/include/lidar_localization/models/registration/registration_interface.hpp:14-24
+(RegistrationInterface: SetInputTarget / ScanMatch / GetFitnessScore) and
+src/models/registration/ndt_registration_manual.cpp:12-78 (NDTRegistrationManual).
+Same names and argument meaning; ScanMatch returns (True, result_pose) — the reference returns true and writes
+result_pose; result_cloud_ptr is never written by NDTRegistrationManual and is omitted.
+Poses are 4x4 float32 numpy arrays (row-major view of Eigen::Matrix4f).
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import capi
+
+
+class RegistrationInterface:
+    def SetInputTarget(self, input_target):  # noqa: N802
+        raise NotImplementedError
+
+    def ScanMatch(self, input_source, predict_pose):  # noqa: N802
+        raise NotImplementedError
+
+    def GetFitnessScore(self):  # noqa: N802
+        raise NotImplementedError
+
+
+class NDTRegistrationHip(RegistrationInterface):
+    """NDTRegistrationManual(res, step_size, trans_eps, max_iter, outlier_ratio) or (node) with the YAML keys
+    of config/mapping/front_end.yaml:24-29."""
+
+    def __init__(self, ctx, res=1.0, step_size=0.1, trans_eps=0.01, max_iter=30, outlier_ratio=0.55, node=None):
+        if node is not None:
+            res, step_size, trans_eps = float(node["res"]), float(node["step_size"]), float(node["trans_eps"])
+            max_iter, outlier_ratio = int(node["max_iter"]), float(node["outlier_ratio"])
+        self.ctx = ctx
+        self.params = (res, step_size, trans_eps, max_iter, outlier_ratio)
+        h = C.c_void_p()
+        ctx.check(capi.lib().lsa_ndt_create(C.byref(h), ctx.h, res, step_size, trans_eps, max_iter, outlier_ratio))
+        self.h = h
+        self.last_stats = None
+        self._cb = None
+        self._keep = None
+
+    # ---- RegistrationInterface -------------------------------------------------------------
+    def SetInputTarget(self, input_target):  # noqa: N802
+        if _is_tensor(input_target):
+            self._keep = input_target
+            self.ctx.check(capi.lib().lsa_ndt_set_input_target_device(self.h, input_target.data_ptr(), input_target.shape[0]))
+        else:
+            pts = np.ascontiguousarray(input_target, dtype=np.float32)
+            w_off = capi.W_OFF if pts.shape[1] >= 5 else 12
+            self.ctx.check(capi.lib().lsa_ndt_set_input_target(self.h, pts.ctypes.data, pts.shape[0], pts.strides[0], w_off))
+        return True
+
+    def ScanMatch(self, input_source, predict_pose):  # noqa: N802
+        guess = capi.colmajor(predict_pose)
+        out = np.zeros(16, dtype=np.float32)
+        st = capi.NdtStats()
+        if _is_tensor(input_source):
+            self._src_keep = input_source
+            rc = capi.lib().lsa_ndt_scan_match_device(self.h, input_source.data_ptr(), input_source.shape[0], capi.fptr(guess), capi.fptr(out), C.byref(st))
+        else:
+            pts = np.ascontiguousarray(input_source, dtype=np.float32)
+            rc = capi.lib().lsa_ndt_scan_match(self.h, pts.ctypes.data, pts.shape[0], pts.strides[0], capi.fptr(guess), capi.fptr(out), C.byref(st))
+        self.ctx.check(rc)
+        self.last_stats = st.as_dict()
+        return True, capi.from_colmajor(out)
+
+    def GetFitnessScore(self):  # noqa: N802
+        v = C.c_float(0)
+        self.ctx.check(capi.lib().lsa_ndt_get_fitness_score(self.h, C.byref(v)))
+        return v.value
+
+    # ---- introspection (parity tests / bench) ---------------------------------------------------
+    def grid_info(self):
+        info = np.zeros(9, dtype=np.int64)
+        self.ctx.check(capi.lib().lsa_ndt_grid_info(self.h, info.ctypes.data_as(C.POINTER(C.c_int64))))
+        return dict(dim=info[0:3].copy(), real_min=info[3:6].copy(), occupied=int(info[6]), valid=int(info[7]), n_target=int(info[8]))
+
+    def grid_dump(self):
+        n = C.c_size_t(0)
+        self.ctx.check(capi.lib().lsa_ndt_grid_dump(self.h, None, None, 0, C.byref(n)))
+        ints = np.zeros((n.value, 5), dtype=np.int32)
+        rec = np.zeros((n.value, 10), dtype=np.float64)
+        self.ctx.check(capi.lib().lsa_ndt_grid_dump(self.h, ints.ctypes.data_as(C.POINTER(C.c_int32)), capi.dptr(rec), n.value, C.byref(n)))
+        return ints, rec
+
+    def set_source(self, src):
+        if _is_tensor(src):
+            self._src_keep = src
+            self.ctx.check(capi.lib().lsa_ndt_set_source_device(self.h, src.data_ptr(), src.shape[0]))
+        else:
+            pts = np.ascontiguousarray(src, dtype=np.float32)
+            self.ctx.check(capi.lib().lsa_ndt_set_source(self.h, pts.ctypes.data, pts.shape[0], pts.strides[0]))
+
+    def derivatives(self, T, p, kind=0):
+        """One pass at (T f32 4x4, p f64[6]) -> (score, g[6], H[6,6], pairs, npoints)."""
+        out = np.zeros(32)
+        Tc = capi.colmajor(T)
+        p = np.ascontiguousarray(p, dtype=np.float64)
+        self.ctx.check(capi.lib().lsa_ndt_derivatives(self.h, capi.fptr(Tc), capi.dptr(p), kind, capi.dptr(out)))
+        return unpack_out32(out)
+
+    def derivatives_timed(self, T, p, kind=0, repeat=20):
+        out = np.zeros(32)
+        ms = C.c_double(0)
+        Tc = capi.colmajor(T)
+        p = np.ascontiguousarray(p, dtype=np.float64)
+        self.ctx.check(capi.lib().lsa_ndt_derivatives_timed(self.h, capi.fptr(Tc), capi.dptr(p), kind, repeat, capi.dptr(out), C.byref(ms)))
+        return unpack_out32(out), ms.value
+
+    def set_allreduce(self, fn):
+        """fn(device_ptr:int, n_doubles:int, stream:int) -> int (0 ok). Pass None to clear."""
+        if fn is None:
+            self._cb = capi.ALLREDUCE_FN(0)
+        else:
+            def _tramp(user, buf, n, stream):
+                try:
+                    return int(fn(buf, n, stream) or 0)
+                except Exception:  # never let an exception cross the C ABI
+                    import traceback
+                    traceback.print_exc()
+                    return 1
+            self._cb = capi.ALLREDUCE_FN(_tramp)
+        self.ctx.check(capi.lib().lsa_ndt_set_allreduce(self.h, self._cb, None))
+
+    def close(self):
+        if self.h:
+            capi.lib().lsa_ndt_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def unpack_out32(out):
+    score = out[0]
+    g = out[1:7].copy()
+    H = np.zeros((6, 6))
+    k = 7
+    for i in range(6):
+        for j in range(i, 6):
+            H[i, j] = H[j, i] = out[k]
+            k += 1
+    return score, g, H, out[28], out[29]
+
+
+def pack_out32(score, g, H, pairs, npoints):
+    out = np.zeros(32)
+    out[0] = score
+    out[1:7] = g
+    k = 7
+    for i in range(6):
+        for j in range(i, 6):
+            out[k] = 0.5 * (H[i, j] + H[j, i])
+            k += 1
+    out[28] = pairs
+    out[29] = npoints
+    return out
+
+
+def gn_solve(eval_fn, res, step_size, trans_eps, max_iter, outlier_ratio, predict_pose):
+    """lsa_gn_solve with a Python evaluator eval_fn(T 4x4 f32, p[6], kind) -> out32 (already summed over ranks)."""
+    def _tramp(user, Tp, pp, kind, outp):
+        try:
+            T = capi.from_colmajor(np.ctypeslib.as_array(Tp, shape=(16,)))
+            p = np.ctypeslib.as_array(pp, shape=(6,)).copy()
+            out = np.asarray(eval_fn(T, p, kind), dtype=np.float64)
+            np.ctypeslib.as_array(outp, shape=(32,))[:] = out
+            return 0
+        except Exception:
+            import traceback
+            traceback.print_exc()
+            return 1
+    cb = capi.PASS_EVAL_FN(_tramp)
+    out = np.zeros(16, dtype=np.float32)
+    st = capi.NdtStats()
+    guess = capi.colmajor(predict_pose)
+    rc = capi.lib().lsa_gn_solve(cb, None, res, step_size, trans_eps, max_iter, outlier_ratio, capi.fptr(guess), capi.fptr(out), C.byref(st))
+    if rc != 0:
+        raise capi.LsaError(rc, "lsa_gn_solve failed")
+    return capi.from_colmajor(out), st.as_dict()
+
+
+def _is_tensor(x):
+    return hasattr(x, "data_ptr") and hasattr(x, "is_cuda")

@@ -1,0 +1,248 @@
+"""GPU parity tests proper: every check goes through the C-ABI (ctypes -> liblidar_slam_amd.so -> HIP kernels)
+and compares with the CPU oracle on the same seeded inputs.
+
+Tolerances (stated per test):
+  * voxel filter: integer structure (count, voxel membership, order) exact; coordinates within a few f32 ulp
+    (PCL sums in f32 in an unspecified order, the GPU sums exactly and rounds once).
+  * NDT voxel table: cell set / counts / valid flags exact; centroid 1e-9 m, inverse covariance 1e-6 relative
+    (the oracle reproduces the reference's cancellation-prone formula, the GPU the shift-invariant one).
+  * derivative pass: score / gradient / Hessian 1e-9 relative to the largest entry (f64 both sides, different order).
+  * ScanMatch final pose: <= 1e-4 m and <= 1e-5 rad against the oracle (faithful f64 mode).
+"""
+import numpy as np
+import pytest
+
+from lidar_slam_amd import capi, cloud_filter, registration, synth
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    c = capi.Context(0)
+    yield c
+    c.close()
+
+
+def _pose_err(Ta, Tb):
+    dt = float(np.linalg.norm(Ta[:3, 3].astype(np.float64) - Tb[:3, 3].astype(np.float64)))
+    R = Ta[:3, :3].astype(np.float64).T @ Tb[:3, :3].astype(np.float64)
+    ang = float(np.arccos(np.clip((np.trace(R) - 1.0) / 2.0, -1.0, 1.0)))
+    return dt, ang
+
+
+# --------------------------------------------------------------------------------------------- filter
+@pytest.mark.parametrize("leaf", [0.5, 0.3, 1.3])
+def test_voxel_filter_matches_oracle(ctx, oracle, scan_pair, leaf):
+    s0, s1, _, _ = scan_pair
+    pts = synth.to_xyzi32(s1)
+    pts[:, 4] = np.random.RandomState(3).uniform(0, 1, pts.shape[0]).astype(np.float32)  # mixed static weights
+    ref, rc = oracle.voxel_filter(pts, leaf)
+    assert rc == 0
+    f = cloud_filter.VoxelFilterHip(ctx, leaf, leaf, leaf)
+    ok, out = f.Filter(pts)
+    assert ok is True
+    assert out.shape[0] == ref.shape[0]  # one output per occupied voxel, same voxel set
+    got = out[:, [0, 1, 2, 4]]
+    # order == ascending voxel index; values == mean of the members
+    err = np.abs(got.astype(np.float64) - ref.astype(np.float64))
+    scale = np.maximum(np.abs(ref.astype(np.float64)), 1.0)
+    assert np.max(err / scale) < 4e-6, np.max(err / scale)
+    assert np.all(out[:, 3] == 1.0)
+    f.close()
+
+
+def test_voxel_filter_edge_cases(ctx, oracle):
+    f = cloud_filter.VoxelFilterHip(ctx, 0.5, 0.5, 0.5)
+    # empty input
+    ok, out = f.Filter(np.zeros((0, 8), dtype=np.float32))
+    assert ok and out.shape[0] == 0
+    # single point, duplicates, negative coordinates, points exactly on voxel faces
+    pts = np.array([[0, 0, 0], [0.5, 0.5, 0.5], [-0.5, -0.5, -0.5], [-0.5, -0.5, -0.5], [1e-7, -1e-7, 0.25], [99.75, -99.75, 3.0]], dtype=np.float32)
+    p8 = synth.to_xyzi32(np.concatenate([pts, np.arange(6, dtype=np.float32)[:, None]], axis=1))
+    ref, _ = oracle.voxel_filter(p8, 0.5)
+    ok, out = f.Filter(p8)
+    assert out.shape[0] == ref.shape[0]
+    assert np.allclose(out[:, [0, 1, 2, 4]], ref, rtol=1e-6, atol=1e-6)
+    # NaN rows are skipped like PCL does for non-dense clouds
+    p8n = p8.copy()
+    p8n[1, 0] = np.nan
+    refn, _ = oracle.voxel_filter(p8n, 0.5)
+    ok, outn = f.Filter(p8n)
+    assert outn.shape[0] == refn.shape[0]
+    # in == out aliasing (viewer.cpp:207): result identical
+    import ctypes as C
+    buf = p8.copy()
+    n_out = C.c_size_t(0)
+    ctx.check(capi.lib().lsa_voxel_filter_apply(f.h, buf.ctypes.data, buf.shape[0], 32, 16, buf.ctypes.data, buf.shape[0], 32, 16, C.byref(n_out)))
+    assert n_out.value == ref.shape[0]
+    assert np.allclose(buf[: n_out.value][:, [0, 1, 2, 4]], ref, rtol=1e-6, atol=1e-6)
+    # leaf too small for the extent: PCL warns and passes the input through
+    tiny = cloud_filter.VoxelFilterHip(ctx, 1e-4, 1e-4, 1e-4)
+    big = synth.to_xyzi32(np.array([[0, 0, 0, 1], [500, 500, 50, 1]], dtype=np.float32))
+    ok, out = tiny.Filter(big)
+    assert ok and out.shape[0] == 2 and np.array_equal(out[:, :3], big[:, :3])
+    tiny.close()
+    f.close()
+
+
+def test_voxel_filter_idempotent_and_deterministic(ctx, scan_pair):
+    s0, _, _, _ = scan_pair
+    pts = synth.to_xyzi32(s0)
+    f = cloud_filter.VoxelFilterHip(ctx, 0.5, 0.5, 0.5)
+    _, a = f.Filter(pts)
+    _, b = f.Filter(pts)
+    assert np.array_equal(a, b)  # fixed-point sums: bitwise reproducible
+    perm = np.random.RandomState(0).permutation(pts.shape[0])
+    _, c = f.Filter(pts[perm])
+    assert np.array_equal(a, c)  # ... and independent of the input order
+    f.close()
+
+
+# --------------------------------------------------------------------------------------------- NDT grid
+def test_ndt_grid_matches_oracle(ctx, scan_pair):
+    import oracle_py
+    s0, _, _, _ = scan_pair
+    tgt = synth.to_xyzi32(s0)
+    tgt[:, 4] = np.random.RandomState(5).uniform(0, 1, tgt.shape[0]).astype(np.float32)
+    o = oracle_py.OracleNDT()
+    o.set_input_target(tgt)
+    oi, od = o.grid_dump()
+    n = registration.NDTRegistrationHip(ctx)
+    n.SetInputTarget(tgt)
+    gi, gr = n.grid_dump()
+    info = n.grid_info()
+    occ, valid = o.grid_counts()
+    assert info["occupied"] == occ == gi.shape[0]
+    assert info["valid"] == valid
+    assert np.array_equal(gi[:, :4], oi[:, :4])  # same cells, same order, same point counts
+    o_valid = oi[:, 4] >= 6
+    assert np.array_equal(gi[:, 4] == 1, o_valid)
+    assert np.max(np.abs(gr[:, :3] - od[:, :3])) < 1e-9          # centroids
+    assert np.max(np.abs(gr[:, 9] - od[:, 12])) < 1e-9           # mean static weight
+    ic = od[:, 3:12].reshape(-1, 3, 3)
+    ic_sym = np.stack([ic[:, 0, 0], 0.5 * (ic[:, 0, 1] + ic[:, 1, 0]), 0.5 * (ic[:, 0, 2] + ic[:, 2, 0]), ic[:, 1, 1],
+                       0.5 * (ic[:, 1, 2] + ic[:, 2, 1]), ic[:, 2, 2]], axis=1)
+    sc = np.max(np.abs(ic_sym[o_valid]), axis=1, keepdims=True)
+    rel = np.abs(gr[o_valid, 3:9] - ic_sym[o_valid]) / sc
+    assert np.max(rel) < 1e-6, np.max(rel)
+    n.close()
+
+
+# --------------------------------------------------------------------------------------------- derivative pass
+@pytest.mark.parametrize("kind", [0, 1, 2])
+def test_derivative_pass_matches_oracle(ctx, oracle, scan_pair, kind):
+    import oracle_py
+    s0, s1, _, _ = scan_pair
+    tgt = synth.to_xyzi32(s0)
+    tgt[:, 4] = np.random.RandomState(5).uniform(0.2, 1, tgt.shape[0]).astype(np.float32)
+    filt, _ = oracle.voxel_filter(synth.to_xyzi32(s1), 0.5)
+    src = synth.to_xyzi32(filt)
+    o = oracle_py.OracleNDT()
+    o.set_input_target(tgt)
+    n = registration.NDTRegistrationHip(ctx)
+    n.SetInputTarget(tgt)
+    n.set_source(src)
+    for p in ([0.0, 0, 0, 0, 0, 0], [0.9, 0.04, 0.0, 0.002, -0.003, 0.02], [1.3, -0.2, 0.05, -0.01, 0.02, -0.03], [0.5, 0.1, 0.0, 3.1, 0.01, 0.0]):
+        p = np.array(p)
+        T = oracle.pose_to_matrix(p)
+        if kind == 2:
+            o.derivatives(src, T, p, True)  # the reference's computeHessian reuses the last angle vectors
+            Href = o.hessian(src, T, p)
+            s, g, H, pairs, npts = n.derivatives(T, p, 2)
+            assert np.max(np.abs(H - 0.5 * (Href + Href.T))) <= 1e-9 * np.max(np.abs(Href))
+            continue
+        sref, gref, Href, pairs_ref = o.derivatives(src, T, p, compute_hessian=(kind == 0))
+        s, g, H, pairs, npts = n.derivatives(T, p, kind)
+        assert int(pairs) == pairs_ref and int(npts) == src.shape[0]
+        assert abs(s - sref) <= 1e-10 * abs(sref)
+        assert np.max(np.abs(g - gref)) <= 1e-9 * np.max(np.abs(gref))
+        if kind == 0:
+            assert np.max(np.abs(H - 0.5 * (Href + Href.T))) <= 1e-9 * np.max(np.abs(Href))
+    n.close()
+
+
+def test_derivative_pass_deterministic_and_linear(ctx, scan_pair, oracle):
+    """Size-independent properties at full scan size (133 k source points, unfiltered):
+    bitwise reproducibility, and additivity over a split of the source cloud (the multi-GPU invariant)."""
+    s0, s1, _, _ = scan_pair
+    tgt = synth.to_xyzi32(s0)
+    src = synth.to_xyzi32(s1)
+    n = registration.NDTRegistrationHip(ctx)
+    n.SetInputTarget(tgt)
+    p = np.array([0.9, 0.04, 0.0, 0.002, -0.003, 0.02])
+    T = oracle.pose_to_matrix(p)
+    n.set_source(src)
+    a = n.derivatives(T, p, 0)
+    b = n.derivatives(T, p, 0)
+    assert a[0] == b[0] and np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2])
+    half = src.shape[0] // 2
+    n.set_source(src[:half])
+    a1 = n.derivatives(T, p, 0)
+    n.set_source(src[half:])
+    a2 = n.derivatives(T, p, 0)
+    assert abs((a1[0] + a2[0]) - a[0]) <= 1e-12 * abs(a[0])
+    assert np.max(np.abs(a1[2] + a2[2] - a[2])) <= 1e-11 * np.max(np.abs(a[2]))
+    assert int(a1[3] + a2[3]) == int(a[3])
+    n.close()
+
+
+# --------------------------------------------------------------------------------------------- ScanMatch
+@pytest.mark.parametrize("guess_kind", ["identity", "offset"])
+def test_scan_match_matches_oracle(ctx, oracle, scan_pair, guess_kind):
+    """cfg1: filter(0.5) -> SetInputTarget(raw scan0) -> ScanMatch(filtered scan1), YAML parameters.
+    Tolerance: 1e-4 m / 1e-5 rad on the final pose; identical iteration / pass counts."""
+    import oracle_py
+    s0, s1, T0, T1 = scan_pair
+    tgt = synth.to_xyzi32(s0)
+    f = cloud_filter.VoxelFilterHip(ctx, 0.5, 0.5, 0.5)
+    _, src = f.Filter(synth.to_xyzi32(s1))
+    o = oracle_py.OracleNDT()
+    o.set_input_target(tgt)
+    guess = np.eye(4, dtype=np.float32)
+    if guess_kind == "offset":
+        guess = synth.pose_matrix(0.7, -0.1, 0.0, -0.004, 0.003, 0.01).astype(np.float32)
+    T_ref, st_ref = o.scan_match(src, guess)
+    n = registration.NDTRegistrationHip(ctx)
+    assert n.SetInputTarget(tgt) is True
+    ok, T = n.ScanMatch(src, guess)
+    assert ok is True
+    st = n.last_stats
+    dt, ang = _pose_err(T, T_ref)
+    assert dt <= 1e-4 and ang <= 1e-5, (dt, ang)
+    assert st["iterations"] == st_ref["iterations"] and st["passes"] == st_ref["passes"] and st["converged"] == 1
+    assert abs(st["trans_probability"] - st_ref["trans_probability"]) <= 1e-8 * abs(st_ref["trans_probability"])
+    # and the answer is physically right: relative motion of the synthetic pair within the NDT's own accuracy
+    T_true = (np.linalg.inv(T0) @ T1)
+    assert np.linalg.norm(T[:3, 3] - T_true[:3, 3]) < 0.1
+    n.close()
+    f.close()
+
+
+def test_scan_match_errors(ctx):
+    n = registration.NDTRegistrationHip(ctx)
+    with pytest.raises(capi.LsaError) as ei:
+        n.ScanMatch(np.zeros((4, 8), dtype=np.float32), np.eye(4, dtype=np.float32))
+    assert ei.value.code == capi.LSA_ERR_NO_TARGET
+    n.close()
+
+
+def test_device_resident_path(ctx, oracle, scan_pair):
+    """Same results when clouds are already resident in HBM (torch tensors as plain device memory)."""
+    import torch
+    s0, s1, _, _ = scan_pair
+    f = cloud_filter.VoxelFilterHip(ctx, 0.5, 0.5, 0.5)
+    _, src_h = f.Filter(synth.to_xyzi32(s1))
+    d_s1 = torch.from_numpy(np.ascontiguousarray(s1)).cuda()
+    d_src = f.filter_device(d_s1)
+    assert np.array_equal(d_src.cpu().numpy(), src_h[:, [0, 1, 2, 4]])
+    n_h = registration.NDTRegistrationHip(ctx)
+    n_d = registration.NDTRegistrationHip(ctx)
+    n_h.SetInputTarget(synth.to_xyzi32(s0))
+    d_s0 = torch.from_numpy(np.ascontiguousarray(s0)).cuda()
+    n_d.SetInputTarget(d_s0)
+    g = np.eye(4, dtype=np.float32)
+    _, Th = n_h.ScanMatch(src_h, g)
+    _, Td = n_d.ScanMatch(d_src.contiguous(), g)
+    assert np.array_equal(Th, Td)
+    n_h.close(); n_d.close(); f.close()
