@@ -57,6 +57,13 @@ def lib():
         return _lib
     if not os.path.exists(LIB_PATH):
         raise LsaError(LSA_ERR_NO_DEVICE, "%s not built; run __graft_entry__.build()" % LIB_PATH)
+    # One HIP runtime per process: the PyTorch wheel bundles its own libamdhip64.so (SONAME libamdhip64.so.7).
+    # Loading torch FIRST makes the dynamic loader satisfy this library's NEEDED libamdhip64.so.7 with that
+    # already-loaded copy; the other order maps two runtimes and the second one sees no GPU.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     L = C.CDLL(LIB_PATH)
     vp, sz, f, i = C.c_void_p, C.c_size_t, C.c_float, C.c_int
     PF, PD, PSZ = C.POINTER(C.c_float), C.POINTER(C.c_double), C.POINTER(C.c_size_t)

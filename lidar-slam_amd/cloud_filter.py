@@ -62,9 +62,10 @@ class VoxelFilterHip(CloudFilterInterface):
         return d_out[: n_out.value]
 
     def close(self):
-        if self.h:
+        # a handle must be destroyed before its context; if the context is already gone, leak rather than touch it
+        if self.h and self.ctx.h:
             capi.lib().lsa_voxel_filter_destroy(self.h)
-            self.h = None
+        self.h = None
 
     def __del__(self):
         try:

@@ -93,15 +93,15 @@ __global__ __launch_bounds__(kBlockD) void k_ndt_pass(const float4 *__restrict__
     float4 s = src[i];
     npts++;
     // pcl::transformPointCloud: x' = m00*x + m01*y + m02*z + m03, f32, left to right, no FMA
-    float tx = __fadd_rn(__fadd_rn(__fadd_rn(__fmul_rn(P.T[0], s.x), __fmul_rn(P.T[1], s.y)), __fmul_rn(P.T[2], s.z)), P.T[3]);
-    float ty = __fadd_rn(__fadd_rn(__fadd_rn(__fmul_rn(P.T[4], s.x), __fmul_rn(P.T[5], s.y)), __fmul_rn(P.T[6], s.z)), P.T[7]);
-    float tz = __fadd_rn(__fadd_rn(__fadd_rn(__fmul_rn(P.T[8], s.x), __fmul_rn(P.T[9], s.y)), __fmul_rn(P.T[10], s.z)), P.T[11]);
+    float tx = lsa_fadd(lsa_fadd(lsa_fadd(lsa_fmul(P.T[0], s.x), lsa_fmul(P.T[1], s.y)), lsa_fmul(P.T[2], s.z)), P.T[3]);
+    float ty = lsa_fadd(lsa_fadd(lsa_fadd(lsa_fmul(P.T[4], s.x), lsa_fmul(P.T[5], s.y)), lsa_fmul(P.T[6], s.z)), P.T[7]);
+    float tz = lsa_fadd(lsa_fadd(lsa_fadd(lsa_fmul(P.T[8], s.x), lsa_fmul(P.T[9], s.y)), lsa_fmul(P.T[10], s.z)), P.T[11]);
     if (!lsa_finite3(tx, ty, tz)) continue;
     // radiusSearch cell box (VoxelGrid.cpp:438-455), relative to real_min
     float r = P.res;
-    int hx = (int)floorf(__fdiv_rn(__fadd_rn(tx, r), r)) - P.min_b[0], lx = (int)floorf(__fdiv_rn(__fsub_rn(tx, r), r)) - P.min_b[0];
-    int hy = (int)floorf(__fdiv_rn(__fadd_rn(ty, r), r)) - P.min_b[1], ly = (int)floorf(__fdiv_rn(__fsub_rn(ty, r), r)) - P.min_b[1];
-    int hz = (int)floorf(__fdiv_rn(__fadd_rn(tz, r), r)) - P.min_b[2], lz = (int)floorf(__fdiv_rn(__fsub_rn(tz, r), r)) - P.min_b[2];
+    int hx = (int)floorf(lsa_fdiv(lsa_fadd(tx, r), r)) - P.min_b[0], lx = (int)floorf(lsa_fdiv(lsa_fsub(tx, r), r)) - P.min_b[0];
+    int hy = (int)floorf(lsa_fdiv(lsa_fadd(ty, r), r)) - P.min_b[1], ly = (int)floorf(lsa_fdiv(lsa_fsub(ty, r), r)) - P.min_b[1];
+    int hz = (int)floorf(lsa_fdiv(lsa_fadd(tz, r), r)) - P.min_b[2], lz = (int)floorf(lsa_fdiv(lsa_fsub(tz, r), r)) - P.min_b[2];
     hx = min(hx, P.dim[0] - 1); hy = min(hy, P.dim[1] - 1); hz = min(hz, P.dim[2] - 1);
     lx = max(lx, 0); ly = max(ly, 0); lz = max(lz, 0);
     if (lx > hx || ly > hy || lz > hz) continue;

@@ -259,7 +259,8 @@ int vi_make_map_pcl(const float mn[3], const float mx[3], const float leaf[3], C
     m->inv[a] = 1.0f / leaf[a];
     d[a] = (long long)((mx[a] - mn[a]) * m->inv[a]) + 1;
   }
-  if (d[0] * d[1] * d[2] > (long long)INT32_MAX) return LSA_ERR_RANGE;
+  // (PCL multiplies in int64, which itself overflows past ~9.2e18 cells; compare in double so that case is caught too)
+  if ((double)d[0] * (double)d[1] * (double)d[2] > (double)INT32_MAX) return LSA_ERR_RANGE;
   for (int a = 0; a < 3; a++) {
     m->min_b[a] = (int)floorf(mn[a] * m->inv[a]);
     int max_b = (int)floorf(mx[a] * m->inv[a]);

@@ -4,6 +4,31 @@
 
 #include "voxel_index.h"
 
+// f32 primitives that must NOT be contracted into FMAs: the reference (PCL / the in-tree VoxelGrid) is built for
+// baseline x86-64 and rounds every product and sum separately.  HIP's __fmul_rn / __fadd_rn are plain `x * y` /
+// `x + y` (clang __clang_hip_math.h) and DO get fused after inlining under the default -ffp-contract, so each
+// operation is fenced with the pragma instead.
+__device__ __forceinline__ float lsa_fmul(float a, float b) {
+#pragma clang fp contract(off)
+  float r = a * b;
+  return r;
+}
+__device__ __forceinline__ float lsa_fadd(float a, float b) {
+#pragma clang fp contract(off)
+  float r = a + b;
+  return r;
+}
+__device__ __forceinline__ float lsa_fsub(float a, float b) {
+#pragma clang fp contract(off)
+  float r = a - b;
+  return r;
+}
+__device__ __forceinline__ float lsa_fdiv(float a, float b) {
+#pragma clang fp contract(off)
+  float r = a / b;  // correctly rounded: built with -fhip-fp32-correctly-rounded-divide-sqrt
+  return r;
+}
+
 __device__ __forceinline__ bool lsa_finite3(float x, float y, float z) {
   return isfinite(x) && isfinite(y) && isfinite(z);
 }
@@ -13,13 +38,13 @@ __device__ __forceinline__ bool lsa_finite3(float x, float y, float z) {
 //  mode 1: reference VoxelGrid.cpp:218-222: floor(p.x / voxel_x_) - min_b   (f32 division, correctly rounded)
 __device__ __forceinline__ void lsa_cell_ijk(const CellMap &m, float x, float y, float z, int ijk[3]) {
   if (m.mode == 0) {
-    ijk[0] = (int)(floorf(__fmul_rn(x, m.inv[0])) - (float)m.min_b[0]);
-    ijk[1] = (int)(floorf(__fmul_rn(y, m.inv[1])) - (float)m.min_b[1]);
-    ijk[2] = (int)(floorf(__fmul_rn(z, m.inv[2])) - (float)m.min_b[2]);
+    ijk[0] = (int)(floorf(lsa_fmul(x, m.inv[0])) - (float)m.min_b[0]);
+    ijk[1] = (int)(floorf(lsa_fmul(y, m.inv[1])) - (float)m.min_b[1]);
+    ijk[2] = (int)(floorf(lsa_fmul(z, m.inv[2])) - (float)m.min_b[2]);
   } else {
-    ijk[0] = (int)floorf(__fdiv_rn(x, m.leaf[0])) - m.min_b[0];
-    ijk[1] = (int)floorf(__fdiv_rn(y, m.leaf[1])) - m.min_b[1];
-    ijk[2] = (int)floorf(__fdiv_rn(z, m.leaf[2])) - m.min_b[2];
+    ijk[0] = (int)floorf(lsa_fdiv(x, m.leaf[0])) - m.min_b[0];
+    ijk[1] = (int)floorf(lsa_fdiv(y, m.leaf[1])) - m.min_b[1];
+    ijk[2] = (int)floorf(lsa_fdiv(z, m.leaf[2])) - m.min_b[2];
   }
 }
 

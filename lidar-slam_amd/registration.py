@@ -126,9 +126,10 @@ class NDTRegistrationHip(RegistrationInterface):
         self.ctx.check(capi.lib().lsa_ndt_set_allreduce(self.h, self._cb, None))
 
     def close(self):
-        if self.h:
+        # a handle must be destroyed before its context; if the context is already gone, leak rather than touch it
+        if self.h and self.ctx.h:
             capi.lib().lsa_ndt_destroy(self.h)
-            self.h = None
+        self.h = None
 
     def __del__(self):
         try:

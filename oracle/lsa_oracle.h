@@ -78,6 +78,8 @@ int orc_grid_radius_search(const orc_grid *g, const float p[3], float radius, in
 /* dump of all occupied cells in ascending (ix + iy*dx + iz*dx*dy over REAL bounds) order:
  * for each: ix,iy,iz (absolute voxel coords), npts, ppv -> ints[5*k..]; centroid(3) icov(9) weight(1) -> dbl[13*k..] */
 int orc_grid_dump(const orc_grid *g, int *ints, double *dbls, int cap);
+/* test hook: overwrite one cell's finalised record (absolute voxel coords) */
+int orc_grid_set_cell(orc_grid *g, int ix, int iy, int iz, const double centroid[3], const double icov[9], double weight);
 
 /* ---- NDT registration (NS/NormalDistributionsTransform.cpp) ------------ */
 

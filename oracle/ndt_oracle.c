@@ -976,3 +976,14 @@ double orc_ndt_fitness(orc_ndt *h, const void *src, size_t n, size_t stride, con
   if (nr > 0) return fitness / nr;
   return DBL_MAX;
 }
+
+/* test hook: overwrite one cell's finalised record (absolute voxel coordinates), so the derivative loops can be
+ * compared on IDENTICAL voxel tables (isolates the pass arithmetic from table round-off) */
+int orc_grid_set_cell(orc_grid *g, int ix, int iy, int iz, const double centroid[3], const double icov[9], double weight) {
+  if (ix < g->real_min[0] || ix > g->real_max[0] || iy < g->real_min[1] || iy > g->real_max[1] || iz < g->real_min[2] || iz > g->real_max[2]) return -1;
+  int vid = vid3(g, ix, iy, iz);
+  memcpy(g->centroid + (size_t)vid * 3, centroid, 3 * sizeof(double));
+  memcpy(g->icov + (size_t)vid * 9, icov, 9 * sizeof(double));
+  g->sval[vid] = weight;
+  return 0;
+}

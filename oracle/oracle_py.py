@@ -93,6 +93,8 @@ class Oracle:
         L.orc_grid_counts.argtypes = [vp, PI, PI]
         L.orc_grid_dump.argtypes = [vp, PI, PD, i]
         L.orc_grid_dump.restype = i
+        L.orc_grid_set_cell.argtypes = [vp, i, i, i, PD, PD, d]
+        L.orc_grid_set_cell.restype = i
         L.orc_grid_radius_search.argtypes = [vp, PF, f, PI, i]
         L.orc_grid_radius_search.restype = i
         L.orc_ndt_create.argtypes = [f, f, f, i, f]
@@ -233,6 +235,16 @@ class OracleNDT:
         k = self.o.L.orc_grid_dump(self.o.L.orc_ndt_grid(self.h), _ip(ints), _dp(dbls), occ)
         assert k == occ
         return ints, dbls
+
+    def override_cells(self, cell_ints, rec10):
+        """Overwrite finalised cells with (centroid, symmetric icov, weight) rows, e.g. the GPU's table."""
+        g = self.o.L.orc_ndt_grid(self.h)
+        for (ix, iy, iz, _, st), r in zip(cell_ints, rec10):
+            if st != 1:
+                continue
+            c = np.ascontiguousarray(r[0:3])
+            ic = np.array([r[3], r[4], r[5], r[4], r[6], r[7], r[5], r[7], r[8]])
+            assert self.o.L.orc_grid_set_cell(g, int(ix), int(iy), int(iz), _dp(c), _dp(ic), float(r[9])) == 0
 
     def derivatives(self, src8, T, p, compute_hessian=True):
         src8 = np.ascontiguousarray(src8, dtype=np.float32)

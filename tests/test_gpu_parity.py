@@ -6,7 +6,10 @@ Tolerances (stated per test):
     (PCL sums in f32 in an unspecified order, the GPU sums exactly and rounds once).
   * NDT voxel table: cell set / counts / valid flags exact; centroid 1e-9 m, inverse covariance 1e-6 relative
     (the oracle reproduces the reference's cancellation-prone formula, the GPU the shift-invariant one).
-  * derivative pass: score / gradient / Hessian 1e-9 relative to the largest entry (f64 both sides, different order).
+  * derivative pass: (a) on IDENTICAL voxel tables (the oracle's cells overwritten with the GPU's records) score /
+    gradient / Hessian agree to 1e-11 relative to the largest entry (f64 both sides, different summation order);
+    (b) on each side's own table 1e-7 relative (the oracle reproduces the reference's cancellation-prone covariance
+    formula whose round-off is amplified by the 1/100 eigenvalue floor; the GPU evaluates the shift-invariant form).
   * ScanMatch final pose: <= 1e-4 m and <= 1e-5 rad against the oracle (faithful f64 mode).
 """
 import numpy as np
@@ -27,7 +30,9 @@ def ctx():
 def _pose_err(Ta, Tb):
     dt = float(np.linalg.norm(Ta[:3, 3].astype(np.float64) - Tb[:3, 3].astype(np.float64)))
     R = Ta[:3, :3].astype(np.float64).T @ Tb[:3, :3].astype(np.float64)
-    ang = float(np.arccos(np.clip((np.trace(R) - 1.0) / 2.0, -1.0, 1.0)))
+    # geodesic angle via the skew part (arccos of the trace is ill-conditioned near 0 for f32 matrices)
+    v = 0.5 * np.array([R[2, 1] - R[1, 2], R[0, 2] - R[2, 0], R[1, 0] - R[0, 1]])
+    ang = float(np.arctan2(np.linalg.norm(v), (np.trace(R) - 1.0) / 2.0))
     return dt, ang
 
 
@@ -78,7 +83,7 @@ def test_voxel_filter_edge_cases(ctx, oracle):
     assert n_out.value == ref.shape[0]
     assert np.allclose(buf[: n_out.value][:, [0, 1, 2, 4]], ref, rtol=1e-6, atol=1e-6)
     # leaf too small for the extent: PCL warns and passes the input through
-    tiny = cloud_filter.VoxelFilterHip(ctx, 1e-4, 1e-4, 1e-4)
+    tiny = cloud_filter.VoxelFilterHip(ctx, 1e-2, 1e-2, 1e-2)
     big = synth.to_xyzi32(np.array([[0, 0, 0, 1], [500, 500, 50, 1]], dtype=np.float32))
     ok, out = tiny.Filter(big)
     assert ok and out.shape[0] == 2 and np.array_equal(out[:, :3], big[:, :3])
@@ -130,9 +135,11 @@ def test_ndt_grid_matches_oracle(ctx, scan_pair):
 
 
 # --------------------------------------------------------------------------------------------- derivative pass
+@pytest.mark.parametrize("same_table", [True, False])
 @pytest.mark.parametrize("kind", [0, 1, 2])
-def test_derivative_pass_matches_oracle(ctx, oracle, scan_pair, kind):
+def test_derivative_pass_matches_oracle(ctx, oracle, scan_pair, kind, same_table):
     import oracle_py
+    tol = 1e-11 if same_table else 1e-7
     s0, s1, _, _ = scan_pair
     tgt = synth.to_xyzi32(s0)
     tgt[:, 4] = np.random.RandomState(5).uniform(0.2, 1, tgt.shape[0]).astype(np.float32)
@@ -143,6 +150,8 @@ def test_derivative_pass_matches_oracle(ctx, oracle, scan_pair, kind):
     n = registration.NDTRegistrationHip(ctx)
     n.SetInputTarget(tgt)
     n.set_source(src)
+    if same_table:
+        o.override_cells(*n.grid_dump())
     for p in ([0.0, 0, 0, 0, 0, 0], [0.9, 0.04, 0.0, 0.002, -0.003, 0.02], [1.3, -0.2, 0.05, -0.01, 0.02, -0.03], [0.5, 0.1, 0.0, 3.1, 0.01, 0.0]):
         p = np.array(p)
         T = oracle.pose_to_matrix(p)
@@ -150,15 +159,15 @@ def test_derivative_pass_matches_oracle(ctx, oracle, scan_pair, kind):
             o.derivatives(src, T, p, True)  # the reference's computeHessian reuses the last angle vectors
             Href = o.hessian(src, T, p)
             s, g, H, pairs, npts = n.derivatives(T, p, 2)
-            assert np.max(np.abs(H - 0.5 * (Href + Href.T))) <= 1e-9 * np.max(np.abs(Href))
+            assert np.max(np.abs(H - 0.5 * (Href + Href.T))) <= tol * np.max(np.abs(Href))
             continue
         sref, gref, Href, pairs_ref = o.derivatives(src, T, p, compute_hessian=(kind == 0))
         s, g, H, pairs, npts = n.derivatives(T, p, kind)
         assert int(pairs) == pairs_ref and int(npts) == src.shape[0]
-        assert abs(s - sref) <= 1e-10 * abs(sref)
-        assert np.max(np.abs(g - gref)) <= 1e-9 * np.max(np.abs(gref))
+        assert abs(s - sref) <= tol * abs(sref)
+        assert np.max(np.abs(g - gref)) <= tol * np.max(np.abs(gref))
         if kind == 0:
-            assert np.max(np.abs(H - 0.5 * (Href + Href.T))) <= 1e-9 * np.max(np.abs(Href))
+            assert np.max(np.abs(H - 0.5 * (Href + Href.T))) <= tol * np.max(np.abs(Href))
     n.close()
 
 
