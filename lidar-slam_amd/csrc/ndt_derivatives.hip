@@ -212,7 +212,7 @@ unsigned ndt_pass_grid(const lsa_ndt *h, size_t n) {
 }
 
 // enqueue one pass: partial kernel + second-stage reduction into h->d_out (device). No sync.
-int ndt_enqueue_pass(lsa_ndt *h, const PassParams &P, int kind) {
+int ndt_enqueue_pass(lsa_ndt *h, const PassParams &P, int kind, bool reduce) {
   lsa_context *ctx = h->ctx;
   unsigned g = ndt_pass_grid(h, h->n_source);
   int rc;
@@ -223,7 +223,7 @@ int ndt_enqueue_pass(lsa_ndt *h, const PassParams &P, int kind) {
   if (kind == 0) hipLaunchKernelGGL(k_ndt_pass<0>, dim3(g), dim3(kBlockD), 0, ctx->stream, h->d_source, h->n_source, P, words, rec, h->partials.p);
   else if (kind == 1) hipLaunchKernelGGL(k_ndt_pass<1>, dim3(g), dim3(kBlockD), 0, ctx->stream, h->d_source, h->n_source, P, words, rec, h->partials.p);
   else hipLaunchKernelGGL(k_ndt_pass<2>, dim3(g), dim3(kBlockD), 0, ctx->stream, h->d_source, h->n_source, P, words, rec, h->partials.p);
-  hipLaunchKernelGGL(k_reduce_partials, dim3(1), dim3(1024), 0, ctx->stream, h->partials.p, (int)g, h->d_out.p);
+  if (reduce) hipLaunchKernelGGL(k_reduce_partials, dim3(1), dim3(1024), 0, ctx->stream, h->partials.p, (int)g, h->d_out.p);
   LSA_HIP(ctx, hipGetLastError());
   return LSA_OK;
 }

@@ -16,6 +16,6 @@ struct PassParams {
 
 void ndt_make_pass_params(const lsa_ndt *h, const float T[16], const double p[6], PassParams *P);
 unsigned ndt_pass_grid(const lsa_ndt *h, size_t n);
-int ndt_enqueue_pass(lsa_ndt *h, const PassParams &P, int kind);
+int ndt_enqueue_pass(lsa_ndt *h, const PassParams &P, int kind, bool reduce = true);
 
 #endif

@@ -2,8 +2,12 @@
 reference tree nor in this image, so every BASELINE.json config is restated on these generators).
 
 A scan is ray-cast from a sensor pose into a closed-form street scene (ground plane, building
-boxes with seeded setbacks on both sides, cross walls, parked-car boxes, pole cylinders) and
-returned in the SENSOR frame as (n, 4) float32 [x, y, z, intensity(w)=1].
+boxes with seeded setbacks on both sides, cross walls, parked-car boxes, pole cylinders, and
+small clutter boxes standing in for vegetation / street furniture) and returned in the SENSOR
+frame as (n, 4) float32 [x, y, z, intensity(w)=1].
+
+Rays are ordered azimuth-major (one column of `beams` shots per azimuth step), so every obstacle
+only has to be tested against the contiguous slice of columns its azimuth interval covers.
 """
 import numpy as np
 
@@ -11,7 +15,7 @@ SENSOR_HEIGHT = 1.73
 
 
 class Scene:
-    def __init__(self, seed: int = 1, length: float = 260.0):
+    def __init__(self, seed: int = 1, length: float = 260.0, clutter: int = 260):
         rng = np.random.RandomState(seed)
         boxes = []
         # buildings: both sides of the street, varying setback / length / height, small gaps
@@ -19,20 +23,29 @@ class Scene:
             x = -60.0
             while x < length:
                 ln = rng.uniform(8.0, 22.0)
-                setback = 12.0 + rng.choice([0.0, 0.0, 1.5, 3.0, 4.5])
+                # left side: a street canyon 12-16.5 m from the lane; right side: an open lot, 26-44 m setback
+                setback = 12.0 + rng.choice([0.0, 0.0, 1.5, 3.0, 4.5]) if side < 0 else rng.uniform(26.0, 44.0)
                 h = rng.uniform(5.0, 11.0)
                 y0, y1 = (setback, setback + 15.0) if side > 0 else (-setback - 15.0, -setback)
                 boxes.append([x, x + ln, y0, y1, -SENSOR_HEIGHT, -SENSOR_HEIGHT + h])
                 x += ln + rng.choice([0.0, 0.0, 2.0, 5.0])
         # cross walls closing the street
-        boxes.append([-62.0, -60.0, -30.0, 30.0, -SENSOR_HEIGHT, 8.0])
-        boxes.append([length, length + 2.0, -30.0, 30.0, -SENSOR_HEIGHT, 8.0])
+        boxes.append([-62.0, -60.0, -30.0, 60.0, -SENSOR_HEIGHT, 8.0])
+        boxes.append([length, length + 2.0, -30.0, 60.0, -SENSOR_HEIGHT, 8.0])
         # parked cars 4 x 1.8 x 1.5
         n_cars = int(12 * (length + 60.0) / 100.0)
         for _ in range(n_cars):
             cx = rng.uniform(-50.0, length - 10.0)
-            cy = rng.choice([-1.0, 1.0]) * rng.uniform(5.0, 9.5)
+            cy = -rng.uniform(5.0, 9.5) if rng.rand() < 0.4 else rng.uniform(5.0, 24.0)
             boxes.append([cx - 2.0, cx + 2.0, cy - 0.9, cy + 0.9, -SENSOR_HEIGHT, -SENSOR_HEIGHT + 1.5])
+        # clutter: bushes, bins, signs, tree crowns (small boxes, some elevated)
+        n_cl = int(clutter * (length + 60.0) / 100.0)
+        for _ in range(n_cl):
+            cx = rng.uniform(-55.0, length - 5.0)
+            cy = -rng.uniform(4.0, 11.8) if rng.rand() < 0.4 else rng.uniform(4.0, 25.0)
+            sx, sy, sz = rng.uniform(0.3, 1.6), rng.uniform(0.3, 1.6), rng.uniform(0.4, 2.2)
+            z0 = -SENSOR_HEIGHT + (rng.uniform(2.0, 4.5) if rng.rand() < 0.35 else 0.0)
+            boxes.append([cx - sx / 2, cx + sx / 2, cy - sy / 2, cy + sy / 2, z0, z0 + sz])
         self.boxes = np.asarray(boxes, dtype=np.float64)
         n_poles = int(8 * (length + 60.0) / 100.0)
         px = rng.uniform(-50.0, length - 10.0, n_poles)
@@ -41,45 +54,97 @@ class Scene:
         self.pole_r = 0.3
         self.pole_top = -SENSOR_HEIGHT + 6.0
 
-    def cast(self, origin, dirs, max_range):
-        """origin (3,), dirs (n,3) unit -> range t (n,), inf where nothing is hit."""
-        n = dirs.shape[0]
-        t = np.full(n, np.inf)
+    # ------------------------------------------------------------------------------------------
+    def cast(self, T_world_sensor, az, elev, max_range):
+        """Ray-cast beams x azimuth columns. Returns t (n_az, beams) ranges (inf where nothing is hit)
+        and the unit directions in the sensor frame (n_az, beams, 3)."""
+        R = T_world_sensor[:3, :3]
+        o = T_world_sensor[:3, 3]
+        ce, se = np.cos(elev), np.sin(elev)
+        d_s = np.stack([np.outer(np.cos(az), ce), np.outer(np.sin(az), ce), np.outer(np.ones_like(az), se)], axis=2)
+        d_w = d_s @ R.T
+        n_az = az.shape[0]
+        t = np.full((n_az, elev.shape[0]), np.inf)
         # ground plane z = -SENSOR_HEIGHT
-        dz = dirs[:, 2]
         with np.errstate(divide="ignore", invalid="ignore"):
-            tg = (-SENSOR_HEIGHT - origin[2]) / dz
+            tg = (-SENSOR_HEIGHT - o[2]) / d_w[:, :, 2]
         tg[~(tg > 0)] = np.inf
         t = np.minimum(t, tg)
-        # boxes (slab method)
-        with np.errstate(divide="ignore", invalid="ignore"):
-            inv = 1.0 / dirs
+        daz = 2.0 * np.pi / n_az
+        Rt = R.T
+
+        def col_slices(a_lo, a_hi):
+            """columns whose azimuth lies in [a_lo, a_hi] (radians, may wrap)"""
+            if a_hi - a_lo >= 2.0 * np.pi - 1e-9:
+                return [slice(0, n_az)]
+            i0 = int(np.floor((a_lo - az[0]) / daz)) - 1
+            i1 = int(np.ceil((a_hi - az[0]) / daz)) + 1
+            i0m, i1m = i0 % n_az, i1 % n_az
+            if i1 - i0 >= n_az:
+                return [slice(0, n_az)]
+            if i0m <= i1m:
+                return [slice(i0m, i1m + 1)]
+            return [slice(i0m, n_az), slice(0, i1m + 1)]
+
         for b in self.boxes:
-            t0 = (b[0::2][None, :] - origin[None, :]) * inv
-            t1 = (b[1::2][None, :] - origin[None, :]) * inv
-            tmin = np.nanmax(np.minimum(t0, t1), axis=1)
-            tmax = np.nanmin(np.maximum(t0, t1), axis=1)
-            hit = (tmax >= tmin) & (tmax > 0)
-            tb = np.where(tmin > 0, tmin, tmax)
-            tb[~hit] = np.inf
-            t = np.minimum(t, tb)
-        # poles: vertical cylinders
-        dxy = dirs[:, :2]
-        a = (dxy ** 2).sum(1)
+            # azimuth interval of the box as seen from the sensor (sensor frame), from its 8 corners
+            cs = np.array([[b[i], b[2 + j], b[4 + k]] for i in (0, 1) for j in (0, 1) for k in (0, 1)])
+            cs_s = (cs - o) @ Rt.T
+            ctr = cs_s.mean(axis=0)
+            inside = (b[0] <= o[0] <= b[1]) and (b[2] <= o[1] <= b[3])
+            if inside:
+                sls = [slice(0, n_az)]
+            else:
+                a_c = np.arctan2(ctr[1], ctr[0])
+                da = np.arctan2(cs_s[:, 1], cs_s[:, 0]) - a_c
+                da = (da + np.pi) % (2.0 * np.pi) - np.pi
+                if da.max() - da.min() > np.pi:
+                    sls = [slice(0, n_az)]
+                else:
+                    lo, hi = a_c + da.min(), a_c + da.max()
+                    # bring into the az array's range [az0, az0 + 2pi)
+                    shift = np.floor((lo - az[0]) / (2.0 * np.pi)) * 2.0 * np.pi
+                    sls = col_slices(lo - shift, hi - shift)
+            for sl in sls:
+                d = d_w[sl]
+                with np.errstate(divide="ignore", invalid="ignore"):
+                    inv = 1.0 / d
+                    t0 = (b[0::2] - o) * inv
+                    t1 = (b[1::2] - o) * inv
+                tmin = np.nanmax(np.minimum(t0, t1), axis=2)
+                tmax = np.nanmin(np.maximum(t0, t1), axis=2)
+                hit = (tmax >= tmin) & (tmax > 0)
+                tb = np.where(tmin > 0, tmin, tmax)
+                tb[~hit] = np.inf
+                t[sl] = np.minimum(t[sl], tb)
         for c in self.poles:
-            oc = origin[:2] - c
-            bq = 2.0 * (dxy @ oc)
-            cq = oc @ oc - self.pole_r ** 2
-            disc = bq * bq - 4.0 * a * cq
-            ok = disc > 0
-            with np.errstate(divide="ignore", invalid="ignore"):
-                tp = (-bq - np.sqrt(np.where(ok, disc, 0.0))) / (2.0 * a)
-            z = origin[2] + tp * dz
-            ok &= (tp > 0) & (z <= self.pole_top) & (z >= -SENSOR_HEIGHT)
-            tp[~ok] = np.inf
-            t = np.minimum(t, tp)
+            oc = o[:2] - c
+            dist = np.hypot(oc[0], oc[1])
+            if dist <= self.pole_r * 1.5:
+                sls = [slice(0, n_az)]
+            else:
+                c_s = (np.array([c[0], c[1], o[2]]) - o) @ Rt.T
+                a_c = np.arctan2(c_s[1], c_s[0])
+                half = np.arcsin(min(1.0, self.pole_r / dist)) + 0.02
+                lo, hi = a_c - half, a_c + half
+                shift = np.floor((lo - az[0]) / (2.0 * np.pi)) * 2.0 * np.pi
+                sls = col_slices(lo - shift, hi - shift)
+            for sl in sls:
+                d = d_w[sl]
+                dxy = d[:, :, :2]
+                a = (dxy ** 2).sum(2)
+                bq = 2.0 * (dxy @ oc)
+                cq = oc @ oc - self.pole_r ** 2
+                disc = bq * bq - 4.0 * a * cq
+                ok = disc > 0
+                with np.errstate(divide="ignore", invalid="ignore"):
+                    tp = (-bq - np.sqrt(np.where(ok, disc, 0.0))) / (2.0 * a)
+                z = o[2] + tp * d[:, :, 2]
+                ok &= (tp > 0) & (z <= self.pole_top) & (z >= -SENSOR_HEIGHT)
+                tp[~ok] = np.inf
+                t[sl] = np.minimum(t[sl], tp)
         t[t > max_range] = np.inf
-        return t
+        return t, d_s
 
 
 def pose_matrix(x=0.0, y=0.0, z=0.0, roll=0.0, pitch=0.0, yaw=0.0):
@@ -102,13 +167,9 @@ def gen_scan(scene: Scene, T_world_sensor, seed: int, beams: int = 64, az_steps:
     rng = np.random.RandomState(seed)
     elev = np.deg2rad(np.linspace(-24.8, 2.0, beams))
     az = np.arange(az_steps) * (2.0 * np.pi / az_steps)
-    ce, se = np.cos(elev), np.sin(elev)
-    # firing order: azimuth-major (a column of `beams` shots per azimuth step), as a spinning unit reports
-    d_s = np.stack([np.outer(np.cos(az), ce), np.outer(np.sin(az), ce), np.outer(np.ones_like(az), se)], axis=2).reshape(-1, 3)
-    R = T_world_sensor[:3, :3]
-    o = T_world_sensor[:3, 3]
-    d_w = d_s @ R.T
-    t = scene.cast(o, d_w, max_range if not clamp else np.inf)
+    t, d_s = scene.cast(np.asarray(T_world_sensor, dtype=np.float64), az, elev, np.inf if clamp else max_range)
+    t = t.reshape(-1)
+    d_s = d_s.reshape(-1, 3)
     if clamp:
         t = np.minimum(t, max_range)
         keep = np.ones(t.shape, dtype=bool)
@@ -145,6 +206,7 @@ def to_xyzi32(xyzw):
 
 
 def transform_points(T, xyzw):
+    """pcl::transformPointCloud on the xyz columns (f32), other columns copied."""
     out = np.array(xyzw, dtype=np.float32, copy=True)
     T32 = np.asarray(T, dtype=np.float32)
     out[:, :3] = xyzw[:, :3] @ T32[:3, :3].T + T32[:3, 3]
