@@ -5,11 +5,12 @@
 //  :391-445 computeDerivatives, :448-482 computePointDerivatives, :485-520 updateDerivatives, :875-899 updateHessian,
 //  :901-936 computeHessian; VoxelGrid.cpp:432-480 radiusSearch; pcl::transformPointCloud, f32).
 //
-// One lane per source point: f32 rigid transform (bit-identical to PCL's, no FMA contraction), probe of the <= 3x3x3
-// cell neighbourhood through the {occupancy, valid, prefix} words, gather of the 80-byte voxel record, f64 pair math
-// exploiting the symmetry of C^-1 (21 unique Hessian entries + 6 gradient + score = 28 values), wave shuffle
-// reduction -> LDS -> one 32-double partial per workgroup, then a fixed-order second-stage reduction (no atomics:
-// bitwise reproducible run to run).  No MFMA: the largest contraction is 6x6.
+// Per 64-point tile: f32 rigid transform (bit-identical to PCL's, no FMA contraction), block-cooperative probe of the
+// <= 3x3x3 cell neighbourhood through the {occupancy, valid, prefix} words, compaction of the hits into an LDS pair
+// queue, then dense f64 pair math on the gathered 80-byte voxel records exploiting the symmetry of C^-1 (21 unique
+// Hessian entries + 6 gradient + score = 28 values), wave shuffle reduction -> LDS -> one 32-double partial per
+// workgroup, then a fixed-order second-stage reduction (no atomics: bitwise reproducible run to run).
+// No MFMA: the largest contraction is 6x6.
 //
 // Algorithmic bytes per pass (SURVEY.md 8d formula C, with this implementation's record size):
 //   16*M (points) + 27*16*M (cell words, worst case) + 80*Kbar*M (records); the word table and the records are
@@ -19,17 +20,13 @@
 
 namespace {
 
-constexpr int kBlockD = 128;
+constexpr int kBlockD = 256;
 
 template <int KIND>
 __device__ __forceinline__ void pair_update(const PassParams &P, const double *__restrict__ R, float tx, float ty, float tz,
-                                            const double pg[8], const double ph[15], double acc[28], unsigned &pairs) {
-  // R: centroid(3), C = icov (xx,xy,xz,yy,yz,zz), w
-  double cx = R[0] - (double)tx, cy = R[1] - (double)ty, cz = R[2] - (double)tz;
-  double dist = sqrt(cx * cx + cy * cy + cz * cz);
-  if (!(dist < (double)P.res)) return;  // VoxelGrid.cpp:470-472
-  pairs++;
-  double d0 = -cx, d1 = -cy, d2 = -cz;  // x_trans - centroid (:434)
+                                            const double pg[8], const double ph[15], double acc[28]) {
+  // R: centroid(3), C = icov (xx,xy,xz,yy,yz,zz), w.  The radius test (VoxelGrid.cpp:470-472) was done by the probe phase.
+  double d0 = (double)tx - R[0], d1 = (double)ty - R[1], d2 = (double)tz - R[2];  // x_trans - centroid (:434)
   double C00 = R[3], C01 = R[4], C02 = R[5], C11 = R[6], C12 = R[7], C22 = R[8];
   double u0 = C00 * d0 + C01 * d1 + C02 * d2;
   double u1 = C01 * d0 + C11 * d1 + C12 * d2;
@@ -81,63 +78,163 @@ __device__ __forceinline__ void pair_update(const PassParams &P, const double *_
   }
 }
 
+// One workgroup (256 lanes) walks tiles of 64 source points in three phases per tile:
+//   0. 64 lanes transform their point (f32, PCL order) and publish it with its clipped 3x3x3 cell box in LDS;
+//   A. all 256 lanes PROBE: 64 points x 27 cells = 1728 probes, 7 per lane, each = one 16-B {occ,valid,prefix} word from
+//      L2, a popcount rank, the 24-B centroid and the radius test.  Hits are compacted into an LDS pair queue at
+//      offsets from a block-wide exclusive scan (not atomics), so the queue order -- and with it every f64 sum -- is
+//      reproducible run to run;
+//   B. all lanes drain the queue: one (point, voxel) pair per lane per step, dense f64 pair math into 28 registers.
+// Only Kbar ~ 2.5-5 of the 27 probed cells hold a usable voxel; separating the cheap probe from the expensive pair
+// math keeps the f64 pipes full instead of leaving ~85 % of the lanes idle in a per-point loop, and spreads a
+// KITTI-sized pass (7-25 k points) over >= 118 workgroups instead of 59 quarter-filled ones.
+constexpr int kTilePts = 64;
+constexpr int kProbesPerPoint = 27;
+constexpr int kProbesPerLane = (kTilePts * kProbesPerPoint + kBlockD - 1) / kBlockD;  // 7
+constexpr int kQueueCap = kTilePts * kProbesPerPoint;                                 // 1728
+
+struct TilePoint {
+  float sx, sy, sz;  // source point (untransformed): feeds the point Jacobian / Hessian terms
+  float tx, ty, tz;  // transformed point
+  int cell0;         // linear index of the box's low corner
+  int nxyz;          // box extent packed nx | ny << 8 | nz << 16 (0 = point contributes nothing)
+};
+
 template <int KIND>
 __global__ __launch_bounds__(kBlockD) void k_ndt_pass(const float4 *__restrict__ src, size_t n, PassParams P, const uint4 *__restrict__ words,
                                                       const double *__restrict__ rec, double *__restrict__ partials) {
+  __shared__ TilePoint tp[kTilePts];
+  __shared__ unsigned queue[kQueueCap];       // point_local | rank << 6
+  __shared__ unsigned wave_tot[kBlockD / 64];
+  __shared__ double sm[kBlockD / 64][kOutDoubles];
   double acc[28];
 #pragma unroll
   for (int k = 0; k < 28; k++) acc[k] = 0.0;
-  unsigned pairs = 0, npts = 0;
+  unsigned long long pairs = 0;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int dimx = P.dim[0], dimxy = P.dim[0] * P.dim[1];
-  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
-    float4 s = src[i];
-    npts++;
-    // pcl::transformPointCloud: x' = m00*x + m01*y + m02*z + m03, f32, left to right, no FMA
-    float tx = lsa_fadd(lsa_fadd(lsa_fadd(lsa_fmul(P.T[0], s.x), lsa_fmul(P.T[1], s.y)), lsa_fmul(P.T[2], s.z)), P.T[3]);
-    float ty = lsa_fadd(lsa_fadd(lsa_fadd(lsa_fmul(P.T[4], s.x), lsa_fmul(P.T[5], s.y)), lsa_fmul(P.T[6], s.z)), P.T[7]);
-    float tz = lsa_fadd(lsa_fadd(lsa_fadd(lsa_fmul(P.T[8], s.x), lsa_fmul(P.T[9], s.y)), lsa_fmul(P.T[10], s.z)), P.T[11]);
-    if (!lsa_finite3(tx, ty, tz)) continue;
-    // radiusSearch cell box (VoxelGrid.cpp:438-455), relative to real_min
-    float r = P.res;
-    int hx = (int)floorf(lsa_fdiv(lsa_fadd(tx, r), r)) - P.min_b[0], lx = (int)floorf(lsa_fdiv(lsa_fsub(tx, r), r)) - P.min_b[0];
-    int hy = (int)floorf(lsa_fdiv(lsa_fadd(ty, r), r)) - P.min_b[1], ly = (int)floorf(lsa_fdiv(lsa_fsub(ty, r), r)) - P.min_b[1];
-    int hz = (int)floorf(lsa_fdiv(lsa_fadd(tz, r), r)) - P.min_b[2], lz = (int)floorf(lsa_fdiv(lsa_fsub(tz, r), r)) - P.min_b[2];
-    hx = min(hx, P.dim[0] - 1); hy = min(hy, P.dim[1] - 1); hz = min(hz, P.dim[2] - 1);
-    lx = max(lx, 0); ly = max(ly, 0); lz = max(lz, 0);
-    if (lx > hx || ly > hy || lz > hz) continue;
-    // point derivative terms depend on the point only (the reference recomputes them per pair)
-    double x = s.x, y = s.y, z = s.z;
-    double pg[8], ph[15];
-#pragma unroll
-    for (int k = 0; k < 8; k++) pg[k] = x * P.ja[k][0] + y * P.ja[k][1] + z * P.ja[k][2];
-    if (KIND != 1) {
-#pragma unroll
-      for (int k = 0; k < 15; k++) ph[k] = x * P.ha[k][0] + y * P.ha[k][1] + z * P.ha[k][2];
-    }
-    for (int iz = lz; iz <= hz; iz++)
-      for (int iy = ly; iy <= hy; iy++) {
-        int base = iy * dimx + iz * dimxy;
-        for (int ix = lx; ix <= hx; ix++) {
-          int cell = base + ix;
-          uint4 w = words[cell >> 5];
-          uint32_t bit = 1u << (cell & 31);
-          if (!(w.y & bit)) continue;  // points_per_voxel >= min_points_per_voxel_ and accepted (:465)
-          unsigned rank = w.z + __popc(w.x & (bit - 1u));
-          pair_update<KIND>(P, rec + (size_t)rank * kRecDoubles, tx, ty, tz, pg, ph, acc, pairs);
+  const size_t ntiles = (n + kTilePts - 1) / kTilePts;
+  for (size_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    // ---- phase 0
+    if (threadIdx.x < kTilePts) {
+      size_t i = tile * kTilePts + threadIdx.x;
+      TilePoint t;
+      t.nxyz = 0; t.cell0 = 0; t.sx = t.sy = t.sz = t.tx = t.ty = t.tz = 0.f;
+      if (i < n) {
+        float4 s = src[i];
+        // pcl::transformPointCloud: x' = m00*x + m01*y + m02*z + m03, f32, left to right, no FMA
+        float tx = lsa_fadd(lsa_fadd(lsa_fadd(lsa_fmul(P.T[0], s.x), lsa_fmul(P.T[1], s.y)), lsa_fmul(P.T[2], s.z)), P.T[3]);
+        float ty = lsa_fadd(lsa_fadd(lsa_fadd(lsa_fmul(P.T[4], s.x), lsa_fmul(P.T[5], s.y)), lsa_fmul(P.T[6], s.z)), P.T[7]);
+        float tz = lsa_fadd(lsa_fadd(lsa_fadd(lsa_fmul(P.T[8], s.x), lsa_fmul(P.T[9], s.y)), lsa_fmul(P.T[10], s.z)), P.T[11]);
+        t.sx = s.x; t.sy = s.y; t.sz = s.z; t.tx = tx; t.ty = ty; t.tz = tz;
+        if (lsa_finite3(tx, ty, tz)) {
+          // radiusSearch cell box (VoxelGrid.cpp:438-455), relative to real_min, clipped to the occupied bounds
+          float r = P.res;
+          int hx = (int)floorf(lsa_fdiv(lsa_fadd(tx, r), r)) - P.min_b[0], lx = (int)floorf(lsa_fdiv(lsa_fsub(tx, r), r)) - P.min_b[0];
+          int hy = (int)floorf(lsa_fdiv(lsa_fadd(ty, r), r)) - P.min_b[1], ly = (int)floorf(lsa_fdiv(lsa_fsub(ty, r), r)) - P.min_b[1];
+          int hz = (int)floorf(lsa_fdiv(lsa_fadd(tz, r), r)) - P.min_b[2], lz = (int)floorf(lsa_fdiv(lsa_fsub(tz, r), r)) - P.min_b[2];
+          hx = min(hx, P.dim[0] - 1); hy = min(hy, P.dim[1] - 1); hz = min(hz, P.dim[2] - 1);
+          lx = max(lx, 0); ly = max(ly, 0); lz = max(lz, 0);
+          // with radius == leaf the box is at most 3 cells wide per axis
+          int nx = min(hx - lx + 1, 3), ny = min(hy - ly + 1, 3), nz = min(hz - lz + 1, 3);
+          if (nx > 0 && ny > 0 && nz > 0) {
+            t.cell0 = lx + ly * dimx + lz * dimxy;
+            t.nxyz = nx | (ny << 8) | (nz << 16);
+          }
         }
       }
+      tp[threadIdx.x] = t;
+    }
+    __syncthreads();
+    // ---- phase A: probe
+    // The 7 probes of a lane are independent; they are staged (all word loads, then all centroid loads) so the L2 round
+    // trips overlap instead of forming 14 dependent hops.  Out-of-box probes read word 0 / record 0 and are masked out.
+    unsigned hit_rank[kProbesPerLane];
+    unsigned hit_mask = 0;
+    int p_pl[kProbesPerLane], p_cell[kProbesPerLane];
+    uint4 p_w[kProbesPerLane];
+#pragma unroll
+    for (int j = 0; j < kProbesPerLane; j++) {
+      int q = threadIdx.x + j * kBlockD;
+      int pl = (q < kQueueCap) ? q / kProbesPerPoint : 0;
+      int o = q - pl * kProbesPerPoint;
+      int dz = o / 9, dy = (o - dz * 9) / 3, dx = o - dz * 9 - dy * 3;
+      int nxyz = tp[pl].nxyz;
+      bool in_box = q < kQueueCap && dx < (nxyz & 0xff) && dy < ((nxyz >> 8) & 0xff) && dz < (nxyz >> 16);
+      p_pl[j] = pl;
+      p_cell[j] = in_box ? tp[pl].cell0 + dx + dy * dimx + dz * dimxy : -1;
+    }
+#pragma unroll
+    for (int j = 0; j < kProbesPerLane; j++) p_w[j] = words[(p_cell[j] < 0 ? 0 : p_cell[j]) >> 5];
+    double p_c[kProbesPerLane][3];
+#pragma unroll
+    for (int j = 0; j < kProbesPerLane; j++) {
+      uint32_t bit = 1u << (p_cell[j] & 31);
+      // points_per_voxel >= min_points_per_voxel_ and accepted eigenvalues (VoxelGrid.cpp:465)
+      bool ok = p_cell[j] >= 0 && (p_w[j].y & bit);
+      unsigned rank = ok ? p_w[j].z + __popc(p_w[j].x & (bit - 1u)) : 0u;
+      hit_rank[j] = ((unsigned)p_pl[j]) | (rank << 6);
+      if (ok) hit_mask |= 1u << j;
+      const double *R = rec + (size_t)rank * kRecDoubles;
+      p_c[j][0] = R[0]; p_c[j][1] = R[1]; p_c[j][2] = R[2];
+    }
+#pragma unroll
+    for (int j = 0; j < kProbesPerLane; j++) {
+      double cx = p_c[j][0] - (double)tp[p_pl[j]].tx, cy = p_c[j][1] - (double)tp[p_pl[j]].ty, cz = p_c[j][2] - (double)tp[p_pl[j]].tz;
+      double dist = sqrt(cx * cx + cy * cy + cz * cz);
+      if (!(dist < (double)P.res)) hit_mask &= ~(1u << j);  // VoxelGrid.cpp:470-472
+    }
+    // deterministic compaction: exclusive scan of the per-lane hit counts over the block
+    unsigned cnt = __popc(hit_mask), incl = cnt;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+      unsigned v = __shfl_up(incl, off, 64);
+      if (lane >= off) incl += v;
+    }
+    if (lane == 63) wave_tot[wave] = incl;
+    __syncthreads();
+    unsigned base = 0, total = 0;
+#pragma unroll
+    for (int w = 0; w < kBlockD / 64; w++) {
+      unsigned t = wave_tot[w];
+      if (w < wave) base += t;
+      total += t;
+    }
+    unsigned pos = base + incl - cnt;
+#pragma unroll
+    for (int j = 0; j < kProbesPerLane; j++)
+      if (hit_mask & (1u << j)) queue[pos++] = hit_rank[j];
+    __syncthreads();
+    // ---- phase B: dense pair math
+    for (unsigned qi = threadIdx.x; qi < total; qi += kBlockD) {
+      unsigned e = queue[qi];
+      const TilePoint &t = tp[e & 63u];
+      const double *R = rec + (size_t)(e >> 6) * kRecDoubles;
+      double x = t.sx, y = t.sy, z = t.sz;
+      double pg[8], ph[15];
+#pragma unroll
+      for (int k = 0; k < 8; k++) pg[k] = x * P.ja[k][0] + y * P.ja[k][1] + z * P.ja[k][2];
+      if (KIND != 1) {
+#pragma unroll
+        for (int k = 0; k < 15; k++) ph[k] = x * P.ha[k][0] + y * P.ha[k][1] + z * P.ha[k][2];
+      }
+      pair_update<KIND>(P, R, t.tx, t.ty, t.tz, pg, ph, acc);
+    }
+    if (threadIdx.x == 0) pairs += total;
+    __syncthreads();  // tp / queue are rewritten by the next tile
   }
   // wave reduction (fixed tree), then across the block's waves through LDS
-  __shared__ double sm[kBlockD / 64][kOutDoubles];
-  int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 #pragma unroll
   for (int k = 0; k < 28; k++) {
     double v = lsa_wave_sum(acc[k]);
     if (lane == 0) sm[wave][k] = v;
   }
-  {
-    double vp = lsa_wave_sum((double)pairs), vn = lsa_wave_sum((double)npts);
-    if (lane == 0) { sm[wave][28] = vp; sm[wave][29] = vn; sm[wave][30] = 0.0; sm[wave][31] = 0.0; }
+  if (lane == 0) {
+    size_t mine = 0;  // points owned by this workgroup (tiles blockIdx.x, +gridDim.x, ...)
+    for (size_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) mine += min((size_t)kTilePts, n - tile * kTilePts);
+    sm[wave][28] = (wave == 0) ? (double)pairs : 0.0;
+    sm[wave][29] = (wave == 0) ? (double)mine : 0.0;
+    sm[wave][30] = 0.0; sm[wave][31] = 0.0;
   }
   __syncthreads();
   if (threadIdx.x < kOutDoubles) {
@@ -204,8 +301,8 @@ void ndt_make_pass_params(const lsa_ndt *h, const float T[16], const double p[6]
 }
 
 unsigned ndt_pass_grid(const lsa_ndt *h, size_t n) {
-  size_t blocks = (n + kBlockD - 1) / kBlockD;
-  size_t cap = (size_t)h->ctx->num_cus * 8;
+  size_t blocks = (n + 63) / 64;  // one 64-point tile per workgroup until the chip is full, then grid-stride
+  size_t cap = (size_t)h->ctx->num_cus * 4;
   if (blocks > cap) blocks = cap;
   if (blocks < 1) blocks = 1;
   return (unsigned)blocks;

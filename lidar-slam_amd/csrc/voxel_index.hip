@@ -78,9 +78,42 @@ __global__ __launch_bounds__(kBlock) void k_bbox_final(const float *__restrict__
   }
 }
 
+// ---- LDS tile hashing ---------------------------------------------------------------------------------------
+// Consecutive lidar returns hit the same few hundred voxels, so a tile of kTile consecutive points is first
+// de-duplicated / pre-aggregated in an LDS open-addressing table keyed by the cell index; only one global atomic per
+// DISTINCT cell of the tile leaves the CU.  (Global atomics execute at the memory side at ~1e10/s and serialise on a
+// shared word; LDS atomics are two orders of magnitude cheaper.)  A point that cannot be placed because the table is
+// full falls back to direct global atomics, so correctness never depends on the tile's diversity.
+constexpr int kTile = 2048;      // points per workgroup
+constexpr int kHashCap = 1024;   // LDS slots (power of two)
+
+__device__ __forceinline__ unsigned lds_hash(int cell) { return ((unsigned)cell * 2654435761u) >> 22; }  // top 10 bits
+
+// returns the slot of `cell` in keys[] (inserting it if new), or -1 if the table is full
+__device__ __forceinline__ int lds_insert(int *keys, int cell) {
+  unsigned h = lds_hash(cell) & (kHashCap - 1);
+  for (int probe = 0; probe < kHashCap; probe++) {
+    int old = keys[h];
+    if (old == cell) return (int)h;
+    if (old == -1) {
+      old = atomicCAS(&keys[h], -1, cell);
+      if (old == -1 || old == cell) return (int)h;
+    }
+    h = (h + 1) & (kHashCap - 1);
+  }
+  return -1;
+}
+
 __global__ __launch_bounds__(kBlock) void k_mark(const float4 *__restrict__ pts, size_t n, CellMap m, uint32_t *__restrict__ bits,
                                                  int32_t *__restrict__ cell_idx) {
-  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+  __shared__ int keys[kHashCap];
+  for (int k = threadIdx.x; k < kHashCap; k += kBlock) keys[k] = -1;
+  __syncthreads();
+  size_t base = (size_t)blockIdx.x * kTile;
+#pragma unroll 2
+  for (int k = 0; k < kTile / kBlock; k++) {
+    size_t i = base + (size_t)k * kBlock + threadIdx.x;
+    if (i >= n) break;
     float4 p = pts[i];
     int cell = -1;
     if (lsa_finite3(p.x, p.y, p.z)) {
@@ -89,12 +122,15 @@ __global__ __launch_bounds__(kBlock) void k_mark(const float4 *__restrict__ pts,
       cell = lsa_cell_linear(m, ijk);
     }
     cell_idx[i] = cell;
+    if (cell >= 0 && lds_insert(keys, cell) < 0) atomicOr(bits + (cell >> 5), 1u << (cell & 31));
+  }
+  __syncthreads();
+  for (int k = threadIdx.x; k < kHashCap; k += kBlock) {
+    int cell = keys[k];
     if (cell >= 0) {
       uint32_t bit = 1u << (cell & 31);
       uint32_t *w = bits + (cell >> 5);
-      // consecutive lidar returns mostly share a voxel: skip the atomic when the bit is already visible
-      // (bits only ever go 0 -> 1 inside this kernel, so a stale 0 merely costs the atomic)
-      if (!(*w & bit)) atomicOr(w, bit);
+      if (!(*w & bit)) atomicOr(w, bit);  // bits only go 0 -> 1 here: a stale 0 merely costs the atomic
     }
   }
 }
@@ -183,32 +219,74 @@ __global__ __launch_bounds__(kBlock) void k_scan_apply(const uint32_t *__restric
 }
 
 template <int NS>
+__device__ __forceinline__ void point_terms(const CellMap &m, const FixScales &fs, int cell, const float4 &p, unsigned long long v[NS]) {
+  double o[3];
+  lsa_cell_origin(m, cell, o);
+  double dx = (double)p.x - o[0], dy = (double)p.y - o[1], dz = (double)p.z - o[2];
+  v[0] = (unsigned long long)__double2ll_rn(dx * fs.s1);
+  v[1] = (unsigned long long)__double2ll_rn(dy * fs.s1);
+  v[2] = (unsigned long long)__double2ll_rn(dz * fs.s1);
+  if (NS == 10) {
+    v[3] = (unsigned long long)__double2ll_rn(dx * dx * fs.s2);
+    v[4] = (unsigned long long)__double2ll_rn(dx * dy * fs.s2);
+    v[5] = (unsigned long long)__double2ll_rn(dx * dz * fs.s2);
+    v[6] = (unsigned long long)__double2ll_rn(dy * dy * fs.s2);
+    v[7] = (unsigned long long)__double2ll_rn(dy * dz * fs.s2);
+    v[8] = (unsigned long long)__double2ll_rn(dz * dz * fs.s2);
+  }
+  v[NS - 1] = (unsigned long long)__double2ll_rn((double)p.w * fs.sw);
+}
+
+__device__ __forceinline__ unsigned cell_rank(const uint32_t *__restrict__ bits, const uint32_t *__restrict__ prefix, int cell) {
+  return prefix[cell >> 5] + __popc(bits[cell >> 5] & ((1u << (cell & 31)) - 1u));
+}
+
+// per-cell fixed-point sums: LDS pre-aggregation per tile, then one set of global atomics per distinct cell
+template <int NS>
 __global__ __launch_bounds__(kBlock) void k_accum(const float4 *__restrict__ pts, const int32_t *__restrict__ cell_idx, size_t n, CellMap m,
                                                   FixScales fs, const uint32_t *__restrict__ bits, const uint32_t *__restrict__ prefix,
                                                   long long *__restrict__ acc, int32_t *__restrict__ cnt) {
-  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+  __shared__ int keys[kHashCap];
+  __shared__ int counts[kHashCap];
+  __shared__ unsigned long long sums[kHashCap][NS];
+  for (int k = threadIdx.x; k < kHashCap; k += kBlock) {
+    keys[k] = -1;
+    counts[k] = 0;
+#pragma unroll
+    for (int j = 0; j < NS; j++) sums[k][j] = 0ull;
+  }
+  __syncthreads();
+  size_t base = (size_t)blockIdx.x * kTile;
+  for (int k = 0; k < kTile / kBlock; k++) {
+    size_t i = base + (size_t)k * kBlock + threadIdx.x;
+    if (i >= n) break;
     int cell = cell_idx[i];
     if (cell < 0) continue;
     float4 p = pts[i];
-    uint32_t w = bits[cell >> 5];
-    unsigned rank = prefix[cell >> 5] + __popc(w & ((1u << (cell & 31)) - 1u));
-    double o[3];
-    lsa_cell_origin(m, cell, o);
-    double dx = (double)p.x - o[0], dy = (double)p.y - o[1], dz = (double)p.z - o[2];
-    unsigned long long *a = (unsigned long long *)(acc + (size_t)rank * NS);
-    atomicAdd(a + 0, (unsigned long long)__double2ll_rn(dx * fs.s1));
-    atomicAdd(a + 1, (unsigned long long)__double2ll_rn(dy * fs.s1));
-    atomicAdd(a + 2, (unsigned long long)__double2ll_rn(dz * fs.s1));
-    if (NS == 10) {
-      atomicAdd(a + 3, (unsigned long long)__double2ll_rn(dx * dx * fs.s2));
-      atomicAdd(a + 4, (unsigned long long)__double2ll_rn(dx * dy * fs.s2));
-      atomicAdd(a + 5, (unsigned long long)__double2ll_rn(dx * dz * fs.s2));
-      atomicAdd(a + 6, (unsigned long long)__double2ll_rn(dy * dy * fs.s2));
-      atomicAdd(a + 7, (unsigned long long)__double2ll_rn(dy * dz * fs.s2));
-      atomicAdd(a + 8, (unsigned long long)__double2ll_rn(dz * dz * fs.s2));
+    unsigned long long v[NS];
+    point_terms<NS>(m, fs, cell, p, v);
+    int slot = lds_insert(keys, cell);
+    if (slot >= 0) {
+#pragma unroll
+      for (int j = 0; j < NS; j++) atomicAdd(&sums[slot][j], v[j]);
+      atomicAdd(&counts[slot], 1);
+    } else {  // table full: straight to memory
+      unsigned rank = cell_rank(bits, prefix, cell);
+      unsigned long long *a = (unsigned long long *)(acc + (size_t)rank * NS);
+#pragma unroll
+      for (int j = 0; j < NS; j++) atomicAdd(a + j, v[j]);
+      atomicAdd(cnt + rank, 1);
     }
-    atomicAdd(a + (NS - 1), (unsigned long long)__double2ll_rn((double)p.w * fs.sw));
-    atomicAdd(cnt + rank, 1);
+  }
+  __syncthreads();
+  for (int k = threadIdx.x; k < kHashCap; k += kBlock) {
+    int cell = keys[k];
+    if (cell < 0) continue;
+    unsigned rank = cell_rank(bits, prefix, cell);
+    unsigned long long *a = (unsigned long long *)(acc + (size_t)rank * NS);
+#pragma unroll
+    for (int j = 0; j < NS; j++) atomicAdd(a + j, sums[k][j]);
+    atomicAdd(cnt + rank, counts[k]);
   }
 }
 
@@ -315,7 +393,7 @@ int vi_build(lsa_context *ctx, VoxelIndex &vi, const float4 *d_pts, size_t n) {
   if ((rc = vi.cell_of_rank.reserve(ctx, n, 1.25))) return rc;  // #occupied <= #points
   if ((rc = vi.h_small.reserve(ctx, 16))) return rc;
   LSA_HIP(ctx, hipMemsetAsync(vi.bits.p, 0, vi.W * sizeof(uint32_t), ctx->stream));
-  hipLaunchKernelGGL(k_mark, dim3(stream_grid(ctx, n)), dim3(kBlock), 0, ctx->stream, d_pts, n, m, vi.bits.p, vi.cell_idx.p);
+  hipLaunchKernelGGL(k_mark, dim3(lsa_div_up(n, kTile)), dim3(kBlock), 0, ctx->stream, d_pts, n, m, vi.bits.p, vi.cell_idx.p);
   hipLaunchKernelGGL(k_scan_block_sums, dim3(nsb), dim3(kBlock), 0, ctx->stream, vi.bits.p, vi.W, vi.blocksums.p);
   hipLaunchKernelGGL(k_scan_top, dim3(1), dim3(1024), 0, ctx->stream, vi.blocksums.p, (int)nsb);
   hipLaunchKernelGGL(k_scan_apply, dim3(nsb), dim3(kBlock), 0, ctx->stream, vi.bits.p, vi.W, vi.blocksums.p, vi.prefix.p, vi.cell_of_rank.p);
@@ -334,7 +412,7 @@ int vi_accumulate(lsa_context *ctx, VoxelIndex &vi, const float4 *d_pts, size_t 
   if ((rc = vi.cnt.reserve(ctx, vi.nocc + 1, 1.25))) return rc;
   LSA_HIP(ctx, hipMemsetAsync(vi.acc.p, 0, (vi.nocc * (size_t)ns + 1) * sizeof(long long), ctx->stream));
   LSA_HIP(ctx, hipMemsetAsync(vi.cnt.p, 0, (vi.nocc + 1) * sizeof(int32_t), ctx->stream));
-  unsigned g = stream_grid(ctx, n);
+  unsigned g = lsa_div_up(n, kTile);
   if (ns == 4)
     hipLaunchKernelGGL(k_accum<4>, dim3(g), dim3(kBlock), 0, ctx->stream, d_pts, vi.cell_idx.p, n, vi.map, vi.fs, vi.bits.p, vi.prefix.p, vi.acc.p, vi.cnt.p);
   else

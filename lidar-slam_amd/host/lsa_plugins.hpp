@@ -1,0 +1,211 @@
+// lsa_plugins.hpp — header-only C++ host side above the C-ABI, mirroring the reference's plugin layer.
+//
+// Same class shapes, method names, argument meaning and error behaviour as
+//   lidar_localization::CloudFilterInterface  (include/lidar_localization/models/cloud_filter/cloud_filter_interface.hpp:13-18)
+//   lidar_localization::VoxelFilter           (src/models/cloud_filter/voxel_filter.cpp:12-41)
+//   lidar_localization::NoFilter              (src/models/cloud_filter/no_filter.cpp:13-16)
+//   lidar_localization::RegistrationInterface (include/lidar_localization/models/registration/registration_interface.hpp:14-24)
+//   lidar_localization::NDTRegistrationManual (src/models/registration/ndt_registration_manual.cpp:12-78)
+//   lidar_localization::ICPRegistrationManual (src/models/registration/icp_registration_manual.cpp:12-67)
+// but free of PCL / Eigen / yaml-cpp so it builds in this image: the cloud and pose types below are layout-compatible
+// with pcl::PointCloud<pcl::PointXYZI>::points and Eigen::Matrix4f.  INTEGRATION.md shows the same adaptors written
+// against the reference's own types (CloudData::CLOUD_PTR, Eigen::Matrix4f, YAML::Node) for its catkin tree.
+//
+// Like the reference, every method returns true and reports problems on stderr (the reference: LOG(ERROR)); unlike it,
+// a failed call leaves the outputs untouched and last_status() holds the lsa_status.
+#ifndef LSA_PLUGINS_HPP_
+#define LSA_PLUGINS_HPP_
+
+#include <cstdio>
+#include <cstring>
+#include <memory>
+#include <stdexcept>
+#include <vector>
+
+#include "lidar_slam_amd.h"
+
+namespace lsa {
+
+struct alignas(16) PointXYZI {  // == pcl::PointXYZI (cloud_data.hpp:35): 32 bytes
+  float x = 0, y = 0, z = 0, data3 = 1.0f;
+  float intensity = 0, pad0 = 0, pad1 = 0, pad2 = 0;
+};
+static_assert(sizeof(PointXYZI) == LSA_POINTXYZI_STRIDE, "PointXYZI must be 32 bytes");
+
+struct Cloud {
+  std::vector<PointXYZI> points;
+  size_t size() const { return points.size(); }
+};
+
+struct CloudData {  // cloud_data.hpp:33-48
+  using POINT = PointXYZI;
+  using CLOUD = Cloud;
+  using CLOUD_PTR = std::shared_ptr<Cloud>;
+  double time = 0.0;
+  CLOUD_PTR cloud_ptr = std::make_shared<Cloud>();
+};
+
+struct Matrix4f {  // column-major like Eigen::Matrix4f
+  float m[16];
+  static Matrix4f Identity() {
+    Matrix4f r;
+    std::memset(r.m, 0, sizeof(r.m));
+    r.m[0] = r.m[5] = r.m[10] = r.m[15] = 1.0f;
+    return r;
+  }
+  float &operator()(int row, int col) { return m[col * 4 + row]; }
+  float operator()(int row, int col) const { return m[col * 4 + row]; }
+  const float *data() const { return m; }
+  float *data() { return m; }
+};
+
+// one per process per GPU; owns the lsa_context
+class Context {
+ public:
+  explicit Context(int device = 0, void *hip_stream = nullptr) {
+    int rc = lsa_context_create(&ctx_, device, hip_stream);
+    if (rc != LSA_OK) throw std::runtime_error(std::string("lsa_context_create: ") + lsa_last_global_error());
+  }
+  ~Context() { lsa_context_destroy(ctx_); }
+  Context(const Context &) = delete;
+  Context &operator=(const Context &) = delete;
+  lsa_context *get() const { return ctx_; }
+
+ private:
+  lsa_context *ctx_ = nullptr;
+};
+
+inline bool report(const char *who, lsa_context *ctx, int rc) {
+  if (rc != LSA_OK) std::fprintf(stderr, "[lsa] %s failed (%d): %s\n", who, rc, lsa_last_error(ctx));
+  return true;  // the reference's plugins return true unconditionally and callers ignore the value
+}
+
+// ---------------------------------------------------------------------------------------------- cloud_filter
+class CloudFilterInterface {
+ public:
+  virtual ~CloudFilterInterface() = default;
+  virtual bool Filter(const CloudData::CLOUD_PTR &input_cloud_ptr, CloudData::CLOUD_PTR &filtered_cloud_ptr) = 0;
+};
+
+class NoFilter : public CloudFilterInterface {
+ public:
+  bool Filter(const CloudData::CLOUD_PTR &in, CloudData::CLOUD_PTR &out) override {
+    if (out.get() != in.get()) out->points = in->points;  // no_filter.cpp:14: deep copy
+    return true;
+  }
+};
+
+class VoxelFilterHip : public CloudFilterInterface {
+ public:
+  VoxelFilterHip(const std::shared_ptr<Context> &ctx, float leaf_size_x, float leaf_size_y, float leaf_size_z) : ctx_(ctx) {
+    report("lsa_voxel_filter_create", ctx_->get(), lsa_voxel_filter_create(&f_, ctx_->get(), leaf_size_x, leaf_size_y, leaf_size_z));
+  }
+  ~VoxelFilterHip() override { lsa_voxel_filter_destroy(f_); }
+  bool Filter(const CloudData::CLOUD_PTR &in, CloudData::CLOUD_PTR &out) override {
+    // `out` may be `in` (viewer.cpp:207) or an empty pre-allocated cloud (front_end.cpp:106-107)
+    std::vector<PointXYZI> tmp(in->points.size());
+    size_t n_out = 0;
+    status_ = lsa_voxel_filter_apply(f_, in->points.data(), in->points.size(), sizeof(PointXYZI), LSA_POINTXYZI_W_OFF, tmp.data(), tmp.size(),
+                                     sizeof(PointXYZI), LSA_POINTXYZI_W_OFF, &n_out);
+    if (status_ == LSA_OK || status_ == LSA_ERR_RANGE) {  // PCL passes the input through when the leaf is too small
+      tmp.resize(n_out);
+      out->points.swap(tmp);
+      return true;
+    }
+    return report("VoxelFilterHip::Filter", ctx_->get(), status_);
+  }
+  int last_status() const { return status_; }
+
+ private:
+  std::shared_ptr<Context> ctx_;
+  lsa_voxel_filter *f_ = nullptr;
+  int status_ = LSA_OK;
+};
+
+// ---------------------------------------------------------------------------------------------- registration
+class RegistrationInterface {
+ public:
+  virtual ~RegistrationInterface() = default;
+  virtual bool SetInputTarget(const CloudData::CLOUD_PTR &input_target) = 0;
+  virtual bool ScanMatch(const CloudData::CLOUD_PTR &input_source, const Matrix4f &predict_pose, CloudData::CLOUD_PTR &result_cloud_ptr,
+                         Matrix4f &result_pose) = 0;
+  virtual float GetFitnessScore() = 0;
+};
+
+class NDTRegistrationHip : public RegistrationInterface {
+ public:
+  NDTRegistrationHip(const std::shared_ptr<Context> &ctx, float res, float step_size, float trans_eps, int max_iter, float outlier_ratio)
+      : ctx_(ctx) {
+    report("lsa_ndt_create", ctx_->get(), lsa_ndt_create(&ndt_, ctx_->get(), res, step_size, trans_eps, max_iter, outlier_ratio));
+    std::printf("NDT HIP params: res %g, step_size %g, trans_eps %g, max_iter %d, outlier_ratio %g\n", res, step_size, trans_eps, max_iter,
+                outlier_ratio);  // the reference echoes its parameters (ndt_registration_manual.cpp:37-44)
+  }
+  ~NDTRegistrationHip() override { lsa_ndt_destroy(ndt_); }
+  bool SetInputTarget(const CloudData::CLOUD_PTR &t) override {
+    status_ = lsa_ndt_set_input_target(ndt_, t->points.data(), t->points.size(), sizeof(PointXYZI), LSA_POINTXYZI_W_OFF);
+    return report("NDTRegistrationHip::SetInputTarget", ctx_->get(), status_);
+  }
+  bool ScanMatch(const CloudData::CLOUD_PTR &src, const Matrix4f &predict_pose, CloudData::CLOUD_PTR &result_cloud_ptr, Matrix4f &result_pose) override {
+    (void)result_cloud_ptr;  // never written by NDTRegistrationManual (Registration.cpp:92-95), read by no caller
+    Matrix4f out = predict_pose;
+    status_ = lsa_ndt_scan_match(ndt_, src->points.data(), src->points.size(), sizeof(PointXYZI), predict_pose.data(), out.data(), &stats_);
+    if (status_ == LSA_OK) result_pose = out;
+    return report("NDTRegistrationHip::ScanMatch", ctx_->get(), status_);
+  }
+  float GetFitnessScore() override {
+    float s = 0.f;
+    status_ = lsa_ndt_get_fitness_score(ndt_, &s);
+    report("NDTRegistrationHip::GetFitnessScore", ctx_->get(), status_);
+    return s;
+  }
+  const lsa_ndt_stats &stats() const { return stats_; }
+  int last_status() const { return status_; }
+  lsa_ndt *handle() const { return ndt_; }
+
+ private:
+  std::shared_ptr<Context> ctx_;
+  lsa_ndt *ndt_ = nullptr;
+  lsa_ndt_stats stats_{};
+  int status_ = LSA_OK;
+};
+
+class ICPRegistrationHip : public RegistrationInterface {
+ public:
+  // mode 0: ICPRegistrationManual semantics (point-to-point GN, icp_registration_manual.cpp:125-178); 1: point-to-plane
+  ICPRegistrationHip(const std::shared_ptr<Context> &ctx, float max_correspond_dis, int max_iter, int mode = 0) : ctx_(ctx) {
+    report("lsa_icp_create", ctx_->get(), lsa_icp_create(&icp_, ctx_->get(), max_correspond_dis, max_iter, mode));
+  }
+  ~ICPRegistrationHip() override { lsa_icp_destroy(icp_); }
+  bool SetInputTarget(const CloudData::CLOUD_PTR &t) override {
+    status_ = lsa_icp_set_input_target(icp_, t->points.data(), t->points.size(), sizeof(PointXYZI));
+    return report("ICPRegistrationHip::SetInputTarget", ctx_->get(), status_);
+  }
+  bool ScanMatch(const CloudData::CLOUD_PTR &src, const Matrix4f &predict_pose, CloudData::CLOUD_PTR &result_cloud_ptr, Matrix4f &result_pose) override {
+    Matrix4f out = predict_pose;
+    status_ = lsa_icp_scan_match(icp_, src->points.data(), src->points.size(), sizeof(PointXYZI), predict_pose.data(), out.data());
+    if (status_ == LSA_OK) {
+      result_pose = out;
+      // ICPRegistrationManual fills result_cloud_ptr with the aligned source (icp_registration_manual.cpp:57)
+      if (result_cloud_ptr) {
+        result_cloud_ptr->points = src->points;
+        for (auto &p : result_cloud_ptr->points) {
+          float x = p.x, y = p.y, z = p.z;
+          p.x = out(0, 0) * x + out(0, 1) * y + out(0, 2) * z + out(0, 3);
+          p.y = out(1, 0) * x + out(1, 1) * y + out(1, 2) * z + out(1, 3);
+          p.z = out(2, 0) * x + out(2, 1) * y + out(2, 2) * z + out(2, 3);
+        }
+      }
+    }
+    return report("ICPRegistrationHip::ScanMatch", ctx_->get(), status_);
+  }
+  float GetFitnessScore() override { return 0.f; }  // unimplemented in the reference, returns 0 (:62-67)
+  int last_status() const { return status_; }
+
+ private:
+  std::shared_ptr<Context> ctx_;
+  lsa_icp *icp_ = nullptr;
+  int status_ = LSA_OK;
+};
+
+}  // namespace lsa
+#endif
