@@ -81,6 +81,7 @@ extern "C" void lsa_ndt_destroy(lsa_ndt *h) {
   if (!h) return;
   (void)hipSetDevice(h->ctx->device);
   (void)hipStreamSynchronize(h->ctx->stream);
+  ndt_fitness_release(h);
   h->vi.release(); h->d_target.release(); h->rec.release(); h->state.release(); h->vbits.release(); h->words.release(); h->d_small.release();
   h->d_source_own.release(); h->h_stage.release(); h->partials.release(); h->d_out.release(); h->h_out.release();
   delete h;

@@ -216,6 +216,8 @@ int ndt_build_grid(lsa_ndt *h, const float4 *d_pts, size_t n) {
   memcpy(&nvalid, vi.h_small.p, sizeof(unsigned));
   h->n_valid = nvalid;
   h->n_target = n;
+  h->d_target_pts = d_pts;
+  ndt_fitness_invalidate(h);
   h->has_target = true;
   return LSA_OK;
 }

@@ -9,6 +9,8 @@ constexpr int kRecDoubles = 10;
 // per-pass result: [score, g(6), H upper triangle (21), #pairs, #points, 0, 0]
 constexpr int kOutDoubles = 32;
 
+struct FitnessState;  // ndt_fitness.hip
+
 struct lsa_ndt {
   lsa_context *ctx = nullptr;
   float resolution = 1.0f;
@@ -26,6 +28,8 @@ struct lsa_ndt {
   DevBuf<double> d_small;
   bool has_target = false;
   size_t n_target = 0, n_valid = 0;
+  const float4 *d_target_pts = nullptr;  // the cloud the table was built from (ours, or the caller's device buffer)
+  FitnessState *fitness = nullptr;       // lazily built leaf table for GetFitnessScore
 
   // source
   DevBuf<float4> d_source_own;
@@ -49,5 +53,7 @@ struct lsa_ndt {
 };
 
 int ndt_build_grid(lsa_ndt *h, const float4 *d_pts, size_t n);
+void ndt_fitness_invalidate(lsa_ndt *h);
+void ndt_fitness_release(lsa_ndt *h);
 
 #endif

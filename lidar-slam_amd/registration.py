@@ -138,6 +138,56 @@ class NDTRegistrationHip(RegistrationInterface):
             pass
 
 
+class ICPRegistrationHip(RegistrationInterface):
+    """ICPRegistrationManual(max_correspond_dis, max_iter) or (node) with the YAML keys of
+    config/mapping/front_end.yaml:37-39 (reference: src/models/registration/icp_registration_manual.cpp:12-67)."""
+
+    def __init__(self, ctx, max_correspond_dis=2.0, max_iter=30, node=None, mode=0):
+        if node is not None:
+            max_correspond_dis, max_iter = float(node["max_correspond_dis"]), int(node["max_iter"])
+        self.ctx = ctx
+        h = C.c_void_p()
+        ctx.check(capi.lib().lsa_icp_create(C.byref(h), ctx.h, max_correspond_dis, max_iter, mode))
+        self.h = h
+        self._keep = None
+
+    def SetInputTarget(self, input_target):  # noqa: N802
+        if _is_tensor(input_target):
+            self._keep = input_target
+            self.ctx.check(capi.lib().lsa_icp_set_input_target_device(self.h, input_target.data_ptr(), input_target.shape[0]))
+        else:
+            pts = np.ascontiguousarray(input_target, dtype=np.float32)
+            self.ctx.check(capi.lib().lsa_icp_set_input_target(self.h, pts.ctypes.data, pts.shape[0], pts.strides[0]))
+        return True
+
+    def ScanMatch(self, input_source, predict_pose):  # noqa: N802
+        guess = capi.colmajor(predict_pose)
+        out = np.zeros(16, dtype=np.float32)
+        if _is_tensor(input_source):
+            rc = capi.lib().lsa_icp_scan_match_device(self.h, input_source.data_ptr(), input_source.shape[0], capi.fptr(guess), capi.fptr(out))
+        else:
+            pts = np.ascontiguousarray(input_source, dtype=np.float32)
+            rc = capi.lib().lsa_icp_scan_match(self.h, pts.ctypes.data, pts.shape[0], pts.strides[0], capi.fptr(guess), capi.fptr(out))
+        self.ctx.check(rc)
+        return True, capi.from_colmajor(out)
+
+    def GetFitnessScore(self):  # noqa: N802
+        v = C.c_float(-1)
+        self.ctx.check(capi.lib().lsa_icp_get_fitness_score(self.h, C.byref(v)))
+        return v.value
+
+    def close(self):
+        if self.h and self.ctx.h:
+            capi.lib().lsa_icp_destroy(self.h)
+        self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 def unpack_out32(out):
     score = out[0]
     g = out[1:7].copy()
