@@ -87,8 +87,9 @@ def pose_err(Ta, Tb):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=300)
-    ap.add_argument("--warmup", type=int, default=30)
+    ap.add_argument("--steps", type=int, default=2000)
+    ap.add_argument("--warmup", type=int, default=100)
+    ap.add_argument("--ramp-seconds", type=float, default=1.5, help="untimed clock-ramp spin before the W warm-up steps")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="bound on the CPU-baseline sample (rank 0, N = 1)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
@@ -197,6 +198,13 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    # clock ramp: a step is ~0.2 ms of latency-bound kernels, so W steps alone end before the GPU has left its idle
+    # DVFS state; spin the same work (untimed, results discarded) for a fixed wall time first, then do the W warm-ups
+    t_ramp = time.perf_counter()
+    i_ramp = 0
+    while time.perf_counter() - t_ramp < args.ramp_seconds:
+        step(i_ramp)
+        i_ramp += 1
     for i in range(args.warmup):
         step(i)
     sync_all()

@@ -275,16 +275,19 @@ int icp_build(lsa_icp *h, const float4 *d_pts, size_t n) {
   lsa_context *ctx = h->ctx;
   VoxelIndex &vi = h->vi;
   h->has_target = false;
-  float mn[3], mx[3];
-  size_t nfin = 0;
-  int rc = vi_bbox(ctx, vi, d_pts, n, mn, mx, &nfin);
-  if (rc) return rc;
-  if (nfin == 0) return lsa_fail(ctx, LSA_ERR_INVALID, "ICP SetInputTarget: no finite points");
   float cell = std::sqrt(h->max_corr);
   if (!(cell > 0.05f)) cell = 0.05f;
-  rc = vi_make_map_ndt(mn, mx, cell, &vi.map);
-  if (rc) return lsa_fail(ctx, LSA_ERR_RANGE, "ICP SetInputTarget: neighbour grid overflows int32");
-  if ((rc = vi_build(ctx, vi, d_pts, n))) return rc;
+  const float leaf[3] = {cell, cell, cell};
+  int rc, status = VI_OK;
+  for (int attempt = 0; attempt < 2; attempt++) {
+    if ((rc = vi_enqueue(ctx, vi, d_pts, n, /*mode NDT-style floor(x / cell)*/ 1, leaf, 4))) return rc;
+    if ((rc = vi_fetch(ctx, vi))) return rc;
+    if ((rc = vi_wait(ctx, vi, &status))) return rc;
+    if (status != VI_CAPACITY) break;
+    if ((rc = vi_grow(ctx, vi))) return rc;
+  }
+  if (status == VI_EMPTY) return lsa_fail(ctx, LSA_ERR_INVALID, "ICP SetInputTarget: no finite points");
+  if (status != VI_OK) return lsa_fail(ctx, LSA_ERR_RANGE, "ICP SetInputTarget: neighbour grid overflows int32");
   size_t V = vi.nocc;
   if ((rc = h->cnt.reserve(ctx, V + 1, 1.25))) return rc;
   if ((rc = h->start.reserve(ctx, V + 2, 1.25))) return rc;

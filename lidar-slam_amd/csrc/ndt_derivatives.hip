@@ -21,6 +21,9 @@
 namespace {
 
 constexpr int kBlockD = 256;
+#ifndef LSA_PASS_WAVES
+#define LSA_PASS_WAVES 2  // min waves per SIMD requested from the register allocator (2 x 256-thread workgroups per CU)
+#endif
 
 template <int KIND>
 __device__ __forceinline__ void pair_update(const PassParams &P, const double *__restrict__ R, float tx, float ty, float tz,
@@ -78,35 +81,50 @@ __device__ __forceinline__ void pair_update(const PassParams &P, const double *_
   }
 }
 
-// One workgroup (256 lanes) walks tiles of 64 source points in three phases per tile:
-//   0. 64 lanes transform their point (f32, PCL order) and publish it with its clipped 3x3x3 cell box in LDS;
+// One workgroup (256 lanes = 4 waves) walks tiles of 64 source points in three phases per tile:
+//   0. every wave loads the tile's 64 points; wave 0 transforms them (f32, PCL order) and publishes the clipped 3x3x3
+//      cell box, and each wave computes its quarter of the 23 point-derivative dot products (8 Jacobian + 15 Hessian
+//      terms, computePointDerivatives) into LDS -- once per POINT, not once per pair as the reference does;
 //   A. all 256 lanes PROBE: 64 points x 27 cells = 1728 probes, 7 per lane, each = one 16-B {occ,valid,prefix} word from
-//      L2, a popcount rank, the 24-B centroid and the radius test.  Hits are compacted into an LDS pair queue at
-//      offsets from a block-wide exclusive scan (not atomics), so the queue order -- and with it every f64 sum -- is
-//      reproducible run to run;
+//      L2, a popcount rank, the 24-B centroid and the radius test (on the squared distance against a host-computed
+//      exact threshold: no f64 sqrt per probe).  Hits are compacted into an LDS pair queue at offsets from a block-wide
+//      exclusive scan (not atomics), so the queue order -- and with it every f64 sum -- is reproducible run to run;
 //   B. all lanes drain the queue: one (point, voxel) pair per lane per step, dense f64 pair math into 28 registers.
 // Only Kbar ~ 2.5-5 of the 27 probed cells hold a usable voxel; separating the cheap probe from the expensive pair
 // math keeps the f64 pipes full instead of leaving ~85 % of the lanes idle in a per-point loop, and spreads a
-// KITTI-sized pass (7-25 k points) over >= 118 workgroups instead of 59 quarter-filled ones.
+// KITTI-sized pass (7-25 k points) over >= 118 workgroups.  The 69 angle-derivative constants are touched only in
+// phase 0 (a quarter per wave), which keeps them out of the pair loop's scalar registers.
 constexpr int kTilePts = 64;
 constexpr int kProbesPerPoint = 27;
 constexpr int kProbesPerLane = (kTilePts * kProbesPerPoint + kBlockD - 1) / kBlockD;  // 7
 constexpr int kQueueCap = kTilePts * kProbesPerPoint;                                 // 1728
+constexpr int kPointTerms = 23;   // pg[8] + ph[15]
+constexpr int kTermStride = 24;
+constexpr int kRedStride = 29;    // 28 accumulators per lane, padded: conflict-free LDS transpose
 
 struct TilePoint {
-  float sx, sy, sz;  // source point (untransformed): feeds the point Jacobian / Hessian terms
+  float sx, sy, sz;  // source point (untransformed)
   float tx, ty, tz;  // transformed point
   int cell0;         // linear index of the box's low corner
   int nxyz;          // box extent packed nx | ny << 8 | nz << 16 (0 = point contributes nothing)
 };
 
+constexpr int kLdsTp = 0;
+constexpr int kLdsTerms = kLdsTp + kTilePts * (int)sizeof(TilePoint);                    // 2048
+constexpr int kLdsQueue = kLdsTerms + kTilePts * kTermStride * 8;                        // + 12288
+constexpr int kLdsWaveTot = kLdsQueue + kQueueCap * 4;                                   // + 6912
+constexpr int kLdsTileEnd = kLdsWaveTot + 16;
+constexpr int kLdsRed = kBlockD * kRedStride * 8;                                        // 59392 (aliases the tile area after the loop)
+constexpr int kLdsBytes = (kLdsRed > kLdsTileEnd ? kLdsRed : kLdsTileEnd) + 8 * 32 * 8;  // + second-stage [8][32]
+
 template <int KIND>
-__global__ __launch_bounds__(kBlockD) void k_ndt_pass(const float4 *__restrict__ src, size_t n, PassParams P, const uint4 *__restrict__ words,
+__global__ __launch_bounds__(kBlockD, LSA_PASS_WAVES) void k_ndt_pass(const float4 *__restrict__ src, size_t n, PassParams P, const uint4 *__restrict__ words,
                                                       const double *__restrict__ rec, double *__restrict__ partials) {
-  __shared__ TilePoint tp[kTilePts];
-  __shared__ unsigned queue[kQueueCap];       // point_local | rank << 6
-  __shared__ unsigned wave_tot[kBlockD / 64];
-  __shared__ double sm[kBlockD / 64][kOutDoubles];
+  __shared__ __align__(16) unsigned char lds[kLdsBytes];
+  TilePoint *tp = reinterpret_cast<TilePoint *>(lds + kLdsTp);
+  double *terms = reinterpret_cast<double *>(lds + kLdsTerms);
+  unsigned *queue = reinterpret_cast<unsigned *>(lds + kLdsQueue);
+  unsigned *wave_tot = reinterpret_cast<unsigned *>(lds + kLdsWaveTot);
   double acc[28];
 #pragma unroll
   for (int k = 0; k < 28; k++) acc[k] = 0.0;
@@ -114,36 +132,52 @@ __global__ __launch_bounds__(kBlockD) void k_ndt_pass(const float4 *__restrict__
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int dimx = P.dim[0], dimxy = P.dim[0] * P.dim[1];
   const size_t ntiles = (n + kTilePts - 1) / kTilePts;
+  const double *jh = &P.ja[0][0];  // ja[8][3] followed by ha[15][3]: 23 constant 3-vectors
+  // software prefetch of the next tile's points (every wave holds its own copy of the 64 points)
+  float4 s_next = make_float4(0.f, 0.f, 0.f, 0.f);
+  {
+    size_t i0 = (size_t)blockIdx.x * kTilePts + lane;
+    if (i0 < n) s_next = src[i0];
+  }
   for (size_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
     // ---- phase 0
-    if (threadIdx.x < kTilePts) {
-      size_t i = tile * kTilePts + threadIdx.x;
-      TilePoint t;
-      t.nxyz = 0; t.cell0 = 0; t.sx = t.sy = t.sz = t.tx = t.ty = t.tz = 0.f;
-      if (i < n) {
-        float4 s = src[i];
-        // pcl::transformPointCloud: x' = m00*x + m01*y + m02*z + m03, f32, left to right, no FMA
-        float tx = lsa_fadd(lsa_fadd(lsa_fadd(lsa_fmul(P.T[0], s.x), lsa_fmul(P.T[1], s.y)), lsa_fmul(P.T[2], s.z)), P.T[3]);
-        float ty = lsa_fadd(lsa_fadd(lsa_fadd(lsa_fmul(P.T[4], s.x), lsa_fmul(P.T[5], s.y)), lsa_fmul(P.T[6], s.z)), P.T[7]);
-        float tz = lsa_fadd(lsa_fadd(lsa_fadd(lsa_fmul(P.T[8], s.x), lsa_fmul(P.T[9], s.y)), lsa_fmul(P.T[10], s.z)), P.T[11]);
-        t.sx = s.x; t.sy = s.y; t.sz = s.z; t.tx = tx; t.ty = ty; t.tz = tz;
-        if (lsa_finite3(tx, ty, tz)) {
-          // radiusSearch cell box (VoxelGrid.cpp:438-455), relative to real_min, clipped to the occupied bounds
-          float r = P.res;
-          int hx = (int)floorf(lsa_fdiv(lsa_fadd(tx, r), r)) - P.min_b[0], lx = (int)floorf(lsa_fdiv(lsa_fsub(tx, r), r)) - P.min_b[0];
-          int hy = (int)floorf(lsa_fdiv(lsa_fadd(ty, r), r)) - P.min_b[1], ly = (int)floorf(lsa_fdiv(lsa_fsub(ty, r), r)) - P.min_b[1];
-          int hz = (int)floorf(lsa_fdiv(lsa_fadd(tz, r), r)) - P.min_b[2], lz = (int)floorf(lsa_fdiv(lsa_fsub(tz, r), r)) - P.min_b[2];
-          hx = min(hx, P.dim[0] - 1); hy = min(hy, P.dim[1] - 1); hz = min(hz, P.dim[2] - 1);
-          lx = max(lx, 0); ly = max(ly, 0); lz = max(lz, 0);
-          // with radius == leaf the box is at most 3 cells wide per axis
-          int nx = min(hx - lx + 1, 3), ny = min(hy - ly + 1, 3), nz = min(hz - lz + 1, 3);
-          if (nx > 0 && ny > 0 && nz > 0) {
-            t.cell0 = lx + ly * dimx + lz * dimxy;
-            t.nxyz = nx | (ny << 8) | (nz << 16);
+    {
+      size_t i = tile * kTilePts + lane;
+      float4 s = s_next;
+      size_t inext = (tile + gridDim.x) * kTilePts + lane;
+      if (inext < n) s_next = src[inext];
+      if (wave == 0) {
+        TilePoint t;
+        t.nxyz = 0; t.cell0 = 0; t.sx = s.x; t.sy = s.y; t.sz = s.z; t.tx = t.ty = t.tz = 0.f;
+        if (i < n) {
+          // pcl::transformPointCloud: x' = m00*x + m01*y + m02*z + m03, f32, left to right, no FMA
+          float tx = lsa_fadd(lsa_fadd(lsa_fadd(lsa_fmul(P.T[0], s.x), lsa_fmul(P.T[1], s.y)), lsa_fmul(P.T[2], s.z)), P.T[3]);
+          float ty = lsa_fadd(lsa_fadd(lsa_fadd(lsa_fmul(P.T[4], s.x), lsa_fmul(P.T[5], s.y)), lsa_fmul(P.T[6], s.z)), P.T[7]);
+          float tz = lsa_fadd(lsa_fadd(lsa_fadd(lsa_fmul(P.T[8], s.x), lsa_fmul(P.T[9], s.y)), lsa_fmul(P.T[10], s.z)), P.T[11]);
+          t.tx = tx; t.ty = ty; t.tz = tz;
+          if (lsa_finite3(tx, ty, tz)) {
+            // radiusSearch cell box (VoxelGrid.cpp:438-455), relative to real_min, clipped to the occupied bounds
+            float r = P.res;
+            int hx = (int)floorf(lsa_fdiv(lsa_fadd(tx, r), r)) - P.min_b[0], lx = (int)floorf(lsa_fdiv(lsa_fsub(tx, r), r)) - P.min_b[0];
+            int hy = (int)floorf(lsa_fdiv(lsa_fadd(ty, r), r)) - P.min_b[1], ly = (int)floorf(lsa_fdiv(lsa_fsub(ty, r), r)) - P.min_b[1];
+            int hz = (int)floorf(lsa_fdiv(lsa_fadd(tz, r), r)) - P.min_b[2], lz = (int)floorf(lsa_fdiv(lsa_fsub(tz, r), r)) - P.min_b[2];
+            hx = min(hx, P.dim[0] - 1); hy = min(hy, P.dim[1] - 1); hz = min(hz, P.dim[2] - 1);
+            lx = max(lx, 0); ly = max(ly, 0); lz = max(lz, 0);
+            // with radius == leaf the box is at most 3 cells wide per axis
+            int nx = min(hx - lx + 1, 3), ny = min(hy - ly + 1, 3), nz = min(hz - lz + 1, 3);
+            if (nx > 0 && ny > 0 && nz > 0) {
+              t.cell0 = lx + ly * dimx + lz * dimxy;
+              t.nxyz = nx | (ny << 8) | (nz << 16);
+            }
           }
         }
+        tp[lane] = t;
       }
-      tp[threadIdx.x] = t;
+      // computePointDerivatives (:448-482): dot products of the source point with the angle-derivative vectors;
+      // wave w owns terms 6w .. 6w+5 (KIND 1 needs only the 8 Jacobian terms)
+      double x = s.x, y = s.y, z = s.z;
+      const int k0 = wave * 6, k1 = min(k0 + 6, (KIND == 1) ? 8 : kPointTerms);
+      for (int k = k0; k < k1; k++) terms[lane * kTermStride + k] = x * jh[k * 3] + y * jh[k * 3 + 1] + z * jh[k * 3 + 2];
     }
     __syncthreads();
     // ---- phase A: probe
@@ -181,8 +215,8 @@ __global__ __launch_bounds__(kBlockD) void k_ndt_pass(const float4 *__restrict__
 #pragma unroll
     for (int j = 0; j < kProbesPerLane; j++) {
       double cx = p_c[j][0] - (double)tp[p_pl[j]].tx, cy = p_c[j][1] - (double)tp[p_pl[j]].ty, cz = p_c[j][2] - (double)tp[p_pl[j]].tz;
-      double dist = sqrt(cx * cx + cy * cy + cz * cz);
-      if (!(dist < (double)P.res)) hit_mask &= ~(1u << j);  // VoxelGrid.cpp:470-472
+      double d2 = cx * cx + cy * cy + cz * cz;
+      if (!(d2 <= P.r2max)) hit_mask &= ~(1u << j);  // sqrt(d2) < radius (VoxelGrid.cpp:470-472)
     }
     // deterministic compaction: exclusive scan of the per-lane hit counts over the block
     unsigned cnt = __popc(hit_mask), incl = cnt;
@@ -208,41 +242,52 @@ __global__ __launch_bounds__(kBlockD) void k_ndt_pass(const float4 *__restrict__
     // ---- phase B: dense pair math
     for (unsigned qi = threadIdx.x; qi < total; qi += kBlockD) {
       unsigned e = queue[qi];
-      const TilePoint &t = tp[e & 63u];
+      const unsigned pl = e & 63u;
       const double *R = rec + (size_t)(e >> 6) * kRecDoubles;
-      double x = t.sx, y = t.sy, z = t.sz;
       double pg[8], ph[15];
+      const double *tm = terms + pl * kTermStride;
 #pragma unroll
-      for (int k = 0; k < 8; k++) pg[k] = x * P.ja[k][0] + y * P.ja[k][1] + z * P.ja[k][2];
+      for (int k = 0; k < 8; k++) pg[k] = tm[k];
       if (KIND != 1) {
 #pragma unroll
-        for (int k = 0; k < 15; k++) ph[k] = x * P.ha[k][0] + y * P.ha[k][1] + z * P.ha[k][2];
+        for (int k = 0; k < 15; k++) ph[k] = tm[8 + k];
       }
-      pair_update<KIND>(P, R, t.tx, t.ty, t.tz, pg, ph, acc);
+      pair_update<KIND>(P, R, tp[pl].tx, tp[pl].ty, tp[pl].tz, pg, ph, acc);
     }
     if (threadIdx.x == 0) pairs += total;
-    __syncthreads();  // tp / queue are rewritten by the next tile
+    __syncthreads();  // tp / terms / queue are rewritten by the next tile
   }
-  // wave reduction (fixed tree), then across the block's waves through LDS
+  // block reduction through LDS in a fixed order (bitwise reproducible): transpose the 28 per-lane accumulators,
+  // 8 x 32 lanes add 32 rows each, then 32 lanes add the 8 partial rows
+  double *red = reinterpret_cast<double *>(lds);
+  double *red2 = reinterpret_cast<double *>(lds + (kLdsRed > kLdsTileEnd ? kLdsRed : kLdsTileEnd));
 #pragma unroll
-  for (int k = 0; k < 28; k++) {
-    double v = lsa_wave_sum(acc[k]);
-    if (lane == 0) sm[wave][k] = v;
-  }
-  if (lane == 0) {
-    size_t mine = 0;  // points owned by this workgroup (tiles blockIdx.x, +gridDim.x, ...)
-    for (size_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) mine += min((size_t)kTilePts, n - tile * kTilePts);
-    sm[wave][28] = (wave == 0) ? (double)pairs : 0.0;
-    sm[wave][29] = (wave == 0) ? (double)mine : 0.0;
-    sm[wave][30] = 0.0; sm[wave][31] = 0.0;
+  for (int k = 0; k < 28; k++) red[threadIdx.x * kRedStride + k] = acc[k];
+  __syncthreads();
+  {
+    int k = threadIdx.x & 31, part = threadIdx.x >> 5;
+    double v = 0.0;
+    if (k < 28) {
+      const double *r = red + (size_t)(part * 32) * kRedStride + k;
+#pragma unroll 8
+      for (int c = 0; c < 32; c++) v += r[c * kRedStride];
+    }
+    red2[part * 32 + k] = v;
   }
   __syncthreads();
   if (threadIdx.x < kOutDoubles) {
     double v = 0.0;
 #pragma unroll
-    for (int w = 0; w < kBlockD / 64; w++) v += sm[w][threadIdx.x];
+    for (int part = 0; part < 8; part++) v += red2[part * 32 + threadIdx.x];
+    if (threadIdx.x == 28) v = 0.0;  // filled below
+    size_t mine = 0;
+    if (threadIdx.x == 29)
+      for (size_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) mine += min((size_t)kTilePts, n - tile * kTilePts);
+    if (threadIdx.x == 29) v = (double)mine;
+    if (threadIdx.x >= 30) v = 0.0;
     partials[(size_t)blockIdx.x * kOutDoubles + threadIdx.x] = v;
   }
+  if (threadIdx.x == 0) partials[(size_t)blockIdx.x * kOutDoubles + 28] = (double)pairs;
 }
 
 // second stage: out[c] = sum_b partials[b][c], fixed order -> deterministic. 1024 threads = 32 columns x 32 row lanes.
@@ -297,6 +342,12 @@ void ndt_make_pass_params(const lsa_ndt *h, const float T[16], const double p[6]
   q[14][0] = -sx * sz + cx * sy * cz; q[14][1] = -cx * sy * sz - sx * cz; q[14][2] = 0;
   P->d1 = h->d1; P->d2 = h->d2;
   P->res = h->resolution;
+  {  // exact squared-distance threshold: the largest double x with sqrt(x) < radius (sqrt is monotone)
+    double r = (double)h->resolution, t = r * r;
+    while (std::sqrt(t) >= r) t = std::nextafter(t, 0.0);
+    while (std::sqrt(std::nextafter(t, INFINITY)) < r) t = std::nextafter(t, INFINITY);
+    P->r2max = t;
+  }
   for (int a = 0; a < 3; a++) { P->min_b[a] = h->vi.map.min_b[a]; P->dim[a] = h->vi.map.dim[a]; }
 }
 

@@ -187,16 +187,17 @@ int ndt_build_grid(lsa_ndt *h, const float4 *d_pts, size_t n) {
   lsa_context *ctx = h->ctx;
   VoxelIndex &vi = h->vi;
   h->has_target = false;
-  float mn[3], mx[3];
-  size_t nfin = 0;
-  int rc = vi_bbox(ctx, vi, d_pts, n, mn, mx, &nfin);
-  if (rc) return rc;
-  if (nfin == 0) return lsa_fail(ctx, LSA_ERR_INVALID, "set_input_target: no finite points");
-  rc = vi_make_map_ndt(mn, mx, h->resolution, &vi.map);
-  if (rc) return lsa_fail(ctx, LSA_ERR_RANGE, "set_input_target: voxel grid of %d x %d x %d cells overflows int32", vi.map.dim[0], vi.map.dim[1], vi.map.dim[2]);
-  vi_make_scales(vi.map, nfin, &vi.fs);
-  if ((rc = vi_build(ctx, vi, d_pts, n))) return rc;
-  if ((rc = vi_accumulate(ctx, vi, d_pts, n, 10))) return rc;
+  int rc, status = VI_OK;
+  const float leaf[3] = {h->resolution, h->resolution, h->resolution};
+  for (int attempt = 0; attempt < 2; attempt++) {
+    if ((rc = vi_enqueue(ctx, vi, d_pts, n, /*mode NDT*/ 1, leaf, 10))) return rc;
+    if ((rc = vi_fetch(ctx, vi))) return rc;
+    if ((rc = vi_wait(ctx, vi, &status))) return rc;
+    if (status != VI_CAPACITY) break;
+    if ((rc = vi_grow(ctx, vi))) return rc;
+  }
+  if (status == VI_EMPTY) return lsa_fail(ctx, LSA_ERR_INVALID, "set_input_target: no finite points");
+  if (status != VI_OK) return lsa_fail(ctx, LSA_ERR_RANGE, "set_input_target: voxel grid of %d x %d x %d cells overflows int32", vi.map.dim[0], vi.map.dim[1], vi.map.dim[2]);
   size_t V = vi.nocc;
   if ((rc = h->rec.reserve(ctx, V * kRecDoubles + kRecDoubles, 1.25))) return rc;
   if ((rc = h->state.reserve(ctx, V + 1, 1.25))) return rc;
@@ -211,9 +212,10 @@ int ndt_build_grid(lsa_ndt *h, const float4 *d_pts, size_t n) {
   hipLaunchKernelGGL(k_count_valid, dim3(lsa_div_up(V, kBlock)), dim3(kBlock), 0, ctx->stream, h->state.p, V, (unsigned *)h->d_small.p);
   LSA_HIP(ctx, hipGetLastError());
   unsigned nvalid = 0;
-  LSA_HIP(ctx, hipMemcpyAsync(vi.h_small.p, h->d_small.p, sizeof(unsigned), hipMemcpyDeviceToHost, ctx->stream));
+  if ((rc = h->h_out.reserve(ctx, kOutDoubles))) return rc;
+  LSA_HIP(ctx, hipMemcpyAsync(h->h_out.p, h->d_small.p, sizeof(unsigned), hipMemcpyDeviceToHost, ctx->stream));
   LSA_HIP(ctx, hipStreamSynchronize(ctx->stream));
-  memcpy(&nvalid, vi.h_small.p, sizeof(unsigned));
+  memcpy(&nvalid, h->h_out.p, sizeof(unsigned));
   h->n_valid = nvalid;
   h->n_target = n;
   h->d_target_pts = d_pts;

@@ -9,6 +9,7 @@ struct PassParams {
   double ja[8][3];   // j_ang_a .. j_ang_h   (NormalDistributionsTransform.cpp:551-581)
   double ha[15][3];  // h_ang_a2,a3,b2,b3,c2,c3,d1,d2,d3,e1,e2,e3,f1,f2,f3 (:584-642)
   double d1, d2;     // gauss_d1_, gauss_d2_
+  double r2max;      // largest double x with sqrt(x) < (double)res: `sqrt(d2) < radius` == `d2 <= r2max`, no sqrt per probe
   float res;         // resolution_ = search radius = leaf
   int min_b[3];      // real_min_b*
   int dim[3];        // real_max_b* - real_min_b* + 1

@@ -20,10 +20,13 @@ namespace {
 constexpr int kBlock = 256;
 
 __global__ __launch_bounds__(kBlock) void k_filter_finalize(const long long *__restrict__ acc, const int32_t *__restrict__ cnt,
-                                                            const int32_t *__restrict__ cell_of_rank, size_t nocc, CellMap m, FixScales fs,
+                                                            const int32_t *__restrict__ cell_of_rank, const DevParams *__restrict__ dp,
                                                             float4 *__restrict__ out) {
+  if (dp->status != VI_OK) return;
   size_t r = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (r >= nocc) return;
+  if (r >= dp->V) return;  // the grid is sized for the point count; the occupied-cell count only exists on the device
+  const CellMap m = dp->map;
+  const FixScales fs = dp->fs;
   const long long *a = acc + r * 4;
   double n = (double)cnt[r];
   double o[3];
@@ -40,23 +43,24 @@ int filter_device(lsa_voxel_filter *f, const float4 *d_in, size_t n, float4 *d_o
   lsa_context *ctx = f->ctx;
   *n_out = 0;
   if (n == 0) return LSA_OK;
-  float mn[3], mx[3];
-  size_t nfin = 0;
-  int rc = vi_bbox(ctx, f->vi, d_in, n, mn, mx, &nfin);
-  if (rc) return rc;
-  if (nfin == 0) return LSA_OK;
-  rc = vi_make_map_pcl(mn, mx, f->leaf, &f->vi.map);
-  if (rc == LSA_ERR_RANGE) return lsa_fail(ctx, LSA_ERR_RANGE, "voxel filter: leaf size too small for the input dataset, integer indices would overflow");
-  vi_make_scales(f->vi.map, nfin, &f->vi.fs);
-  if ((rc = vi_build(ctx, f->vi, d_in, n))) return rc;
-  if ((rc = vi_accumulate(ctx, f->vi, d_in, n, 4))) return rc;
-  size_t V = f->vi.nocc;
-  if (V) {
-    hipLaunchKernelGGL(k_filter_finalize, dim3(lsa_div_up(V, kBlock)), dim3(kBlock), 0, ctx->stream, f->vi.acc.p, f->vi.cnt.p,
-                       f->vi.cell_of_rank.p, V, f->vi.map, f->vi.fs, d_out);
+  // The whole pipeline (bbox -> grid definition -> bitmap -> scan -> sums -> means) is enqueued without a host round
+  // trip; the host then waits ONCE for the 200-byte parameter block that carries the voxel count and the status.
+  VoxelIndex &vi = f->vi;
+  int rc, status = VI_OK;
+  for (int attempt = 0; attempt < 2; attempt++) {
+    if ((rc = vi_enqueue(ctx, vi, d_in, n, /*mode PCL*/ 0, f->leaf, 4))) return rc;
+    hipLaunchKernelGGL(k_filter_finalize, dim3(lsa_div_up(n, kBlock)), dim3(kBlock), 0, ctx->stream, vi.acc.p, vi.cnt.p, vi.cell_of_rank.p, vi.dparams.p,
+                       d_out);
     LSA_HIP(ctx, hipGetLastError());
+    if ((rc = vi_fetch(ctx, vi))) return rc;
+    if ((rc = vi_cleanup(ctx, vi, n))) return rc;  // behind the completion event: off the caller's critical path
+    if ((rc = vi_wait(ctx, vi, &status))) return rc;
+    if (status != VI_CAPACITY) break;
+    if ((rc = vi_grow(ctx, vi))) return rc;  // first call / bigger extent than ever seen: size the bitmap and redo
   }
-  *n_out = V;
+  if (status == VI_RANGE) return lsa_fail(ctx, LSA_ERR_RANGE, "voxel filter: leaf size too small for the input dataset, integer indices would overflow");
+  if (status == VI_CAPACITY) return lsa_fail(ctx, LSA_ERR_HIP, "voxel filter: bitmap capacity could not be established");
+  *n_out = (status == VI_OK) ? vi.nocc : 0;
   return LSA_OK;
 }
 }  // namespace
@@ -81,10 +85,9 @@ extern "C" void lsa_voxel_filter_destroy(lsa_voxel_filter *f) {
 extern "C" int lsa_voxel_filter_apply_device(lsa_voxel_filter *f, const float *d_in_xyzw, size_t n, float *d_out_xyzw, size_t *n_out) {
   if (!f || !n_out || (n && (!d_in_xyzw || !d_out_xyzw))) return f ? lsa_fail(f->ctx, LSA_ERR_INVALID, "lsa_voxel_filter_apply_device: null argument") : LSA_ERR_INVALID;
   LSA_HIP(f->ctx, hipSetDevice(f->ctx->device));
-  int rc = filter_device(f, (const float4 *)d_in_xyzw, n, (float4 *)d_out_xyzw, n_out);
-  if (rc) return rc;
-  LSA_HIP(f->ctx, hipStreamSynchronize(f->ctx->stream));
-  return LSA_OK;
+  // filter_device returns once the output is complete (it waits on the pipeline's completion event); the bitmap
+  // clean-up kernel queued behind that event keeps running and is ordered before anything enqueued later
+  return filter_device(f, (const float4 *)d_in_xyzw, n, (float4 *)d_out_xyzw, n_out);
 }
 
 extern "C" int lsa_voxel_filter_apply(lsa_voxel_filter *f, const void *in_pts, size_t n, size_t in_stride, size_t in_w_off, void *out_pts,

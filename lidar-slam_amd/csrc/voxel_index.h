@@ -1,15 +1,18 @@
-// voxel_index.h — internal: sparse voxel index shared by the VoxelFilter and the NDT target grid.
+// voxel_index.h — internal: sparse voxel index shared by the VoxelFilter, the NDT target grid and the ICP neighbour grid.
 //
 // Data layout in HBM (all device-resident, grow-only):
 //   bits[W]        u32   occupancy bitmap over the dense cell box, cell = i + j*dx + k*dx*dy (x fastest),
-//                        W = ceil(ncells / 32).  At KITTI sizes this is 20 KB (NDT, 1 m cells) to
-//                        ~1 MB (0.3 m filter over a 250 m map): L2-resident, unlike a dense record grid.
+//                        W = ceil(ncells / 32).  At KITTI size this is 20 KB (NDT, 1 m cells) to ~1 MB (0.3 m filter
+//                        over a 250 m map): L2-resident, unlike a dense record grid.
 //   prefix[W]      u32   exclusive prefix of popcount(bits): rank(cell) = prefix[w] + popc(bits[w] & below(b)).
-//                        Ranks enumerate occupied cells in ASCENDING linear index, which is exactly the
-//                        output order PCL's sort produces, so no sort is needed anywhere.
+//                        Ranks enumerate occupied cells in ASCENDING linear index, which is exactly the output order
+//                        PCL's sort produces, so no sort is needed anywhere.
 //   cell_of_rank[V] i32  inverse map (cell linear index per occupied rank).
 //   acc[V][NS]     i64   per-cell fixed-point sums (order-independent => bitwise reproducible),
 //   cnt[V]         i32   per-cell point counts.
+//   dparams        the grid definition itself (CellMap, scales, W, V, status) lives in device memory: the bounding-box
+//                  kernel derives it on the device, so the whole pipeline is enqueued without a host round trip and the
+//                  host reads it back once, together with the result count.
 #ifndef LSA_VOXEL_INDEX_H_
 #define LSA_VOXEL_INDEX_H_
 
@@ -30,31 +33,59 @@ struct FixScales {
   double sw, inv_sw;  // intensity / static weight
 };
 
+enum { VI_OK = 0, VI_CAPACITY = 1, VI_RANGE = 2, VI_EMPTY = 3 };
+
+struct DevParams {
+  CellMap map;
+  FixScales fs;
+  unsigned long long W;         // bitmap words in use
+  unsigned long long W_cap;     // bitmap words allocated (input)
+  unsigned long long n_finite;
+  unsigned nsb;                 // scan blocks in use
+  unsigned V;                   // occupied cells (written by the scan)
+  int status;                   // VI_*
+  int req_mode;                 // requested rule set (input)
+  float req_leaf[3];            // requested leaf (input)
+  float mn[3], mx[3];           // bounding box of the finite points
+};
+
 struct VoxelIndex {
   DevBuf<uint32_t> bits, prefix, blocksums;
   DevBuf<int32_t> cell_of_rank, cnt, cell_idx;
   DevBuf<long long> acc;
   DevBuf<float> scratch;  // bbox partials
-  PinnedBuf<float> h_small;
-  size_t W = 0;
-  size_t nocc = 0;
+  DevBuf<DevParams> dparams;
+  PinnedBuf<DevParams> h_params;
+  hipEvent_t ev_done = nullptr;
+  size_t W_cap = 0;       // bitmap capacity in words
+  size_t acc_rows = 0;    // rows of acc / cnt known to be zero ("clean") on entry
+  int acc_ns = 0;
+  bool clean = false;     // bits[0..W_cap), acc, cnt are all zero
+  // host copies after vi_fetch()
+  size_t W = 0, nocc = 0;
   CellMap map{};
   FixScales fs{};
   void release() {
     bits.release(); prefix.release(); blocksums.release(); cell_of_rank.release(); cnt.release(); cell_idx.release();
-    acc.release(); scratch.release(); h_small.release();
+    acc.release(); scratch.release(); dparams.release(); h_params.release();
+    if (ev_done) { (void)hipEventDestroy(ev_done); ev_done = nullptr; }
+    W_cap = 0; acc_rows = 0; clean = false;
   }
 };
 
-// min/max over finite points; out[0..2] = min, [3..5] = max, [6] = #finite (as float bits of an int). One sync.
-int vi_bbox(lsa_context *ctx, VoxelIndex &vi, const float4 *d_pts, size_t n, float mn[3], float mx[3], size_t *n_finite);
-// PCL rule set (filter) / reference NDT rule set; returns LSA_ERR_RANGE on int32 overflow of the cell count
-int vi_make_map_pcl(const float mn[3], const float mx[3], const float leaf[3], CellMap *m);
-int vi_make_map_ndt(const float mn[3], const float mx[3], float leaf, CellMap *m);
-void vi_make_scales(const CellMap &m, size_t n, FixScales *fs);
-// mark + scan + inverse map; sets vi.nocc. One sync.
-int vi_build(lsa_context *ctx, VoxelIndex &vi, const float4 *d_pts, size_t n);
-// accumulate NS sums per point: NS = 4 (dx,dy,dz,w) or 10 (dx,dy,dz,dxx,dxy,dxz,dyy,dyz,dzz,w). No sync.
-int vi_accumulate(lsa_context *ctx, VoxelIndex &vi, const float4 *d_pts, size_t n, int ns);
+// Enqueue the whole index build for `n` points with the given rule set (mode 0 PCL / 1 NDT) and leaf:
+//   bbox -> grid definition (device) -> mark bitmap -> popcount scan (+ inverse map) -> per-cell sums (ns = 4 or 10).
+// No host synchronisation.  Buffers are sized for n; the bitmap uses the capacity left by earlier calls (the device flags
+// VI_CAPACITY if it does not fit).
+int vi_enqueue(lsa_context *ctx, VoxelIndex &vi, const float4 *d_pts, size_t n, int mode, const float leaf[3], int ns);
+// Enqueue the D2H copy of the grid definition + result count, record the completion event (call after the caller's own
+// finalize kernel).  vi_wait() blocks on that event only and refreshes vi.map / vi.fs / vi.W / vi.nocc.
+// Returns VI_* in *status.  On VI_CAPACITY the caller calls vi_grow() and re-enqueues.
+int vi_fetch(lsa_context *ctx, VoxelIndex &vi);
+int vi_wait(lsa_context *ctx, VoxelIndex &vi, int *status);
+int vi_grow(lsa_context *ctx, VoxelIndex &vi);
+// Enqueue the clean-up (zero the bitmap words / sums / counts this build touched) so the next build needs no memset.
+// Runs behind the completion event, i.e. off the caller's critical path.
+int vi_cleanup(lsa_context *ctx, VoxelIndex &vi, size_t n);
 
 #endif

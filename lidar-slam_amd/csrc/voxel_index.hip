@@ -1,6 +1,7 @@
-// voxel_index.hip — sparse voxel index: bbox reduce, occupancy bitmap, popcount prefix scan,
-// fixed-point per-cell accumulation.  HBM-bound streaming kernels over packed float4 points
-// (16 B/point, one global_load_dwordx4 per lane, grid-stride, grid sized >> 256 CUs).
+// voxel_index.hip — sparse voxel index: bbox reduce, grid definition on the device, occupancy bitmap, popcount prefix
+// scan, fixed-point per-cell accumulation.  HBM-bound streaming kernels over packed float4 points (16 B/point, one
+// global_load_dwordx4 per lane); at KITTI size (131 k points = 2.1 MB = 0.3 us of HBM time) they are launch-latency
+// bound, which is why the pipeline is enqueued back to back with no host round trip in between.
 #include "voxel_index_dev.h"
 
 #include <cfloat>
@@ -47,7 +48,15 @@ __global__ __launch_bounds__(kBlock) void k_bbox_partial(const float4 *__restric
   }
 }
 
-__global__ __launch_bounds__(kBlock) void k_bbox_final(const float *__restrict__ partial, int nb, float *__restrict__ out) {
+__device__ int ceil_log2_dev(double v) {
+  if (!(v > 0)) return 0;
+  int e;
+  double f = frexp(v, &e);
+  return (f == 0.5) ? e - 1 : e;
+}
+
+// single block: final bbox reduction, then the grid definition by the requested rule set, on the device
+__global__ __launch_bounds__(kBlock) void k_bbox_final_params(const float *__restrict__ partial, int nb, DevParams *__restrict__ dp) {
   float mn0 = INFINITY, mn1 = INFINITY, mn2 = INFINITY, mx0 = -INFINITY, mx1 = -INFINITY, mx2 = -INFINITY;
   unsigned long long cnt = 0;
   for (int i = threadIdx.x; i < nb; i += blockDim.x) {
@@ -70,12 +79,65 @@ __global__ __launch_bounds__(kBlock) void k_bbox_final(const float *__restrict__
     }
     __syncthreads();
   }
-  if (threadIdx.x == 0) {
-    for (int a = 0; a < 6; a++) out[a] = s[0][a];
-    unsigned long long c = sc[0];
-    out[6] = __uint_as_float((unsigned)(c & 0xffffffffu));
-    out[7] = __uint_as_float((unsigned)(c >> 32));
+  if (threadIdx.x != 0) return;
+  float mn[3] = {s[0][0], s[0][1], s[0][2]}, mx[3] = {s[0][3], s[0][4], s[0][5]};
+  unsigned long long nfin = sc[0];
+  CellMap m;
+  m.mode = dp->req_mode;
+  int status = VI_OK;
+  for (int a = 0; a < 3; a++) {
+    dp->mn[a] = mn[a]; dp->mx[a] = mx[a];
+    m.leaf[a] = dp->req_leaf[a];
+    m.inv[a] = 1.0f / m.leaf[a];
+    m.min_b[a] = 0; m.dim[a] = 1;
   }
+  m.ncells = 1;
+  dp->n_finite = nfin;
+  if (nfin == 0) {
+    status = VI_EMPTY;
+  } else if (m.mode == 0) {
+    // PCL 1.7 filters/impl/voxel_grid.hpp applyFilter: overflow check on (max - min) * inverse_leaf, then
+    // min_b / max_b = floor(min|max * inverse_leaf), div_b = max_b - min_b + 1.  (PCL multiplies the three extents in
+    // int64, which itself overflows past ~9.2e18 cells; the product is compared in double so that case is caught too.)
+    double prod = 1.0;
+    for (int a = 0; a < 3; a++) prod *= (double)((long long)(lsa_fmul(lsa_fsub(mx[a], mn[a]), m.inv[a])) + 1);
+    if (prod > (double)INT32_MAX) status = VI_RANGE;
+    for (int a = 0; a < 3; a++) {
+      m.min_b[a] = (int)floorf(lsa_fmul(mn[a], m.inv[a]));
+      int max_b = (int)floorf(lsa_fmul(mx[a], m.inv[a]));
+      m.dim[a] = max_b - m.min_b[a] + 1;
+    }
+  } else {
+    // reference VoxelGrid::findBoundaries (VoxelGrid.cpp:366-372): real_min/real_max = floor(min|max / leaf).  The
+    // reference additionally pads its DENSE allocation to multiples of 16x16x8 cells (:379-392); every lookup is clipped
+    // to the real bounds (:449-455), so the padding is an allocation detail with no observable effect.
+    for (int a = 0; a < 3; a++) {
+      m.min_b[a] = (int)floorf(lsa_fdiv(mn[a], m.leaf[a]));
+      int max_b = (int)floorf(lsa_fdiv(mx[a], m.leaf[a]));
+      m.dim[a] = max_b - m.min_b[a] + 1;
+    }
+  }
+  if (status == VI_OK) {
+    double nc = (double)m.dim[0] * (double)m.dim[1] * (double)m.dim[2];
+    if (m.dim[0] <= 0 || m.dim[1] <= 0 || m.dim[2] <= 0 || nc > (double)INT32_MAX) status = VI_RANGE;
+    else m.ncells = (long long)m.dim[0] * m.dim[1] * m.dim[2];
+  }
+  unsigned long long W = (unsigned long long)((m.ncells + 31) / 32);
+  if (status == VI_OK && W > dp->W_cap) status = VI_CAPACITY;
+  // fixed-point scales: |d| <= leaf (+ slop) < 2 * leaf, N <= n_finite summands, |intensity| < 1024 => no int64 overflow
+  double leaf_max = fmax(fmax((double)m.leaf[0], (double)m.leaf[1]), (double)m.leaf[2]);
+  int bits_n = ceil_log2_dev((double)nfin + 1.0), bits_d = ceil_log2_dev(2.0 * leaf_max);
+  int k1 = min(62 - bits_n - bits_d, 44), k2 = min(62 - bits_n - 2 * bits_d, 44), kw = min(62 - bits_n - 10, 40);
+  FixScales fs;
+  fs.s1 = ldexp(1.0, k1); fs.inv_s1 = ldexp(1.0, -k1);
+  fs.s2 = ldexp(1.0, k2); fs.inv_s2 = ldexp(1.0, -k2);
+  fs.sw = ldexp(1.0, kw); fs.inv_sw = ldexp(1.0, -kw);
+  dp->map = m;
+  dp->fs = fs;
+  dp->W = W;
+  dp->nsb = (unsigned)((W + kScanTile - 1) / kScanTile);
+  dp->V = 0;
+  dp->status = status;
 }
 
 // ---- LDS tile hashing ---------------------------------------------------------------------------------------
@@ -104,8 +166,10 @@ __device__ __forceinline__ int lds_insert(int *keys, int cell) {
   return -1;
 }
 
-__global__ __launch_bounds__(kBlock) void k_mark(const float4 *__restrict__ pts, size_t n, CellMap m, uint32_t *__restrict__ bits,
+__global__ __launch_bounds__(kBlock) void k_mark(const float4 *__restrict__ pts, size_t n, const DevParams *__restrict__ dp, uint32_t *__restrict__ bits,
                                                  int32_t *__restrict__ cell_idx) {
+  if (dp->status != VI_OK) return;
+  const CellMap m = dp->map;
   __shared__ int keys[kHashCap];
   for (int k = threadIdx.x; k < kHashCap; k += kBlock) keys[k] = -1;
   __syncthreads();
@@ -135,7 +199,9 @@ __global__ __launch_bounds__(kBlock) void k_mark(const float4 *__restrict__ pts,
   }
 }
 
-__global__ __launch_bounds__(kBlock) void k_scan_block_sums(const uint32_t *__restrict__ bits, size_t W, uint32_t *__restrict__ blocksums) {
+__global__ __launch_bounds__(kBlock) void k_scan_block_sums(const uint32_t *__restrict__ bits, const DevParams *__restrict__ dp, uint32_t *__restrict__ blocksums) {
+  if (dp->status != VI_OK || blockIdx.x >= dp->nsb) return;
+  const size_t W = dp->W;
   size_t base = (size_t)blockIdx.x * kScanTile;
   unsigned s = 0;
   for (int k = 0; k < kScanTile / kBlock; k++) {
@@ -154,8 +220,10 @@ __global__ __launch_bounds__(kBlock) void k_scan_block_sums(const uint32_t *__re
   }
 }
 
-// single block: exclusive scan of blocksums[nb] in place, total -> blocksums[nb]
-__global__ __launch_bounds__(1024) void k_scan_top(uint32_t *__restrict__ blocksums, int nb) {
+// single block: exclusive scan of blocksums[nsb] in place; the total (= #occupied cells) goes to dp->V
+__global__ __launch_bounds__(1024) void k_scan_top(uint32_t *__restrict__ blocksums, DevParams *__restrict__ dp) {
+  if (dp->status != VI_OK) return;
+  const int nb = (int)dp->nsb;
   __shared__ unsigned s[1024];
   __shared__ unsigned carry;
   if (threadIdx.x == 0) carry = 0;
@@ -178,11 +246,13 @@ __global__ __launch_bounds__(1024) void k_scan_top(uint32_t *__restrict__ blocks
     if (threadIdx.x == 1023) carry = c + incl;
     __syncthreads();
   }
-  if (threadIdx.x == 0) blocksums[nb] = carry;
+  if (threadIdx.x == 0) dp->V = carry;
 }
 
-__global__ __launch_bounds__(kBlock) void k_scan_apply(const uint32_t *__restrict__ bits, size_t W, const uint32_t *__restrict__ blocksums,
+__global__ __launch_bounds__(kBlock) void k_scan_apply(const uint32_t *__restrict__ bits, const DevParams *__restrict__ dp, const uint32_t *__restrict__ blocksums,
                                                        uint32_t *__restrict__ prefix, int32_t *__restrict__ cell_of_rank) {
+  if (dp->status != VI_OK || blockIdx.x >= dp->nsb) return;
+  const size_t W = dp->W;
   // thread t owns 8 consecutive words of the tile so the in-block scan is one value per thread
   size_t base = (size_t)blockIdx.x * kScanTile + (size_t)threadIdx.x * 8;
   uint32_t wv[8];
@@ -243,9 +313,12 @@ __device__ __forceinline__ unsigned cell_rank(const uint32_t *__restrict__ bits,
 
 // per-cell fixed-point sums: LDS pre-aggregation per tile, then one set of global atomics per distinct cell
 template <int NS>
-__global__ __launch_bounds__(kBlock) void k_accum(const float4 *__restrict__ pts, const int32_t *__restrict__ cell_idx, size_t n, CellMap m,
-                                                  FixScales fs, const uint32_t *__restrict__ bits, const uint32_t *__restrict__ prefix,
+__global__ __launch_bounds__(kBlock) void k_accum(const float4 *__restrict__ pts, const int32_t *__restrict__ cell_idx, size_t n,
+                                                  const DevParams *__restrict__ dp, const uint32_t *__restrict__ bits, const uint32_t *__restrict__ prefix,
                                                   long long *__restrict__ acc, int32_t *__restrict__ cnt) {
+  if (dp->status != VI_OK) return;
+  const CellMap m = dp->map;
+  const FixScales fs = dp->fs;
   __shared__ int keys[kHashCap];
   __shared__ int counts[kHashCap];
   __shared__ unsigned long long sums[kHashCap][NS];
@@ -290,6 +363,17 @@ __global__ __launch_bounds__(kBlock) void k_accum(const float4 *__restrict__ pts
   }
 }
 
+// zero what this build touched: the bitmap words of the occupied cells and the V rows of sums / counts
+__global__ __launch_bounds__(kBlock) void k_cleanup(const DevParams *__restrict__ dp, const int32_t *__restrict__ cell_of_rank, uint32_t *__restrict__ bits,
+                                                    long long *__restrict__ acc, int32_t *__restrict__ cnt, int ns) {
+  if (dp->status != VI_OK) return;
+  size_t r = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= dp->V) return;
+  bits[cell_of_rank[r] >> 5] = 0u;
+  for (int j = 0; j < ns; j++) acc[r * ns + j] = 0;
+  cnt[r] = 0;
+}
+
 inline unsigned stream_grid(lsa_context *ctx, size_t n) {
   size_t blocks = (n + kBlock - 1) / kBlock;
   size_t cap = (size_t)ctx->num_cus * 8;  // >> 256 workgroups, grid-stride beyond (guide: ~2048 blocks)
@@ -298,125 +382,97 @@ inline unsigned stream_grid(lsa_context *ctx, size_t n) {
   return (unsigned)blocks;
 }
 
-int ceil_log2(double v) {
-  if (!(v > 0)) return 0;
-  int e;
-  double f = frexp(v, &e);  // v = f * 2^e, f in [0.5,1)
-  return (f == 0.5) ? e - 1 : e;
-}
-
 }  // namespace
 
-int vi_bbox(lsa_context *ctx, VoxelIndex &vi, const float4 *d_pts, size_t n, float mn[3], float mx[3], size_t *n_finite) {
+int vi_enqueue(lsa_context *ctx, VoxelIndex &vi, const float4 *d_pts, size_t n, int mode, const float leaf[3], int ns) {
+  int rc;
   unsigned nb = stream_grid(ctx, n);
-  int rc = vi.scratch.reserve(ctx, (size_t)nb * 8 + 8);
-  if (rc) return rc;
-  rc = vi.h_small.reserve(ctx, 16);
-  if (rc) return rc;
-  float *partial = vi.scratch.p;
-  float *out = vi.scratch.p + (size_t)nb * 8;
-  hipLaunchKernelGGL(k_bbox_partial, dim3(nb), dim3(kBlock), 0, ctx->stream, d_pts, n, partial);
-  hipLaunchKernelGGL(k_bbox_final, dim3(1), dim3(kBlock), 0, ctx->stream, partial, (int)nb, out);
-  LSA_HIP(ctx, hipGetLastError());
-  LSA_HIP(ctx, hipMemcpyAsync(vi.h_small.p, out, 8 * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
-  LSA_HIP(ctx, hipStreamSynchronize(ctx->stream));
-  for (int a = 0; a < 3; a++) { mn[a] = vi.h_small.p[a]; mx[a] = vi.h_small.p[3 + a]; }
-  uint32_t lo, hi;
-  memcpy(&lo, &vi.h_small.p[6], 4);
-  memcpy(&hi, &vi.h_small.p[7], 4);
-  *n_finite = (size_t)(((unsigned long long)hi << 32) | lo);
-  return LSA_OK;
-}
-
-int vi_make_map_pcl(const float mn[3], const float mx[3], const float leaf[3], CellMap *m) {
-  // PCL 1.7 filters/impl/voxel_grid.hpp applyFilter: overflow check, min_b/max_b/div_b
-  m->mode = 0;
-  long long d[3];
-  for (int a = 0; a < 3; a++) {
-    m->leaf[a] = leaf[a];
-    m->inv[a] = 1.0f / leaf[a];
-    d[a] = (long long)((mx[a] - mn[a]) * m->inv[a]) + 1;
-  }
-  // (PCL multiplies in int64, which itself overflows past ~9.2e18 cells; compare in double so that case is caught too)
-  if ((double)d[0] * (double)d[1] * (double)d[2] > (double)INT32_MAX) return LSA_ERR_RANGE;
-  for (int a = 0; a < 3; a++) {
-    m->min_b[a] = (int)floorf(mn[a] * m->inv[a]);
-    int max_b = (int)floorf(mx[a] * m->inv[a]);
-    m->dim[a] = max_b - m->min_b[a] + 1;
-  }
-  m->ncells = (long long)m->dim[0] * m->dim[1] * m->dim[2];
-  if (m->ncells > (long long)INT32_MAX) return LSA_ERR_RANGE;
-  return LSA_OK;
-}
-
-int vi_make_map_ndt(const float mn[3], const float mx[3], float leaf, CellMap *m) {
-  // reference VoxelGrid::findBoundaries (VoxelGrid.cpp:366-372): real_min/real_max = floor(min|max / leaf).
-  // The reference additionally pads its DENSE allocation to multiples of 16x16x8 cells (:379-392); every lookup
-  // is clipped to the real bounds (:449-455), so the padding is an allocation detail with no observable effect.
-  m->mode = 1;
-  for (int a = 0; a < 3; a++) {
-    m->leaf[a] = leaf;
-    m->inv[a] = 1.0f / leaf;
-    m->min_b[a] = (int)floorf(mn[a] / leaf);
-    int max_b = (int)floorf(mx[a] / leaf);
-    m->dim[a] = max_b - m->min_b[a] + 1;
-  }
-  m->ncells = (long long)m->dim[0] * m->dim[1] * m->dim[2];
-  if (m->ncells > (long long)INT32_MAX || m->dim[0] <= 0 || m->dim[1] <= 0 || m->dim[2] <= 0) return LSA_ERR_RANGE;
-  return LSA_OK;
-}
-
-void vi_make_scales(const CellMap &m, size_t n, FixScales *fs) {
-  double leaf_max = fmax(fmax(m.leaf[0], m.leaf[1]), m.leaf[2]);
-  int bits_n = ceil_log2((double)n + 1.0);
-  int bits_d = ceil_log2(2.0 * leaf_max);  // |d| <= leaf (+ rounding slop) < 2 * leaf
-  int k1 = 62 - bits_n - bits_d;
-  int k2 = 62 - bits_n - 2 * bits_d;
-  int kw = 62 - bits_n - 10;  // |intensity| < 1024
-  if (k1 > 44) k1 = 44;
-  if (k2 > 44) k2 = 44;
-  if (kw > 40) kw = 40;
-  fs->s1 = ldexp(1.0, k1); fs->inv_s1 = ldexp(1.0, -k1);
-  fs->s2 = ldexp(1.0, k2); fs->inv_s2 = ldexp(1.0, -k2);
-  fs->sw = ldexp(1.0, kw); fs->inv_sw = ldexp(1.0, -kw);
-}
-
-int vi_build(lsa_context *ctx, VoxelIndex &vi, const float4 *d_pts, size_t n) {
-  const CellMap &m = vi.map;
-  vi.W = (size_t)((m.ncells + 31) / 32);
-  unsigned nsb = lsa_div_up(vi.W, kScanTile);
-  int rc;
-  if ((rc = vi.bits.reserve(ctx, vi.W, 1.25))) return rc;
-  if ((rc = vi.prefix.reserve(ctx, vi.W, 1.25))) return rc;
-  if ((rc = vi.blocksums.reserve(ctx, (size_t)nsb + 1, 1.25))) return rc;
+  if ((rc = vi.scratch.reserve(ctx, (size_t)nb * 8 + 8))) return rc;
+  if ((rc = vi.dparams.reserve(ctx, 1))) return rc;
+  if ((rc = vi.h_params.reserve(ctx, 2))) return rc;
+  if (!vi.ev_done) LSA_HIP(ctx, hipEventCreateWithFlags(&vi.ev_done, hipEventDisableTiming));
+  // buffers sized by the point count (#occupied <= #points)
+  size_t old_cor = vi.cell_of_rank.cap, old_cnt = vi.cnt.cap, old_acc = vi.acc.cap;
   if ((rc = vi.cell_idx.reserve(ctx, n, 1.25))) return rc;
-  if ((rc = vi.cell_of_rank.reserve(ctx, n, 1.25))) return rc;  // #occupied <= #points
-  if ((rc = vi.h_small.reserve(ctx, 16))) return rc;
-  LSA_HIP(ctx, hipMemsetAsync(vi.bits.p, 0, vi.W * sizeof(uint32_t), ctx->stream));
-  hipLaunchKernelGGL(k_mark, dim3(lsa_div_up(n, kTile)), dim3(kBlock), 0, ctx->stream, d_pts, n, m, vi.bits.p, vi.cell_idx.p);
-  hipLaunchKernelGGL(k_scan_block_sums, dim3(nsb), dim3(kBlock), 0, ctx->stream, vi.bits.p, vi.W, vi.blocksums.p);
-  hipLaunchKernelGGL(k_scan_top, dim3(1), dim3(1024), 0, ctx->stream, vi.blocksums.p, (int)nsb);
-  hipLaunchKernelGGL(k_scan_apply, dim3(nsb), dim3(kBlock), 0, ctx->stream, vi.bits.p, vi.W, vi.blocksums.p, vi.prefix.p, vi.cell_of_rank.p);
-  LSA_HIP(ctx, hipGetLastError());
-  LSA_HIP(ctx, hipMemcpyAsync(vi.h_small.p, vi.blocksums.p + nsb, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
-  LSA_HIP(ctx, hipStreamSynchronize(ctx->stream));
-  uint32_t tot;
-  memcpy(&tot, vi.h_small.p, 4);
-  vi.nocc = tot;
-  return LSA_OK;
-}
-
-int vi_accumulate(lsa_context *ctx, VoxelIndex &vi, const float4 *d_pts, size_t n, int ns) {
-  int rc;
-  if ((rc = vi.acc.reserve(ctx, vi.nocc * (size_t)ns + 1, 1.25))) return rc;
-  if ((rc = vi.cnt.reserve(ctx, vi.nocc + 1, 1.25))) return rc;
-  LSA_HIP(ctx, hipMemsetAsync(vi.acc.p, 0, (vi.nocc * (size_t)ns + 1) * sizeof(long long), ctx->stream));
-  LSA_HIP(ctx, hipMemsetAsync(vi.cnt.p, 0, (vi.nocc + 1) * sizeof(int32_t), ctx->stream));
+  if ((rc = vi.cell_of_rank.reserve(ctx, n, 1.25))) return rc;
+  if ((rc = vi.cnt.reserve(ctx, n + 1, 1.25))) return rc;
+  if ((rc = vi.acc.reserve(ctx, (n + 1) * (size_t)ns, 1.25))) return rc;
+  if (vi.cnt.cap != old_cnt || vi.acc.cap != old_acc || vi.cell_of_rank.cap != old_cor || vi.acc_ns != ns) vi.clean = false;
+  if (vi.W_cap == 0) {  // first use: a small bitmap; the device reports VI_CAPACITY with the bbox and vi_grow() sizes it
+    vi.W_cap = 4096;
+    if ((rc = vi.bits.reserve(ctx, vi.W_cap))) return rc;
+    if ((rc = vi.prefix.reserve(ctx, vi.W_cap))) return rc;
+    if ((rc = vi.blocksums.reserve(ctx, vi.W_cap / kScanTile + 2))) return rc;
+    vi.clean = false;
+  }
+  if (!vi.clean) {
+    LSA_HIP(ctx, hipMemsetAsync(vi.bits.p, 0, vi.W_cap * sizeof(uint32_t), ctx->stream));
+    LSA_HIP(ctx, hipMemsetAsync(vi.acc.p, 0, vi.acc.cap * sizeof(long long), ctx->stream));
+    LSA_HIP(ctx, hipMemsetAsync(vi.cnt.p, 0, vi.cnt.cap * sizeof(int32_t), ctx->stream));
+  }
+  vi.clean = false;
+  vi.acc_ns = ns;
+  // request block -> device
+  DevParams *hp = vi.h_params.p + 1;
+  memset(hp, 0, sizeof(DevParams));
+  hp->req_mode = mode;
+  for (int a = 0; a < 3; a++) hp->req_leaf[a] = leaf[a];
+  hp->W_cap = vi.W_cap;
+  hp->status = VI_OK;
+  LSA_HIP(ctx, hipMemcpyAsync(vi.dparams.p, hp, sizeof(DevParams), hipMemcpyHostToDevice, ctx->stream));
+  unsigned nsb_cap = (unsigned)((vi.W_cap + kScanTile - 1) / kScanTile);
+  const DevParams *dp = vi.dparams.p;
+  hipLaunchKernelGGL(k_bbox_partial, dim3(nb), dim3(kBlock), 0, ctx->stream, d_pts, n, vi.scratch.p);
+  hipLaunchKernelGGL(k_bbox_final_params, dim3(1), dim3(kBlock), 0, ctx->stream, vi.scratch.p, (int)nb, vi.dparams.p);
+  hipLaunchKernelGGL(k_mark, dim3(lsa_div_up(n, kTile)), dim3(kBlock), 0, ctx->stream, d_pts, n, dp, vi.bits.p, vi.cell_idx.p);
+  hipLaunchKernelGGL(k_scan_block_sums, dim3(nsb_cap), dim3(kBlock), 0, ctx->stream, vi.bits.p, dp, vi.blocksums.p);
+  hipLaunchKernelGGL(k_scan_top, dim3(1), dim3(1024), 0, ctx->stream, vi.blocksums.p, vi.dparams.p);
+  hipLaunchKernelGGL(k_scan_apply, dim3(nsb_cap), dim3(kBlock), 0, ctx->stream, vi.bits.p, dp, vi.blocksums.p, vi.prefix.p, vi.cell_of_rank.p);
   unsigned g = lsa_div_up(n, kTile);
   if (ns == 4)
-    hipLaunchKernelGGL(k_accum<4>, dim3(g), dim3(kBlock), 0, ctx->stream, d_pts, vi.cell_idx.p, n, vi.map, vi.fs, vi.bits.p, vi.prefix.p, vi.acc.p, vi.cnt.p);
+    hipLaunchKernelGGL(k_accum<4>, dim3(g), dim3(kBlock), 0, ctx->stream, d_pts, vi.cell_idx.p, n, dp, vi.bits.p, vi.prefix.p, vi.acc.p, vi.cnt.p);
   else
-    hipLaunchKernelGGL(k_accum<10>, dim3(g), dim3(kBlock), 0, ctx->stream, d_pts, vi.cell_idx.p, n, vi.map, vi.fs, vi.bits.p, vi.prefix.p, vi.acc.p, vi.cnt.p);
+    hipLaunchKernelGGL(k_accum<10>, dim3(g), dim3(kBlock), 0, ctx->stream, d_pts, vi.cell_idx.p, n, dp, vi.bits.p, vi.prefix.p, vi.acc.p, vi.cnt.p);
   LSA_HIP(ctx, hipGetLastError());
+  return LSA_OK;
+}
+
+int vi_fetch(lsa_context *ctx, VoxelIndex &vi) {
+  LSA_HIP(ctx, hipMemcpyAsync(vi.h_params.p, vi.dparams.p, sizeof(DevParams), hipMemcpyDeviceToHost, ctx->stream));
+  LSA_HIP(ctx, hipEventRecord(vi.ev_done, ctx->stream));
+  return LSA_OK;
+}
+
+int vi_wait(lsa_context *ctx, VoxelIndex &vi, int *status) {
+  LSA_HIP(ctx, hipEventSynchronize(vi.ev_done));
+  const DevParams &p = vi.h_params.p[0];
+  vi.map = p.map;
+  vi.fs = p.fs;
+  vi.W = (size_t)p.W;
+  vi.nocc = (p.status == VI_OK) ? p.V : 0;
+  *status = p.status;
+  return LSA_OK;
+}
+
+int vi_grow(lsa_context *ctx, VoxelIndex &vi) {
+  // called after a VI_CAPACITY report: h_params holds the grid the device wanted
+  const DevParams &p = vi.h_params.p[0];
+  size_t need = (size_t)p.W + 1;
+  size_t want = need + need / 4;
+  LSA_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  int rc;
+  if ((rc = vi.bits.reserve(ctx, want))) return rc;
+  if ((rc = vi.prefix.reserve(ctx, want))) return rc;
+  if ((rc = vi.blocksums.reserve(ctx, want / kScanTile + 2))) return rc;
+  vi.W_cap = want;
+  vi.clean = false;
+  return LSA_OK;
+}
+
+int vi_cleanup(lsa_context *ctx, VoxelIndex &vi, size_t n) {
+  hipLaunchKernelGGL(k_cleanup, dim3(lsa_div_up(n, kBlock)), dim3(kBlock), 0, ctx->stream, vi.dparams.p, vi.cell_of_rank.p, vi.bits.p, vi.acc.p, vi.cnt.p,
+                     vi.acc_ns);
+  LSA_HIP(ctx, hipGetLastError());
+  vi.clean = true;
   return LSA_OK;
 }
