@@ -61,7 +61,7 @@ struct PinnedBuf {
     if (n <= cap) return LSA_OK;
     if (p) { (void)hipHostFree(p); p = nullptr; cap = 0; }
     size_t want = n + n / 4;
-    hipError_t e = hipHostMalloc((void **)&p, want * sizeof(T), hipHostMallocDefault);
+    hipError_t e = hipHostMalloc((void **)&p, want * sizeof(T), hipHostMallocMapped | hipHostMallocCoherent);
     if (e != hipSuccess) return lsa_fail(ctx, LSA_ERR_HIP, "hipHostMalloc(%zu B) failed: %s", want * sizeof(T), hipGetErrorString(e));
     cap = want;
     return LSA_OK;

@@ -62,6 +62,10 @@ extern "C" int lsa_context_create(lsa_context **out, int device, void *hip_strea
     lsa_set_global_error("lsa_context_create: device %d out of range (have %d)", device, count);
     return LSA_ERR_NO_DEVICE;
   }
+  // The hot path waits for a ~10 us kernel dozens of times per scan: ask the runtime to spin rather than block in
+  // hipStreamSynchronize / hipEventSynchronize (refused once the device is active in this process, which is harmless).
+  if (!getenv("LSA_NO_SPIN")) (void)hipSetDeviceFlags(hipDeviceScheduleSpin);
+  (void)hipGetLastError();
   e = hipSetDevice(device);
   if (e != hipSuccess) { lsa_set_global_error("hipSetDevice(%d): %s", device, hipGetErrorString(e)); return LSA_ERR_NO_DEVICE; }
   hipDeviceProp_t prop;

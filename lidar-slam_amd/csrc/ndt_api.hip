@@ -26,7 +26,15 @@ int run_pass(lsa_ndt *h, const float T[16], const double p[6], int kind, double 
   lsa_context *ctx = h->ctx;
   PassParams P;
   ndt_make_pass_params(h, T, p, &P);
-  int rc = ndt_enqueue_pass(h, P, kind);
+  int rc;
+  if (ndt_pass_host_reduce(h)) {
+    unsigned g = 0;
+    if ((rc = ndt_enqueue_pass_host(h, P, kind, &g))) return rc;
+    LSA_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    ndt_reduce_partials_host(h->h_partials.p, g, out32);
+    return LSA_OK;
+  }
+  rc = ndt_enqueue_pass(h, P, kind);
   if (rc) return rc;
   if (h->allreduce) {
     int crc = h->allreduce(h->allreduce_user, h->d_out.p, kOutDoubles, (void *)ctx->stream);
@@ -83,7 +91,7 @@ extern "C" void lsa_ndt_destroy(lsa_ndt *h) {
   (void)hipStreamSynchronize(h->ctx->stream);
   ndt_fitness_release(h);
   h->vi.release(); h->d_target.release(); h->rec.release(); h->state.release(); h->vbits.release(); h->words.release(); h->d_small.release();
-  h->d_source_own.release(); h->h_stage.release(); h->partials.release(); h->d_out.release(); h->h_out.release();
+  h->d_source_own.release(); h->h_stage.release(); h->partials.release(); h->d_out.release(); h->h_out.release(); h->h_partials.release();
   delete h;
 }
 

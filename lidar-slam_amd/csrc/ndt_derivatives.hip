@@ -274,20 +274,24 @@ __global__ __launch_bounds__(kBlockD, LSA_PASS_WAVES) void k_ndt_pass(const floa
     }
     red2[part * 32 + k] = v;
   }
+  // slot 28 of every partial row carries the pair count (thread 0 holds it); rows 28..31 of red2 part 0 are unused sums
+  __syncthreads();
+  if (threadIdx.x == 0) red2[28] = (double)pairs;
   __syncthreads();
   if (threadIdx.x < kOutDoubles) {
     double v = 0.0;
+    if (threadIdx.x < 28) {
 #pragma unroll
-    for (int part = 0; part < 8; part++) v += red2[part * 32 + threadIdx.x];
-    if (threadIdx.x == 28) v = 0.0;  // filled below
-    size_t mine = 0;
-    if (threadIdx.x == 29)
+      for (int part = 0; part < 8; part++) v += red2[part * 32 + threadIdx.x];
+    } else if (threadIdx.x == 28) {
+      v = red2[28];
+    } else if (threadIdx.x == 29) {
+      size_t mine = 0;  // points owned by this workgroup (tiles blockIdx.x, + gridDim.x, ...)
       for (size_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) mine += min((size_t)kTilePts, n - tile * kTilePts);
-    if (threadIdx.x == 29) v = (double)mine;
-    if (threadIdx.x >= 30) v = 0.0;
-    partials[(size_t)blockIdx.x * kOutDoubles + threadIdx.x] = v;
+      v = (double)mine;
+    }
+    partials[(size_t)blockIdx.x * kOutDoubles + threadIdx.x] = v;  // one 256-byte row per workgroup, written once
   }
-  if (threadIdx.x == 0) partials[(size_t)blockIdx.x * kOutDoubles + 28] = (double)pairs;
 }
 
 // second stage: out[c] = sum_b partials[b][c], fixed order -> deterministic. 1024 threads = 32 columns x 32 row lanes.
@@ -374,4 +378,44 @@ int ndt_enqueue_pass(lsa_ndt *h, const PassParams &P, int kind, bool reduce) {
   if (reduce) hipLaunchKernelGGL(k_reduce_partials, dim3(1), dim3(1024), 0, ctx->stream, h->partials.p, (int)g, h->d_out.p);
   LSA_HIP(ctx, hipGetLastError());
   return LSA_OK;
+}
+
+// Single-GPU, KITTI-sized passes (<= kHostReduceMaxBlocks workgroups): the workgroup partials are written straight into
+// host-mapped pinned memory and the fixed-order second stage runs on the host, which removes a kernel launch and a copy
+// kernel (~8 us) from every pass.  The summation order is the one k_reduce_partials uses, so both paths give the same bits.
+constexpr unsigned kHostReduceMaxBlocks = 512;
+
+bool ndt_pass_host_reduce(const lsa_ndt *h) { return !h->allreduce && ndt_pass_grid(h, h->n_source) <= kHostReduceMaxBlocks; }
+
+int ndt_enqueue_pass_host(lsa_ndt *h, const PassParams &P, int kind, unsigned *grid_out) {
+  lsa_context *ctx = h->ctx;
+  unsigned g = ndt_pass_grid(h, h->n_source);
+  int rc;
+  if ((rc = h->h_partials.reserve(ctx, (size_t)kHostReduceMaxBlocks * kOutDoubles))) return rc;
+  const uint4 *words = h->words.p;
+  const double *rec = h->rec.p;
+  double *dst = h->h_partials.p;  // pinned + mapped: the same pointer is valid on the device
+  if (kind == 0) hipLaunchKernelGGL(k_ndt_pass<0>, dim3(g), dim3(kBlockD), 0, ctx->stream, h->d_source, h->n_source, P, words, rec, dst);
+  else if (kind == 1) hipLaunchKernelGGL(k_ndt_pass<1>, dim3(g), dim3(kBlockD), 0, ctx->stream, h->d_source, h->n_source, P, words, rec, dst);
+  else hipLaunchKernelGGL(k_ndt_pass<2>, dim3(g), dim3(kBlockD), 0, ctx->stream, h->d_source, h->n_source, P, words, rec, dst);
+  LSA_HIP(ctx, hipGetLastError());
+  *grid_out = g;
+  return LSA_OK;
+}
+
+void ndt_reduce_partials_host(const double *partials, unsigned nb, double out32[32]) {
+  // sm[b % 32][col] accumulates rows b, b + 32, ... in ascending b (the order k_reduce_partials uses); the rows are
+  // read front to back once, because they sit in device-written pinned memory that is cold in the CPU caches
+  double sm[32][32];
+  for (int rl = 0; rl < 32; rl++)
+    for (int col = 0; col < 32; col++) sm[rl][col] = 0.0;
+  for (unsigned b = 0; b < nb; b++) {
+    const double *row = partials + (size_t)b * kOutDoubles;
+    double *dst = sm[b & 31];
+    for (int col = 0; col < 32; col++) dst[col] += row[col];
+  }
+  for (int st = 16; st > 0; st >>= 1)
+    for (int rl = 0; rl < st; rl++)
+      for (int col = 0; col < 32; col++) sm[rl][col] += sm[rl + st][col];
+  for (int col = 0; col < 32; col++) out32[col] = sm[0][col];
 }

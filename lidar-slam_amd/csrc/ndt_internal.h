@@ -41,6 +41,7 @@ struct lsa_ndt {
   DevBuf<double> partials;      // [grid][kOutDoubles]
   DevBuf<double> d_out;         // kOutDoubles
   PinnedBuf<double> h_out;
+  PinnedBuf<double> h_partials;  // host-mapped: small passes write their workgroup partials here directly
 
   // multi-GPU
   lsa_allreduce_fn allreduce = nullptr;

@@ -21,7 +21,10 @@ constexpr int kBlock = 256;
 
 __global__ __launch_bounds__(kBlock) void k_filter_finalize(const long long *__restrict__ acc, const int32_t *__restrict__ cnt,
                                                             const int32_t *__restrict__ cell_of_rank, const DevParams *__restrict__ dp,
-                                                            float4 *__restrict__ out) {
+                                                            float4 *__restrict__ out, DevParams *__restrict__ host_mirror) {
+  // the grid definition + voxel count + status go straight into host-mapped pinned memory (no copy kernel): the host
+  // reads them after the completion event
+  if (blockIdx.x == 0 && threadIdx.x == 0) *host_mirror = *dp;
   if (dp->status != VI_OK) return;
   size_t r = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (r >= dp->V) return;  // the grid is sized for the point count; the occupied-cell count only exists on the device
@@ -50,9 +53,9 @@ int filter_device(lsa_voxel_filter *f, const float4 *d_in, size_t n, float4 *d_o
   for (int attempt = 0; attempt < 2; attempt++) {
     if ((rc = vi_enqueue(ctx, vi, d_in, n, /*mode PCL*/ 0, f->leaf, 4))) return rc;
     hipLaunchKernelGGL(k_filter_finalize, dim3(lsa_div_up(n, kBlock)), dim3(kBlock), 0, ctx->stream, vi.acc.p, vi.cnt.p, vi.cell_of_rank.p, vi.dparams.p,
-                       d_out);
+                       d_out, vi.h_params.p);
     LSA_HIP(ctx, hipGetLastError());
-    if ((rc = vi_fetch(ctx, vi))) return rc;
+    if ((rc = vi_mark_done(ctx, vi))) return rc;
     if ((rc = vi_cleanup(ctx, vi, n))) return rc;  // behind the completion event: off the caller's critical path
     if ((rc = vi_wait(ctx, vi, &status))) return rc;
     if (status != VI_CAPACITY) break;

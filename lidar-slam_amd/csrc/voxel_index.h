@@ -82,6 +82,9 @@ int vi_enqueue(lsa_context *ctx, VoxelIndex &vi, const float4 *d_pts, size_t n, 
 // finalize kernel).  vi_wait() blocks on that event only and refreshes vi.map / vi.fs / vi.W / vi.nocc.
 // Returns VI_* in *status.  On VI_CAPACITY the caller calls vi_grow() and re-enqueues.
 int vi_fetch(lsa_context *ctx, VoxelIndex &vi);
+// Variant for callers whose own last kernel mirrors *dparams into vi.h_params.p[0] (host-mapped pinned memory): only the
+// completion event is recorded, no copy kernel runs.
+int vi_mark_done(lsa_context *ctx, VoxelIndex &vi);
 int vi_wait(lsa_context *ctx, VoxelIndex &vi, int *status);
 int vi_grow(lsa_context *ctx, VoxelIndex &vi);
 // Enqueue the clean-up (zero the bitmap words / sums / counts this build touched) so the next build needs no memset.

@@ -56,7 +56,13 @@ __device__ int ceil_log2_dev(double v) {
 }
 
 // single block: final bbox reduction, then the grid definition by the requested rule set, on the device
-__global__ __launch_bounds__(kBlock) void k_bbox_final_params(const float *__restrict__ partial, int nb, DevParams *__restrict__ dp) {
+struct ReqParams {  // the request travels as a kernel argument: no H2D copy on the critical path
+  int mode;
+  float leaf[3];
+  unsigned long long W_cap;
+};
+
+__global__ __launch_bounds__(kBlock) void k_bbox_final_params(const float *__restrict__ partial, int nb, ReqParams req, DevParams *__restrict__ dp) {
   float mn0 = INFINITY, mn1 = INFINITY, mn2 = INFINITY, mx0 = -INFINITY, mx1 = -INFINITY, mx2 = -INFINITY;
   unsigned long long cnt = 0;
   for (int i = threadIdx.x; i < nb; i += blockDim.x) {
@@ -83,11 +89,14 @@ __global__ __launch_bounds__(kBlock) void k_bbox_final_params(const float *__res
   float mn[3] = {s[0][0], s[0][1], s[0][2]}, mx[3] = {s[0][3], s[0][4], s[0][5]};
   unsigned long long nfin = sc[0];
   CellMap m;
-  m.mode = dp->req_mode;
+  m.mode = req.mode;
+  dp->req_mode = req.mode;
+  dp->W_cap = req.W_cap;
   int status = VI_OK;
   for (int a = 0; a < 3; a++) {
     dp->mn[a] = mn[a]; dp->mx[a] = mx[a];
-    m.leaf[a] = dp->req_leaf[a];
+    m.leaf[a] = req.leaf[a];
+    dp->req_leaf[a] = req.leaf[a];
     m.inv[a] = 1.0f / m.leaf[a];
     m.min_b[a] = 0; m.dim[a] = 1;
   }
@@ -123,7 +132,7 @@ __global__ __launch_bounds__(kBlock) void k_bbox_final_params(const float *__res
     else m.ncells = (long long)m.dim[0] * m.dim[1] * m.dim[2];
   }
   unsigned long long W = (unsigned long long)((m.ncells + 31) / 32);
-  if (status == VI_OK && W > dp->W_cap) status = VI_CAPACITY;
+  if (status == VI_OK && W > req.W_cap) status = VI_CAPACITY;
   // fixed-point scales: |d| <= leaf (+ slop) < 2 * leaf, N <= n_finite summands, |intensity| < 1024 => no int64 overflow
   double leaf_max = fmax(fmax((double)m.leaf[0], (double)m.leaf[1]), (double)m.leaf[2]);
   int bits_n = ceil_log2_dev((double)nfin + 1.0), bits_d = ceil_log2_dev(2.0 * leaf_max);
@@ -174,11 +183,18 @@ __global__ __launch_bounds__(kBlock) void k_mark(const float4 *__restrict__ pts,
   for (int k = threadIdx.x; k < kHashCap; k += kBlock) keys[k] = -1;
   __syncthreads();
   size_t base = (size_t)blockIdx.x * kTile;
-#pragma unroll 2
+  // all 8 loads of a lane are issued before the first use: one HBM latency per tile instead of eight
+  float4 pv[kTile / kBlock];
+#pragma unroll
+  for (int k = 0; k < kTile / kBlock; k++) {
+    size_t i = base + (size_t)k * kBlock + threadIdx.x;
+    pv[k] = (i < n) ? pts[i] : make_float4(NAN, NAN, NAN, 0.f);
+  }
+#pragma unroll
   for (int k = 0; k < kTile / kBlock; k++) {
     size_t i = base + (size_t)k * kBlock + threadIdx.x;
     if (i >= n) break;
-    float4 p = pts[i];
+    float4 p = pv[k];
     int cell = -1;
     if (lsa_finite3(p.x, p.y, p.z)) {
       int ijk[3];
@@ -253,39 +269,44 @@ __global__ __launch_bounds__(kBlock) void k_scan_apply(const uint32_t *__restric
                                                        uint32_t *__restrict__ prefix, int32_t *__restrict__ cell_of_rank) {
   if (dp->status != VI_OK || blockIdx.x >= dp->nsb) return;
   const size_t W = dp->W;
-  // thread t owns 8 consecutive words of the tile so the in-block scan is one value per thread
+  // thread t owns 8 consecutive words (two 16-byte loads; the bitmap capacity is a multiple of the tile, and words past
+  // W are zero), so the in-block scan is one value per thread: wave shuffle scan + one barrier for the 4 wave totals
   size_t base = (size_t)blockIdx.x * kScanTile + (size_t)threadIdx.x * 8;
-  uint32_t wv[8];
+  const uint4 *src = reinterpret_cast<const uint4 *>(bits + base);
+  uint4 lo = src[0], hi = src[1];
+  uint32_t wv[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
   unsigned local = 0;
 #pragma unroll
   for (int k = 0; k < 8; k++) {
-    size_t i = base + k;
-    wv[k] = (i < W) ? bits[i] : 0u;
+    if (base + k >= W) wv[k] = 0u;
     local += __popc(wv[k]);
   }
-  __shared__ unsigned s[kBlock];
-  s[threadIdx.x] = local;
-  __syncthreads();
-  for (int off = 1; off < kBlock; off <<= 1) {
-    unsigned t = (threadIdx.x >= (unsigned)off) ? s[threadIdx.x - off] : 0;
-    __syncthreads();
-    s[threadIdx.x] += t;
-    __syncthreads();
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  unsigned incl = local;
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    unsigned v = __shfl_up(incl, off, 64);
+    if (lane >= off) incl += v;
   }
-  unsigned run = blocksums[blockIdx.x] + s[threadIdx.x] - local;
+  __shared__ unsigned wt[kBlock / 64];
+  if (lane == 63) wt[wave] = incl;
+  __syncthreads();
+  unsigned run = blocksums[blockIdx.x] + incl - local;
+  for (int w = 0; w < wave; w++) run += wt[w];
+  unsigned pf[8];
 #pragma unroll
   for (int k = 0; k < 8; k++) {
-    size_t i = base + k;
-    if (i < W) {
-      prefix[i] = run;
-      uint32_t b = wv[k];
-      while (b) {
-        int bit = __ffs(b) - 1;
-        b &= b - 1;
-        cell_of_rank[run++] = (int32_t)(i * 32 + bit);
-      }
+    pf[k] = run;
+    uint32_t b = wv[k];
+    while (b) {
+      int bit = __ffs(b) - 1;
+      b &= b - 1;
+      cell_of_rank[run++] = (int32_t)((base + k) * 32 + bit);
     }
   }
+  uint4 *dst = reinterpret_cast<uint4 *>(prefix + base);
+  dst[0] = make_uint4(pf[0], pf[1], pf[2], pf[3]);
+  dst[1] = make_uint4(pf[4], pf[5], pf[6], pf[7]);
 }
 
 template <int NS>
@@ -330,12 +351,19 @@ __global__ __launch_bounds__(kBlock) void k_accum(const float4 *__restrict__ pts
   }
   __syncthreads();
   size_t base = (size_t)blockIdx.x * kTile;
-  for (int k = 0; k < kTile / kBlock; k++) {
+  float4 pv[kTile / kBlock];
+  int cv[kTile / kBlock];
+#pragma unroll
+  for (int k = 0; k < kTile / kBlock; k++) {  // issue every load of the lane up front
     size_t i = base + (size_t)k * kBlock + threadIdx.x;
-    if (i >= n) break;
-    int cell = cell_idx[i];
+    cv[k] = (i < n) ? cell_idx[i] : -1;
+    pv[k] = (i < n) ? pts[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+#pragma unroll
+  for (int k = 0; k < kTile / kBlock; k++) {
+    int cell = cv[k];
     if (cell < 0) continue;
-    float4 p = pts[i];
+    float4 p = pv[k];
     unsigned long long v[NS];
     point_terms<NS>(m, fs, cell, p, v);
     int slot = lds_insert(keys, cell);
@@ -390,7 +418,7 @@ int vi_enqueue(lsa_context *ctx, VoxelIndex &vi, const float4 *d_pts, size_t n, 
   if ((rc = vi.scratch.reserve(ctx, (size_t)nb * 8 + 8))) return rc;
   if ((rc = vi.dparams.reserve(ctx, 1))) return rc;
   if ((rc = vi.h_params.reserve(ctx, 2))) return rc;
-  if (!vi.ev_done) LSA_HIP(ctx, hipEventCreateWithFlags(&vi.ev_done, hipEventDisableTiming));
+  if (!vi.ev_done) LSA_HIP(ctx, hipEventCreateWithFlags(&vi.ev_done, hipEventDisableTiming | hipEventReleaseToSystem));
   // buffers sized by the point count (#occupied <= #points)
   size_t old_cor = vi.cell_of_rank.cap, old_cnt = vi.cnt.cap, old_acc = vi.acc.cap;
   if ((rc = vi.cell_idx.reserve(ctx, n, 1.25))) return rc;
@@ -413,17 +441,14 @@ int vi_enqueue(lsa_context *ctx, VoxelIndex &vi, const float4 *d_pts, size_t n, 
   vi.clean = false;
   vi.acc_ns = ns;
   // request block -> device
-  DevParams *hp = vi.h_params.p + 1;
-  memset(hp, 0, sizeof(DevParams));
-  hp->req_mode = mode;
-  for (int a = 0; a < 3; a++) hp->req_leaf[a] = leaf[a];
-  hp->W_cap = vi.W_cap;
-  hp->status = VI_OK;
-  LSA_HIP(ctx, hipMemcpyAsync(vi.dparams.p, hp, sizeof(DevParams), hipMemcpyHostToDevice, ctx->stream));
+  ReqParams req;
+  req.mode = mode;
+  for (int a = 0; a < 3; a++) req.leaf[a] = leaf[a];
+  req.W_cap = vi.W_cap;
   unsigned nsb_cap = (unsigned)((vi.W_cap + kScanTile - 1) / kScanTile);
   const DevParams *dp = vi.dparams.p;
   hipLaunchKernelGGL(k_bbox_partial, dim3(nb), dim3(kBlock), 0, ctx->stream, d_pts, n, vi.scratch.p);
-  hipLaunchKernelGGL(k_bbox_final_params, dim3(1), dim3(kBlock), 0, ctx->stream, vi.scratch.p, (int)nb, vi.dparams.p);
+  hipLaunchKernelGGL(k_bbox_final_params, dim3(1), dim3(kBlock), 0, ctx->stream, vi.scratch.p, (int)nb, req, vi.dparams.p);
   hipLaunchKernelGGL(k_mark, dim3(lsa_div_up(n, kTile)), dim3(kBlock), 0, ctx->stream, d_pts, n, dp, vi.bits.p, vi.cell_idx.p);
   hipLaunchKernelGGL(k_scan_block_sums, dim3(nsb_cap), dim3(kBlock), 0, ctx->stream, vi.bits.p, dp, vi.blocksums.p);
   hipLaunchKernelGGL(k_scan_top, dim3(1), dim3(1024), 0, ctx->stream, vi.blocksums.p, vi.dparams.p);
@@ -439,6 +464,11 @@ int vi_enqueue(lsa_context *ctx, VoxelIndex &vi, const float4 *d_pts, size_t n, 
 
 int vi_fetch(lsa_context *ctx, VoxelIndex &vi) {
   LSA_HIP(ctx, hipMemcpyAsync(vi.h_params.p, vi.dparams.p, sizeof(DevParams), hipMemcpyDeviceToHost, ctx->stream));
+  LSA_HIP(ctx, hipEventRecord(vi.ev_done, ctx->stream));
+  return LSA_OK;
+}
+
+int vi_mark_done(lsa_context *ctx, VoxelIndex &vi) {
   LSA_HIP(ctx, hipEventRecord(vi.ev_done, ctx->stream));
   return LSA_OK;
 }
@@ -459,6 +489,7 @@ int vi_grow(lsa_context *ctx, VoxelIndex &vi) {
   const DevParams &p = vi.h_params.p[0];
   size_t need = (size_t)p.W + 1;
   size_t want = need + need / 4;
+  want = (want + kScanTile - 1) / kScanTile * kScanTile;  // whole scan tiles: k_scan_apply reads / writes 16-byte vectors
   LSA_HIP(ctx, hipStreamSynchronize(ctx->stream));
   int rc;
   if ((rc = vi.bits.reserve(ctx, want))) return rc;

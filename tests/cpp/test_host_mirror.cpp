@@ -1,0 +1,135 @@
+// test_host_mirror.cpp — drives the C++ host mirror (lidar-slam_amd/host/lsa_plugins.hpp) the way
+// FrontEnd::Update does (front_end.cpp:88-341: Filter -> SetInputTarget -> ScanMatch -> GetFitnessScore) and checks every
+// result against the CPU oracle (oracle/lsa_oracle.h, plain C).  Built and run by tests/test_gpu_cpp_host.py on the GPU box:
+//   g++ -std=c++17 -O1 -Iinclude -Ilidar-slam_amd/host -Ioracle tests/cpp/test_host_mirror.cpp
+//       -Llidar-slam_amd -llidar_slam_amd -Loracle -llsa_oracle -Wl,-rpath,...
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <memory>
+#include <random>
+
+#include "lsa_oracle.h"
+#include "lsa_plugins.hpp"
+
+using namespace lsa;
+
+static int g_fail = 0;
+#define CHECK(cond, ...)                                  \
+  do {                                                    \
+    if (!(cond)) {                                        \
+      std::printf("FAIL %s:%d: ", __FILE__, __LINE__);    \
+      std::printf(__VA_ARGS__);                           \
+      std::printf("\n");                                  \
+      g_fail++;                                           \
+    }                                                     \
+  } while (0)
+
+// a small street: ground, two walls, a few boxes; sampled from a moving viewpoint
+static CloudData::CLOUD_PTR make_cloud(unsigned seed, float ox, float yaw, size_t n) {
+  std::mt19937 rng(seed);
+  std::uniform_real_distribution<float> U(0.f, 1.f);
+  std::normal_distribution<float> N(0.f, 0.02f);
+  auto c = std::make_shared<Cloud>();
+  c->points.reserve(n);
+  float cy = std::cos(-yaw), sy = std::sin(-yaw);
+  for (size_t i = 0; i < n; i++) {
+    float x, y, z;
+    float pick = U(rng);
+    if (pick < 0.5f) { x = -30.f + 60.f * U(rng); y = -11.f + 22.f * U(rng); z = -1.73f; }                 // ground
+    else if (pick < 0.7f) { x = -30.f + 60.f * U(rng); y = 11.f + 0.8f * std::floor(x / 9.f) * 0.5f; z = -1.73f + 5.f * U(rng); }   // wall with setbacks
+    else if (pick < 0.9f) { x = -30.f + 60.f * U(rng); y = -11.f - 0.6f * std::floor(x / 7.f) * 0.5f; z = -1.73f + 5.f * U(rng); }
+    else { int b = (int)(U(rng) * 6); x = -25.f + 10.f * b + 2.f * U(rng); y = (b % 2 ? 6.f : -6.f) + 1.5f * U(rng); z = -1.73f + 1.5f * U(rng); }  // boxes
+    x += N(rng); y += N(rng); z += N(rng);
+    // world -> sensor at (ox, 0, 0) with heading yaw
+    float dx = x - ox, dy = y;
+    PointXYZI p;
+    p.x = cy * dx - sy * dy; p.y = sy * dx + cy * dy; p.z = z; p.intensity = 0.2f + 0.8f * U(rng);
+    c->points.push_back(p);
+  }
+  return c;
+}
+
+static void pose_err(const Matrix4f &a, const float b[16], double *dt, double *dr) {
+  double t = 0, r = 0;
+  for (int i = 0; i < 3; i++) t += (a(i, 3) - b[12 + i]) * (a(i, 3) - b[12 + i]);
+  for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) r += (a(i, j) - b[j * 4 + i]) * (a(i, j) - b[j * 4 + i]);
+  *dt = std::sqrt(t); *dr = std::sqrt(r);
+}
+
+int main() {
+  std::shared_ptr<Context> ctx;
+  try { ctx = std::make_shared<Context>(0); } catch (const std::exception &e) { std::printf("FAIL: %s\n", e.what()); return 2; }
+
+  auto scan0 = make_cloud(1, 0.f, 0.f, 60000);
+  auto scan1 = make_cloud(2, 0.6f, 0.01f, 60000);
+
+  // ---- CloudFilterInterface: VoxelFilterHip / NoFilter, including in == out (viewer.cpp:207)
+  std::shared_ptr<CloudFilterInterface> frame_filter = std::make_shared<VoxelFilterHip>(ctx, 0.5f, 0.5f, 0.5f);
+  CloudData::CLOUD_PTR filtered(new Cloud());
+  CHECK(frame_filter->Filter(scan1, filtered), "Filter returned false");
+  std::vector<float> ref(scan1->size() * 4);
+  size_t n_ref = 0;
+  int rc = orc_voxel_filter(scan1->points.data(), scan1->size(), 32, 16, 0.5f, 0.5f, 0.5f, ref.data(), scan1->size(), &n_ref);
+  CHECK(rc == 0 && n_ref == filtered->size(), "voxel count %zu vs oracle %zu", filtered->size(), n_ref);
+  double worst = 0;
+  for (size_t i = 0; i < n_ref && i < filtered->size(); i++) {
+    const PointXYZI &p = filtered->points[i];
+    worst = std::fmax(worst, std::fabs(p.x - ref[4 * i]));
+    worst = std::fmax(worst, std::fabs(p.y - ref[4 * i + 1]));
+    worst = std::fmax(worst, std::fabs(p.z - ref[4 * i + 2]));
+    worst = std::fmax(worst, std::fabs(p.intensity - ref[4 * i + 3]));
+  }
+  CHECK(worst < 2e-5, "filter values differ by %g", worst);
+  CloudData::CLOUD_PTR alias(new Cloud(*scan1));
+  frame_filter->Filter(alias, alias);
+  CHECK(alias->size() == filtered->size(), "in==out filter size %zu vs %zu", alias->size(), filtered->size());
+  NoFilter nf;
+  CloudData::CLOUD_PTR copy(new Cloud());
+  nf.Filter(scan1, copy);
+  CHECK(copy->size() == scan1->size() && copy->points[7].x == scan1->points[7].x, "NoFilter is not a deep copy");
+  std::printf("filter: %zu -> %zu points, max |diff| vs oracle %.2e\n", scan1->size(), filtered->size(), worst);
+
+  // ---- RegistrationInterface: NDT
+  std::shared_ptr<RegistrationInterface> reg = std::make_shared<NDTRegistrationHip>(ctx, 1.0f, 0.1f, 0.01f, 30, 0.55f);
+  CHECK(reg->SetInputTarget(scan0), "SetInputTarget returned false");
+  Matrix4f guess = Matrix4f::Identity(), pose = Matrix4f::Identity();
+  CloudData::CLOUD_PTR result_cloud(new Cloud());
+  CHECK(reg->ScanMatch(filtered, guess, result_cloud, pose), "ScanMatch returned false");
+  orc_ndt *o = orc_ndt_create(1.0f, 0.1f, 0.01f, 30, 0.55f);
+  orc_ndt_set_target(o, scan0->points.data(), scan0->size(), 32, 16);
+  float opose[16];
+  orc_ndt_stats ost;
+  orc_ndt_align(o, filtered->points.data(), filtered->size(), 32, guess.data(), opose, &ost);
+  double dt, dr;
+  pose_err(pose, opose, &dt, &dr);
+  auto *ndt = static_cast<NDTRegistrationHip *>(reg.get());
+  CHECK(dt < 1e-4 && dr < 1e-5, "NDT pose differs from oracle: dt %g dR %g", dt, dr);
+  CHECK(ndt->stats().iterations == ost.iterations && ndt->stats().passes == ost.passes, "NDT iterations %d/%d passes %d/%d", ndt->stats().iterations,
+        ost.iterations, ndt->stats().passes, ost.passes);
+  CHECK(std::fabs(pose(0, 3) - 0.6f) < 0.08f, "NDT did not recover the 0.6 m motion: %g", pose(0, 3));
+  float fit = reg->GetFitnessScore();
+  double ofit = orc_ndt_fitness(o, filtered->points.data(), filtered->size(), 32, opose);
+  CHECK(std::fabs(fit - ofit) < 1e-5 * ofit, "fitness %g vs oracle %g", fit, ofit);
+  std::printf("ndt: %d iterations, x = %.4f, |dt| %.2e |dR| %.2e vs oracle, fitness %.6f (oracle %.6f)\n", ost.iterations, pose(0, 3), dt, dr, fit, ofit);
+  orc_ndt_free(o);
+
+  // ---- RegistrationInterface: ICP (ICPRegistrationManual semantics)
+  std::shared_ptr<CloudFilterInterface> map_filter = std::make_shared<VoxelFilterHip>(ctx, 0.3f, 0.3f, 0.3f);
+  CloudData::CLOUD_PTR map(new Cloud());
+  map_filter->Filter(scan0, map);
+  std::shared_ptr<RegistrationInterface> icp = std::make_shared<ICPRegistrationHip>(ctx, 2.0f, 30);
+  icp->SetInputTarget(map);
+  Matrix4f ipose = Matrix4f::Identity();
+  icp->ScanMatch(filtered, guess, result_cloud, ipose);
+  float oipose[16];
+  orc_icp_manual(map->points.data(), map->size(), 32, filtered->points.data(), filtered->size(), 32, 2.0f, 30, guess.data(), oipose);
+  pose_err(ipose, oipose, &dt, &dr);
+  CHECK(dt < 3e-4 && dr < 3e-5, "ICP pose differs from oracle: dt %g dR %g", dt, dr);
+  CHECK(result_cloud->size() == filtered->size(), "ICP result cloud not filled");
+  CHECK(icp->GetFitnessScore() == 0.f, "ICP fitness must be 0 like the reference");
+  std::printf("icp: x = %.4f, |dt| %.2e |dR| %.2e vs oracle\n", ipose(0, 3), dt, dr);
+
+  std::printf(g_fail ? "FAILED (%d)\n" : "ALL OK\n", g_fail);
+  return g_fail ? 1 : 0;
+}
