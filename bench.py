@@ -109,16 +109,23 @@ def main():
     from lidar_slam_amd import capi, cloud_filter, registration, synth
     from lidar_slam_amd import dist as lsa_dist
 
-    torch.cuda.set_device(local_rank)
+    # rehearsal on a one-GPU box: LSA_BENCH_ONE_GPU=1 maps every rank to cuda:0 and swaps the collective for gloo
+    # (RCCL refuses two ranks on one device); the production launch is one rank per GPU over RCCL
+    one_gpu = os.environ.get("LSA_BENCH_ONE_GPU") == "1"
+    dev_index = 0 if one_gpu else local_rank
+    torch.cuda.set_device(dev_index)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
-    dev = torch.device("cuda", local_rank)
+        if one_gpu:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", dev_index))
+    dev = torch.device("cuda", dev_index)
     # one non-default stream shared by torch (uploads, RCCL collectives) and the library (kernels, copies):
     # everything the hot path does is ordered on it, no cross-stream events needed
     tstream = torch.cuda.Stream(device=dev)
     torch.cuda.set_stream(tstream)
-    ctx = capi.Context(local_rank, tstream.cuda_stream)
+    ctx = capi.Context(dev_index, tstream.cuda_stream)
 
     frame_filter = cloud_filter.VoxelFilterHip(ctx, 0.5, 0.5, 0.5)       # front_end.yaml:46-47
     map_filter = cloud_filter.VoxelFilterHip(ctx, 0.3, 0.3, 0.3)         # front_end.yaml:44-45
@@ -151,7 +158,7 @@ def main():
         truths.append((P0inv @ poses[k]).astype(np.float32))
     d_filt = torch.empty((max(s.shape[0] for s in d_scans), 4), dtype=torch.float32, device=dev)
     if world > 1:
-        ndt.set_allreduce(lsa_dist.make_rccl_allreduce())
+        ndt.set_allreduce(lsa_dist.make_gloo_staged_allreduce() if one_gpu else lsa_dist.make_rccl_allreduce())
 
     results = {}
 
@@ -202,9 +209,14 @@ def main():
     # DVFS state; spin the same work (untimed, results discarded) for a fixed wall time first, then do the W warm-ups
     t_ramp = time.perf_counter()
     i_ramp = 0
-    while time.perf_counter() - t_ramp < args.ramp_seconds:
-        step(i_ramp)
-        i_ramp += 1
+    if world > 1:
+        # every step contains collectives, so all ranks must run the SAME number of ramp steps: count-based, not timed
+        for i_ramp in range(int(args.ramp_seconds * 2000)):
+            step(i_ramp)
+    else:
+        while time.perf_counter() - t_ramp < args.ramp_seconds:
+            step(i_ramp)
+            i_ramp += 1
     for i in range(args.warmup):
         step(i)
     sync_all()
@@ -215,7 +227,7 @@ def main():
     elapsed = time.perf_counter() - t0
     collect()
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if one_gpu else dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
@@ -239,6 +251,14 @@ def main():
             ndt.ScanMatch(f, guesses[k])
         torch.cuda.synchronize()
         split["align_ms"] = (time.perf_counter() - t0) * 1e3 / reps
+        # PCIe-inclusive rate through the host-pointer boundary (what a PCL caller sees): pack 32-B PointXYZI -> 16 B,
+        # H2D, filter, D2H, H2D, align.  Reported for DESIGN.md; it is never the headline `value`.
+        raw8 = synth.to_xyzi32(scans[TEST_SCANS[k]])
+        t0 = time.perf_counter()
+        for _ in range(20):
+            _, f8 = frame_filter.Filter(raw8)
+            ndt.ScanMatch(f8, guesses[k])
+        split["host_boundary_ms_per_scan"] = (time.perf_counter() - t0) * 1e3 / 20
         ndt.set_source(f)
         L = capi.lib()
         p = np.zeros(6)

@@ -43,6 +43,26 @@ def make_rccl_allreduce(group=None):
     return fn
 
 
+def make_gloo_staged_allreduce(group=None):
+    """Rehearsal variant for boxes with fewer GPUs than ranks: stage the 32 doubles through the host and all-reduce
+    them with gloo.  Same call protocol as make_rccl_allreduce()."""
+    import torch
+    import torch.distributed as dist
+    cache = {}
+
+    def fn(ptr, n, stream):
+        t = cache.get(ptr)
+        if t is None:
+            t = torch.as_tensor(_DevPtr(ptr, n), device="cuda")
+            cache[ptr] = t
+        h = t.cpu()  # synchronises the current stream
+        dist.all_reduce(h, op=dist.ReduceOp.SUM, group=group)
+        t.copy_(h)
+        return 0
+
+    return fn
+
+
 def allreduce_out32_cpu(out32, group=None):
     """gloo path used by the CPU tests: sum a host 32-double block over ranks."""
     import torch
