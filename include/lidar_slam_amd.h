@@ -195,6 +195,48 @@ int lsa_icp_scan_match_device(lsa_icp *icp, const float *d_src_xyzw, size_t n, c
 /* GetFitnessScore(): unimplemented in the reference, returns 0 (:62-67) */
 int lsa_icp_get_fitness_score(lsa_icp *icp, float *score);
 
+/* ---------------------------------------------------------------------------------------------
+ * Front end with a device-resident sliding local map — the caller of the two plugin
+ * interfaces above: FrontEnd::Update / UpdateWithNewFrame / SetInitPose
+ * (lidar_localization/src/mapping/front_end/front_end.cpp:88-341, :348-424, :343-346), without the detector-box
+ * static-weight bookkeeping (:111-161, :247-334).  The key-frame clouds, the concatenated local map, its 0.3 m
+ * filtered version and the NDT voxel table all stay in HBM; a key-frame costs no host <-> device transfer.
+ * ------------------------------------------------------------------------------------------- */
+typedef struct lsa_front_end lsa_front_end;
+
+typedef struct {
+  float key_frame_distance;   /* front_end.yaml:11, L1 translation (front_end.cpp:243-245) */
+  int32_t local_frame_num;    /* front_end.yaml:12 */
+  int32_t use_frame_filter;   /* frame_filter: voxel_filter (1) / no_filter (0) */
+  int32_t use_map_filter;     /* local_map_filter */
+  float frame_leaf[3];        /* front_end.yaml:46-47 */
+  float map_leaf[3];          /* front_end.yaml:44-45 */
+  float ndt_res, ndt_step_size, ndt_trans_eps, ndt_outlier_ratio; /* front_end.yaml:24-29 */
+  int32_t ndt_max_iter;
+  int32_t reset_intensity;    /* 1: like the reference, key-frames after the first are stored with static weight 1.0
+                                 (front_end.cpp:304-306); 0: keep the incoming intensities */
+} lsa_front_end_config;
+
+typedef struct {
+  int32_t key_frame;          /* this scan became a key-frame (local map + target rebuilt) */
+  int32_t local_map_frames;
+  int64_t filtered_points;    /* source points after the frame filter */
+  int64_t local_map_points;   /* concatenated key-frame points */
+  int64_t target_points;      /* points handed to SetInputTarget (filtered once >= 10 key-frames) */
+  lsa_ndt_stats ndt;          /* of this scan's ScanMatch (zero for the first frame) */
+} lsa_front_end_stats;
+
+int lsa_front_end_create(lsa_front_end **out, lsa_context *ctx, const lsa_front_end_config *cfg);
+void lsa_front_end_destroy(lsa_front_end *fe);
+/* FrontEnd::SetInitPose */
+int lsa_front_end_set_init_pose(lsa_front_end *fe, const float pose[16]);
+/* FrontEnd::Update(cloud_data, cloud_pose): one scan in, its pose (map <- lidar, column-major) out */
+int lsa_front_end_update(lsa_front_end *fe, const void *cloud, size_t n, size_t stride, size_t w_off, float pose_out[16],
+                         lsa_front_end_stats *stats);
+int lsa_front_end_update_device(lsa_front_end *fe, const float *d_xyzw, size_t n, float pose_out[16], lsa_front_end_stats *stats);
+/* the NDT handle the front end owns (for GetFitnessScore / introspection); do not destroy it */
+lsa_ndt *lsa_front_end_registration(lsa_front_end *fe);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,274 @@
+// front_end.hip — lsa_front_end_*: the caller of the hot path, with the sliding local map kept in HBM.
+//
+// SURVEY.md section 8f row 1.  Mirrors FrontEnd::Update and FrontEnd::UpdateWithNewFrame
+// (reference: lidar_localization/src/mapping/front_end/front_end.cpp:88-341 and :348-424) for the scan-to-local-map
+// odometry loop, without the detector-box static-weight bookkeeping (:111-161, :247-334, inactive without the bbox
+// files the reference loads from an absolute path outside its tree):
+//   frame filter -> [first frame: becomes key-frame 0 at the init pose] -> ScanMatch(filtered, predict_pose)
+//   -> constant-velocity prediction step = last^-1 * cur, predict = cur * step (:238-240)
+//   -> key-frame if the L1 translation from the last key-frame exceeds key_frame_distance (:243-245)
+//   -> UpdateWithNewFrame: keep the RAW (unfiltered) cloud of the last `local_frame_num` key-frames, transform each by
+//      its pose (pcl::transformPointCloud, f32), concatenate, and SetInputTarget with the raw map while there are fewer
+//      than 10 key-frames, else with the map filtered at the local-map leaf (:394-410).
+// In the reference every key-frame re-uploads nothing (CPU) but re-transforms 20 x 120 k points and re-filters 2.4 M
+// points on one core (~100 ms); here the key-frame clouds stay on the device, so a key-frame costs one D2D copy, 20 small
+// transform kernels, one filter and one voxel-table build, with no host <-> device traffic at all.
+#include "voxel_index_dev.h"
+
+#include <cmath>
+#include <deque>
+#include <vector>
+
+namespace {
+constexpr int kBlock = 256;
+
+struct T12 { float v[12]; };
+
+// pcl::transformPointCloud: xyz' = M * xyz + t in f32 (left to right, no FMA); every other field copied
+__global__ __launch_bounds__(kBlock) void k_transform(const float4 *__restrict__ in, size_t n, T12 T, float4 *__restrict__ out, int force_w_one) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  float4 s = in[i];
+  float4 o;
+  o.x = lsa_fadd(lsa_fadd(lsa_fadd(lsa_fmul(T.v[0], s.x), lsa_fmul(T.v[1], s.y)), lsa_fmul(T.v[2], s.z)), T.v[3]);
+  o.y = lsa_fadd(lsa_fadd(lsa_fadd(lsa_fmul(T.v[4], s.x), lsa_fmul(T.v[5], s.y)), lsa_fmul(T.v[6], s.z)), T.v[7]);
+  o.z = lsa_fadd(lsa_fadd(lsa_fadd(lsa_fmul(T.v[8], s.x), lsa_fmul(T.v[9], s.y)), lsa_fmul(T.v[10], s.z)), T.v[11]);
+  o.w = force_w_one ? 1.0f : s.w;
+  out[i] = o;
+}
+
+__global__ __launch_bounds__(kBlock) void k_copy_w(const float4 *__restrict__ in, size_t n, float4 *__restrict__ out, int force_w_one) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  float4 s = in[i];
+  if (force_w_one) s.w = 1.0f;
+  out[i] = s;
+}
+
+void mat4_mul(const float a[16], const float b[16], float c[16]) {  // column-major, f32 like Eigen::Matrix4f
+  float r[16];
+  for (int col = 0; col < 4; col++)
+    for (int row = 0; row < 4; row++) {
+      float s = 0.f;
+      for (int k = 0; k < 4; k++) s += a[k * 4 + row] * b[col * 4 + k];
+      r[col * 4 + row] = s;
+    }
+  memcpy(c, r, sizeof(r));
+}
+
+bool mat4_inverse(const float m[16], float inv_out[16]) {  // general 4x4 inverse by cofactors (what Matrix4f::inverse() does), f32
+  float inv[16];
+  inv[0] = m[5] * m[10] * m[15] - m[5] * m[11] * m[14] - m[9] * m[6] * m[15] + m[9] * m[7] * m[14] + m[13] * m[6] * m[11] - m[13] * m[7] * m[10];
+  inv[4] = -m[4] * m[10] * m[15] + m[4] * m[11] * m[14] + m[8] * m[6] * m[15] - m[8] * m[7] * m[14] - m[12] * m[6] * m[11] + m[12] * m[7] * m[10];
+  inv[8] = m[4] * m[9] * m[15] - m[4] * m[11] * m[13] - m[8] * m[5] * m[15] + m[8] * m[7] * m[13] + m[12] * m[5] * m[11] - m[12] * m[7] * m[9];
+  inv[12] = -m[4] * m[9] * m[14] + m[4] * m[10] * m[13] + m[8] * m[5] * m[14] - m[8] * m[6] * m[13] - m[12] * m[5] * m[10] + m[12] * m[6] * m[9];
+  inv[1] = -m[1] * m[10] * m[15] + m[1] * m[11] * m[14] + m[9] * m[2] * m[15] - m[9] * m[3] * m[14] - m[13] * m[2] * m[11] + m[13] * m[3] * m[10];
+  inv[5] = m[0] * m[10] * m[15] - m[0] * m[11] * m[14] - m[8] * m[2] * m[15] + m[8] * m[3] * m[14] + m[12] * m[2] * m[11] - m[12] * m[3] * m[10];
+  inv[9] = -m[0] * m[9] * m[15] + m[0] * m[11] * m[13] + m[8] * m[1] * m[15] - m[8] * m[3] * m[13] - m[12] * m[1] * m[11] + m[12] * m[3] * m[9];
+  inv[13] = m[0] * m[9] * m[14] - m[0] * m[10] * m[13] - m[8] * m[1] * m[14] + m[8] * m[2] * m[13] + m[12] * m[1] * m[10] - m[12] * m[2] * m[9];
+  inv[2] = m[1] * m[6] * m[15] - m[1] * m[7] * m[14] - m[5] * m[2] * m[15] + m[5] * m[3] * m[14] + m[13] * m[2] * m[7] - m[13] * m[3] * m[6];
+  inv[6] = -m[0] * m[6] * m[15] + m[0] * m[7] * m[14] + m[4] * m[2] * m[15] - m[4] * m[3] * m[14] - m[12] * m[2] * m[7] + m[12] * m[3] * m[6];
+  inv[10] = m[0] * m[5] * m[15] - m[0] * m[7] * m[13] - m[4] * m[1] * m[15] + m[4] * m[3] * m[13] + m[12] * m[1] * m[7] - m[12] * m[3] * m[5];
+  inv[14] = -m[0] * m[5] * m[14] + m[0] * m[6] * m[13] + m[4] * m[1] * m[14] - m[4] * m[2] * m[13] - m[12] * m[1] * m[6] + m[12] * m[2] * m[5];
+  inv[3] = -m[1] * m[6] * m[11] + m[1] * m[7] * m[10] + m[5] * m[2] * m[11] - m[5] * m[3] * m[10] - m[9] * m[2] * m[7] + m[9] * m[3] * m[6];
+  inv[7] = m[0] * m[6] * m[11] - m[0] * m[7] * m[10] - m[4] * m[2] * m[11] + m[4] * m[3] * m[10] + m[8] * m[2] * m[7] - m[8] * m[3] * m[6];
+  inv[11] = -m[0] * m[5] * m[11] + m[0] * m[7] * m[9] + m[4] * m[1] * m[11] - m[4] * m[3] * m[9] - m[8] * m[1] * m[7] + m[8] * m[3] * m[5];
+  inv[15] = m[0] * m[5] * m[10] - m[0] * m[6] * m[9] - m[4] * m[1] * m[10] + m[4] * m[2] * m[9] + m[8] * m[1] * m[6] - m[8] * m[2] * m[5];
+  float det = m[0] * inv[0] + m[1] * inv[4] + m[2] * inv[8] + m[3] * inv[12];
+  if (det == 0.f) return false;
+  float id = 1.0f / det;
+  for (int i = 0; i < 16; i++) inv_out[i] = inv[i] * id;
+  return true;
+}
+
+void identity16(float m[16]) {
+  memset(m, 0, 16 * sizeof(float));
+  m[0] = m[5] = m[10] = m[15] = 1.0f;
+}
+}  // namespace
+
+struct KeyFrame {
+  DevBuf<float4> pts;
+  size_t n = 0;
+  float pose[16];
+};
+
+struct lsa_front_end {
+  lsa_context *ctx = nullptr;
+  lsa_front_end_config cfg{};
+  lsa_voxel_filter *frame_filter = nullptr, *map_filter = nullptr;
+  lsa_ndt *ndt = nullptr;
+  std::deque<KeyFrame *> frames;
+  std::vector<KeyFrame *> pool;
+  DevBuf<float4> d_in, d_filtered, d_map, d_map_f;
+  PinnedBuf<float> h_stage;
+  float init_pose[16], last_pose[16], predict_pose[16], step_pose[16], last_kf_pose[16];
+  size_t map_points = 0, target_points = 0;
+  long frames_seen = 0;
+};
+
+namespace {
+int fe_rebuild_map(lsa_front_end *fe) {
+  lsa_context *ctx = fe->ctx;
+  size_t total = 0;
+  for (KeyFrame *f : fe->frames) total += f->n;
+  int rc;
+  if ((rc = fe->d_map.reserve(ctx, total, 1.25))) return rc;
+  size_t off = 0;
+  for (KeyFrame *f : fe->frames) {
+    if (!f->n) continue;
+    T12 T;
+    for (int r = 0; r < 3; r++)
+      for (int c = 0; c < 4; c++) T.v[r * 4 + c] = f->pose[c * 4 + r];
+    hipLaunchKernelGGL(k_transform, dim3(lsa_div_up(f->n, kBlock)), dim3(kBlock), 0, ctx->stream, f->pts.p, f->n, T, fe->d_map.p + off, 0);
+    off += f->n;
+  }
+  LSA_HIP(ctx, hipGetLastError());
+  fe->map_points = total;
+  if ((int)fe->frames.size() < 10 || !fe->cfg.use_map_filter) {  // front_end.cpp:394-396: few key-frames -> unfiltered map
+    fe->target_points = total;
+    return lsa_ndt_set_input_target_device(fe->ndt, (const float *)fe->d_map.p, total);
+  }
+  if ((rc = fe->d_map_f.reserve(ctx, total, 1.25))) return rc;
+  size_t V = 0;
+  rc = lsa_voxel_filter_apply_device(fe->map_filter, (const float *)fe->d_map.p, total, (float *)fe->d_map_f.p, &V);
+  if (rc == LSA_ERR_RANGE) {  // PCL passes the input through
+    fe->target_points = total;
+    return lsa_ndt_set_input_target_device(fe->ndt, (const float *)fe->d_map.p, total);
+  }
+  if (rc) return rc;
+  fe->target_points = V;
+  return lsa_ndt_set_input_target_device(fe->ndt, (const float *)fe->d_map_f.p, V);
+}
+
+int fe_add_key_frame(lsa_front_end *fe, const float4 *d_cloud, size_t n, const float pose[16], bool reset_w) {
+  lsa_context *ctx = fe->ctx;
+  KeyFrame *kf;
+  if ((int)fe->frames.size() >= fe->cfg.local_frame_num && !fe->frames.empty()) {  // :364-372: slide the window
+    kf = fe->frames.front();
+    fe->frames.pop_front();
+  } else if (!fe->pool.empty()) {
+    kf = fe->pool.back();
+    fe->pool.pop_back();
+  } else {
+    kf = new KeyFrame();
+  }
+  int rc = kf->pts.reserve(ctx, n, 1.1);
+  if (rc) { fe->pool.push_back(kf); return rc; }
+  kf->n = n;
+  memcpy(kf->pose, pose, 16 * sizeof(float));
+  if (n) hipLaunchKernelGGL(k_copy_w, dim3(lsa_div_up(n, kBlock)), dim3(kBlock), 0, ctx->stream, d_cloud, n, kf->pts.p, reset_w ? 1 : 0);
+  fe->frames.push_back(kf);
+  while ((int)fe->frames.size() > fe->cfg.local_frame_num) {
+    fe->pool.push_back(fe->frames.front());
+    fe->frames.pop_front();
+  }
+  return fe_rebuild_map(fe);
+}
+
+int fe_update_device(lsa_front_end *fe, const float4 *d_cloud, size_t n, float pose_out[16], lsa_front_end_stats *stats) {
+  lsa_context *ctx = fe->ctx;
+  lsa_front_end_stats st;
+  memset(&st, 0, sizeof(st));
+  int rc;
+  // frame filter (:106-107)
+  const float4 *src = d_cloud;
+  size_t n_src = n;
+  if (fe->cfg.use_frame_filter) {
+    if ((rc = fe->d_filtered.reserve(ctx, n ? n : 1, 1.25))) return rc;
+    size_t V = 0;
+    rc = lsa_voxel_filter_apply_device(fe->frame_filter, (const float *)d_cloud, n, (float *)fe->d_filtered.p, &V);
+    if (rc == LSA_OK) { src = fe->d_filtered.p; n_src = V; }
+    else if (rc != LSA_ERR_RANGE) return rc;
+  }
+  st.filtered_points = (int64_t)n_src;
+  if (fe->frames.empty()) {  // first frame: key-frame 0 at the init pose, raw intensities kept (:203-218)
+    if ((rc = fe_add_key_frame(fe, d_cloud, n, fe->init_pose, false))) return rc;
+    memcpy(pose_out, fe->init_pose, 16 * sizeof(float));
+    memcpy(fe->last_pose, fe->init_pose, sizeof(fe->last_pose));
+    memcpy(fe->predict_pose, fe->init_pose, sizeof(fe->predict_pose));
+    memcpy(fe->last_kf_pose, fe->init_pose, sizeof(fe->last_kf_pose));
+    identity16(fe->step_pose);
+    st.key_frame = 1;
+  } else {
+    float cur[16];
+    if ((rc = lsa_ndt_scan_match_device(fe->ndt, (const float *)src, n_src, fe->predict_pose, cur, &st.ndt))) return rc;
+    memcpy(pose_out, cur, sizeof(cur));
+    float inv_last[16];
+    if (mat4_inverse(fe->last_pose, inv_last)) mat4_mul(inv_last, cur, fe->step_pose);  // :238
+    mat4_mul(cur, fe->step_pose, fe->predict_pose);                                      // :239
+    memcpy(fe->last_pose, cur, sizeof(cur));                                             // :240
+    float l1 = std::fabs(fe->last_kf_pose[12] - cur[12]) + std::fabs(fe->last_kf_pose[13] - cur[13]) + std::fabs(fe->last_kf_pose[14] - cur[14]);
+    if (l1 > fe->cfg.key_frame_distance) {  // :243-245
+      // the reference resets every point's static weight to 1.0 before storing a later key-frame (:304-306)
+      if ((rc = fe_add_key_frame(fe, d_cloud, n, cur, fe->cfg.reset_intensity != 0))) return rc;
+      memcpy(fe->last_kf_pose, cur, sizeof(cur));
+      st.key_frame = 1;
+    }
+  }
+  fe->frames_seen++;
+  st.local_map_frames = (int32_t)fe->frames.size();
+  st.local_map_points = (int64_t)fe->map_points;
+  st.target_points = (int64_t)fe->target_points;
+  if (stats) *stats = st;
+  return LSA_OK;
+}
+}  // namespace
+
+extern "C" int lsa_front_end_create(lsa_front_end **out, lsa_context *ctx, const lsa_front_end_config *cfg) {
+  if (!out || !ctx || !cfg) { lsa_set_global_error("lsa_front_end_create: null argument"); return LSA_ERR_INVALID; }
+  *out = nullptr;
+  if (cfg->local_frame_num < 1) return lsa_fail(ctx, LSA_ERR_INVALID, "lsa_front_end_create: local_frame_num must be >= 1");
+  lsa_front_end *fe = new lsa_front_end();
+  fe->ctx = ctx;
+  fe->cfg = *cfg;
+  int rc = LSA_OK;
+  if (cfg->use_frame_filter) rc = lsa_voxel_filter_create(&fe->frame_filter, ctx, cfg->frame_leaf[0], cfg->frame_leaf[1], cfg->frame_leaf[2]);
+  if (!rc && cfg->use_map_filter) rc = lsa_voxel_filter_create(&fe->map_filter, ctx, cfg->map_leaf[0], cfg->map_leaf[1], cfg->map_leaf[2]);
+  if (!rc) rc = lsa_ndt_create(&fe->ndt, ctx, cfg->ndt_res, cfg->ndt_step_size, cfg->ndt_trans_eps, cfg->ndt_max_iter, cfg->ndt_outlier_ratio);
+  if (rc) { lsa_front_end_destroy(fe); return rc; }
+  identity16(fe->init_pose); identity16(fe->last_pose); identity16(fe->predict_pose); identity16(fe->step_pose); identity16(fe->last_kf_pose);
+  *out = fe;
+  return LSA_OK;
+}
+
+extern "C" void lsa_front_end_destroy(lsa_front_end *fe) {
+  if (!fe) return;
+  (void)hipSetDevice(fe->ctx->device);
+  (void)hipStreamSynchronize(fe->ctx->stream);
+  for (KeyFrame *f : fe->frames) { f->pts.release(); delete f; }
+  for (KeyFrame *f : fe->pool) { f->pts.release(); delete f; }
+  fe->d_in.release(); fe->d_filtered.release(); fe->d_map.release(); fe->d_map_f.release(); fe->h_stage.release();
+  lsa_voxel_filter_destroy(fe->frame_filter);
+  lsa_voxel_filter_destroy(fe->map_filter);
+  lsa_ndt_destroy(fe->ndt);
+  delete fe;
+}
+
+extern "C" int lsa_front_end_set_init_pose(lsa_front_end *fe, const float pose[16]) {  // FrontEnd::SetInitPose (:343-346)
+  if (!fe || !pose) return LSA_ERR_INVALID;
+  memcpy(fe->init_pose, pose, sizeof(fe->init_pose));
+  return LSA_OK;
+}
+
+extern "C" int lsa_front_end_update_device(lsa_front_end *fe, const float *d_xyzw, size_t n, float pose_out[16], lsa_front_end_stats *stats) {
+  if (!fe || !pose_out || (n && !d_xyzw)) return fe ? lsa_fail(fe->ctx, LSA_ERR_INVALID, "lsa_front_end_update_device: null argument") : LSA_ERR_INVALID;
+  LSA_HIP(fe->ctx, hipSetDevice(fe->ctx->device));
+  return fe_update_device(fe, (const float4 *)d_xyzw, n, pose_out, stats);
+}
+
+extern "C" int lsa_front_end_update(lsa_front_end *fe, const void *cloud, size_t n, size_t stride, size_t w_off, float pose_out[16],
+                                    lsa_front_end_stats *stats) {
+  if (!fe || !pose_out || (n && (!cloud || stride < 12))) return fe ? lsa_fail(fe->ctx, LSA_ERR_INVALID, "lsa_front_end_update: bad argument") : LSA_ERR_INVALID;
+  lsa_context *ctx = fe->ctx;
+  LSA_HIP(ctx, hipSetDevice(ctx->device));
+  int rc;
+  if ((rc = fe->h_stage.reserve(ctx, (n ? n : 1) * 4))) return rc;
+  if ((rc = fe->d_in.reserve(ctx, n ? n : 1, 1.25))) return rc;
+  LSA_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  lsa_pack_xyzw(cloud, n, stride, w_off, fe->h_stage.p);
+  LSA_HIP(ctx, hipMemcpyAsync(fe->d_in.p, fe->h_stage.p, n * sizeof(float4), hipMemcpyHostToDevice, ctx->stream));
+  return fe_update_device(fe, fe->d_in.p, n, pose_out, stats);
+}
+
+extern "C" lsa_ndt *lsa_front_end_registration(lsa_front_end *fe) { return fe ? fe->ndt : nullptr; }

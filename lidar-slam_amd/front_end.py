@@ -1,0 +1,103 @@
+"""Host-side mirror of lidar_localization::FrontEnd over the C-ABI (device-resident sliding local map).
+
+Reference: lidar_localization/src/mapping/front_end/front_end.cpp:88-341 (Update), :348-424 (UpdateWithNewFrame),
+:343-346 (SetInitPose); configuration keys of config/mapping/front_end.yaml.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import capi
+
+
+class FrontEndConfig(C.Structure):
+    _fields_ = [
+        ("key_frame_distance", C.c_float),
+        ("local_frame_num", C.c_int32),
+        ("use_frame_filter", C.c_int32),
+        ("use_map_filter", C.c_int32),
+        ("frame_leaf", C.c_float * 3),
+        ("map_leaf", C.c_float * 3),
+        ("ndt_res", C.c_float),
+        ("ndt_step_size", C.c_float),
+        ("ndt_trans_eps", C.c_float),
+        ("ndt_outlier_ratio", C.c_float),
+        ("ndt_max_iter", C.c_int32),
+        ("reset_intensity", C.c_int32),
+    ]
+
+
+class FrontEndStats(C.Structure):
+    _fields_ = [
+        ("key_frame", C.c_int32),
+        ("local_map_frames", C.c_int32),
+        ("filtered_points", C.c_int64),
+        ("local_map_points", C.c_int64),
+        ("target_points", C.c_int64),
+        ("ndt", capi.NdtStats),
+    ]
+
+
+def default_config():
+    """config/mapping/front_end.yaml as committed in the reference."""
+    c = FrontEndConfig()
+    c.key_frame_distance = 2.0
+    c.local_frame_num = 20
+    c.use_frame_filter = 1
+    c.use_map_filter = 1
+    c.frame_leaf[:] = [0.5, 0.5, 0.5]
+    c.map_leaf[:] = [0.3, 0.3, 0.3]
+    c.ndt_res, c.ndt_step_size, c.ndt_trans_eps, c.ndt_outlier_ratio, c.ndt_max_iter = 1.0, 0.1, 0.01, 0.55, 30
+    c.reset_intensity = 1
+    return c
+
+
+class FrontEndHip:
+    def __init__(self, ctx, config=None):
+        L = capi.lib()
+        L.lsa_front_end_create.argtypes = [C.POINTER(C.c_void_p), C.c_void_p, C.POINTER(FrontEndConfig)]
+        L.lsa_front_end_destroy.argtypes = [C.c_void_p]
+        L.lsa_front_end_destroy.restype = None
+        L.lsa_front_end_set_init_pose.argtypes = [C.c_void_p, C.POINTER(C.c_float)]
+        L.lsa_front_end_update.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, C.c_size_t, C.POINTER(C.c_float), C.POINTER(FrontEndStats)]
+        L.lsa_front_end_update_device.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.POINTER(C.c_float), C.POINTER(FrontEndStats)]
+        L.lsa_front_end_registration.argtypes = [C.c_void_p]
+        L.lsa_front_end_registration.restype = C.c_void_p
+        self.ctx = ctx
+        self.cfg = config or default_config()
+        h = C.c_void_p()
+        ctx.check(L.lsa_front_end_create(C.byref(h), ctx.h, C.byref(self.cfg)))
+        self.h = h
+        self.last_stats = None
+
+    def SetInitPose(self, init_pose):  # noqa: N802
+        p = capi.colmajor(init_pose)
+        self.ctx.check(capi.lib().lsa_front_end_set_init_pose(self.h, capi.fptr(p)))
+        return True
+
+    def Update(self, cloud):  # noqa: N802
+        """cloud: (n, 8) float32 host array in PointXYZI layout, or a CUDA float32 tensor (n, 4). Returns (True, pose 4x4)."""
+        out = np.zeros(16, dtype=np.float32)
+        st = FrontEndStats()
+        if hasattr(cloud, "data_ptr"):
+            self._keep = cloud
+            rc = capi.lib().lsa_front_end_update_device(self.h, cloud.data_ptr(), cloud.shape[0], capi.fptr(out), C.byref(st))
+        else:
+            pts = np.ascontiguousarray(cloud, dtype=np.float32)
+            w_off = capi.W_OFF if pts.shape[1] >= 5 else 12
+            rc = capi.lib().lsa_front_end_update(self.h, pts.ctypes.data, pts.shape[0], pts.strides[0], w_off, capi.fptr(out), C.byref(st))
+        self.ctx.check(rc)
+        self.last_stats = dict(key_frame=st.key_frame, local_map_frames=st.local_map_frames, filtered_points=st.filtered_points,
+                               local_map_points=st.local_map_points, target_points=st.target_points, ndt=st.ndt.as_dict())
+        return True, capi.from_colmajor(out)
+
+    def close(self):
+        if self.h and self.ctx.h:
+            capi.lib().lsa_front_end_destroy(self.h)
+        self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
