@@ -127,7 +127,12 @@ def main():
     torch.cuda.set_stream(tstream)
     ctx = capi.Context(dev_index, tstream.cuda_stream)
 
-    frame_filter = cloud_filter.VoxelFilterHip(ctx, 0.5, 0.5, 0.5)       # front_end.yaml:46-47
+    # the frame filter gets its own context / HIP stream: the filter of scan k+1 is enqueued before the registration of
+    # scan k and overlaps it (two-stage software pipeline over the stream of scans; every scan still goes through both
+    # stages, and the timed region contains exactly K filters and K registrations)
+    fstream = torch.cuda.Stream(device=dev)
+    ctx_f = capi.Context(dev_index, fstream.cuda_stream)
+    frame_filter = cloud_filter.VoxelFilterHip(ctx_f, 0.5, 0.5, 0.5)     # front_end.yaml:46-47
     map_filter = cloud_filter.VoxelFilterHip(ctx, 0.3, 0.3, 0.3)         # front_end.yaml:44-45
     ndt = registration.NDTRegistrationHip(ctx, **NDT_PARAMS)
 
@@ -156,7 +161,8 @@ def main():
         delta = synth.pose_matrix(er.normal(0, 0.08), er.normal(0, 0.08), er.normal(0, 0.02), er.normal(0, 0.003), er.normal(0, 0.003), er.normal(0, 0.009))
         guesses.append((Tk1 @ (np.linalg.inv(Tk2) @ Tk1) @ delta).astype(np.float32))
         truths.append((P0inv @ poses[k]).astype(np.float32))
-    d_filt = torch.empty((max(s.shape[0] for s in d_scans), 4), dtype=torch.float32, device=dev)
+    d_filt2 = [torch.empty((max(s.shape[0] for s in d_scans), 4), dtype=torch.float32, device=dev) for _ in range(2)]
+    d_filt = d_filt2[0]
     if world > 1:
         ndt.set_allreduce(lsa_dist.make_gloo_staged_allreduce() if one_gpu else lsa_dist.make_rccl_allreduce())
 
@@ -169,7 +175,7 @@ def main():
     ns = len(d_scans)
     in_ptrs = [C.c_void_p(t.data_ptr()) for t in d_scans]
     in_n = [C.c_size_t(t.shape[0]) for t in d_scans]
-    filt_ptr = d_filt.data_ptr()
+    filt_ptrs = [t.data_ptr() for t in d_filt2]
     guess_c = [capi.colmajor(g) for g in guesses]
     guess_p = [capi.fptr(g) for g in guess_c]
     out_c = [np.zeros(16, dtype=np.float32) for _ in range(ns)]
@@ -179,20 +185,31 @@ def main():
     n_out = C.c_size_t(0)
     n_out_r = C.byref(n_out)
     m_of = [0] * ns
-    f_apply, f_match = L.lsa_voxel_filter_apply_device, L.lsa_ndt_scan_match_device
+    f_async, f_wait, f_match = L.lsa_voxel_filter_apply_device_async, L.lsa_voxel_filter_wait, L.lsa_ndt_scan_match_device
     hf, hn = frame_filter.h, ndt.h
+    in_flight = [-1]
 
-    def step(i):
+    def step(i, more=True):
         k = i % ns
-        rc = f_apply(hf, in_ptrs[k], in_n[k], filt_ptr, n_out_r)
+        fp = filt_ptrs[i & 1]
+        rc = 0
+        if in_flight[0] != i:      # first step of a run: nothing was prefetched
+            rc = f_async(hf, in_ptrs[k], in_n[k], fp)
+        rc |= f_wait(hf, n_out_r)
         m = n_out.value
+        if more:                   # prefetch: filter of the next scan overlaps this scan's registration
+            k1 = (i + 1) % ns
+            rc |= f_async(hf, in_ptrs[k1], in_n[k1], filt_ptrs[(i + 1) & 1])
+            in_flight[0] = i + 1
+        else:
+            in_flight[0] = -1
         if world > 1:
             lo, hi = lsa_dist.shard_bounds(m, rank, world)
-            rc |= f_match(hn, filt_ptr + 16 * lo, hi - lo, guess_p[k], out_p[k], stats_r[k])
+            rc |= f_match(hn, fp + 16 * lo, hi - lo, guess_p[k], out_p[k], stats_r[k])
         else:
-            rc |= f_match(hn, filt_ptr, m, guess_p[k], out_p[k], stats_r[k])
+            rc |= f_match(hn, fp, m, guess_p[k], out_p[k], stats_r[k])
         if rc:
-            ctx.check(rc)
+            ctx_f.check(rc if rc < 0 else -3)
         m_of[k] = m
 
     def collect():
@@ -212,17 +229,17 @@ def main():
     if world > 1:
         # every step contains collectives, so all ranks must run the SAME number of ramp steps: count-based, not timed
         for i_ramp in range(int(args.ramp_seconds * 2000)):
-            step(i_ramp)
+            step(i_ramp, more=False)
     else:
         while time.perf_counter() - t_ramp < args.ramp_seconds:
-            step(i_ramp)
+            step(i_ramp, more=False)
             i_ramp += 1
     for i in range(args.warmup):
-        step(i)
+        step(i, more=(i + 1 < args.warmup))
     sync_all()
     t0 = time.perf_counter()
     for i in range(args.steps):
-        step(i)
+        step(i, more=(i + 1 < args.steps))
     sync_all()
     elapsed = time.perf_counter() - t0
     collect()
@@ -350,7 +367,7 @@ def main():
             line["pose_rmse_vs_truth"] = {"t_m": float(np.sqrt(np.mean(ge[:, 0] ** 2))), "r_rad": float(np.sqrt(np.mean(ge[:, 1] ** 2)))}
         print(json.dumps(line), flush=True)
 
-    ndt.close(); frame_filter.close(); map_filter.close()
+    ndt.close(); frame_filter.close(); map_filter.close(); ctx_f.close()
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

@@ -92,6 +92,12 @@ int lsa_voxel_filter_apply(lsa_voxel_filter *f, const void *in_pts, size_t n, si
 /* Device-resident variant: d_in / d_out are device pointers to packed float4 {x,y,z,intensity}
  * (16 B / point, 16-B aligned).  d_out must hold n points.  *n_out is written on the host (one sync). */
 int lsa_voxel_filter_apply_device(lsa_voxel_filter *f, const float *d_in_xyzw, size_t n, float *d_out_xyzw, size_t *n_out);
+/* The same call split in two so that a caller can overlap the filter of scan k+1 (on this filter's context / HIP stream)
+ * with the registration of scan k (on another context): _async enqueues the whole pipeline and returns at once, _wait
+ * blocks until the output is complete and returns the voxel count.  One call in flight per handle; d_in / d_out must stay
+ * valid and untouched until _wait returns. */
+int lsa_voxel_filter_apply_device_async(lsa_voxel_filter *f, const float *d_in_xyzw, size_t n, float *d_out_xyzw);
+int lsa_voxel_filter_wait(lsa_voxel_filter *f, size_t *n_out);
 
 /* ---------------------------------------------------------------------------------------------
  * NDT registration — replaces NDTRegistrationManual (ndt_registration_manual.cpp) and, behind it,

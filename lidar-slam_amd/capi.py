@@ -83,6 +83,8 @@ def lib():
     L.lsa_voxel_filter_destroy.restype = None
     L.lsa_voxel_filter_apply.argtypes = [vp, vp, sz, sz, sz, vp, sz, sz, sz, PSZ]
     L.lsa_voxel_filter_apply_device.argtypes = [vp, vp, sz, vp, PSZ]
+    L.lsa_voxel_filter_apply_device_async.argtypes = [vp, vp, sz, vp]
+    L.lsa_voxel_filter_wait.argtypes = [vp, PSZ]
     L.lsa_ndt_create.argtypes = [PVP, vp, f, f, f, i, f]
     L.lsa_ndt_destroy.argtypes = [vp]
     L.lsa_ndt_destroy.restype = None

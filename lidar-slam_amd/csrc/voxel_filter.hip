@@ -8,12 +8,31 @@
 // the points once per streaming pass (bbox, mark, accumulate: 3 x 16*N + 2 x 4*N cell ids).
 #include "voxel_index_dev.h"
 
+#include <atomic>
+#include <condition_variable>
+#include <mutex>
+#include <thread>
+
 struct lsa_voxel_filter {
   lsa_context *ctx = nullptr;
   float leaf[3] = {0, 0, 0};
   VoxelIndex vi;
   DevBuf<float4> d_in, d_out;
   PinnedBuf<float> h_stage;
+  // asynchronous call in flight (lsa_voxel_filter_apply_device_async .. lsa_voxel_filter_wait)
+  bool pending = false;
+  const float4 *p_in = nullptr;
+  float4 *p_out = nullptr;
+  size_t p_n = 0;
+  // The ~10 kernel launches of one filter cost ~30 us of HOST time; the async entry point hands them to a helper
+  // thread so that the caller's thread is free to drive the registration of the previous scan meanwhile.
+  // job_state: 0 idle, 1 posted, 2 enqueued (job_rc valid), -1 shut down.
+  std::thread worker;
+  std::mutex mu;
+  std::condition_variable cv;
+  std::atomic<int> job_state{0};
+  int job_rc = LSA_OK;
+  bool worker_started = false;
 };
 
 namespace {
@@ -66,7 +85,83 @@ int filter_device(lsa_voxel_filter *f, const float4 *d_in, size_t n, float4 *d_o
   *n_out = (status == VI_OK) ? vi.nocc : 0;
   return LSA_OK;
 }
+
+// the enqueue half of filter_device (attempt 0 only); filter_wait() completes it and falls back to the synchronous path
+// if the bitmap capacity has to grow
+int filter_enqueue(lsa_voxel_filter *f, const float4 *d_in, size_t n, float4 *d_out) {
+  lsa_context *ctx = f->ctx;
+  VoxelIndex &vi = f->vi;
+  int rc;
+  if ((rc = vi_enqueue(ctx, vi, d_in, n, /*mode PCL*/ 0, f->leaf, 4))) return rc;
+  hipLaunchKernelGGL(k_filter_finalize, dim3(lsa_div_up(n, kBlock)), dim3(kBlock), 0, ctx->stream, vi.acc.p, vi.cnt.p, vi.cell_of_rank.p, vi.dparams.p, d_out,
+                     vi.h_params.p);
+  LSA_HIP(ctx, hipGetLastError());
+  if ((rc = vi_mark_done(ctx, vi))) return rc;
+  return vi_cleanup(ctx, vi, n);
+}
 }  // namespace
+
+namespace {
+void filter_worker(lsa_voxel_filter *f) {
+  (void)hipSetDevice(f->ctx->device);
+  for (;;) {
+    // spin briefly (scans arrive back to back in a pipeline), then sleep on the condition variable
+    int st = 0;
+    for (int spin = 0; spin < 20000; spin++) {
+      st = f->job_state.load(std::memory_order_acquire);
+      if (st == 1 || st == -1) break;
+    }
+    if (st != 1 && st != -1) {
+      std::unique_lock<std::mutex> lk(f->mu);
+      f->cv.wait(lk, [&] { int s = f->job_state.load(std::memory_order_acquire); return s == 1 || s == -1; });
+      st = f->job_state.load(std::memory_order_acquire);
+    }
+    if (st == -1) return;
+    f->job_rc = filter_enqueue(f, f->p_in, f->p_n, f->p_out);
+    f->job_state.store(2, std::memory_order_release);
+  }
+}
+}  // namespace
+
+extern "C" int lsa_voxel_filter_apply_device_async(lsa_voxel_filter *f, const float *d_in_xyzw, size_t n, float *d_out_xyzw) {
+  if (!f || (n && (!d_in_xyzw || !d_out_xyzw))) return f ? lsa_fail(f->ctx, LSA_ERR_INVALID, "lsa_voxel_filter_apply_device_async: null argument") : LSA_ERR_INVALID;
+  if (f->pending) return lsa_fail(f->ctx, LSA_ERR_INVALID, "lsa_voxel_filter_apply_device_async: a filter is already in flight on this handle");
+  f->p_in = (const float4 *)d_in_xyzw; f->p_out = (float4 *)d_out_xyzw; f->p_n = n;
+  f->pending = true;
+  if (n == 0) return LSA_OK;
+  if (!f->worker_started) {
+    f->worker = std::thread(filter_worker, f);
+    f->worker_started = true;
+  }
+  {
+    std::lock_guard<std::mutex> lk(f->mu);
+    f->job_state.store(1, std::memory_order_release);
+  }
+  f->cv.notify_one();
+  return LSA_OK;
+}
+
+extern "C" int lsa_voxel_filter_wait(lsa_voxel_filter *f, size_t *n_out) {
+  if (!f || !n_out) return f ? lsa_fail(f->ctx, LSA_ERR_INVALID, "lsa_voxel_filter_wait: null argument") : LSA_ERR_INVALID;
+  if (!f->pending) return lsa_fail(f->ctx, LSA_ERR_INVALID, "lsa_voxel_filter_wait: nothing in flight");
+  f->pending = false;
+  *n_out = 0;
+  if (f->p_n == 0) return LSA_OK;
+  LSA_HIP(f->ctx, hipSetDevice(f->ctx->device));
+  while (f->job_state.load(std::memory_order_acquire) != 2) {}  // the helper is still issuing the launches (<= ~30 us)
+  f->job_state.store(0, std::memory_order_release);
+  if (f->job_rc) return f->job_rc;
+  int status = VI_OK;
+  int rc = vi_wait(f->ctx, f->vi, &status);
+  if (rc) return rc;
+  if (status == VI_CAPACITY) {  // rare: extent larger than ever seen; size the bitmap and run the synchronous path
+    if ((rc = vi_grow(f->ctx, f->vi))) return rc;
+    return filter_device(f, f->p_in, f->p_n, f->p_out, n_out);
+  }
+  if (status == VI_RANGE) return lsa_fail(f->ctx, LSA_ERR_RANGE, "voxel filter: leaf size too small for the input dataset, integer indices would overflow");
+  *n_out = (status == VI_OK) ? f->vi.nocc : 0;
+  return LSA_OK;
+}
 
 extern "C" int lsa_voxel_filter_create(lsa_voxel_filter **out, lsa_context *ctx, float lx, float ly, float lz) {
   if (!out || !ctx) { lsa_set_global_error("lsa_voxel_filter_create: null argument"); return LSA_ERR_INVALID; }
@@ -80,7 +175,16 @@ extern "C" int lsa_voxel_filter_create(lsa_voxel_filter **out, lsa_context *ctx,
 
 extern "C" void lsa_voxel_filter_destroy(lsa_voxel_filter *f) {
   if (!f) return;
+  if (f->worker_started) {
+    {
+      std::lock_guard<std::mutex> lk(f->mu);
+      f->job_state.store(-1, std::memory_order_release);
+    }
+    f->cv.notify_one();
+    f->worker.join();
+  }
   (void)hipSetDevice(f->ctx->device);
+  (void)hipStreamSynchronize(f->ctx->stream);
   f->vi.release(); f->d_in.release(); f->d_out.release(); f->h_stage.release();
   delete f;
 }

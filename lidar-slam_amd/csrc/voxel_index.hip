@@ -205,13 +205,12 @@ __global__ __launch_bounds__(kBlock) void k_mark(const float4 *__restrict__ pts,
     if (cell >= 0 && lds_insert(keys, cell) < 0) atomicOr(bits + (cell >> 5), 1u << (cell & 31));
   }
   __syncthreads();
-  for (int k = threadIdx.x; k < kHashCap; k += kBlock) {
-    int cell = keys[k];
-    if (cell >= 0) {
-      uint32_t bit = 1u << (cell & 31);
-      uint32_t *w = bits + (cell >> 5);
-      if (!(*w & bit)) atomicOr(w, bit);  // bits only go 0 -> 1 here: a stale 0 merely costs the atomic
-    }
+  // one fire-and-forget atomic per distinct cell of the tile (no read-before-write: a dependent load per slot would
+  // serialise four memory round trips per lane)
+#pragma unroll
+  for (int k = 0; k < kHashCap / kBlock; k++) {
+    int cell = keys[k * kBlock + threadIdx.x];
+    if (cell >= 0) atomicOr(bits + (cell >> 5), 1u << (cell & 31));
   }
 }
 
@@ -380,14 +379,25 @@ __global__ __launch_bounds__(kBlock) void k_accum(const float4 *__restrict__ pts
     }
   }
   __syncthreads();
-  for (int k = threadIdx.x; k < kHashCap; k += kBlock) {
-    int cell = keys[k];
-    if (cell < 0) continue;
-    unsigned rank = cell_rank(bits, prefix, cell);
+  // flush: the 4 slots of a lane are independent; their rank look-ups are issued together, then the atomics
+  int fcell[kHashCap / kBlock];
+  uint32_t fw[kHashCap / kBlock], fp[kHashCap / kBlock];
+#pragma unroll
+  for (int k = 0; k < kHashCap / kBlock; k++) {
+    fcell[k] = keys[k * kBlock + threadIdx.x];
+    int c = fcell[k] < 0 ? 0 : fcell[k];
+    fw[k] = bits[c >> 5];
+    fp[k] = prefix[c >> 5];
+  }
+#pragma unroll
+  for (int k = 0; k < kHashCap / kBlock; k++) {
+    if (fcell[k] < 0) continue;
+    int slot = k * kBlock + threadIdx.x;
+    unsigned rank = fp[k] + __popc(fw[k] & ((1u << (fcell[k] & 31)) - 1u));
     unsigned long long *a = (unsigned long long *)(acc + (size_t)rank * NS);
 #pragma unroll
-    for (int j = 0; j < NS; j++) atomicAdd(a + j, sums[k][j]);
-    atomicAdd(cnt + rank, counts[k]);
+    for (int j = 0; j < NS; j++) atomicAdd(a + j, sums[slot][j]);
+    atomicAdd(cnt + rank, counts[slot]);
   }
 }
 

@@ -236,6 +236,36 @@ def test_scan_match_errors(ctx):
     n.close()
 
 
+def test_voxel_filter_async_pipeline(ctx, scan_pair):
+    """lsa_voxel_filter_apply_device_async / _wait: same bits as the synchronous call, on a second context (HIP stream),
+    back-to-back over alternating buffers the way bench.py pipelines filter(k+1) under ScanMatch(k)."""
+    import ctypes as C
+    import torch
+    s0, s1, _, _ = scan_pair
+    ctx2 = capi.Context(0)  # own stream
+    f_sync = cloud_filter.VoxelFilterHip(ctx, 0.5, 0.5, 0.5)
+    f_async = cloud_filter.VoxelFilterHip(ctx2, 0.5, 0.5, 0.5)
+    d_in = [torch.from_numpy(np.ascontiguousarray(s)).cuda() for s in (s0, s1)]
+    ref = [f_sync.filter_device(d).clone() for d in d_in]
+    outs = [torch.empty((d.shape[0], 4), dtype=torch.float32, device="cuda") for d in d_in]
+    torch.cuda.synchronize()
+    L = capi.lib()
+    n = C.c_size_t(0)
+    ctx2.check(L.lsa_voxel_filter_apply_device_async(f_async.h, d_in[0].data_ptr(), d_in[0].shape[0], outs[0].data_ptr()))
+    # a second call while one is in flight is refused
+    assert L.lsa_voxel_filter_apply_device_async(f_async.h, d_in[1].data_ptr(), d_in[1].shape[0], outs[1].data_ptr()) == capi.LSA_ERR_INVALID
+    for it in range(6):
+        k = it & 1
+        ctx2.check(L.lsa_voxel_filter_wait(f_async.h, C.byref(n)))
+        assert n.value == ref[k].shape[0]
+        got = outs[k][: n.value].clone()
+        ctx2.check(L.lsa_voxel_filter_apply_device_async(f_async.h, d_in[1 - k].data_ptr(), d_in[1 - k].shape[0], outs[1 - k].data_ptr()))
+        assert torch.equal(got, ref[k])
+    ctx2.check(L.lsa_voxel_filter_wait(f_async.h, C.byref(n)))
+    assert L.lsa_voxel_filter_wait(f_async.h, C.byref(n)) == capi.LSA_ERR_INVALID  # nothing in flight
+    f_async.close(); f_sync.close(); ctx2.close()
+
+
 def test_device_resident_path(ctx, oracle, scan_pair):
     """Same results when clouds are already resident in HBM (torch tensors as plain device memory)."""
     import torch
