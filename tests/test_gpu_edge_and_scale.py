@@ -1,0 +1,198 @@
+"""GPU: edge cases against the oracle, and size-independent properties at BASELINE.json's full sizes
+(cfg4: 2 M-point target, 132 k-point source; cfg5: 2,097,152-point source), where the oracle would take minutes.
+
+Properties used at full size: bitwise run-to-run reproducibility, additivity of the pass over a split of the source
+(the multi-GPU invariant: shard sums == whole), permutation invariance of the fixed-point voxel sums, idempotence of
+the voxel filter, agreement between the host-mapped (small grid) and device (large grid) reduction paths.
+"""
+import numpy as np
+import pytest
+
+from lidar_slam_amd import capi, cloud_filter, registration, synth
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    c = capi.Context(0)
+    yield c
+    c.close()
+
+
+# --------------------------------------------------------------------------------------------- edge cases
+def test_empty_and_degenerate_sources(ctx, oracle, scan_pair):
+    import oracle_py
+    s0, s1, _, _ = scan_pair
+    tgt = synth.to_xyzi32(s0)
+    o = oracle_py.OracleNDT()
+    o.set_input_target(tgt)
+    n = registration.NDTRegistrationHip(ctx)
+    n.SetInputTarget(tgt)
+    guess = synth.pose_matrix(0.3, 0.1, 0.0, 0.0, 0.0, 0.01).astype(np.float32)
+    # empty source: zero gradient -> zero Newton step -> early exit at the guess (NormalDistributionsTransform.cpp:359-363)
+    for src in (np.zeros((0, 8), dtype=np.float32),):
+        Tr, st_r = o.scan_match(src, guess)
+        _, T = n.ScanMatch(src, guess)
+        assert np.array_equal(T, Tr) and np.array_equal(T, guess)
+        assert n.last_stats["iterations"] == st_r["iterations"] == 0 and n.last_stats["converged"] == st_r["converged"] == 1
+    # a source that never touches an occupied voxel (1 km away), and one with NaN / inf rows mixed in
+    far = synth.to_xyzi32(s1[:500] + np.array([1000.0, 0, 0, 0], dtype=np.float32))
+    Tr, st_r = o.scan_match(far, guess)
+    _, T = n.ScanMatch(far, guess)
+    assert np.array_equal(T, Tr) and n.last_stats["passes"] == st_r["passes"] == 1
+    filt, _ = oracle.voxel_filter(synth.to_xyzi32(s1), 0.5)
+    good = synth.to_xyzi32(filt)
+    bad = good.copy()
+    bad[::97, 0] = np.nan
+    bad[5::131, 2] = np.inf
+    clean = bad[np.isfinite(bad[:, :3]).all(axis=1)]
+    _, T_bad = n.ScanMatch(bad, np.eye(4, dtype=np.float32))     # non-finite points contribute nothing
+    _, T_clean = n.ScanMatch(clean, np.eye(4, dtype=np.float32))
+    assert np.max(np.abs(T_bad - T_clean)) <= 1e-6
+    n.close()
+
+
+def test_target_without_valid_voxels_and_retargeting(ctx, oracle, scan_pair):
+    import oracle_py
+    s0, s1, _, _ = scan_pair
+    filt, _ = oracle.voxel_filter(synth.to_xyzi32(s1), 0.5)
+    src = synth.to_xyzi32(filt)
+    sparse = synth.to_xyzi32(s0[::400])   # ~330 points: (almost) no voxel reaches 6 points
+    o = oracle_py.OracleNDT()
+    o.set_input_target(sparse)
+    n = registration.NDTRegistrationHip(ctx)
+    n.SetInputTarget(sparse)
+    info = n.grid_info()
+    occ, valid = o.grid_counts()
+    assert info["occupied"] == occ and info["valid"] == valid
+    guess = np.eye(4, dtype=np.float32)
+    Tr, st_r = o.scan_match(src, guess)
+    _, T = n.ScanMatch(src, guess)
+    assert n.last_stats["iterations"] == st_r["iterations"] and np.max(np.abs(T - Tr)) <= 1e-5
+    # SetInputTarget again with a dense target on the same handle (every key-frame does this, front_end.cpp:396,410)
+    tgt = synth.to_xyzi32(s0)
+    o.set_input_target(tgt)
+    n.SetInputTarget(tgt)
+    Tr, st_r = o.scan_match(src, guess)
+    _, T = n.ScanMatch(src, guess)
+    assert n.last_stats["iterations"] == st_r["iterations"]
+    assert np.linalg.norm(T[:3, 3] - Tr[:3, 3]) <= 1e-4
+    # an empty target is ignored (NormalDistributionsTransform.cpp:92-95): the previous table stays
+    n.SetInputTarget(np.zeros((0, 8), dtype=np.float32))
+    _, T2 = n.ScanMatch(src, guess)
+    assert np.array_equal(T, T2)
+    n.close()
+
+
+def test_line_search_branch_on_gpu(ctx, oracle, scan_pair):
+    """step_max == step_min forces the More-Thuente trial loop (kind-1 passes + the Hessian-only pass)."""
+    import oracle_py
+    s0, s1, _, _ = scan_pair
+    tgt = synth.to_xyzi32(s0)
+    filt, _ = oracle.voxel_filter(synth.to_xyzi32(s1), 1.0)
+    src = synth.to_xyzi32(filt)
+    o = oracle_py.OracleNDT(step_size=1.5, trans_eps=3.0, max_iter=4)
+    o.set_input_target(tgt)
+    Tr, st_r = o.scan_match(src, np.eye(4, dtype=np.float32))
+    assert st_r["ls_iterations"] > 0
+    n = registration.NDTRegistrationHip(ctx, 1.0, 1.5, 3.0, 4, 0.55)
+    n.SetInputTarget(tgt)
+    _, T = n.ScanMatch(src, np.eye(4, dtype=np.float32))
+    st = n.last_stats
+    assert st["ls_iterations"] == st_r["ls_iterations"] and st["passes"] == st_r["passes"] and st["iterations"] == st_r["iterations"]
+    assert np.max(np.abs(T - Tr)) <= 1e-5
+    n.close()
+
+
+def test_filter_extremes(ctx, oracle):
+    f = cloud_filter.VoxelFilterHip(ctx, 0.3, 0.5, 0.7)  # anisotropic leaf
+    rng = np.random.RandomState(9)
+    pts = np.concatenate([rng.uniform(-60, 60, (5000, 2)), rng.uniform(-3, 8, (5000, 1)), rng.uniform(0, 255, (5000, 1))], axis=1).astype(np.float32)
+    p8 = synth.to_xyzi32(pts)
+    ref, _ = oracle.voxel_filter(p8, (0.3, 0.5, 0.7))
+    _, out = f.Filter(p8)
+    assert out.shape[0] == ref.shape[0]
+    assert np.allclose(out[:, [0, 1, 2, 4]], ref, rtol=2e-6, atol=2e-5)
+    # all points identical -> one voxel; all points non-finite -> empty output
+    same = synth.to_xyzi32(np.tile(np.array([[3.25, -7.5, 0.125, 0.5]], dtype=np.float32), (1000, 1)))
+    _, o1 = f.Filter(same)
+    assert o1.shape[0] == 1 and np.allclose(o1[0, [0, 1, 2, 4]], [3.25, -7.5, 0.125, 0.5])
+    nan = same.copy()
+    nan[:, 1] = np.nan
+    _, o2 = f.Filter(nan)
+    assert o2.shape[0] == 0
+    f.close()
+
+
+# --------------------------------------------------------------------------------------------- full BASELINE sizes
+@pytest.fixture(scope="module")
+def big(scene):
+    poses = synth.trajectory(20)
+    P0inv = np.linalg.inv(poses[0])
+    parts = [synth.transform_points(P0inv @ poses[k], synth.gen_scan(scene, poses[k], seed=100 + k)) for k in range(0, 17)]
+    target = np.ascontiguousarray(np.concatenate(parts, 0))[:2000000]
+    src5 = synth.gen_scan(scene, poses[8], seed=55, beams=128, az_steps=16384, max_range=120.0, clamp=True)
+    assert src5.shape[0] == 2097152
+    guess = (P0inv @ poses[8]).astype(np.float32)
+    return target, src5, guess
+
+
+def test_cfg5_pass_properties_at_full_size(ctx, oracle, big):
+    import torch
+    target, src5, guess = big
+    d_t = torch.from_numpy(target).cuda()
+    d_s = torch.from_numpy(src5).cuda()
+    n = registration.NDTRegistrationHip(ctx, 1.0, 0.1, 0.0, 30, 0.55)
+    n.SetInputTarget(d_t)
+    info = n.grid_info()
+    assert info["n_target"] == 2000000 and info["valid"] > 1000
+    p = oracle.matrix_to_pose(guess)
+    n.set_source(d_s)
+    a = n.derivatives(guess, p, 0)
+    b = n.derivatives(guess, p, 0)
+    assert a[0] == b[0] and np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2])      # reproducible
+    assert int(a[4]) == 2097152 and a[3] > 2097152                                            # every point counted, K-bar > 1
+    # additivity over 8 contiguous shards (SURVEY.md 8e sharding): sum of shard passes == whole pass
+    tot_s, tot_g, tot_H, tot_pairs = 0.0, np.zeros(6), np.zeros((6, 6)), 0
+    for r in range(8):
+        lo, hi = (2097152 * r) // 8, (2097152 * (r + 1)) // 8
+        n.set_source(d_s[lo:hi])
+        s, g, H, pairs, npts = n.derivatives(guess, p, 0)   # 262 144 points: the host-mapped reduction path
+        assert int(npts) == hi - lo
+        tot_s += s; tot_g += g; tot_H += H; tot_pairs += int(pairs)
+    assert tot_pairs == int(a[3])
+    assert abs(tot_s - a[0]) <= 1e-11 * abs(a[0])
+    assert np.max(np.abs(tot_g - a[1])) <= 1e-10 * np.max(np.abs(a[1]))
+    assert np.max(np.abs(tot_H - a[2])) <= 1e-10 * np.max(np.abs(a[2]))
+    # full align: max_iter 30, trans_eps 0 -> exactly 31 + 1 Newton iterations, every one a descent step on the score
+    _, T = n.ScanMatch(d_s, guess)
+    st = n.last_stats
+    assert st["iterations"] == 32 and st["passes"] == 33
+    dt = np.linalg.norm(T[:3, 3] - guess[:3, 3])
+    assert dt < 0.2  # the guess is the true pose: NDT stays there
+    n.close()
+
+
+def test_filter_properties_at_2m_points(ctx, big):
+    import torch
+    target, _, _ = big
+    f = cloud_filter.VoxelFilterHip(ctx, 0.3, 0.3, 0.3)
+    d_t = torch.from_numpy(target).cuda()
+    a = f.filter_device(d_t).clone()
+    perm = torch.randperm(d_t.shape[0], generator=torch.Generator().manual_seed(1)).cuda()
+    d_p = d_t[perm].contiguous()
+    torch.cuda.synchronize()                       # the gather ran on torch's stream, the filter runs on the context's
+    b = f.filter_device(d_p).clone()
+    assert torch.equal(a, b)                       # order-independent fixed-point sums, deterministic output order
+    c = f.filter_device(a.contiguous()).clone()
+    assert c.shape == a.shape                      # idempotent: one point per voxel stays one point per voxel
+    assert torch.allclose(c, a, rtol=0, atol=1e-5)
+    # output sorted by voxel index: cell coordinates (z, y, x) non-decreasing lexicographically
+    inv = np.float32(1.0) / np.float32(0.3)
+    ijk = torch.floor(a[:, :3] * float(inv)).to(torch.int64)
+    mn = ijk.min(dim=0).values
+    d = ijk.max(dim=0).values - mn + 1
+    lin = (ijk[:, 0] - mn[0]) + (ijk[:, 1] - mn[1]) * d[0] + (ijk[:, 2] - mn[2]) * d[0] * d[1]
+    assert bool((lin[1:] > lin[:-1]).all())
+    f.close()
