@@ -123,6 +123,20 @@ int lsa_ndt_create(lsa_ndt **out, lsa_context *ctx, float res, float step_size, 
                    float outlier_ratio);
 void lsa_ndt_destroy(lsa_ndt *ndt);
 
+/* Which of the reference's two NDT plugins the handle stands in for (call before SetInputTarget):
+ *   LSA_NDT_MODE_MANUAL (default): "NDTMANUAL", the in-tree arithmetic with all its quirks (covariance seeded with I,
+ *     hand-rolled eigen-solver, static weight, `phi_t -= score`), GetFitnessScore = mean distance to the nearest voxel
+ *     centroid (NormalDistributionsTransform.cpp:940-965).
+ *   LSA_NDT_MODE_PCL: "NDT" = NDTRegistration(res, step_size, trans_eps, max_iter) (ndt_registration.cpp:18-66) ->
+ *     pcl::NormalDistributionsTransform of third-party PCL 1.7 (not in the tree; parity UNPINNED): covariance from zero,
+ *     accurate symmetric eigen-solver, rejected leaves keep a zero inverse covariance, no static weight, the
+ *     More-Thuente trial loop assigns phi_t, outlier_ratio 0.55 (PCL's default; the plugin never sets it), and
+ *     GetFitnessScore = pcl::Registration::getFitnessScore = mean SQUARED distance to the nearest target POINT — the
+ *     quantity LoopClosing gates at 0.2 (loop_closing.cpp:253, config/mapping/loop_closing.yaml:11) and Matching logs. */
+#define LSA_NDT_MODE_MANUAL 0
+#define LSA_NDT_MODE_PCL 1
+int lsa_ndt_set_mode(lsa_ndt *ndt, int mode);
+
 /* SetInputTarget(input_target) (ndt_registration_manual.cpp:48-54 -> NormalDistributionsTransform::setInputTarget
  * -> VoxelGrid::setInput, VoxelGrid.cpp:326-358).  The target is copied to the device; the caller's
  * buffer is not retained. */
@@ -178,19 +192,39 @@ int lsa_ndt_set_allreduce(lsa_ndt *ndt, lsa_allreduce_fn fn, void *user);
 typedef int (*lsa_pass_eval_fn)(void *user, const float T[16], const double p[6], int kind, double out32[32]);
 int lsa_gn_solve(lsa_pass_eval_fn eval, void *user, float res, float step_size, float trans_eps, int max_iter,
                  float outlier_ratio, const float predict_pose[16], float result_pose[16], lsa_ndt_stats *stats);
+/* same with the NDT mode (LSA_NDT_MODE_*) that selects the line-search bookkeeping; lsa_gn_solve is mode 0 */
+int lsa_gn_solve_mode(lsa_pass_eval_fn eval, void *user, float res, float step_size, float trans_eps, int max_iter,
+                      float outlier_ratio, int mode, const float predict_pose[16], float result_pose[16],
+                      lsa_ndt_stats *stats);
 /* pose helpers of that driver (f32 rigid transform <-> the reference's (t, Euler XYZ) chart) */
 void lsa_pose_to_matrix(const double p[6], float T[16]);
 void lsa_matrix_to_pose(const float T[16], double p[6]);
 void lsa_ndt_gauss_constants(float res, float outlier_ratio, double *d1, double *d2);
 
 /* ---------------------------------------------------------------------------------------------
- * ICP registration — replaces ICPRegistrationManual (icp_registration_manual.cpp:12-179):
- * point-to-point Gauss-Newton, fixed max_iter iterations, exact 1-NN correspondences gated by
- * squared-distance <= max_correspond_dis (sic, :147).  mode 1 = point-to-plane extension
- * (normals from the target's NDT voxel covariances; not in the reference, BASELINE.json config 3).
+ * ICP registration.
+ *   LSA_ICP_MODE_MANUAL (0) replaces ICPRegistrationManual (icp_registration_manual.cpp:12-179): point-to-point
+ *     Gauss-Newton, fixed max_iter iterations, exact 1-NN correspondences gated by squared-distance <=
+ *     max_correspond_dis (sic, :147).
+ *   LSA_ICP_MODE_PCL (2) replaces ICPRegistration (icp_registration.cpp:20-64) -> pcl::IterativeClosestPoint of
+ *     third-party PCL 1.7 (not in the tree; parity UNPINNED): 1-NN correspondences gated at max_correspond_dis,
+ *     SVD (Umeyama) increment, DefaultConvergenceCriteria with euclid_eps / trans_eps (lsa_icp_set_criteria; defaults
+ *     0.01 / 0.01 = config/mapping/front_end.yaml:31-35), GetFitnessScore = mean squared nearest-point distance.
+ *   mode 1 is reserved for a point-to-plane extension (not in the reference; BASELINE.json config 3) and is rejected.
  * ------------------------------------------------------------------------------------------- */
+#define LSA_ICP_MODE_MANUAL 0
+#define LSA_ICP_MODE_PCL 2
 typedef struct lsa_icp lsa_icp;
+typedef struct {
+  int32_t iterations;      /* nr_iterations_ (manual mode: max_iter) */
+  int32_t converged;       /* hasConverged() */
+  double correspondences;  /* pairs in the last iteration */
+  double mse;              /* last mean squared correspondence distance the criteria looked at (PCL mode) */
+} lsa_icp_stats;
 int lsa_icp_create(lsa_icp **out, lsa_context *ctx, float max_correspond_dis, int max_iter, int mode);
+/* ICPRegistration::SetRegistrationParam's setEuclideanFitnessEpsilon / setTransformationEpsilon (icp_registration.cpp:30-33) */
+int lsa_icp_set_criteria(lsa_icp *icp, float euclid_eps, float trans_eps);
+int lsa_icp_get_stats(lsa_icp *icp, lsa_icp_stats *stats);
 void lsa_icp_destroy(lsa_icp *icp);
 int lsa_icp_set_input_target(lsa_icp *icp, const void *pts, size_t n, size_t stride);
 int lsa_icp_set_input_target_device(lsa_icp *icp, const float *d_xyzw, size_t n);
@@ -198,7 +232,7 @@ int lsa_icp_scan_match(lsa_icp *icp, const void *src, size_t n, size_t stride, c
                        float result_pose[16]);
 int lsa_icp_scan_match_device(lsa_icp *icp, const float *d_src_xyzw, size_t n, const float predict_pose[16],
                               float result_pose[16]);
-/* GetFitnessScore(): unimplemented in the reference, returns 0 (:62-67) */
+/* GetFitnessScore(): ICPMANUAL: unimplemented in the reference, returns 0 (:62-67); PCL mode: icp_registration.cpp:60-63 */
 int lsa_icp_get_fitness_score(lsa_icp *icp, float *score);
 
 /* ---------------------------------------------------------------------------------------------

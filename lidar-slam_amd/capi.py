@@ -25,6 +25,14 @@ class LsaError(RuntimeError):
         self.code = code
 
 
+NDT_MODE_MANUAL, NDT_MODE_PCL = 0, 1
+ICP_MODE_MANUAL, ICP_MODE_PCL = 0, 2
+
+
+class IcpStats(C.Structure):
+    _fields_ = [("iterations", C.c_int32), ("converged", C.c_int32), ("correspondences", C.c_double), ("mse", C.c_double)]
+
+
 class NdtStats(C.Structure):
     _fields_ = [
         ("iterations", C.c_int32),
@@ -115,6 +123,10 @@ def lib():
     L.lsa_icp_scan_match.argtypes = [vp, vp, sz, sz, PF, PF]
     L.lsa_icp_scan_match_device.argtypes = [vp, vp, sz, PF, PF]
     L.lsa_icp_get_fitness_score.argtypes = [vp, PF]
+    L.lsa_icp_set_criteria.argtypes = [vp, f, f]
+    L.lsa_icp_get_stats.argtypes = [vp, C.POINTER(IcpStats)]
+    L.lsa_ndt_set_mode.argtypes = [vp, i]
+    L.lsa_gn_solve_mode.argtypes = [PASS_EVAL_FN, vp, f, f, f, i, f, i, PF, PF, C.POINTER(NdtStats)]
     _lib = L
     return L
 

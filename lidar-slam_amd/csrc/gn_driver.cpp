@@ -138,6 +138,7 @@ struct Driver {
   void *user;
   double step_size, trans_eps;
   int max_iter;
+  int mode = 0;  // LSA_NDT_MODE_*
   double score = 0, g[6] = {0}, H[6][6] = {{0}};
   float T[16];
   int passes = 0, ls_iters = 0;
@@ -194,10 +195,15 @@ struct Driver {
       for (int i = 0; i < 6; i++) x_t[i] = x[i] + dir[i] * a_t;
       lsa_pose_to_matrix(x_t, T);
       if (!pass(x_t, 1)) return NAN;
-      phi_t -= score;  // sic (:726)
       double dd = 0;
       for (int i = 0; i < 6; i++) dd += g[i] * dir[i];
-      d_phi_t -= dd;  // sic (:727)
+      if (mode == LSA_NDT_MODE_PCL) {  // pcl ndt.hpp assigns
+        phi_t = -score;
+        d_phi_t = -dd;
+      } else {
+        phi_t -= score;  // sic (:726)
+        d_phi_t -= dd;   // sic (:727)
+      }
       psi_t = psi_mt(a_t, phi_t, phi_0, d_phi_0, mu);
       d_psi_t = dpsi_mt(d_phi_t, d_phi_0, mu);
       if (open_interval && (psi_t <= 0 && d_psi_t >= 0)) {
@@ -266,10 +272,15 @@ extern "C" void lsa_ndt_gauss_constants(float res, float outlier_ratio_f, double
 
 extern "C" int lsa_gn_solve(lsa_pass_eval_fn eval, void *user, float res, float step_size, float trans_eps, int max_iter,
                             float outlier_ratio, const float predict_pose[16], float result_pose[16], lsa_ndt_stats *stats) {
+  return lsa_gn_solve_mode(eval, user, res, step_size, trans_eps, max_iter, outlier_ratio, LSA_NDT_MODE_MANUAL, predict_pose, result_pose, stats);
+}
+
+extern "C" int lsa_gn_solve_mode(lsa_pass_eval_fn eval, void *user, float res, float step_size, float trans_eps, int max_iter,
+                                 float outlier_ratio, int mode, const float predict_pose[16], float result_pose[16], lsa_ndt_stats *stats) {
   (void)res; (void)outlier_ratio;  // the evaluator owns d1/d2; kept in the signature to mirror the plugin ctor
   if (!eval || !predict_pose || !result_pose) return LSA_ERR_INVALID;
   Driver d;
-  d.eval = eval; d.user = user;
+  d.eval = eval; d.user = user; d.mode = mode;
   d.step_size = step_size; d.trans_eps = trans_eps; d.max_iter = max_iter;  // float -> double like the plugin (:14-22)
   memcpy(d.T, predict_pose, sizeof(d.T));  // final_transformation_ = guess (Registration.cpp:80, Normal...:323-328)
   double p[6], delta[6];

@@ -6,12 +6,22 @@
 //   distance) (:146) -> drop the pair if sqdist > max_correspond_distance_ (squared vs un-squared, sic, :147) ->
 //   e = p' - q, J = [I3 | -R hat(p)] (:156-159) -> H += J^T J, B -= J^T e (:161-162) -> skip the update if det H == 0
 //   (:165) -> delta = H^-1 B in f32 (:169) -> t += delta[0:3], R *= SO3::exp(delta[3:6]) (:171-176).
-// The kd-tree becomes a uniform grid (cell = sqrt(gate) so the gated neighbour lies within +-1 cell) over the same
-// sparse voxel index as the NDT table: target points are counting-sorted by cell rank once per SetInputTarget, and one
-// lane per source point scans the 27 neighbouring cells.  J^T J / J^T e are formed from f32 J, e exactly as the
+// The kd-tree becomes the uniform grid of nn_grid.h (cell = sqrt(gate) so the gated neighbour lies within +-1 cell):
+// target points are counting-sorted by cell rank once per SetInputTarget, and one lane per source point scans the 27
+// neighbouring cells.  J^T J / J^T e are formed from f32 J, e exactly as the
 // reference forms them, but ACCUMULATED in f64 with a fixed reduction tree (the reference's running f32 sums depend on
 // point order); the 6x6 solve and the pose update stay in f32 on the host.
-#include "voxel_index_dev.h"
+//
+// mode 2 (LSA_ICP_MODE_PCL) is the "ICP" plugin instead (reference: lidar_localization/src/models/registration/
+// icp_registration.cpp:20-64 -> pcl::IterativeClosestPoint, PCL 1.7, third-party and absent from the tree: UNPINNED):
+//   correspondences = exact 1-NN gated at max_correspond_dis (CorrespondenceEstimation::determineCorrespondences),
+//   increment = Umeyama / SVD rigid fit of the pairs (TransformationEstimationSVD), the working cloud is transformed IN
+//   PLACE by each increment in f32 as PCL does, final = increment * final, and DefaultConvergenceCriteria stops the loop
+//   (max_iter; translation^2 <= trans_eps and cos(angle) >= 1 - trans_eps; relative MSE change < euclid_eps; absolute
+//   MSE change < 1e-12).  One kernel per iteration applies the pending increment, finds the neighbour and reduces the 17
+//   sums the fit needs (n, sum p, sum q, sum q p^T, sum d^2) in f64; the 3x3 SVD runs on the host.
+//   GetFitnessScore = pcl::Registration::getFitnessScore: mean squared distance to the nearest target point.
+#include "nn_grid_dev.h"
 
 #include <cmath>
 
@@ -19,70 +29,16 @@ namespace {
 constexpr int kBlock = 256;
 constexpr int kOut = 32;
 
-__global__ __launch_bounds__(kBlock) void k_count(const int32_t *__restrict__ cell_idx, size_t n, const uint32_t *__restrict__ bits,
-                                                  const uint32_t *__restrict__ prefix, uint32_t *__restrict__ cnt) {
-  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  int cell = cell_idx[i];
-  if (cell < 0) return;
-  unsigned rank = prefix[cell >> 5] + __popc(bits[cell >> 5] & ((1u << (cell & 31)) - 1u));
-  atomicAdd(cnt + rank, 1u);
-}
-
-// single block: start[i] = exclusive prefix of cnt[0..n), start[n] = total
-__global__ __launch_bounds__(1024) void k_excl_scan(const uint32_t *__restrict__ cnt, size_t n, uint32_t *__restrict__ start) {
-  __shared__ unsigned s[1024];
-  __shared__ unsigned carry;
-  if (threadIdx.x == 0) carry = 0;
-  __syncthreads();
-  for (size_t base = 0; base < n; base += 1024) {
-    size_t i = base + threadIdx.x;
-    unsigned v = (i < n) ? cnt[i] : 0;
-    s[threadIdx.x] = v;
-    __syncthreads();
-    for (int off = 1; off < 1024; off <<= 1) {
-      unsigned t = (threadIdx.x >= (unsigned)off) ? s[threadIdx.x - off] : 0;
-      __syncthreads();
-      s[threadIdx.x] += t;
-      __syncthreads();
-    }
-    unsigned incl = s[threadIdx.x], c = carry;
-    if (i < n) start[i] = c + incl - v;
-    __syncthreads();
-    if (threadIdx.x == 1023) carry = c + incl;
-    __syncthreads();
-  }
-  if (threadIdx.x == 0) start[n] = carry;
-}
-
-__global__ __launch_bounds__(kBlock) void k_scatter(const float4 *__restrict__ pts, const int32_t *__restrict__ cell_idx, size_t n,
-                                                    const uint32_t *__restrict__ bits, const uint32_t *__restrict__ prefix,
-                                                    const uint32_t *__restrict__ start, uint32_t *__restrict__ fill, float4 *__restrict__ sorted) {
-  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  int cell = cell_idx[i];
-  if (cell < 0) return;
-  unsigned rank = prefix[cell >> 5] + __popc(bits[cell >> 5] & ((1u << (cell & 31)) - 1u));
-  unsigned slot = start[rank] + atomicAdd(fill + rank, 1u);
-  float4 p = pts[i];
-  p.w = __uint_as_float((unsigned)i);  // original index: deterministic tie-break, and what the kd-tree would return
-  sorted[slot] = p;
-}
-
 struct IcpParams {
   float T[12];   // row-major 3x4 current pose
   float gate;    // max_correspond_distance_ compared with the SQUARED distance (sic)
-  CellMap map;
 };
 
-__global__ __launch_bounds__(kBlock) void k_icp_pass(const float4 *__restrict__ src, size_t n, IcpParams P, const uint32_t *__restrict__ bits,
-                                                     const uint32_t *__restrict__ prefix, const uint32_t *__restrict__ start,
-                                                     const float4 *__restrict__ sorted, double *__restrict__ partials) {
+__global__ __launch_bounds__(kBlock) void k_icp_pass(const float4 *__restrict__ src, size_t n, IcpParams P, NNView G, double *__restrict__ partials) {
   double acc[27];
 #pragma unroll
   for (int k = 0; k < 27; k++) acc[k] = 0.0;
   unsigned ncorr = 0, npts = 0;
-  const CellMap &m = P.map;
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
     float4 s = src[i];
     if (!lsa_finite3(s.x, s.y, s.z)) continue;  // pcl::isFinite(ori_point) (:141)
@@ -91,35 +47,9 @@ __global__ __launch_bounds__(kBlock) void k_icp_pass(const float4 *__restrict__ 
     float qy = lsa_fadd(lsa_fadd(lsa_fadd(lsa_fmul(P.T[4], s.x), lsa_fmul(P.T[5], s.y)), lsa_fmul(P.T[6], s.z)), P.T[7]);
     float qz = lsa_fadd(lsa_fadd(lsa_fadd(lsa_fmul(P.T[8], s.x), lsa_fmul(P.T[9], s.y)), lsa_fmul(P.T[10], s.z)), P.T[11]);
     if (!lsa_finite3(qx, qy, qz)) continue;
-    int c[3];
-    lsa_cell_ijk(m, qx, qy, qz, c);
-    float best = INFINITY;
-    unsigned best_id = 0xffffffffu;
-    float bx = 0, by = 0, bz = 0;
-    for (int dz = -1; dz <= 1; dz++) {
-      int iz = c[2] + dz;
-      if ((unsigned)iz >= (unsigned)m.dim[2]) continue;
-      for (int dy = -1; dy <= 1; dy++) {
-        int iy = c[1] + dy;
-        if ((unsigned)iy >= (unsigned)m.dim[1]) continue;
-        for (int dx = -1; dx <= 1; dx++) {
-          int ix = c[0] + dx;
-          if ((unsigned)ix >= (unsigned)m.dim[0]) continue;
-          int cell = ix + iy * m.dim[0] + iz * m.dim[0] * m.dim[1];
-          uint32_t w = bits[cell >> 5], bit = 1u << (cell & 31);
-          if (!(w & bit)) continue;
-          unsigned rank = prefix[cell >> 5] + __popc(w & (bit - 1u));
-          unsigned a = start[rank], b = start[rank + 1];
-          for (unsigned k = a; k < b; k++) {
-            float4 t = sorted[k];
-            float ex = lsa_fsub(qx, t.x), ey = lsa_fsub(qy, t.y), ez = lsa_fsub(qz, t.z);
-            float d = lsa_fadd(lsa_fadd(lsa_fmul(ex, ex), lsa_fmul(ey, ey)), lsa_fmul(ez, ez));  // FLANN L2_Simple, f32
-            unsigned id = __float_as_uint(t.w);
-            if (d < best || (d == best && id < best_id)) { best = d; best_id = id; bx = t.x; by = t.y; bz = t.z; }
-          }
-        }
-      }
-    }
+    NNHit hit = nn_nearest(G, qx, qy, qz, /*gate <= cell^2: one ring*/ 1);
+    float best = hit.d2, bx = hit.x, by = hit.y, bz = hit.z;
+    unsigned best_id = hit.id;
     if (best_id == 0xffffffffu || best > P.gate) continue;  // :147
     ncorr++;
     float e0 = lsa_fsub(qx, bx), e1 = lsa_fsub(qy, by), e2 = lsa_fsub(qz, bz);
@@ -160,6 +90,59 @@ __global__ __launch_bounds__(kBlock) void k_icp_pass(const float4 *__restrict__ 
   {
     double vc = lsa_wave_sum((double)ncorr), vn = lsa_wave_sum((double)npts);
     if (lane == 0) { sm[wave][0] = 0.0; sm[wave][28] = vc; sm[wave][29] = vn; sm[wave][30] = 0.0; sm[wave][31] = 0.0; }
+  }
+  __syncthreads();
+  if (threadIdx.x < kOut) {
+    double v = 0.0;
+    for (int w = 0; w < kBlock / 64; w++) v += sm[w][threadIdx.x];
+    partials[(size_t)blockIdx.x * kOut + threadIdx.x] = v;
+  }
+}
+
+struct T12 { float v[12]; };
+
+// PCL-mode iteration: work[i] = T * in[i] (the pending increment, f32 like IterativeClosestPoint::transformCloud), then
+// the gated nearest neighbour and the sums of the rigid fit.
+// out32: [0] sum d2, [1..3] sum p (source side), [4..6] sum q (target side), [7..15] sum q_r * p_c, [28] #pairs, [29] #finite
+__global__ __launch_bounds__(kBlock) void k_pcl_pass(const float4 *__restrict__ in, float4 *__restrict__ work, size_t n, T12 T, double gate2, NNView G,
+                                                     double *__restrict__ partials) {
+  double acc[16];
+#pragma unroll
+  for (int k = 0; k < 16; k++) acc[k] = 0.0;
+  unsigned ncorr = 0, npts = 0;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    float4 s = in[i];
+    if (!lsa_finite3(s.x, s.y, s.z)) { work[i] = s; continue; }
+    float px = lsa_fadd(lsa_fadd(lsa_fadd(lsa_fmul(T.v[0], s.x), lsa_fmul(T.v[1], s.y)), lsa_fmul(T.v[2], s.z)), T.v[3]);
+    float py = lsa_fadd(lsa_fadd(lsa_fadd(lsa_fmul(T.v[4], s.x), lsa_fmul(T.v[5], s.y)), lsa_fmul(T.v[6], s.z)), T.v[7]);
+    float pz = lsa_fadd(lsa_fadd(lsa_fadd(lsa_fmul(T.v[8], s.x), lsa_fmul(T.v[9], s.y)), lsa_fmul(T.v[10], s.z)), T.v[11]);
+    work[i] = make_float4(px, py, pz, s.w);
+    if (!lsa_finite3(px, py, pz)) continue;
+    npts++;
+    NNHit hit = nn_nearest(G, px, py, pz, /*gate <= cell: one ring*/ 1);
+    if (hit.id == 0xffffffffu || (double)hit.d2 > gate2) continue;  // distance[0] > max_dist_sqr
+    ncorr++;
+    acc[0] += (double)hit.d2;
+    double p[3] = {px, py, pz}, q[3] = {hit.x, hit.y, hit.z};
+#pragma unroll
+    for (int a = 0; a < 3; a++) { acc[1 + a] += p[a]; acc[4 + a] += q[a]; }
+#pragma unroll
+    for (int r = 0; r < 3; r++)
+#pragma unroll
+      for (int c = 0; c < 3; c++) acc[7 + r * 3 + c] += q[r] * p[c];
+  }
+  __shared__ double sm[kBlock / 64][kOut];
+  int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (threadIdx.x < kOut) for (int w = 0; w < kBlock / 64; w++) sm[w][threadIdx.x] = 0.0;
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < 16; k++) {
+    double v = lsa_wave_sum(acc[k]);
+    if (lane == 0) sm[wave][k] = v;
+  }
+  {
+    double vc = lsa_wave_sum((double)ncorr), vn = lsa_wave_sum((double)npts);
+    if (lane == 0) { sm[wave][28] = vc; sm[wave][29] = vn; }
   }
   __syncthreads();
   if (threadIdx.x < kOut) {
@@ -242,14 +225,20 @@ struct lsa_icp {
   float max_corr = 2.0f;
   int max_iter = 30;
   int mode = 0;
-  VoxelIndex vi;
-  DevBuf<float4> d_target, d_sorted, d_source_own;
-  DevBuf<uint32_t> cnt, start, fill;
+  float euclid_eps = 0.01f, trans_eps = 0.01f;  // PCL mode (config/mapping/front_end.yaml:31-35)
+  NNGrid grid;
+  DevBuf<float4> d_target, d_source_own, d_work;
   DevBuf<double> partials, d_out;
   PinnedBuf<double> h_out;
   PinnedBuf<float> h_stage;
   bool has_target = false;
   size_t n_target = 0;
+  // last ScanMatch (PCL mode: GetFitnessScore re-reads the source)
+  const float4 *d_last_src = nullptr;
+  size_t n_last_src = 0;
+  float last_T[16];
+  bool has_result = false;
+  lsa_icp_stats stats{};
 };
 
 namespace {
@@ -272,43 +261,34 @@ int icp_upload(lsa_icp *h, const void *pts, size_t n, size_t stride, DevBuf<floa
 }
 
 int icp_build(lsa_icp *h, const float4 *d_pts, size_t n) {
-  lsa_context *ctx = h->ctx;
-  VoxelIndex &vi = h->vi;
   h->has_target = false;
-  float cell = std::sqrt(h->max_corr);
-  if (!(cell > 0.05f)) cell = 0.05f;
-  const float leaf[3] = {cell, cell, cell};
-  int rc, status = VI_OK;
-  for (int attempt = 0; attempt < 2; attempt++) {
-    if ((rc = vi_enqueue(ctx, vi, d_pts, n, /*mode NDT-style floor(x / cell)*/ 1, leaf, 4))) return rc;
-    if ((rc = vi_fetch(ctx, vi))) return rc;
-    if ((rc = vi_wait(ctx, vi, &status))) return rc;
-    if (status != VI_CAPACITY) break;
-    if ((rc = vi_grow(ctx, vi))) return rc;
-  }
-  if (status == VI_EMPTY) return lsa_fail(ctx, LSA_ERR_INVALID, "ICP SetInputTarget: no finite points");
-  if (status != VI_OK) return lsa_fail(ctx, LSA_ERR_RANGE, "ICP SetInputTarget: neighbour grid overflows int32");
-  size_t V = vi.nocc;
-  if ((rc = h->cnt.reserve(ctx, V + 1, 1.25))) return rc;
-  if ((rc = h->start.reserve(ctx, V + 2, 1.25))) return rc;
-  if ((rc = h->fill.reserve(ctx, V + 1, 1.25))) return rc;
-  if ((rc = h->d_sorted.reserve(ctx, n, 1.25))) return rc;
-  LSA_HIP(ctx, hipMemsetAsync(h->cnt.p, 0, (V + 1) * sizeof(uint32_t), ctx->stream));
-  LSA_HIP(ctx, hipMemsetAsync(h->fill.p, 0, (V + 1) * sizeof(uint32_t), ctx->stream));
-  hipLaunchKernelGGL(k_count, dim3(lsa_div_up(n, kBlock)), dim3(kBlock), 0, ctx->stream, vi.cell_idx.p, n, vi.bits.p, vi.prefix.p, h->cnt.p);
-  hipLaunchKernelGGL(k_excl_scan, dim3(1), dim3(1024), 0, ctx->stream, h->cnt.p, V, h->start.p);
-  hipLaunchKernelGGL(k_scatter, dim3(lsa_div_up(n, kBlock)), dim3(kBlock), 0, ctx->stream, d_pts, vi.cell_idx.p, n, vi.bits.p, vi.prefix.p, h->start.p,
-                     h->fill.p, h->d_sorted.p);
-  LSA_HIP(ctx, hipGetLastError());
-  LSA_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  h->has_result = false;
+  // manual mode gates the SQUARED distance at max_corr (sic) -> cell sqrt(max_corr); PCL mode gates the distance
+  float cell = (h->mode == LSA_ICP_MODE_PCL) ? h->max_corr : std::sqrt(h->max_corr);
+  int rc = nn_grid_build(h->ctx, h->grid, d_pts, n, cell, "ICP SetInputTarget");
+  if (rc) return rc;
   h->n_target = n;
   h->has_target = true;
   return LSA_OK;
 }
 
-int icp_match(lsa_icp *h, const float4 *d_src, size_t n, const float predict[16], float result[16]) {
+unsigned icp_grid_size(const lsa_icp *h, size_t n) {
+  unsigned g = (unsigned)std::min<size_t>((n + kBlock - 1) / kBlock, (size_t)h->ctx->num_cus * 8);
+  return g < 1 ? 1 : g;
+}
+
+// launches the block reduction of `g` partial rows and brings the 32 doubles to the host
+int icp_fetch_sums(lsa_icp *h, unsigned g) {
   lsa_context *ctx = h->ctx;
-  if (!h->has_target) return lsa_fail(ctx, LSA_ERR_NO_TARGET, "ICP ScanMatch before SetInputTarget");
+  hipLaunchKernelGGL(k_reduce32, dim3(1), dim3(1024), 0, ctx->stream, h->partials.p, (int)g, h->d_out.p);
+  LSA_HIP(ctx, hipGetLastError());
+  LSA_HIP(ctx, hipMemcpyAsync(h->h_out.p, h->d_out.p, kOut * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+  LSA_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return LSA_OK;
+}
+
+int icp_match_manual(lsa_icp *h, const float4 *d_src, size_t n, const float predict[16], float result[16]) {
+  lsa_context *ctx = h->ctx;
   float T[16];
   memcpy(T, predict, sizeof(T));
   float R[9], t[3];
@@ -316,12 +296,12 @@ int icp_match(lsa_icp *h, const float4 *d_src, size_t n, const float predict[16]
     for (int c = 0; c < 3; c++) R[r * 3 + c] = T[c * 4 + r];
     t[r] = T[12 + r];
   }
-  unsigned g = (unsigned)std::min<size_t>((n + kBlock - 1) / kBlock, (size_t)ctx->num_cus * 8);
-  if (g < 1) g = 1;
+  unsigned g = icp_grid_size(h, n);
   int rc;
   if ((rc = h->partials.reserve(ctx, (size_t)g * kOut, 1.0))) return rc;
   if ((rc = h->d_out.reserve(ctx, kOut))) return rc;
   if ((rc = h->h_out.reserve(ctx, kOut))) return rc;
+  NNView G = nn_view(h->grid);
   for (int it = 0; it < h->max_iter; it++) {
     IcpParams P;
     for (int r = 0; r < 3; r++) {
@@ -329,12 +309,8 @@ int icp_match(lsa_icp *h, const float4 *d_src, size_t n, const float predict[16]
       P.T[r * 4 + 3] = t[r];
     }
     P.gate = h->max_corr;
-    P.map = h->vi.map;
-    hipLaunchKernelGGL(k_icp_pass, dim3(g), dim3(kBlock), 0, ctx->stream, d_src, n, P, h->vi.bits.p, h->vi.prefix.p, h->start.p, h->d_sorted.p, h->partials.p);
-    hipLaunchKernelGGL(k_reduce32, dim3(1), dim3(1024), 0, ctx->stream, h->partials.p, (int)g, h->d_out.p);
-    LSA_HIP(ctx, hipGetLastError());
-    LSA_HIP(ctx, hipMemcpyAsync(h->h_out.p, h->d_out.p, kOut * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
-    LSA_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    hipLaunchKernelGGL(k_icp_pass, dim3(g), dim3(kBlock), 0, ctx->stream, d_src, n, P, G, h->partials.p);
+    if ((rc = icp_fetch_sums(h, g))) return rc;
     const double *o = h->h_out.p;
     float H[36], B[6];
     int k = 7;
@@ -362,6 +338,154 @@ int icp_match(lsa_icp *h, const float4 *d_src, size_t n, const float predict[16]
     T[12 + r] = t[r];
   }
   memcpy(result, T, sizeof(T));
+  h->stats.iterations = h->max_iter; h->stats.converged = 1; h->stats.correspondences = h->max_iter ? h->h_out.p[28] : 0; h->stats.mse = 0;
+  return LSA_OK;
+}
+
+// ---- PCL mode host side: 3x3 SVD (one-sided Jacobi, f64) and Eigen::umeyama(src, dst, false) from the 17 sums ----
+void svd3(const double M[9], double U[9], double S[3], double V[9]) {
+  double A[3][3], W[3][3] = {{1, 0, 0}, {0, 1, 0}, {0, 0, 1}};
+  for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) A[i][j] = M[i * 3 + j];
+  for (int sweep = 0; sweep < 60; sweep++) {
+    double off = 0;
+    for (int p = 0; p < 2; p++)
+      for (int q = p + 1; q < 3; q++) {
+        double al = 0, be = 0, ga = 0;
+        for (int k = 0; k < 3; k++) { al += A[k][p] * A[k][p]; be += A[k][q] * A[k][q]; ga += A[k][p] * A[k][q]; }
+        double lim = std::sqrt(al * be);
+        if (ga == 0.0 || std::fabs(ga) <= 1e-18 * lim) continue;
+        off = std::fmax(off, std::fabs(ga) / (lim > 0 ? lim : 1));
+        double zeta = (be - al) / (2.0 * ga);
+        double t = ((zeta >= 0) ? 1.0 : -1.0) / (std::fabs(zeta) + std::sqrt(1.0 + zeta * zeta));
+        double c = 1.0 / std::sqrt(1.0 + t * t), s = c * t;
+        for (int k = 0; k < 3; k++) {
+          double ap = A[k][p], aq = A[k][q];
+          A[k][p] = c * ap - s * aq; A[k][q] = s * ap + c * aq;
+          double wp = W[k][p], wq = W[k][q];
+          W[k][p] = c * wp - s * wq; W[k][q] = s * wp + c * wq;
+        }
+      }
+    if (off < 1e-16) break;
+  }
+  int ord[3] = {0, 1, 2};
+  double sv[3];
+  for (int j = 0; j < 3; j++) sv[j] = std::sqrt(A[0][j] * A[0][j] + A[1][j] * A[1][j] + A[2][j] * A[2][j]);
+  for (int i = 0; i < 3; i++)
+    for (int j = i + 1; j < 3; j++)
+      if (sv[ord[j]] > sv[ord[i]]) std::swap(ord[i], ord[j]);
+  for (int c = 0; c < 3; c++) {
+    int j = ord[c];
+    S[c] = sv[j];
+    for (int r = 0; r < 3; r++) { V[r * 3 + c] = W[r][j]; U[r * 3 + c] = (sv[j] > 0) ? A[r][j] / sv[j] : 0.0; }
+  }
+  if (S[2] == 0 || S[2] <= 1e-300 * (S[0] > 0 ? S[0] : 1)) {  // rank deficient: complete U to an orthonormal basis
+    if (S[1] == 0) {
+      double u0[3] = {U[0], U[3], U[6]};
+      if (S[0] == 0) { u0[0] = 1; u0[1] = 0; u0[2] = 0; U[0] = 1; U[3] = 0; U[6] = 0; }
+      double e[3] = {0, 0, 0};
+      e[(std::fabs(u0[0]) < 0.9) ? 0 : 1] = 1;
+      double u1[3] = {u0[1] * e[2] - u0[2] * e[1], u0[2] * e[0] - u0[0] * e[2], u0[0] * e[1] - u0[1] * e[0]};
+      double nn = std::sqrt(u1[0] * u1[0] + u1[1] * u1[1] + u1[2] * u1[2]);
+      for (int r = 0; r < 3; r++) U[r * 3 + 1] = u1[r] / nn;
+    }
+    double a[3] = {U[0], U[3], U[6]}, b[3] = {U[1], U[4], U[7]};
+    U[2] = a[1] * b[2] - a[2] * b[1]; U[5] = a[2] * b[0] - a[0] * b[2]; U[8] = a[0] * b[1] - a[1] * b[0];
+  }
+}
+
+double det3(const double m[9]) {
+  return m[0] * (m[4] * m[8] - m[5] * m[7]) - m[1] * (m[3] * m[8] - m[5] * m[6]) + m[2] * (m[3] * m[7] - m[4] * m[6]);
+}
+
+// sums: n pairs, sp = sum p (source), sq = sum q (target), sqp[r][c] = sum q_r p_c.  T: column-major increment.
+void umeyama_from_sums(double n, const double sp[3], const double sq[3], const double sqp[9], float T[16]) {
+  double pm[3], qm[3], M[9], U[9], S[3], V[9];
+  for (int a = 0; a < 3; a++) { pm[a] = sp[a] / n; qm[a] = sq[a] / n; }
+  for (int r = 0; r < 3; r++)
+    for (int c = 0; c < 3; c++) M[r * 3 + c] = sqp[r * 3 + c] / n - qm[r] * pm[c];  // sigma = 1/n sum (q - qm)(p - pm)^T
+  svd3(M, U, S, V);
+  double Sd[3] = {1, 1, 1};
+  if (det3(M) < 0) Sd[2] = -1;
+  int rank = 0;
+  for (int i = 0; i < 3; i++)
+    if (!(std::fabs(S[i]) <= std::fabs(S[0]) * 1.1920929e-07)) rank++;  // !isMuchSmallerThan(d(i), d(0)) at f32 precision
+  if (rank == 2) Sd[2] = (det3(U) * det3(V) > 0) ? 1 : -1;
+  float Rf[9];
+  for (int r = 0; r < 3; r++)
+    for (int c = 0; c < 3; c++)
+      Rf[r * 3 + c] = (float)(U[r * 3 + 0] * Sd[0] * V[c * 3 + 0] + U[r * 3 + 1] * Sd[1] * V[c * 3 + 1] + U[r * 3 + 2] * Sd[2] * V[c * 3 + 2]);
+  float pmf[3] = {(float)pm[0], (float)pm[1], (float)pm[2]}, qmf[3] = {(float)qm[0], (float)qm[1], (float)qm[2]};
+  for (int k = 0; k < 16; k++) T[k] = 0.0f;
+  for (int r = 0; r < 3; r++) {
+    for (int c = 0; c < 3; c++) T[c * 4 + r] = Rf[r * 3 + c];
+    T[12 + r] = qmf[r] - ((Rf[r * 3 + 0] * pmf[0] + Rf[r * 3 + 1] * pmf[1]) + Rf[r * 3 + 2] * pmf[2]);
+  }
+  T[15] = 1.0f;
+}
+
+void mat4_mul_f32(const float A[16], const float B[16], float C[16]) {  // column-major, C = A * B (Eigen::Matrix4f product)
+  float o[16];
+  for (int c = 0; c < 4; c++)
+    for (int r = 0; r < 4; r++) o[c * 4 + r] = ((A[0 * 4 + r] * B[c * 4 + 0] + A[1 * 4 + r] * B[c * 4 + 1]) + A[2 * 4 + r] * B[c * 4 + 2]) + A[3 * 4 + r] * B[c * 4 + 3];
+  memcpy(C, o, sizeof(o));
+}
+
+T12 to_t12(const float T[16]) {
+  T12 o;
+  for (int r = 0; r < 3; r++)
+    for (int c = 0; c < 4; c++) o.v[r * 4 + c] = T[c * 4 + r];
+  return o;
+}
+
+int icp_match_pcl(lsa_icp *h, const float4 *d_src, size_t n, const float predict[16], float result[16]) {
+  lsa_context *ctx = h->ctx;
+  unsigned g = icp_grid_size(h, n);
+  int rc;
+  if ((rc = h->partials.reserve(ctx, (size_t)g * kOut, 1.0))) return rc;
+  if ((rc = h->d_out.reserve(ctx, kOut))) return rc;
+  if ((rc = h->h_out.reserve(ctx, kOut))) return rc;
+  if ((rc = h->d_work.reserve(ctx, n ? n : 1, 1.25))) return rc;
+  NNView G = nn_view(h->grid);
+  float final_T[16], incr[16];
+  memcpy(final_T, predict, sizeof(final_T));
+  memcpy(incr, predict, sizeof(incr));  // the first pass applies the guess to the input
+  const double gate2 = (double)h->max_corr * (double)h->max_corr;
+  const double rot_thr = 1.0 - (double)h->trans_eps, tr_thr = (double)h->trans_eps, mse_rel = (double)h->euclid_eps, mse_abs = 1e-12;
+  double prev_mse = 1.7976931348623157e308, cur_mse = 0, cnt = 0;
+  int iterations = 0, converged = 0;
+  const float4 *in = d_src;
+  for (;;) {
+    hipLaunchKernelGGL(k_pcl_pass, dim3(g), dim3(kBlock), 0, ctx->stream, in, h->d_work.p, n, to_t12(incr), gate2, G, h->partials.p);
+    if ((rc = icp_fetch_sums(h, g))) return rc;
+    in = h->d_work.p;
+    const double *o = h->h_out.p;
+    cnt = o[28];
+    if (cnt < 3) { converged = 0; break; }  // min_number_correspondences_: "Not enough correspondences found"
+    umeyama_from_sums(cnt, o + 1, o + 4, o + 7, incr);
+    mat4_mul_f32(incr, final_T, final_T);
+    ++iterations;
+    // DefaultConvergenceCriteria::hasConverged
+    if (iterations >= h->max_iter) { converged = 1; break; }
+    double cos_angle = 0.5 * ((double)incr[0] + (double)incr[5] + (double)incr[10] - 1.0);
+    double tsq = (double)incr[12] * incr[12] + (double)incr[13] * incr[13] + (double)incr[14] * incr[14];
+    if (cos_angle >= rot_thr && tsq <= tr_thr) { converged = 1; break; }
+    cur_mse = o[0] / cnt;
+    if (std::fabs(cur_mse - prev_mse) < mse_abs) { converged = 1; break; }
+    if (std::fabs(cur_mse - prev_mse) / prev_mse < mse_rel) { converged = 1; break; }
+    prev_mse = cur_mse;
+  }
+  memcpy(result, final_T, sizeof(final_T));
+  h->stats.iterations = iterations; h->stats.converged = converged; h->stats.correspondences = cnt; h->stats.mse = cur_mse;
+  return LSA_OK;
+}
+
+int icp_match(lsa_icp *h, const float4 *d_src, size_t n, const float predict[16], float result[16]) {
+  if (!h->has_target) return lsa_fail(h->ctx, LSA_ERR_NO_TARGET, "ICP ScanMatch before SetInputTarget");
+  int rc = (h->mode == LSA_ICP_MODE_PCL) ? icp_match_pcl(h, d_src, n, predict, result) : icp_match_manual(h, d_src, n, predict, result);
+  if (rc) return rc;
+  h->d_last_src = d_src; h->n_last_src = n;
+  memcpy(h->last_T, result, sizeof(h->last_T));
+  h->has_result = true;
   return LSA_OK;
 }
 }  // namespace
@@ -369,7 +493,8 @@ int icp_match(lsa_icp *h, const float4 *d_src, size_t n, const float predict[16]
 extern "C" int lsa_icp_create(lsa_icp **out, lsa_context *ctx, float max_correspond_dis, int max_iter, int mode) {
   if (!out || !ctx) { lsa_set_global_error("lsa_icp_create: null argument"); return LSA_ERR_INVALID; }
   *out = nullptr;
-  if (mode != 0) return lsa_fail(ctx, LSA_ERR_INVALID, "lsa_icp_create: mode %d (point-to-plane) is not available in this build", mode);
+  if (mode != LSA_ICP_MODE_MANUAL && mode != LSA_ICP_MODE_PCL)
+    return lsa_fail(ctx, LSA_ERR_INVALID, "lsa_icp_create: mode %d is not available in this build (0 = ICPMANUAL, 2 = ICP / PCL semantics)", mode);
   if (!(max_correspond_dis > 0) || max_iter < 0) return lsa_fail(ctx, LSA_ERR_INVALID, "lsa_icp_create: bad parameters");
   lsa_icp *h = new lsa_icp();
   h->ctx = ctx; h->max_corr = max_correspond_dis; h->max_iter = max_iter; h->mode = mode;
@@ -377,11 +502,23 @@ extern "C" int lsa_icp_create(lsa_icp **out, lsa_context *ctx, float max_corresp
   return LSA_OK;
 }
 
+extern "C" int lsa_icp_set_criteria(lsa_icp *h, float euclid_eps, float trans_eps) {
+  if (!h) return LSA_ERR_INVALID;
+  h->euclid_eps = euclid_eps; h->trans_eps = trans_eps;
+  return LSA_OK;
+}
+
+extern "C" int lsa_icp_get_stats(lsa_icp *h, lsa_icp_stats *st) {
+  if (!h || !st) return LSA_ERR_INVALID;
+  *st = h->stats;
+  return LSA_OK;
+}
+
 extern "C" void lsa_icp_destroy(lsa_icp *h) {
   if (!h) return;
   (void)hipSetDevice(h->ctx->device);
   (void)hipStreamSynchronize(h->ctx->stream);
-  h->vi.release(); h->d_target.release(); h->d_sorted.release(); h->d_source_own.release(); h->cnt.release(); h->start.release(); h->fill.release();
+  h->grid.release(); h->d_target.release(); h->d_source_own.release(); h->d_work.release();
   h->partials.release(); h->d_out.release(); h->h_out.release(); h->h_stage.release();
   delete h;
 }
@@ -418,6 +555,13 @@ extern "C" int lsa_icp_scan_match(lsa_icp *h, const void *src, size_t n, size_t 
 
 extern "C" int lsa_icp_get_fitness_score(lsa_icp *h, float *score) {
   if (!h || !score) return LSA_ERR_INVALID;
-  *score = 0.0f;  // "not implemented" in the reference: prints a notice and returns 0 (:62-67)
+  *score = 0.0f;  // ICPMANUAL: "not implemented" in the reference, prints a notice and returns 0 (:62-67)
+  if (h->mode != LSA_ICP_MODE_PCL) return LSA_OK;
+  int rc = icp_check(h);
+  if (rc) return rc;
+  if (!h->has_target || !h->has_result) return lsa_fail(h->ctx, LSA_ERR_NO_TARGET, "GetFitnessScore before SetInputTarget + ScanMatch");
+  double v = 0;
+  if ((rc = nn_fitness(h->ctx, h->grid, h->d_last_src, h->n_last_src, h->last_T, INFINITY, &v))) return rc;
+  *score = (float)v;  // icp_registration.cpp:60-63: float GetFitnessScore() { return icp_ptr_->getFitnessScore(); }
   return LSA_OK;
 }

@@ -64,7 +64,7 @@ int scan_match_common(lsa_ndt *h, const float predict_pose[16], float result_pos
   lsa_ndt_gauss_constants(h->resolution, h->outlier_ratio, &h->d1, &h->d2);
   lsa_ndt_stats st;
   memset(&st, 0, sizeof(st));
-  int rc = lsa_gn_solve(eval_trampoline, h, h->resolution, h->step_size, h->trans_eps, h->max_iter, h->outlier_ratio, predict_pose, result_pose, &st);
+  int rc = lsa_gn_solve_mode(eval_trampoline, h, h->resolution, h->step_size, h->trans_eps, h->max_iter, h->outlier_ratio, h->mode, predict_pose, result_pose, &st);
   if (rc) return rc;
   memcpy(h->last_T, result_pose, sizeof(h->last_T));
   h->has_result = true;
@@ -85,11 +85,20 @@ extern "C" int lsa_ndt_create(lsa_ndt **out, lsa_context *ctx, float res, float 
   return LSA_OK;
 }
 
+extern "C" int lsa_ndt_set_mode(lsa_ndt *h, int mode) {
+  if (!h) return LSA_ERR_INVALID;
+  if (mode != LSA_NDT_MODE_MANUAL && mode != LSA_NDT_MODE_PCL) return lsa_fail(h->ctx, LSA_ERR_INVALID, "lsa_ndt_set_mode: unknown mode %d", mode);
+  if (mode != h->mode) { h->has_target = false; h->has_result = false; }  // the voxel table depends on the mode
+  h->mode = mode;
+  return LSA_OK;
+}
+
 extern "C" void lsa_ndt_destroy(lsa_ndt *h) {
   if (!h) return;
   (void)hipSetDevice(h->ctx->device);
   (void)hipStreamSynchronize(h->ctx->stream);
   ndt_fitness_release(h);
+  h->nn.release();
   h->vi.release(); h->d_target.release(); h->rec.release(); h->state.release(); h->vbits.release(); h->words.release(); h->d_small.release();
   h->d_source_own.release(); h->h_stage.release(); h->partials.release(); h->d_out.release(); h->h_out.release(); h->h_partials.release();
   delete h;
@@ -190,6 +199,13 @@ extern "C" int lsa_ndt_get_fitness_score(lsa_ndt *h, float *score) {
   if (rc) return rc;
   if (!score) return lsa_fail(h->ctx, LSA_ERR_INVALID, "GetFitnessScore: null output");
   if (!h->has_target || !h->has_result) return lsa_fail(h->ctx, LSA_ERR_NO_TARGET, "GetFitnessScore before SetInputTarget + ScanMatch");
+  if (h->mode == LSA_NDT_MODE_PCL) {  // pcl::Registration::getFitnessScore over the target POINTS (ndt_registration.cpp:63-66)
+    if (!h->nn.built && (rc = nn_grid_build(h->ctx, h->nn, h->d_target_pts, h->n_target, h->resolution, "GetFitnessScore"))) return rc;
+    double v = 0;
+    if ((rc = nn_fitness(h->ctx, h->nn, h->d_source, h->n_source, h->last_T, INFINITY, &v))) return rc;
+    *score = (float)v;
+    return LSA_OK;
+  }
   return ndt_fitness(h, score);
 }
 

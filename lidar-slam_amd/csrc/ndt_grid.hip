@@ -91,6 +91,36 @@ __device__ void eig3_reference(const double a_in[6] /*xx,xy,xz,yy,yz,zz*/, doubl
   evals[0] *= maxAbs; evals[1] *= maxAbs; evals[2] *= maxAbs;
 }
 
+// PCL mode: Eigen::SelfAdjointEigenSolver<Matrix3d> stand-in (cyclic Jacobi; same eigen-pairs up to rounding and sign,
+// and V L V^-1 does not depend on the sign).  Eigenvalues ascending, eigenvectors in the columns of V.
+__device__ void eig3_jacobi(const double a_in[6] /*xx,xy,xz,yy,yz,zz*/, double evals[3], double V[3][3]) {
+  double A[3][3] = {{a_in[0], a_in[1], a_in[2]}, {a_in[1], a_in[3], a_in[4]}, {a_in[2], a_in[4], a_in[5]}};
+  double W[3][3] = {{1, 0, 0}, {0, 1, 0}, {0, 0, 1}};
+  for (int sweep = 0; sweep < 32; sweep++) {
+    double off = fabs(A[0][1]) + fabs(A[0][2]) + fabs(A[1][2]);
+    double diag = fabs(A[0][0]) + fabs(A[1][1]) + fabs(A[2][2]);
+    if (off <= 1e-300 || off <= 1e-17 * diag) break;
+    for (int p = 0; p < 2; p++)
+      for (int q = p + 1; q < 3; q++) {
+        double apq = A[p][q];
+        if (apq == 0.0) continue;
+        double theta = (A[q][q] - A[p][p]) / (2.0 * apq);
+        double t = ((theta >= 0) ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
+        double c = 1.0 / sqrt(t * t + 1.0), s = t * c;
+        for (int k = 0; k < 3; k++) { double akp = A[k][p], akq = A[k][q]; A[k][p] = c * akp - s * akq; A[k][q] = s * akp + c * akq; }
+        for (int k = 0; k < 3; k++) { double apk = A[p][k], aqk = A[q][k]; A[p][k] = c * apk - s * aqk; A[q][k] = s * apk + c * aqk; }
+        for (int k = 0; k < 3; k++) { double wkp = W[k][p], wkq = W[k][q]; W[k][p] = c * wkp - s * wkq; W[k][q] = s * wkp + c * wkq; }
+      }
+  }
+  int o0 = 0, o1 = 1, o2 = 2;
+  double d0 = A[0][0], d1 = A[1][1], d2 = A[2][2];
+  if (d1 < d0) { double t = d0; d0 = d1; d1 = t; int ti = o0; o0 = o1; o1 = ti; }
+  if (d2 < d0) { double t = d0; d0 = d2; d2 = t; int ti = o0; o0 = o2; o2 = ti; }
+  if (d2 < d1) { double t = d1; d1 = d2; d2 = t; int ti = o1; o1 = o2; o2 = ti; }
+  evals[0] = d0; evals[1] = d1; evals[2] = d2;
+  for (int r = 0; r < 3; r++) { V[r][0] = W[r][o0]; V[r][1] = W[r][o1]; V[r][2] = W[r][o2]; }
+}
+
 // general 3x3 cofactor inverse (Eigen LU/InverseImpl.h:124-169, what Matrix3d::inverse() runs)
 __device__ void inv3(const double m[3][3], double o[3][3]) {
   double c0 = m[1][1] * m[2][2] - m[1][2] * m[2][1];
@@ -110,7 +140,7 @@ __device__ void inv3(const double m[3][3], double o[3][3]) {
 // one thread per occupied cell (computeCentroidAndCovariance, VoxelGrid.cpp:273-323)
 __global__ __launch_bounds__(kBlock) void k_ndt_finalize(const long long *__restrict__ acc, const int32_t *__restrict__ cnt,
                                                          const int32_t *__restrict__ cell_of_rank, size_t nocc, CellMap m, FixScales fs,
-                                                         double *__restrict__ rec, int32_t *__restrict__ state, uint32_t *__restrict__ vbits) {
+                                                         double *__restrict__ rec, int32_t *__restrict__ state, uint32_t *__restrict__ vbits, int pcl) {
   size_t r = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (r >= nocc) return;
   const long long *a = acc + r * 10;
@@ -122,14 +152,14 @@ __global__ __launch_bounds__(kBlock) void k_ndt_finalize(const long long *__rest
   double md[3] = {((double)a[0] * fs.inv_s1) / n, ((double)a[1] * fs.inv_s1) / n, ((double)a[2] * fs.inv_s1) / n};
   double *R = rec + r * kRecDoubles;
   R[0] = o[0] + md[0]; R[1] = o[1] + md[1]; R[2] = o[2] + md[2];  // centroid (:286)
-  R[9] = ((double)a[9] * fs.inv_sw) / n;                            // mean static weight (:287)
+  R[9] = pcl ? 1.0 : ((double)a[9] * fs.inv_sw) / n;                // mean static weight (:287); PCL has none
   for (int k = 3; k < 9; k++) R[k] = 0.0;
   int st = 0;  // 0: fewer than min_points_per_voxel_ (6) points, 1: valid, -1: rejected eigenvalues
   if (ni >= 6) {
     // reference: cov = ((I + sum p p^T) - 2 (sum p) mu^T) / n + mu mu^T, then *= (n - 1) / n (:257, :293-294)
     //          = (C_pop + I / n) * (n - 1) / n with C_pop the population covariance, which is shift invariant and is
     // evaluated here from the corner-relative sums (no 1e4 m^2 - 1e4 m^2 cancellation).
-    double f = (n - 1.0) / n, in = 1.0 / n;
+    double f = (n - 1.0) / n, in = pcl ? 0.0 : 1.0 / n;  // PCL's VoxelGridCovariance accumulates from zero, not from I
     double sxx = (double)a[3] * fs.inv_s2, sxy = (double)a[4] * fs.inv_s2, sxz = (double)a[5] * fs.inv_s2;
     double syy = (double)a[6] * fs.inv_s2, syz = (double)a[7] * fs.inv_s2, szz = (double)a[8] * fs.inv_s2;
     double c[6];
@@ -140,9 +170,16 @@ __global__ __launch_bounds__(kBlock) void k_ndt_finalize(const long long *__rest
     c[4] = (syz / n - md[1] * md[2]) * f;
     c[5] = (szz / n - md[2] * md[2] + in) * f;
     double ev[3], V[3][3];
-    eig3_reference(c, ev, V);
-    if (ev[0] < 0 || ev[1] < 0 || ev[2] <= 0) {  // :303-306
-      st = -1;
+    if (pcl) eig3_jacobi(c, ev, V);
+    else eig3_reference(c, ev, V);
+    // PCL mode: points of one azimuth column of a spinning lidar are exactly coplanar, so the smallest eigenvalue is 0
+    // up to rounding and the sign PCL tests is a coin flip of its summation order; here a value within rounding of zero
+    // counts as zero (the floor below then lifts it), only a clearly negative one rejects the leaf.
+    const double neg = pcl ? -1e-12 * fabs(ev[2]) : 0.0;
+    if (ev[0] < neg || ev[1] < neg || ev[2] <= 0) {  // :303-306
+      // PCL sets nr_points = -1 too, but the leaf's centroid is already in the kd-tree cloud and ndt.hpp never looks at
+      // nr_points: the leaf keeps contributing with its zero-initialised icov_ (score only)
+      st = pcl ? 1 : -1;
     } else {
       double cov[3][3] = {{c[0], c[1], c[2]}, {c[1], c[3], c[4]}, {c[2], c[4], c[5]}};
       double mine = ev[2] * 0.01;
@@ -161,6 +198,11 @@ __global__ __launch_bounds__(kBlock) void k_ndt_finalize(const long long *__rest
       R[3] = ic[0][0]; R[4] = 0.5 * (ic[0][1] + ic[1][0]); R[5] = 0.5 * (ic[0][2] + ic[2][0]);
       R[6] = ic[1][1]; R[7] = 0.5 * (ic[1][2] + ic[2][1]); R[8] = ic[2][2];
       st = 1;
+      if (pcl) {  // icov_.maxCoeff() == inf || icov_.minCoeff() == -inf: leaf dropped
+        bool inf = false;
+        for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) inf = inf || isinf(ic[i][j]);
+        if (inf) { st = -1; for (int k = 3; k < 9; k++) R[k] = 0.0; }
+      }
     }
   }
   state[r] = st;
@@ -207,7 +249,7 @@ int ndt_build_grid(lsa_ndt *h, const float4 *d_pts, size_t n) {
   LSA_HIP(ctx, hipMemsetAsync(h->vbits.p, 0, vi.W * sizeof(uint32_t), ctx->stream));
   LSA_HIP(ctx, hipMemsetAsync(h->d_small.p, 0, 64 * sizeof(double), ctx->stream));
   hipLaunchKernelGGL(k_ndt_finalize, dim3(lsa_div_up(V, kBlock)), dim3(kBlock), 0, ctx->stream, vi.acc.p, vi.cnt.p, vi.cell_of_rank.p, V, vi.map, vi.fs,
-                     h->rec.p, h->state.p, h->vbits.p);
+                     h->rec.p, h->state.p, h->vbits.p, h->mode == LSA_NDT_MODE_PCL ? 1 : 0);
   hipLaunchKernelGGL(k_pack_words, dim3(lsa_div_up(vi.W, kBlock)), dim3(kBlock), 0, ctx->stream, vi.bits.p, h->vbits.p, vi.prefix.p, vi.W, h->words.p);
   hipLaunchKernelGGL(k_count_valid, dim3(lsa_div_up(V, kBlock)), dim3(kBlock), 0, ctx->stream, h->state.p, V, (unsigned *)h->d_small.p);
   LSA_HIP(ctx, hipGetLastError());
@@ -220,6 +262,7 @@ int ndt_build_grid(lsa_ndt *h, const float4 *d_pts, size_t n) {
   h->n_target = n;
   h->d_target_pts = d_pts;
   ndt_fitness_invalidate(h);
+  h->nn.built = false;
   h->has_target = true;
   return LSA_OK;
 }

@@ -2,6 +2,7 @@
 #ifndef LSA_NDT_INTERNAL_H_
 #define LSA_NDT_INTERNAL_H_
 
+#include "nn_grid.h"
 #include "voxel_index_dev.h"
 
 // per occupied cell: centroid(3), inverse covariance symmetric (xx,xy,xz,yy,yz,zz), mean static weight
@@ -16,6 +17,7 @@ struct lsa_ndt {
   float resolution = 1.0f;
   float step_size = 0.1f, trans_eps = 0.01f, outlier_ratio = 0.55f;
   int max_iter = 30;
+  int mode = 0;  // LSA_NDT_MODE_MANUAL / LSA_NDT_MODE_PCL
   double d1 = 0, d2 = 0;
 
   // target
@@ -30,6 +32,7 @@ struct lsa_ndt {
   size_t n_target = 0, n_valid = 0;
   const float4 *d_target_pts = nullptr;  // the cloud the table was built from (ours, or the caller's device buffer)
   FitnessState *fitness = nullptr;       // lazily built leaf table for GetFitnessScore
+  NNGrid nn;                             // PCL mode: lazily built point-level neighbour grid for GetFitnessScore
 
   // source
   DevBuf<float4> d_source_own;

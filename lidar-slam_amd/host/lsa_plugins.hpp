@@ -132,6 +132,17 @@ class RegistrationInterface {
   virtual float GetFitnessScore() = 0;
 };
 
+// pcl::transformPointCloud(src, out, T): what the PCL-backed plugins leave in result_cloud_ptr
+inline void transform_into(const CloudData::CLOUD &src, const Matrix4f &T, CloudData::CLOUD &out) {
+  out.points = src.points;
+  for (auto &p : out.points) {
+    float x = p.x, y = p.y, z = p.z;
+    p.x = T(0, 0) * x + T(0, 1) * y + T(0, 2) * z + T(0, 3);
+    p.y = T(1, 0) * x + T(1, 1) * y + T(1, 2) * z + T(1, 3);
+    p.z = T(2, 0) * x + T(2, 1) * y + T(2, 2) * z + T(2, 3);
+  }
+}
+
 class NDTRegistrationHip : public RegistrationInterface {
  public:
   NDTRegistrationHip(const std::shared_ptr<Context> &ctx, float res, float step_size, float trans_eps, int max_iter, float outlier_ratio)
@@ -140,16 +151,27 @@ class NDTRegistrationHip : public RegistrationInterface {
     std::printf("NDT HIP params: res %g, step_size %g, trans_eps %g, max_iter %d, outlier_ratio %g\n", res, step_size, trans_eps, max_iter,
                 outlier_ratio);  // the reference echoes its parameters (ndt_registration_manual.cpp:37-44)
   }
+  // NDTRegistration(float res, float step_size, float trans_eps, int max_iter) (ndt_registration.cpp:18-22): the "NDT"
+  // plugin = pcl::NormalDistributionsTransform semantics (LSA_NDT_MODE_PCL); PCL's default outlier ratio 0.55.
+  NDTRegistrationHip(const std::shared_ptr<Context> &ctx, float res, float step_size, float trans_eps, int max_iter) : ctx_(ctx) {
+    report("lsa_ndt_create", ctx_->get(), lsa_ndt_create(&ndt_, ctx_->get(), res, step_size, trans_eps, max_iter, 0.55f));
+    report("lsa_ndt_set_mode", ctx_->get(), lsa_ndt_set_mode(ndt_, LSA_NDT_MODE_PCL));
+    pcl_mode_ = true;
+    std::printf("NDT HIP (PCL semantics) params: res %g, step_size %g, trans_eps %g, max_iter %d\n", res, step_size, trans_eps, max_iter);
+  }
   ~NDTRegistrationHip() override { lsa_ndt_destroy(ndt_); }
   bool SetInputTarget(const CloudData::CLOUD_PTR &t) override {
     status_ = lsa_ndt_set_input_target(ndt_, t->points.data(), t->points.size(), sizeof(PointXYZI), LSA_POINTXYZI_W_OFF);
     return report("NDTRegistrationHip::SetInputTarget", ctx_->get(), status_);
   }
   bool ScanMatch(const CloudData::CLOUD_PTR &src, const Matrix4f &predict_pose, CloudData::CLOUD_PTR &result_cloud_ptr, Matrix4f &result_pose) override {
-    (void)result_cloud_ptr;  // never written by NDTRegistrationManual (Registration.cpp:92-95), read by no caller
+    // never written by NDTRegistrationManual (Registration.cpp:92-95), read by no caller; pcl's align() fills it
     Matrix4f out = predict_pose;
     status_ = lsa_ndt_scan_match(ndt_, src->points.data(), src->points.size(), sizeof(PointXYZI), predict_pose.data(), out.data(), &stats_);
-    if (status_ == LSA_OK) result_pose = out;
+    if (status_ == LSA_OK) {
+      result_pose = out;
+      if (pcl_mode_ && result_cloud_ptr) transform_into(*src, out, *result_cloud_ptr);
+    }
     return report("NDTRegistrationHip::ScanMatch", ctx_->get(), status_);
   }
   float GetFitnessScore() override {
@@ -167,13 +189,21 @@ class NDTRegistrationHip : public RegistrationInterface {
   lsa_ndt *ndt_ = nullptr;
   lsa_ndt_stats stats_{};
   int status_ = LSA_OK;
+  bool pcl_mode_ = false;
 };
 
 class ICPRegistrationHip : public RegistrationInterface {
  public:
-  // mode 0: ICPRegistrationManual semantics (point-to-point GN, icp_registration_manual.cpp:125-178); 1: point-to-plane
-  ICPRegistrationHip(const std::shared_ptr<Context> &ctx, float max_correspond_dis, int max_iter, int mode = 0) : ctx_(ctx) {
+  // ICPRegistrationManual(max_correspond_dis, max_iter) (icp_registration_manual.cpp:29-33): point-to-point GN (:125-178)
+  ICPRegistrationHip(const std::shared_ptr<Context> &ctx, float max_correspond_dis, int max_iter, int mode = LSA_ICP_MODE_MANUAL) : ctx_(ctx), mode_(mode) {
     report("lsa_icp_create", ctx_->get(), lsa_icp_create(&icp_, ctx_->get(), max_correspond_dis, max_iter, mode));
+  }
+  // ICPRegistration(euclid_eps, max_correspond_dis, trans_eps, max_iter) (icp_registration.cpp:20-33): the "ICP" plugin =
+  // pcl::IterativeClosestPoint semantics (LSA_ICP_MODE_PCL)
+  ICPRegistrationHip(const std::shared_ptr<Context> &ctx, float euclid_eps, float max_correspond_dis, float trans_eps, int max_iter)
+      : ctx_(ctx), mode_(LSA_ICP_MODE_PCL) {
+    report("lsa_icp_create", ctx_->get(), lsa_icp_create(&icp_, ctx_->get(), max_correspond_dis, max_iter, LSA_ICP_MODE_PCL));
+    report("lsa_icp_set_criteria", ctx_->get(), lsa_icp_set_criteria(icp_, euclid_eps, trans_eps));
   }
   ~ICPRegistrationHip() override { lsa_icp_destroy(icp_); }
   bool SetInputTarget(const CloudData::CLOUD_PTR &t) override {
@@ -185,26 +215,25 @@ class ICPRegistrationHip : public RegistrationInterface {
     status_ = lsa_icp_scan_match(icp_, src->points.data(), src->points.size(), sizeof(PointXYZI), predict_pose.data(), out.data());
     if (status_ == LSA_OK) {
       result_pose = out;
-      // ICPRegistrationManual fills result_cloud_ptr with the aligned source (icp_registration_manual.cpp:57)
-      if (result_cloud_ptr) {
-        result_cloud_ptr->points = src->points;
-        for (auto &p : result_cloud_ptr->points) {
-          float x = p.x, y = p.y, z = p.z;
-          p.x = out(0, 0) * x + out(0, 1) * y + out(0, 2) * z + out(0, 3);
-          p.y = out(1, 0) * x + out(1, 1) * y + out(1, 2) * z + out(1, 3);
-          p.z = out(2, 0) * x + out(2, 1) * y + out(2, 2) * z + out(2, 3);
-        }
-      }
+      // both ICP plugins fill result_cloud_ptr with the aligned source (icp_registration_manual.cpp:57, icp_registration.cpp:55)
+      if (result_cloud_ptr) transform_into(*src, out, *result_cloud_ptr);
     }
     return report("ICPRegistrationHip::ScanMatch", ctx_->get(), status_);
   }
-  float GetFitnessScore() override { return 0.f; }  // unimplemented in the reference, returns 0 (:62-67)
+  float GetFitnessScore() override {  // ICPMANUAL: unimplemented in the reference, returns 0 (:62-67); "ICP": pcl's getFitnessScore
+    float s = 0.f;
+    status_ = lsa_icp_get_fitness_score(icp_, &s);
+    report("ICPRegistrationHip::GetFitnessScore", ctx_->get(), status_);
+    return s;
+  }
   int last_status() const { return status_; }
+  lsa_icp_stats stats() const { lsa_icp_stats st{}; lsa_icp_get_stats(icp_, &st); return st; }
 
  private:
   std::shared_ptr<Context> ctx_;
   lsa_icp *icp_ = nullptr;
   int status_ = LSA_OK;
+  int mode_ = LSA_ICP_MODE_MANUAL;
 };
 
 }  // namespace lsa

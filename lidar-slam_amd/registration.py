@@ -29,15 +29,18 @@ class NDTRegistrationHip(RegistrationInterface):
     """NDTRegistrationManual(res, step_size, trans_eps, max_iter, outlier_ratio) or (node) with the YAML keys
     of config/mapping/front_end.yaml:24-29."""
 
-    def __init__(self, ctx, res=1.0, step_size=0.1, trans_eps=0.01, max_iter=30, outlier_ratio=0.55, node=None):
+    def __init__(self, ctx, res=1.0, step_size=0.1, trans_eps=0.01, max_iter=30, outlier_ratio=0.55, node=None, pcl_mode=False):
         if node is not None:
             res, step_size, trans_eps = float(node["res"]), float(node["step_size"]), float(node["trans_eps"])
-            max_iter, outlier_ratio = int(node["max_iter"]), float(node["outlier_ratio"])
+            max_iter = int(node["max_iter"])
+            outlier_ratio = float(node["outlier_ratio"]) if "outlier_ratio" in node else 0.55  # the "NDT" node has none
         self.ctx = ctx
         self.params = (res, step_size, trans_eps, max_iter, outlier_ratio)
         h = C.c_void_p()
         ctx.check(capi.lib().lsa_ndt_create(C.byref(h), ctx.h, res, step_size, trans_eps, max_iter, outlier_ratio))
         self.h = h
+        if pcl_mode:  # stand in for the "NDT" plugin (ndt_registration.cpp, PCL semantics) instead of "NDTMANUAL"
+            ctx.check(capi.lib().lsa_ndt_set_mode(h, capi.NDT_MODE_PCL))
         self.last_stats = None
         self._cb = None
         self._keep = None
@@ -142,14 +145,26 @@ class ICPRegistrationHip(RegistrationInterface):
     """ICPRegistrationManual(max_correspond_dis, max_iter) or (node) with the YAML keys of
     config/mapping/front_end.yaml:37-39 (reference: src/models/registration/icp_registration_manual.cpp:12-67)."""
 
-    def __init__(self, ctx, max_correspond_dis=2.0, max_iter=30, node=None, mode=0):
+    def __init__(self, ctx, max_correspond_dis=2.0, max_iter=30, node=None, mode=0, euclid_eps=0.01, trans_eps=0.01):
+        """mode 0 = ICPRegistrationManual; mode capi.ICP_MODE_PCL = ICPRegistration(euclid_eps, max_correspond_dis,
+        trans_eps, max_iter) (icp_registration.cpp:20-33; YAML node 'ICP', config/mapping/front_end.yaml:31-35)."""
         if node is not None:
             max_correspond_dis, max_iter = float(node["max_correspond_dis"]), int(node["max_iter"])
+            if "euclid_eps" in node:
+                euclid_eps, trans_eps = float(node["euclid_eps"]), float(node["trans_eps"])
         self.ctx = ctx
         h = C.c_void_p()
         ctx.check(capi.lib().lsa_icp_create(C.byref(h), ctx.h, max_correspond_dis, max_iter, mode))
         self.h = h
+        ctx.check(capi.lib().lsa_icp_set_criteria(h, euclid_eps, trans_eps))
         self._keep = None
+        self._src_keep = None
+
+    @property
+    def last_stats(self):
+        st = capi.IcpStats()
+        self.ctx.check(capi.lib().lsa_icp_get_stats(self.h, C.byref(st)))
+        return dict(iterations=st.iterations, converged=st.converged, correspondences=st.correspondences, mse=st.mse)
 
     def SetInputTarget(self, input_target):  # noqa: N802
         if _is_tensor(input_target):
@@ -164,6 +179,7 @@ class ICPRegistrationHip(RegistrationInterface):
         guess = capi.colmajor(predict_pose)
         out = np.zeros(16, dtype=np.float32)
         if _is_tensor(input_source):
+            self._src_keep = input_source
             rc = capi.lib().lsa_icp_scan_match_device(self.h, input_source.data_ptr(), input_source.shape[0], capi.fptr(guess), capi.fptr(out))
         else:
             pts = np.ascontiguousarray(input_source, dtype=np.float32)
@@ -214,7 +230,7 @@ def pack_out32(score, g, H, pairs, npoints):
     return out
 
 
-def gn_solve(eval_fn, res, step_size, trans_eps, max_iter, outlier_ratio, predict_pose):
+def gn_solve(eval_fn, res, step_size, trans_eps, max_iter, outlier_ratio, predict_pose, mode=0):
     """lsa_gn_solve with a Python evaluator eval_fn(T 4x4 f32, p[6], kind) -> out32 (already summed over ranks)."""
     def _tramp(user, Tp, pp, kind, outp):
         try:
@@ -231,7 +247,7 @@ def gn_solve(eval_fn, res, step_size, trans_eps, max_iter, outlier_ratio, predic
     out = np.zeros(16, dtype=np.float32)
     st = capi.NdtStats()
     guess = capi.colmajor(predict_pose)
-    rc = capi.lib().lsa_gn_solve(cb, None, res, step_size, trans_eps, max_iter, outlier_ratio, capi.fptr(guess), capi.fptr(out), C.byref(st))
+    rc = capi.lib().lsa_gn_solve_mode(cb, None, res, step_size, trans_eps, max_iter, outlier_ratio, mode, capi.fptr(guess), capi.fptr(out), C.byref(st))
     if rc != 0:
         raise capi.LsaError(rc, "lsa_gn_solve failed")
     return capi.from_colmajor(out), st.as_dict()

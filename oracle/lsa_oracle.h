@@ -66,6 +66,8 @@ void orc_cov_floor_rebuild(const double evecs[9], const double evals[3], double 
 typedef struct orc_grid orc_grid;
 
 orc_grid *orc_grid_build(const void *pts, size_t n, size_t stride, size_t w_off, float leaf);
+/* mode 0 = orc_grid_build; mode 1 = PCL 1.7 VoxelGridCovariance semantics (the "NDT" plugin's table; UNPINNED) */
+orc_grid *orc_grid_build_mode(const void *pts, size_t n, size_t stride, size_t w_off, float leaf, int mode);
 void orc_grid_free(orc_grid *g);
 /* info[0..2]=vgrid dims, [3..5]=min_b, [6..8]=real_min, [9..11]=real_max, [12]=voxel_num */
 void orc_grid_info(const orc_grid *g, int info[13]);
@@ -100,6 +102,11 @@ typedef struct {
  * (S/models/registration/ndt_registration_manual.cpp:14-22) */
 orc_ndt *orc_ndt_create(float res, float step_size, float trans_eps, int max_iter, float outlier_ratio);
 void orc_ndt_free(orc_ndt *h);
+/* 0 (default): in-tree NDTMANUAL arithmetic. 1: PCL-semantics mode for the "NDT" plugin
+ * (S/models/registration/ndt_registration.cpp:46-66 -> pcl::NormalDistributionsTransform, PCL 1.7, not in the tree):
+ * zero-seeded covariance, accurate eigen-solver, no static weight, More-Thuente phi_t assigned. UNPINNED. Call before
+ * orc_ndt_set_target. */
+void orc_ndt_set_mode(orc_ndt *h, int mode);
 int orc_ndt_set_target(orc_ndt *h, const void *pts, size_t n, size_t stride, size_t w_off);
 const orc_grid *orc_ndt_grid(const orc_ndt *h);
 void orc_ndt_gauss(const orc_ndt *h, double *d1, double *d2);
@@ -131,6 +138,23 @@ int orc_voxel_filter(const void *pts, size_t n, size_t stride, size_t w_off, flo
 /* ---- ICP (S/models/registration/icp_registration_manual.cpp:125-178) --- */
 int orc_icp_manual(const void *tgt, size_t nt, size_t tstride, const void *src, size_t ns, size_t sstride,
                    float max_correspond_dis, int max_iter, const float guess[16], float out_pose[16]);
+
+/* ---- PCL-semantics pieces (pcl_oracle.c; third-party PCL 1.7, absent from the tree: UNPINNED) -------------- */
+/* symmetric 3x3 eigen-decomposition, eigenvalues ascending, eigenvectors in columns (row-major storage):
+ * what Eigen::SelfAdjointEigenSolver<Matrix3d> returns up to rounding and sign. cyclic Jacobi. */
+void orc_eig3_jacobi(const double a[9], double evals[3], double evecs[9]);
+/* pcl::Registration::getFitnessScore(max_range) (registration/impl/registration.hpp): mean over transformed source
+ * points of the SQUARED f32 distance to the nearest TARGET POINT, pairs with d2 > max_range dropped; DBL_MAX if none.
+ * Consumer: S/mapping/loop_closing/loop_closing.cpp:253. */
+double orc_fitness_pcl(const void *tgt, size_t nt, size_t tstride, const void *src, size_t ns, size_t sstride,
+                       const float T[16], double max_range);
+/* pcl::IterativeClosestPoint::computeTransformation with the parameters of S/models/registration/icp_registration.cpp:
+ * 30-33 (nearest-neighbour correspondences gated at max_correspond_dis, TransformationEstimationSVD = f32 Umeyama,
+ * DefaultConvergenceCriteria: max_iter / translation^2 <= trans_eps && cos(angle) >= 1 - trans_eps / relative MSE change
+ * < euclid_eps / absolute MSE change < 1e-12). stats: [iterations, converged, last #correspondences, last mse]. */
+int orc_icp_pcl(const void *tgt, size_t nt, size_t tstride, const void *src, size_t ns, size_t sstride,
+                float euclid_eps, float max_correspond_dis, float trans_eps, int max_iter, const float guess[16],
+                float out_pose[16], double stats[4]);
 
 #ifdef __cplusplus
 }

@@ -292,6 +292,7 @@ void orc_transform_point(const float T[16], const float in[3], float out[3]) {
 /* ======================================================================== */
 
 struct orc_grid {
+  int mode;             /* 0: in-tree NDTMANUAL VoxelGrid; 1: PCL 1.7 VoxelGridCovariance semantics (unpinned) */
   float leaf;
   float max_x, max_y, max_z, min_x, min_y, min_z;
   int max_b[3], min_b[3], vgrid[3], real_max[3], real_min[3];
@@ -352,10 +353,23 @@ void orc_grid_free(orc_grid *g) {
   free(g);
 }
 
+void orc_eig3_jacobi(const double a[9], double evals[3], double evecs[9]); /* pcl_oracle.c */
+
 orc_grid *orc_grid_build(const void *pts, size_t n, size_t stride, size_t w_off, float leaf) {
+  return orc_grid_build_mode(pts, n, stride, w_off, leaf, 0);
+}
+
+/* mode 1 = the deltas of pcl::VoxelGridCovariance<PointXYZI>::applyFilter (PCL 1.7 filters/impl/
+ * voxel_grid_covariance.hpp) against the in-tree grid, as SURVEY.md 8c lists them: sum p p^T starts at 0 (not I),
+ * Eigen::SelfAdjointEigenSolver (restated as cyclic Jacobi: same eigen-pairs to rounding), a leaf whose eigenvalues
+ * are rejected keeps its zero icov_ and STAYS in the centroid kd-tree, +-inf in icov_ drops the leaf, and there is
+ * no static weight (w == 1). Cell geometry and the radius search stay as in mode 0 (for res = 1 PCL's
+ * floor(x * inv_leaf) and the in-tree floor(x / leaf) coincide). */
+orc_grid *orc_grid_build_mode(const void *pts, size_t n, size_t stride, size_t w_off, float leaf, int mode) {
   if (n == 0) return NULL;
   orc_grid *g = (orc_grid *)calloc(1, sizeof(orc_grid));
   g->leaf = leaf;
+  g->mode = mode;
   /* findBoundaries, NS/VoxelGrid.cpp:402-430 */
   g->max_x = g->max_y = g->max_z = -FLT_MAX;
   g->min_x = g->min_y = g->min_z = FLT_MAX;
@@ -402,7 +416,7 @@ orc_grid *orc_grid_build(const void *pts, size_t n, size_t stride, size_t w_off,
     if (g->npts[vid] == 0) {
       double *tc = g->tmp_cov + (size_t)vid * 9;
       memset(tc, 0, 9 * sizeof(double));
-      tc[0] = tc[4] = tc[8] = 1.0; /* seeded with identity (:257) */
+      if (mode == 0) tc[0] = tc[4] = tc[8] = 1.0; /* seeded with identity (:257); PCL starts from zero */
       g->ppv[vid] = 0;
     }
     double *ts = g->tmp_centroid + (size_t)vid * 3;
@@ -413,7 +427,7 @@ orc_grid *orc_grid_build(const void *pts, size_t n, size_t stride, size_t w_off,
     tc[6] += z * x; tc[7] += z * y; tc[8] += z * z;
     g->npts[vid]++;
     g->ppv[vid]++;
-    g->tmp_sval[vid] += pt_w(pts, stride, w_off, pid);
+    g->tmp_sval[vid] += (mode == 0) ? pt_w(pts, stride, w_off, pid) : 1.0f;
   }
 
   /* computeCentroidAndCovariance, :273-323 */
@@ -433,9 +447,13 @@ orc_grid *orc_grid_build(const void *pts, size_t n, size_t stride, size_t w_off,
           double cov[9];
           orc_cov_expr(g->tmp_cov + (size_t)i * 9, ps, pn, cov);
           double evals[3], evecs[9];
-          orc_eig3(cov, evals, evecs);
+          if (mode == 0) orc_eig3(cov, evals, evecs);
+          else orc_eig3_jacobi(cov, evals, evecs);
           if (evals[0] < 0 || evals[1] < 0 || evals[2] <= 0) { /* :303-306 */
-            g->ppv[i] = -1;
+            if (mode == 0) g->ppv[i] = -1;
+            /* PCL: nr_points = -1 but the centroid was already pushed into the kd-tree cloud, and ndt.hpp never
+             * looks at nr_points: the leaf keeps contributing with icov_ == 0 (score only). Restated by leaving
+             * ppv >= 6 and the calloc'ed zero icov. */
             continue;
           }
           double min_ev = evals[2] * 0.01;
@@ -445,6 +463,11 @@ orc_grid *orc_grid_build(const void *pts, size_t n, size_t stride, size_t w_off,
             orc_cov_floor_rebuild(evecs, evals, cov);
           }
           orc_inv3(cov, g->icov + (size_t)i * 9); /* :320 */
+          if (mode == 1) { /* icov_.maxCoeff() == inf || icov_.minCoeff() == -inf -> leaf dropped */
+            const double *ic = g->icov + (size_t)i * 9;
+            for (int k = 0; k < 9; k++)
+              if (isinf(ic[k])) { g->ppv[i] = -1; break; }
+          }
         }
       }
   return g;
@@ -564,6 +587,7 @@ struct orc_ndt {
   double j_ang[8][3];
   double h_ang[15][3];
   int real_iterations;
+  int mode; /* 0 NDTMANUAL (in-tree), 1 PCL-semantics (the "NDT" plugin, unpinned) */
   /* trace */
   double *trace; int trace_cap; int *trace_n;
   /* per-align bookkeeping */
@@ -590,9 +614,11 @@ int orc_ndt_set_target(orc_ndt *h, const void *pts, size_t n, size_t stride, siz
   /* NS/NormalDistributionsTransform.cpp:89-98 */
   if (n == 0) return 0;
   orc_grid_free(h->grid);
-  h->grid = orc_grid_build(pts, n, stride, w_off, h->resolution);
+  h->grid = orc_grid_build_mode(pts, n, stride, w_off, h->resolution, h->mode);
   return h->grid ? 0 : -1;
 }
+
+void orc_ndt_set_mode(orc_ndt *h, int mode) { h->mode = mode; }
 
 const orc_grid *orc_ndt_grid(const orc_ndt *h) { return h->grid; }
 
@@ -890,11 +916,16 @@ static double step_length_mt(orc_ndt *h, const void *src, size_t n, size_t strid
     orc_pose_to_matrix(x_t, final_T);
     *score = orc_ndt_derivatives(h, src, n, stride, final_T, x_t, 0, g, H, NULL);
     trace_row(h, x_t, *score, a_t, 1);
-    phi_t -= *score; /* sic (:726): accumulates instead of assigning */
     {
       double dd = 0;
       for (int i = 0; i < 6; i++) dd += g[i] * step_dir[i];
-      d_phi_t -= dd; /* sic (:727) */
+      if (h->mode == 0) {
+        phi_t -= *score; /* sic (:726): accumulates instead of assigning */
+        d_phi_t -= dd;   /* sic (:727) */
+      } else {           /* PCL ndt.hpp assigns */
+        phi_t = -(*score);
+        d_phi_t = -dd;
+      }
     }
     psi_t = psi_mt(a_t, phi_t, phi_0, d_phi_0, mu);
     d_psi_t = dpsi_mt(d_phi_t, d_phi_0, mu);

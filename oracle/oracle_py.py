@@ -117,6 +117,12 @@ class Oracle:
         L.orc_voxel_filter.restype = i
         L.orc_icp_manual.argtypes = [vp, sz, sz, vp, sz, sz, f, i, PF, PF]
         L.orc_icp_manual.restype = i
+        L.orc_ndt_set_mode.argtypes = [vp, i]
+        L.orc_eig3_jacobi.argtypes = [PD, PD, PD]
+        L.orc_fitness_pcl.argtypes = [vp, sz, sz, vp, sz, sz, PF, d]
+        L.orc_fitness_pcl.restype = d
+        L.orc_icp_pcl.argtypes = [vp, sz, sz, vp, sz, sz, f, f, f, i, PF, PF, PD]
+        L.orc_icp_pcl.restype = i
 
     # ---- building blocks -------------------------------------------------
     def eig3(self, a):
@@ -195,9 +201,12 @@ def _colmajor(T):
 class OracleNDT:
     """Mirror of NDTRegistrationManual (S/models/registration/ndt_registration_manual.cpp)."""
 
-    def __init__(self, res=1.0, step_size=0.1, trans_eps=0.01, max_iter=30, outlier_ratio=0.55, fast=False):
+    def __init__(self, res=1.0, step_size=0.1, trans_eps=0.01, max_iter=30, outlier_ratio=0.55, fast=False, pcl_mode=False):
         self.o = Oracle(fast=fast)
         self.h = self.o.L.orc_ndt_create(res, step_size, trans_eps, max_iter, outlier_ratio)
+        self.pcl_mode = bool(pcl_mode)
+        if pcl_mode:  # the "NDT" plugin (pcl::NormalDistributionsTransform semantics, unpinned)
+            self.o.L.orc_ndt_set_mode(self.h, 1)
         self._src = None
         self._T = np.eye(4, dtype=np.float32)
         self._keep = None
@@ -289,6 +298,8 @@ class OracleNDT:
 
     def fitness(self):
         src8 = self._src
+        if self.pcl_mode:  # pcl::Registration::getFitnessScore: mean squared distance to the nearest target POINT
+            return fitness_pcl(self._keep, src8, self._T)
         return self.o.L.orc_ndt_fitness(self.h, src8.ctypes.data, src8.shape[0], POINT_STRIDE, _fp(_colmajor(self._T)))
 
 
@@ -300,3 +311,25 @@ def icp_manual(tgt8, src8, guess, max_correspond_dis=2.0, max_iter=30):
     o.L.orc_icp_manual(tgt8.ctypes.data, tgt8.shape[0], POINT_STRIDE, src8.ctypes.data, src8.shape[0], POINT_STRIDE,
                        max_correspond_dis, max_iter, _fp(_colmajor(guess)), _fp(out))
     return out.reshape(4, 4).T.copy()
+
+
+def fitness_pcl(tgt8, src8, T, max_range=float("inf")):
+    """pcl::Registration::getFitnessScore (PCL 1.7 registration.hpp), consumer loop_closing.cpp:253."""
+    o = Oracle()
+    tgt8 = np.ascontiguousarray(tgt8, dtype=np.float32)
+    src8 = np.ascontiguousarray(src8, dtype=np.float32)
+    return o.L.orc_fitness_pcl(tgt8.ctypes.data, tgt8.shape[0], POINT_STRIDE, src8.ctypes.data, src8.shape[0], POINT_STRIDE,
+                               _fp(_colmajor(T)), max_range)
+
+
+def icp_pcl(tgt8, src8, guess, euclid_eps=0.01, max_correspond_dis=2.0, trans_eps=0.01, max_iter=30):
+    """The "ICP" plugin (icp_registration.cpp:20-64 -> pcl::IterativeClosestPoint). Returns (T, stats)."""
+    o = Oracle()
+    tgt8 = np.ascontiguousarray(tgt8, dtype=np.float32)
+    src8 = np.ascontiguousarray(src8, dtype=np.float32)
+    out = np.zeros(16, dtype=np.float32)
+    st = np.zeros(4)
+    rc = o.L.orc_icp_pcl(tgt8.ctypes.data, tgt8.shape[0], POINT_STRIDE, src8.ctypes.data, src8.shape[0], POINT_STRIDE,
+                         euclid_eps, max_correspond_dis, trans_eps, max_iter, _fp(_colmajor(guess)), _fp(out), _dp(st))
+    assert rc == 0
+    return out.reshape(4, 4).T.copy(), dict(iterations=int(st[0]), converged=int(st[1]), correspondences=int(st[2]), mse=st[3])

@@ -130,6 +130,44 @@ int main() {
   CHECK(icp->GetFitnessScore() == 0.f, "ICP fitness must be 0 like the reference");
   std::printf("icp: x = %.4f, |dt| %.2e |dR| %.2e vs oracle\n", ipose(0, 3), dt, dr);
 
+  // ---- the PCL-backed plugins: "NDT" (ndt_registration.cpp) and "ICP" (icp_registration.cpp); oracle = pcl_oracle.c (unpinned)
+  {
+    std::shared_ptr<RegistrationInterface> pndt = std::make_shared<NDTRegistrationHip>(ctx, 1.0f, 0.1f, 0.01f, 30);
+    pndt->SetInputTarget(map);
+    Matrix4f ppose = Matrix4f::Identity();
+    CloudData::CLOUD_PTR aligned(new Cloud());
+    pndt->ScanMatch(filtered, guess, aligned, ppose);
+    orc_ndt *po = orc_ndt_create(1.0f, 0.1f, 0.01f, 30, 0.55f);
+    orc_ndt_set_mode(po, 1);
+    orc_ndt_set_target(po, map->points.data(), map->size(), 32, 16);
+    float popose[16];
+    orc_ndt_align(po, filtered->points.data(), filtered->size(), 32, guess.data(), popose, &ost);
+    pose_err(ppose, popose, &dt, &dr);
+    CHECK(dt < 1e-4 && dr < 1e-5, "NDT (PCL mode) pose differs from oracle: dt %g dR %g", dt, dr);
+    CHECK(aligned->size() == filtered->size(), "NDT (PCL mode) must fill result_cloud_ptr like pcl's align()");
+    float pfit = pndt->GetFitnessScore();
+    double pofit = orc_fitness_pcl(map->points.data(), map->size(), 32, filtered->points.data(), filtered->size(), 32, ppose.data(), INFINITY);
+    CHECK(std::fabs(pfit - pofit) < 1e-5 * pofit, "PCL fitness %g vs oracle %g", pfit, pofit);
+    std::printf("ndt(pcl): x = %.4f, |dt| %.2e |dR| %.2e vs oracle, fitness %.6f (oracle %.6f)\n", ppose(0, 3), dt, dr, pfit, pofit);
+    orc_ndt_free(po);
+
+    std::shared_ptr<RegistrationInterface> picp = std::make_shared<ICPRegistrationHip>(ctx, 0.01f, 2.0f, 0.01f, 30);
+    picp->SetInputTarget(map);
+    Matrix4f pip = Matrix4f::Identity();
+    picp->ScanMatch(filtered, guess, aligned, pip);
+    float opip[16];
+    double ist[4];
+    orc_icp_pcl(map->points.data(), map->size(), 32, filtered->points.data(), filtered->size(), 32, 0.01f, 2.0f, 0.01f, 30, guess.data(), opip, ist);
+    pose_err(pip, opip, &dt, &dr);
+    auto st = static_cast<ICPRegistrationHip *>(picp.get())->stats();
+    CHECK(dt < 3e-4 && dr < 3e-5, "ICP (PCL mode) pose differs from oracle: dt %g dR %g", dt, dr);
+    CHECK(st.iterations == (int)ist[0] && st.converged == (int)ist[1], "ICP (PCL mode) iterations %d/%d", st.iterations, (int)ist[0]);
+    float ifit = picp->GetFitnessScore();
+    double oifit = orc_fitness_pcl(map->points.data(), map->size(), 32, filtered->points.data(), filtered->size(), 32, pip.data(), INFINITY);
+    CHECK(std::fabs(ifit - oifit) < 1e-5 * oifit, "ICP PCL fitness %g vs oracle %g", ifit, oifit);
+    std::printf("icp(pcl): %d iterations, x = %.4f, |dt| %.2e |dR| %.2e vs oracle, fitness %.6f\n", st.iterations, pip(0, 3), dt, dr, ifit);
+  }
+
   std::printf(g_fail ? "FAILED (%d)\n" : "ALL OK\n", g_fail);
   return g_fail ? 1 : 0;
 }

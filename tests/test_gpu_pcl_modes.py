@@ -1,0 +1,155 @@
+"""GPU: the PCL-backed plugins of the reference ("NDT" -> pcl::NormalDistributionsTransform, "ICP" ->
+pcl::IterativeClosestPoint, and pcl::Registration::getFitnessScore behind both), against oracle/pcl_oracle.c.
+
+PARITY UNPINNED for this whole file: PCL 1.7 is third-party, absent from the reference tree and from this image, and
+the reference has no tests at these call sites — the oracle restates PCL's published algorithm.  What is
+checked here is that the HIP path and that restatement agree.
+"""
+import numpy as np
+import pytest
+
+from lidar_slam_amd import capi, registration, synth
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    c = capi.Context(0)
+    yield c
+    c.close()
+
+
+@pytest.fixture(scope="module")
+def clouds(oracle, scan_pair):
+    s0, s1, _, T1 = scan_pair
+    tgt = synth.to_xyzi32(s0)
+    # One azimuth column of the synthetic lidar is an exact vertical plane through the sensor: a voxel holding a single
+    # column has a smallest covariance eigenvalue of 0 +- rounding, and PCL's `eigenvalue < 0` leaf rejection becomes a
+    # coin flip of the summation order (no two implementations agree there).  0.1 mm of seeded jitter makes the
+    # decision well-posed; the product treats |lambda| <= 1e-12 lambda_max as zero.
+    tgt[:, :3] += np.random.RandomState(3).normal(0.0, 1e-4, (tgt.shape[0], 3)).astype(np.float32)
+    filt, _ = oracle.voxel_filter(synth.to_xyzi32(s1), 0.5)
+    return tgt, synth.to_xyzi32(filt), T1
+
+
+def rot_angle(A, B):
+    R = A[:3, :3].astype(np.float64).T @ B[:3, :3].astype(np.float64)
+    return float(np.arctan2(np.linalg.norm([R[2, 1] - R[1, 2], R[0, 2] - R[2, 0], R[1, 0] - R[0, 1]]) / 2, (np.trace(R) - 1) / 2))
+
+
+def test_ndt_pcl_mode_table_and_scan_match(ctx, clouds):
+    import oracle_py
+    tgt, src, _ = clouds
+    o = oracle_py.OracleNDT(pcl_mode=True)
+    o.set_input_target(tgt)
+    n = registration.NDTRegistrationHip(ctx, pcl_mode=True)
+    n.SetInputTarget(tgt)
+    occ, valid = o.grid_counts()
+    info = n.grid_info()
+    assert info["occupied"] == occ and info["valid"] == valid
+    # voxel records: same centroids, inverse covariances to rounding, weight 1
+    ints_o, rec_o = o.grid_dump()
+    ints_g, rec_g = n.grid_dump()
+    key_o = {tuple(r[:3]): k for k, r in enumerate(ints_o)}
+    worst = 0.0
+    for k, r in enumerate(ints_g):
+        if r[4] != 1:
+            continue
+        ko = key_o[tuple(r[:3])]
+        ic_o = rec_o[ko, 3:12].reshape(3, 3)
+        ic_g = np.array([[rec_g[k, 3], rec_g[k, 4], rec_g[k, 5]], [rec_g[k, 4], rec_g[k, 6], rec_g[k, 7]], [rec_g[k, 5], rec_g[k, 7], rec_g[k, 8]]])
+        worst = max(worst, np.max(np.abs(ic_o - ic_g)) / max(np.max(np.abs(ic_o)), 1e-300))
+        assert np.allclose(rec_g[k, 0:3], rec_o[ko, 0:3], atol=1e-9)
+        assert rec_g[k, 9] == 1.0 and rec_o[ko, 12] == 1.0
+    assert worst < 1e-7, worst
+    guess = np.eye(4, dtype=np.float32)
+    Tr, st_r = o.scan_match(src, guess)
+    _, T = n.ScanMatch(src, guess)
+    st = n.last_stats
+    assert st["iterations"] == st_r["iterations"] and st["passes"] == st_r["passes"]
+    assert np.linalg.norm(T[:3, 3] - Tr[:3, 3]) <= 1e-4 and rot_angle(T, Tr) <= 1e-5   # SURVEY.md 8d tolerance
+    # the mode really is a different estimator: the manual table (covariance seeded with I) lands elsewhere
+    m = registration.NDTRegistrationHip(ctx)
+    m.SetInputTarget(tgt)
+    _, Tm = m.ScanMatch(src, guess)
+    assert np.linalg.norm(Tm[:3, 3] - T[:3, 3]) > 1e-3
+    # GetFitnessScore in PCL semantics: mean squared nearest-POINT distance (loop_closing.cpp:253 gates it at 0.2)
+    fr = o.fitness()
+    fg = n.GetFitnessScore()
+    assert abs(fg - fr) <= 2e-6 * fr, (fg, fr)
+    m.close()
+    n.close()
+
+
+def test_ndt_pcl_mode_line_search_assignment(ctx, clouds):
+    import oracle_py
+    tgt, src, _ = clouds
+    o = oracle_py.OracleNDT(step_size=1.5, trans_eps=3.0, max_iter=4, pcl_mode=True)
+    o.set_input_target(tgt)
+    Tr, st_r = o.scan_match(src, np.eye(4, dtype=np.float32))
+    assert st_r["ls_iterations"] > 0
+    n = registration.NDTRegistrationHip(ctx, 1.0, 1.5, 3.0, 4, 0.55, pcl_mode=True)
+    n.SetInputTarget(tgt)
+    _, T = n.ScanMatch(src, np.eye(4, dtype=np.float32))
+    st = n.last_stats
+    assert (st["ls_iterations"], st["passes"], st["iterations"]) == (st_r["ls_iterations"], st_r["passes"], st_r["iterations"])
+    assert np.max(np.abs(T - Tr)) <= 1e-5
+    n.close()
+
+
+def test_pcl_fitness_far_and_outside_points(ctx, clouds):
+    """Unbounded nearest-point search: points far outside the target's bounding box still find their true neighbour."""
+    import oracle_py
+    import torch
+    tgt, src, T1 = clouds
+    src2 = src.copy()
+    src2[:50, 0] += 500.0
+    src2[50:60, 2] -= 40.0
+    src2[60:70, 1] += 90.0
+    n = registration.NDTRegistrationHip(ctx, pcl_mode=True)
+    d_t = torch.from_numpy(np.ascontiguousarray(tgt[:, [0, 1, 2, 4]])).cuda()
+    d_s = torch.from_numpy(np.ascontiguousarray(src2[:, [0, 1, 2, 4]])).cuda()
+    n.SetInputTarget(d_t)
+    _, T = n.ScanMatch(d_s, T1.astype(np.float32))
+    fg = n.GetFitnessScore()
+    fr = oracle_py.fitness_pcl(tgt, src2, T)
+    n.close()
+    assert fr > 100.0                      # 50 points 500 m away dominate: (500 m)^2 * 50 / 6.9 k ~ 1.8e3
+    assert abs(fg - fr) <= 2e-6 * fr, (fg, fr)
+
+
+def test_icp_pcl_mode(ctx, clouds):
+    import oracle_py
+    tgt, src, T1 = clouds
+    guess = np.eye(4, dtype=np.float32)
+    for kw in (dict(), dict(euclid_eps=1e-6, trans_eps=1e-8)):
+        Tr, st_r = oracle_py.icp_pcl(tgt, src, guess, max_correspond_dis=2.0, max_iter=30, **kw)
+        icp = registration.ICPRegistrationHip(ctx, 2.0, 30, mode=capi.ICP_MODE_PCL, **kw)
+        icp.SetInputTarget(tgt)
+        _, T = icp.ScanMatch(src, guess)
+        st = icp.last_stats
+        assert st["iterations"] == st_r["iterations"] and st["converged"] == st_r["converged"], (st, st_r)
+        assert st["correspondences"] == st_r["correspondences"]
+        # f32 Umeyama in the restatement (sequential f32 sums) vs f64 sums here: agreement at f32 round-off of the sums
+        assert np.linalg.norm(T[:3, 3] - Tr[:3, 3]) <= 2e-4 and rot_angle(T, Tr) <= 2e-5, (T, Tr)
+        fr = oracle_py.fitness_pcl(tgt, src, T)
+        fg = icp.GetFitnessScore()
+        assert abs(fg - fr) <= 2e-6 * fr
+        icp.close()
+    # defaults stop early (translation^2 <= 0.01 is a 10 cm gate); the tight criteria run longer
+    assert st_r["iterations"] > 5
+
+
+def test_icp_pcl_too_few_correspondences(ctx, clouds):
+    tgt, src, _ = clouds
+    icp = registration.ICPRegistrationHip(ctx, 2.0, 30, mode=capi.ICP_MODE_PCL)
+    icp.SetInputTarget(tgt)
+    far = synth.pose_matrix(900.0, 0, 0, 0, 0, 0).astype(np.float32)
+    _, T = icp.ScanMatch(src, far)      # PCL: "Not enough correspondences found", converged_ = false, pose = guess
+    assert np.array_equal(T, far)
+    st = icp.last_stats
+    assert st["converged"] == 0 and st["iterations"] == 0
+    icp.close()
+    with pytest.raises(RuntimeError):
+        registration.ICPRegistrationHip(ctx, 2.0, 30, mode=1)   # point-to-plane: not in the reference, not built
