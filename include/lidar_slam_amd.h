@@ -100,6 +100,25 @@ int lsa_voxel_filter_apply_device_async(lsa_voxel_filter *f, const float *d_in_x
 int lsa_voxel_filter_wait(lsa_voxel_filter *f, size_t *n_out);
 
 /* ---------------------------------------------------------------------------------------------
+ * BoxFilter — replaces BoxFilter (box_filter.cpp:14-73 -> pcl::CropBox): keeps, in input order, the points with
+ * edge_min <= p <= edge_max on every axis, edge = box_filter_size + origin (:62-68).  Not behind the filter string
+ * switch in the reference; Matching::ResetLocalMap (matching.cpp:117-131) and the viewer call it directly.
+ * ------------------------------------------------------------------------------------------- */
+typedef struct lsa_box_filter lsa_box_filter;
+/* BoxFilter(YAML::Node node): node["box_filter_size"] = [min_x, max_x, min_y, max_y, min_z, max_z] (box_filter.cpp:14-25) */
+int lsa_box_filter_create(lsa_box_filter **out, lsa_context *ctx, const float box_filter_size[6]);
+void lsa_box_filter_destroy(lsa_box_filter *f);
+int lsa_box_filter_set_size(lsa_box_filter *f, const float box_filter_size[6]);   /* SetSize   (:39-54) */
+int lsa_box_filter_set_origin(lsa_box_filter *f, const float origin[3]);          /* SetOrigin (:56-60) */
+int lsa_box_filter_get_edge(lsa_box_filter *f, float edge[6]);                    /* GetEdge   (:70-73) */
+/* Filter(input_cloud_ptr, output_cloud_ptr) (:27-37). Same buffer conventions as lsa_voxel_filter_apply; out_pts may
+ * alias in_pts. */
+int lsa_box_filter_apply(lsa_box_filter *f, const void *in_pts, size_t n, size_t in_stride, size_t in_w_off,
+                         void *out_pts, size_t out_cap, size_t out_stride, size_t out_w_off, size_t *n_out);
+/* device-resident variant: packed float4 {x,y,z,intensity}; d_out must hold n points and must not alias d_in */
+int lsa_box_filter_apply_device(lsa_box_filter *f, const float *d_in_xyzw, size_t n, float *d_out_xyzw, size_t *n_out);
+
+/* ---------------------------------------------------------------------------------------------
  * NDT registration — replaces NDTRegistrationManual (ndt_registration_manual.cpp) and, behind it,
  * lidar_localization::NormalDistributionsTransform / VoxelGrid (ndt_registration_manual/ *.cpp)
  * ------------------------------------------------------------------------------------------- */

@@ -124,6 +124,14 @@ def lib():
     L.lsa_icp_scan_match_device.argtypes = [vp, vp, sz, PF, PF]
     L.lsa_icp_get_fitness_score.argtypes = [vp, PF]
     L.lsa_icp_set_criteria.argtypes = [vp, f, f]
+    L.lsa_box_filter_create.argtypes = [PVP, vp, PF]
+    L.lsa_box_filter_destroy.argtypes = [vp]
+    L.lsa_box_filter_destroy.restype = None
+    L.lsa_box_filter_set_size.argtypes = [vp, PF]
+    L.lsa_box_filter_set_origin.argtypes = [vp, PF]
+    L.lsa_box_filter_get_edge.argtypes = [vp, PF]
+    L.lsa_box_filter_apply.argtypes = [vp, vp, sz, sz, sz, vp, sz, sz, sz, C.POINTER(sz)]
+    L.lsa_box_filter_apply_device.argtypes = [vp, vp, sz, vp, C.POINTER(sz)]
     L.lsa_icp_get_stats.argtypes = [vp, C.POINTER(IcpStats)]
     L.lsa_ndt_set_mode.argtypes = [vp, i]
     L.lsa_gn_solve_mode.argtypes = [PASS_EVAL_FN, vp, f, f, f, i, f, i, PF, PF, C.POINTER(NdtStats)]

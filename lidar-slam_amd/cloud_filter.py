@@ -72,3 +72,62 @@ class VoxelFilterHip(CloudFilterInterface):
             self.close()
         except Exception:
             pass
+
+
+class BoxFilterHip(CloudFilterInterface):
+    """BoxFilter(node) with node['box_filter_size'] = [min_x, max_x, min_y, max_y, min_z, max_z]
+    (reference: src/models/cloud_filter/box_filter.cpp:14-73 -> pcl::CropBox)."""
+
+    def __init__(self, ctx, size=None, node=None):
+        if node is not None:
+            size = [float(v) for v in node["box_filter_size"]]
+        self.ctx = ctx
+        sz = np.ascontiguousarray(size, dtype=np.float32)
+        assert sz.shape == (6,)
+        h = C.c_void_p()
+        ctx.check(capi.lib().lsa_box_filter_create(C.byref(h), ctx.h, capi.fptr(sz)))
+        self.h = h
+
+    def SetSize(self, size):  # noqa: N802
+        sz = np.ascontiguousarray(size, dtype=np.float32)
+        self.ctx.check(capi.lib().lsa_box_filter_set_size(self.h, capi.fptr(sz)))
+
+    def SetOrigin(self, origin):  # noqa: N802
+        o = np.ascontiguousarray(origin, dtype=np.float32)
+        self.ctx.check(capi.lib().lsa_box_filter_set_origin(self.h, capi.fptr(o)))
+
+    def GetEdge(self):  # noqa: N802
+        e = np.zeros(6, dtype=np.float32)
+        self.ctx.check(capi.lib().lsa_box_filter_get_edge(self.h, capi.fptr(e)))
+        return e
+
+    def Filter(self, input_cloud, filtered_cloud=None):  # noqa: N802
+        pts = np.ascontiguousarray(input_cloud, dtype=np.float32)
+        n = pts.shape[0]
+        w_off = capi.W_OFF if pts.shape[1] >= 5 else 12
+        out = np.zeros((max(n, 1), 8), dtype=np.float32)
+        n_out = C.c_size_t(0)
+        self.ctx.check(capi.lib().lsa_box_filter_apply(self.h, pts.ctypes.data, n, pts.strides[0], w_off, out.ctypes.data, n, capi.POINT_STRIDE,
+                                                       capi.W_OFF, C.byref(n_out)))
+        return True, out[: n_out.value]
+
+    def filter_device(self, d_in, d_out=None):
+        import torch
+        assert d_in.is_cuda and d_in.dtype == torch.float32 and d_in.is_contiguous() and d_in.shape[1] == 4
+        n = d_in.shape[0]
+        if d_out is None:
+            d_out = torch.empty((max(n, 1), 4), dtype=torch.float32, device=d_in.device)
+        n_out = C.c_size_t(0)
+        self.ctx.check(capi.lib().lsa_box_filter_apply_device(self.h, d_in.data_ptr(), n, d_out.data_ptr(), C.byref(n_out)))
+        return d_out[: n_out.value]
+
+    def close(self):
+        if self.h and self.ctx.h:
+            capi.lib().lsa_box_filter_destroy(self.h)
+        self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -102,3 +102,23 @@ int orc_voxel_filter(const void *pts, size_t n, size_t stride, size_t w_off, flo
   *n_out = total;
   return 0;
 }
+
+/* ---- BoxFilter (S/models/cloud_filter/box_filter.cpp:27-37,62-68 -> pcl::CropBox<PointXYZI>::applyFilter, PCL 1.7
+ * filters/impl/crop_box.hpp; identity transform, negative_ = false; third-party: UNPINNED) ------------------------- */
+int orc_box_filter(const void *pts, size_t n, size_t stride, size_t w_off, const float size[6], const float origin[3],
+                   float *out_xyzi, size_t cap, size_t *n_out) {
+  float edge[6];
+  for (int i = 0; i < 3; i++) { edge[2 * i] = size[2 * i] + origin[i]; edge[2 * i + 1] = size[2 * i + 1] + origin[i]; }
+  size_t m = 0;
+  for (size_t i = 0; i < n; i++) {
+    const float *p = (const float *)((const char *)pts + i * stride);
+    if (!isfinite(p[0]) || !isfinite(p[1]) || !isfinite(p[2])) continue; /* !input_->is_dense branch */
+    if ((p[0] < edge[0] || p[1] < edge[2] || p[2] < edge[4]) || (p[0] > edge[1] || p[1] > edge[3] || p[2] > edge[5])) continue;
+    if (m >= cap) return -1;
+    out_xyzi[4 * m] = p[0]; out_xyzi[4 * m + 1] = p[1]; out_xyzi[4 * m + 2] = p[2];
+    out_xyzi[4 * m + 3] = *(const float *)((const char *)p + w_off);
+    m++;
+  }
+  *n_out = m;
+  return 0;
+}

@@ -135,6 +135,10 @@ typedef int (*orc_eval_fn)(void *user, const double p[6], const float T[16], int
 int orc_voxel_filter(const void *pts, size_t n, size_t stride, size_t w_off, float lx, float ly, float lz,
                      float *out_xyzi, size_t cap, size_t *n_out);
 
+/* BoxFilter::Filter (S/models/cloud_filter/box_filter.cpp:27-37 -> pcl::CropBox, UNPINNED): input order kept */
+int orc_box_filter(const void *pts, size_t n, size_t stride, size_t w_off, const float size[6], const float origin[3],
+                   float *out_xyzi, size_t cap, size_t *n_out);
+
 /* ---- ICP (S/models/registration/icp_registration_manual.cpp:125-178) --- */
 int orc_icp_manual(const void *tgt, size_t nt, size_t tstride, const void *src, size_t ns, size_t sstride,
                    float max_correspond_dis, int max_iter, const float guess[16], float out_pose[16]);

@@ -118,6 +118,8 @@ class Oracle:
         L.orc_icp_manual.argtypes = [vp, sz, sz, vp, sz, sz, f, i, PF, PF]
         L.orc_icp_manual.restype = i
         L.orc_ndt_set_mode.argtypes = [vp, i]
+        L.orc_box_filter.argtypes = [vp, sz, sz, sz, PF, PF, PF, sz, C.POINTER(sz)]
+        L.orc_box_filter.restype = i
         L.orc_eig3_jacobi.argtypes = [PD, PD, PD]
         L.orc_fitness_pcl.argtypes = [vp, sz, sz, vp, sz, sz, PF, d]
         L.orc_fitness_pcl.restype = d
@@ -192,6 +194,20 @@ class Oracle:
         n_out = C.c_size_t(0)
         rc = self.L.orc_voxel_filter(pts8.ctypes.data, n, POINT_STRIDE, W_OFF, lx, ly, lz, _fp(out), n, C.byref(n_out))
         return out[: n_out.value].copy(), rc
+
+
+def box_filter(pts8, size, origin=(0.0, 0.0, 0.0)):
+    """BoxFilter::Filter (box_filter.cpp:27-37). Returns (m, 4) x,y,z,intensity in input order."""
+    o = Oracle()
+    pts8 = np.ascontiguousarray(pts8, dtype=np.float32)
+    n = pts8.shape[0]
+    out = np.zeros((max(n, 1), 4), dtype=np.float32)
+    n_out = C.c_size_t(0)
+    sz_ = np.ascontiguousarray(size, dtype=np.float32)
+    og = np.ascontiguousarray(origin, dtype=np.float32)
+    rc = o.L.orc_box_filter(pts8.ctypes.data, n, POINT_STRIDE, W_OFF, _fp(sz_), _fp(og), _fp(out), n, C.byref(n_out))
+    assert rc == 0
+    return out[: n_out.value].copy()
 
 
 def _colmajor(T):
