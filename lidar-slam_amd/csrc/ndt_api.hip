@@ -27,7 +27,7 @@ int run_pass(lsa_ndt *h, const float T[16], const double p[6], int kind, double 
   PassParams P;
   ndt_make_pass_params(h, T, p, &P);
   int rc;
-  if (ndt_pass_host_reduce(h)) {
+  if (ndt_pass_host_reduce(h, kind)) {
     unsigned g = 0;
     if ((rc = ndt_enqueue_pass_host(h, P, kind, &g))) return rc;
     LSA_HIP(ctx, hipStreamSynchronize(ctx->stream));

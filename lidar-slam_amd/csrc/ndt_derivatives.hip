@@ -21,13 +21,21 @@
 namespace {
 
 constexpr int kBlockD = 256;
+// Waves per SIMD requested from the register allocator = 256-lane workgroups resident per CU.  The pass is latency bound
+// (three dependent L2 round trips per tile), so occupancy is throughput: 2 -> 3 waves bought ~20 %.  The full pass
+// (28 f64 accumulators = 56 VGPRs live throughout) fits 3 waves (<= 168 VGPRs) without spilling, the gradient-only pass
+// of the line search fits 4 (<= 128).
 #ifndef LSA_PASS_WAVES
-#define LSA_PASS_WAVES 2  // min waves per SIMD requested from the register allocator (2 x 256-thread workgroups per CU)
+#define LSA_PASS_WAVES 3
 #endif
+#ifndef LSA_PASS_WAVES_GRAD
+#define LSA_PASS_WAVES_GRAD 4
+#endif
+constexpr int pass_waves(int kind) { return kind == 1 ? LSA_PASS_WAVES_GRAD : LSA_PASS_WAVES; }
 
 template <int KIND>
 __device__ __forceinline__ void pair_update(const PassParams &P, const double *__restrict__ R, float tx, float ty, float tz,
-                                            const double pg[8], const double ph[15], double acc[28]) {
+                                            const double pg[8], const double *ph /* LDS, read at the point of use */, double acc[28]) {
   // R: centroid(3), C = icov (xx,xy,xz,yy,yz,zz), w.  The radius test (VoxelGrid.cpp:470-472) was done by the probe phase.
   double d0 = (double)tx - R[0], d1 = (double)ty - R[1], d2 = (double)tz - R[2];  // x_trans - centroid (:434)
   double C00 = R[3], C01 = R[4], C02 = R[5], C11 = R[6], C12 = R[7], C22 = R[8];
@@ -49,106 +57,157 @@ __device__ __forceinline__ void pair_update(const PassParams &P, const double *_
     acc[4] += f * uJ3; acc[5] += f * uJ4; acc[6] += f * uJ5;
   }
   if (KIND != 1) {
-    double nd2 = -P.d2;
-    // C * J_j for j = 3..5
-    double a3x = C01 * pg[0] + C02 * pg[1], a3y = C11 * pg[0] + C12 * pg[1], a3z = C12 * pg[0] + C22 * pg[1];
-    double a4x = C00 * pg[2] + C01 * pg[3] + C02 * pg[4], a4y = C01 * pg[2] + C11 * pg[3] + C12 * pg[4], a4z = C02 * pg[2] + C12 * pg[3] + C22 * pg[4];
-    double a5x = C00 * pg[5] + C01 * pg[6] + C02 * pg[7], a5y = C01 * pg[5] + C11 * pg[6] + C12 * pg[7], a5z = C02 * pg[5] + C12 * pg[6] + C22 * pg[7];
-    // rows 0..2 (translation)
+    const double nd2 = -P.d2;
+    // H_ij += f * (-d2 (u.J_i)(u.J_j) + u.H_E(i,j) + J_j^T C J_i)   (:512-514).  Written column group by column group so
+    // that each C J_j (3 values) dies as soon as its column is done: the pair math is register-bound (28 f64
+    // accumulators stay live), and every register saved here buys occupancy.
+    // translation x translation: J_j^T C J_i = C_ij
     acc[7] += f * (nd2 * u0 * u0 + C00);
     acc[8] += f * (nd2 * u0 * u1 + C01);
     acc[9] += f * (nd2 * u0 * u2 + C02);
-    acc[10] += f * (nd2 * u0 * uJ3 + a3x);
-    acc[11] += f * (nd2 * u0 * uJ4 + a4x);
-    acc[12] += f * (nd2 * u0 * uJ5 + a5x);
     acc[13] += f * (nd2 * u1 * u1 + C11);
     acc[14] += f * (nd2 * u1 * u2 + C12);
-    acc[15] += f * (nd2 * u1 * uJ3 + a3y);
-    acc[16] += f * (nd2 * u1 * uJ4 + a4y);
-    acc[17] += f * (nd2 * u1 * uJ5 + a5y);
     acc[18] += f * (nd2 * u2 * u2 + C22);
-    acc[19] += f * (nd2 * u2 * uJ3 + a3z);
-    acc[20] += f * (nd2 * u2 * uJ4 + a4z);
-    acc[21] += f * (nd2 * u2 * uJ5 + a5z);
-    // rows 3..5 (rotation): u . H_E block + J_j . (C J_i)   (:465-480, :512-514)
-    // blocks: (3,3)=a=(0,ph0,ph1) (3,4)=b=(0,ph2,ph3) (3,5)=c=(0,ph4,ph5) (4,4)=d=(ph6..8) (4,5)=e=(ph9..11) (5,5)=f=(ph12..14)
-    acc[22] += f * (nd2 * uJ3 * uJ3 + (u1 * ph[0] + u2 * ph[1]) + (pg[0] * a3y + pg[1] * a3z));
-    acc[23] += f * (nd2 * uJ3 * uJ4 + (u1 * ph[2] + u2 * ph[3]) + (pg[2] * a3x + pg[3] * a3y + pg[4] * a3z));
-    acc[24] += f * (nd2 * uJ3 * uJ5 + (u1 * ph[4] + u2 * ph[5]) + (pg[5] * a3x + pg[6] * a3y + pg[7] * a3z));
-    acc[25] += f * (nd2 * uJ4 * uJ4 + (u0 * ph[6] + u1 * ph[7] + u2 * ph[8]) + (pg[2] * a4x + pg[3] * a4y + pg[4] * a4z));
-    acc[26] += f * (nd2 * uJ4 * uJ5 + (u0 * ph[9] + u1 * ph[10] + u2 * ph[11]) + (pg[5] * a4x + pg[6] * a4y + pg[7] * a4z));
-    acc[27] += f * (nd2 * uJ5 * uJ5 + (u0 * ph[12] + u1 * ph[13] + u2 * ph[14]) + (pg[5] * a5x + pg[6] * a5y + pg[7] * a5z));
+    // H_E blocks (:465-480): (3,3)=(0,ph0,ph1) (3,4)=(0,ph2,ph3) (3,5)=(0,ph4,ph5) (4,4)=(ph6..8) (4,5)=(ph9..11) (5,5)=(ph12..14)
+    {  // column 3: a = C J_3, J_3 = (0, pg0, pg1)
+      double ax = C01 * pg[0] + C02 * pg[1], ay = C11 * pg[0] + C12 * pg[1], az = C12 * pg[0] + C22 * pg[1];
+      acc[10] += f * (nd2 * u0 * uJ3 + ax);
+      acc[15] += f * (nd2 * u1 * uJ3 + ay);
+      acc[19] += f * (nd2 * u2 * uJ3 + az);
+      acc[22] += f * (nd2 * uJ3 * uJ3 + (u1 * ph[0] + u2 * ph[1]) + (pg[0] * ay + pg[1] * az));
+      acc[23] += f * (nd2 * uJ3 * uJ4 + (u1 * ph[2] + u2 * ph[3]) + (pg[2] * ax + pg[3] * ay + pg[4] * az));
+      acc[24] += f * (nd2 * uJ3 * uJ5 + (u1 * ph[4] + u2 * ph[5]) + (pg[5] * ax + pg[6] * ay + pg[7] * az));
+    }
+    {  // column 4: a = C J_4, J_4 = (pg2, pg3, pg4)
+      double ax = C00 * pg[2] + C01 * pg[3] + C02 * pg[4], ay = C01 * pg[2] + C11 * pg[3] + C12 * pg[4], az = C02 * pg[2] + C12 * pg[3] + C22 * pg[4];
+      acc[11] += f * (nd2 * u0 * uJ4 + ax);
+      acc[16] += f * (nd2 * u1 * uJ4 + ay);
+      acc[20] += f * (nd2 * u2 * uJ4 + az);
+      acc[25] += f * (nd2 * uJ4 * uJ4 + (u0 * ph[6] + u1 * ph[7] + u2 * ph[8]) + (pg[2] * ax + pg[3] * ay + pg[4] * az));
+      acc[26] += f * (nd2 * uJ4 * uJ5 + (u0 * ph[9] + u1 * ph[10] + u2 * ph[11]) + (pg[5] * ax + pg[6] * ay + pg[7] * az));
+    }
+    {  // column 5: a = C J_5, J_5 = (pg5, pg6, pg7)
+      double ax = C00 * pg[5] + C01 * pg[6] + C02 * pg[7], ay = C01 * pg[5] + C11 * pg[6] + C12 * pg[7], az = C02 * pg[5] + C12 * pg[6] + C22 * pg[7];
+      acc[12] += f * (nd2 * u0 * uJ5 + ax);
+      acc[17] += f * (nd2 * u1 * uJ5 + ay);
+      acc[21] += f * (nd2 * u2 * uJ5 + az);
+      acc[27] += f * (nd2 * uJ5 * uJ5 + (u0 * ph[12] + u1 * ph[13] + u2 * ph[14]) + (pg[5] * ax + pg[6] * ay + pg[7] * az));
+    }
   }
 }
 
-// One workgroup (256 lanes = 4 waves) walks tiles of 64 source points in three phases per tile:
-//   0. every wave loads the tile's 64 points; wave 0 transforms them (f32, PCL order) and publishes the clipped 3x3x3
-//      cell box, and each wave computes its quarter of the 23 point-derivative dot products (8 Jacobian + 15 Hessian
-//      terms, computePointDerivatives) into LDS -- once per POINT, not once per pair as the reference does;
-//   A. all 256 lanes PROBE: 64 points x 27 cells = 1728 probes, 7 per lane, each = one 16-B {occ,valid,prefix} word from
-//      L2, a popcount rank, the 24-B centroid and the radius test (on the squared distance against a host-computed
-//      exact threshold: no f64 sqrt per probe).  Hits are compacted into an LDS pair queue at offsets from a block-wide
-//      exclusive scan (not atomics), so the queue order -- and with it every f64 sum -- is reproducible run to run;
-//   B. all lanes drain the queue: one (point, voxel) pair per lane per step, dense f64 pair math into 28 registers.
-// Only Kbar ~ 2.5-5 of the 27 probed cells hold a usable voxel; separating the cheap probe from the expensive pair
-// math keeps the f64 pipes full instead of leaving ~85 % of the lanes idle in a per-point loop, and spreads a
-// KITTI-sized pass (7-25 k points) over >= 118 workgroups.  The 69 angle-derivative constants are touched only in
-// phase 0 (a quarter per wave), which keeps them out of the pair loop's scalar registers.
-constexpr int kTilePts = 64;
-constexpr int kProbesPerPoint = 27;
-constexpr int kProbesPerLane = (kTilePts * kProbesPerPoint + kBlockD - 1) / kBlockD;  // 7
-constexpr int kQueueCap = kTilePts * kProbesPerPoint;                                 // 1728
+// Each WAVE of a 256-lane workgroup walks its own tiles of 16 source points, in four phases per tile, without ever
+// waiting for the other three waves (the only workgroup barrier is the one before the final reduction):
+//   0. 4 lanes per point: one transforms it (f32, PCL order) and publishes the clipped 3x3x3 cell box, and each of the
+//      four computes its share of the 23 point-derivative dot products (8 Jacobian + 15 Hessian terms,
+//      computePointDerivatives) into LDS -- once per POINT, not once per pair as the reference does;
+//   A1. ROW probes: the <= 3 cells of one (y, z) row of a box are consecutive linear indices, i.e. adjacent bits of one
+//      (rarely two) 16-B {occ, valid, prefix} words.  16 points x 9 rows = 144 row probes (<= 3 per lane) read the word
+//      from L2, mask the valid bits and emit one CANDIDATE {point, record rank} per valid cell -- integer work only;
+//   A2. candidates (valid voxels inside the box, ~10 per point) load the 24-B centroid and take the radius test on the
+//      squared distance against a host-computed exact threshold (no f64 sqrt); survivors (Kbar ~ 2.5-5 per point) become
+//      PAIRS.  Both compactions place their output at offsets from wave-wide exclusive scans (no atomics), so the queue
+//      order -- and with it every f64 sum -- is reproducible run to run;
+//   B. the wave drains the pair queue: one (point, voxel) pair per lane per step, dense f64 pair math into 28 registers.
+// Separating the cheap integer probe from the centroid test and that from the expensive pair math keeps the f64 pipes on
+// useful work (the reference computes a distance for all 27 cells of every point).  All hand-offs inside a tile go
+// through the wave's private LDS slice and need only wave-level ordering (LDS is in order per wave), so the 8 waves
+// resident on a CU drift apart and hide each other's L2 latency; a workgroup-wide formulation of the same phases (6
+// s_barrier per 64-point tile) left the VALUs idle half of the time.  A KITTI-sized pass (7-25 k points) spreads over
+// >= 470 waves.  The 69 angle-derivative constants are touched only in phase 0, which keeps them out of the pair loop's
+// scalar registers.
+constexpr int kWaves = kBlockD / 64;
+constexpr int kTilePts = 16;                                             // points per wave tile, 4 lanes per point in phase 0
+constexpr int kRowsPerPoint = 9;
+constexpr int kRowProbes = kTilePts * kRowsPerPoint;                     // 144
+constexpr int kRowRounds = (kRowProbes + 63) / 64;                       // 3
+constexpr int kQueueCap = kTilePts * 27;                                 // 432 candidates / pairs at most
+constexpr int kCandPerLane = 4;                                          // A2 candidates per lane per round
 constexpr int kPointTerms = 23;   // pg[8] + ph[15]
 constexpr int kTermStride = 24;
 constexpr int kRedStride = 29;    // 28 accumulators per lane, padded: conflict-free LDS transpose
+constexpr int kRedLanes = 128;    // the transpose runs in two rounds of 128 lanes to halve its LDS footprint
 
 struct TilePoint {
-  float sx, sy, sz;  // source point (untransformed)
   float tx, ty, tz;  // transformed point
   int cell0;         // linear index of the box's low corner
   int nxyz;          // box extent packed nx | ny << 8 | nz << 16 (0 = point contributes nothing)
 };
 
+// per-wave LDS slice
 constexpr int kLdsTp = 0;
-constexpr int kLdsTerms = kLdsTp + kTilePts * (int)sizeof(TilePoint);                    // 2048
-constexpr int kLdsQueue = kLdsTerms + kTilePts * kTermStride * 8;                        // + 12288
-constexpr int kLdsWaveTot = kLdsQueue + kQueueCap * 4;                                   // + 6912
-constexpr int kLdsTileEnd = kLdsWaveTot + 16;
-constexpr int kLdsRed = kBlockD * kRedStride * 8;                                        // 59392 (aliases the tile area after the loop)
-constexpr int kLdsBytes = (kLdsRed > kLdsTileEnd ? kLdsRed : kLdsTileEnd) + 8 * 32 * 8;  // + second-stage [8][32]
+constexpr int kLdsTerms = 512;                                                           // 16 * 20 B, rounded up
+constexpr int kLdsCand = kLdsTerms + kTilePts * kTermStride * 8;                         // + 3072
+constexpr int kLdsQueue = kLdsCand + kQueueCap * 4;                                      // + 1728
+constexpr int kLdsSlice = ((kLdsQueue + kQueueCap * 4 + 255) / 256) * 256;               // 7168
+constexpr int kLdsTiles = kLdsSlice * kWaves;                                            // 28672
+constexpr int kLdsRed = kRedLanes * kRedStride * 8;                                      // 29696 (aliases the slices after the loops)
+constexpr int kLdsRed2 = (kLdsRed > kLdsTiles ? kLdsRed : kLdsTiles);
+constexpr int kLdsConst = kLdsRed2 + (8 * 32 + 2 * kWaves) * 8;                          // + second-stage [8][32] + per-wave counters
+constexpr int kLdsBytes = kLdsConst + 72 * 8;                                            // + the 69 angle-derivative constants
+static_assert(kTilePts * (int)sizeof(TilePoint) <= kLdsTerms, "tile points overflow their LDS slot");
+
+// wave-level ordering point for LDS hand-offs between lanes of ONE wave: LDS operations of a wave execute in order, so it
+// is enough to stop the compiler from moving accesses across it (this is what a workgroup barrier of a single-wave
+// workgroup is lowered to)
+__device__ __forceinline__ void wave_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// exclusive scan of one count per lane over the wave; returns this lane's offset, *total = wave sum
+__device__ __forceinline__ unsigned wave_excl_scan(unsigned cnt, int lane, unsigned *total) {
+  unsigned incl = cnt;
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    unsigned v = __shfl_up(incl, off, 64);
+    if (lane >= off) incl += v;
+  }
+  *total = __shfl(incl, 63, 64);
+  return incl - cnt;
+}
 
 template <int KIND>
-__global__ __launch_bounds__(kBlockD, LSA_PASS_WAVES) void k_ndt_pass(const float4 *__restrict__ src, size_t n, PassParams P, const uint4 *__restrict__ words,
+__global__ __launch_bounds__(kBlockD, pass_waves(KIND)) void k_ndt_pass(const float4 *__restrict__ src, size_t n, PassParams P, const uint4 *__restrict__ words,
                                                       const double *__restrict__ rec, double *__restrict__ partials) {
   __shared__ __align__(16) unsigned char lds[kLdsBytes];
-  TilePoint *tp = reinterpret_cast<TilePoint *>(lds + kLdsTp);
-  double *terms = reinterpret_cast<double *>(lds + kLdsTerms);
-  unsigned *queue = reinterpret_cast<unsigned *>(lds + kLdsQueue);
-  unsigned *wave_tot = reinterpret_cast<unsigned *>(lds + kLdsWaveTot);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  unsigned char *slice = lds + wave * kLdsSlice;
+  TilePoint *tp = reinterpret_cast<TilePoint *>(slice + kLdsTp);
+  double *terms = reinterpret_cast<double *>(slice + kLdsTerms);
+  unsigned *cand = reinterpret_cast<unsigned *>(slice + kLdsCand);
+  unsigned *queue = reinterpret_cast<unsigned *>(slice + kLdsQueue);
   double acc[28];
 #pragma unroll
   for (int k = 0; k < 28; k++) acc[k] = 0.0;
-  unsigned long long pairs = 0;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  unsigned long long pairs = 0, npts = 0;  // wave totals (meaningful in lane 0)
+  const int ppl = lane & (kTilePts - 1), part4 = lane / kTilePts;  // phase 0: 4 lanes per point
   const int dimx = P.dim[0], dimxy = P.dim[0] * P.dim[1];
   const size_t ntiles = (n + kTilePts - 1) / kTilePts;
-  const double *jh = &P.ja[0][0];  // ja[8][3] followed by ha[15][3]: 23 constant 3-vectors
-  // software prefetch of the next tile's points (every wave holds its own copy of the 64 points)
+  const size_t tile0 = (size_t)blockIdx.x * kWaves + wave, tstride = (size_t)gridDim.x * kWaves;
+  // ja[8][3] followed by ha[15][3]: 23 constant 3-vectors.  Phase 0 indexes them per LANE (each of the 4 lanes of a
+  // point owns 6 of the 23 terms), which kernel arguments cannot do without turning into per-lane global loads: stage
+  // them in LDS once per workgroup.
+  double *jh = reinterpret_cast<double *>(lds + kLdsConst);
+  if (threadIdx.x < 69) jh[threadIdx.x] = (&P.ja[0][0])[threadIdx.x];
+  __syncthreads();
+  // software prefetch of the next tile's points (each of the 4 lanes of a point holds its own copy)
   float4 s_next = make_float4(0.f, 0.f, 0.f, 0.f);
   {
-    size_t i0 = (size_t)blockIdx.x * kTilePts + lane;
+    size_t i0 = tile0 * kTilePts + ppl;
     if (i0 < n) s_next = src[i0];
   }
-  for (size_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+  for (size_t tile = tile0; tile < ntiles; tile += tstride) {
     // ---- phase 0
     {
-      size_t i = tile * kTilePts + lane;
+      size_t i = tile * kTilePts + ppl;
       float4 s = s_next;
-      size_t inext = (tile + gridDim.x) * kTilePts + lane;
+      size_t inext = (tile + tstride) * kTilePts + ppl;
       if (inext < n) s_next = src[inext];
-      if (wave == 0) {
+      if (part4 == 0) {
         TilePoint t;
-        t.nxyz = 0; t.cell0 = 0; t.sx = s.x; t.sy = s.y; t.sz = s.z; t.tx = t.ty = t.tz = 0.f;
+        t.nxyz = 0; t.cell0 = 0; t.tx = t.ty = t.tz = 0.f;
         if (i < n) {
           // pcl::transformPointCloud: x' = m00*x + m01*y + m02*z + m03, f32, left to right, no FMA
           float tx = lsa_fadd(lsa_fadd(lsa_fadd(lsa_fmul(P.T[0], s.x), lsa_fmul(P.T[1], s.y)), lsa_fmul(P.T[2], s.z)), P.T[3]);
@@ -171,124 +230,159 @@ __global__ __launch_bounds__(kBlockD, LSA_PASS_WAVES) void k_ndt_pass(const floa
             }
           }
         }
-        tp[lane] = t;
+        tp[ppl] = t;
       }
       // computePointDerivatives (:448-482): dot products of the source point with the angle-derivative vectors;
-      // wave w owns terms 6w .. 6w+5 (KIND 1 needs only the 8 Jacobian terms)
+      // lane group g of a point owns terms 6g .. 6g+5 (KIND 1 needs only the 8 Jacobian terms)
       double x = s.x, y = s.y, z = s.z;
-      const int k0 = wave * 6, k1 = min(k0 + 6, (KIND == 1) ? 8 : kPointTerms);
-      for (int k = k0; k < k1; k++) terms[lane * kTermStride + k] = x * jh[k * 3] + y * jh[k * 3 + 1] + z * jh[k * 3 + 2];
+      const int k0 = part4 * 6, k1 = min(k0 + 6, (KIND == 1) ? 8 : kPointTerms);
+      for (int k = k0; k < k1; k++) terms[ppl * kTermStride + k] = x * jh[k * 3] + y * jh[k * 3 + 1] + z * jh[k * 3 + 2];
+      if (lane == 0) npts += min((size_t)kTilePts, n - tile * kTilePts);
     }
-    __syncthreads();
-    // ---- phase A: probe
-    // The 7 probes of a lane are independent; they are staged (all word loads, then all centroid loads) so the L2 round
-    // trips overlap instead of forming 14 dependent hops.  Out-of-box probes read word 0 / record 0 and are masked out.
-    unsigned hit_rank[kProbesPerLane];
-    unsigned hit_mask = 0;
-    int p_pl[kProbesPerLane], p_cell[kProbesPerLane];
-    uint4 p_w[kProbesPerLane];
+    wave_sync();
+    // ---- phase A1: row probes -> candidates (valid voxels inside the box)
+    unsigned c_ent[kRowRounds * 3];
+    unsigned c_mask = 0;
+    // The probe -> (point, row) mapping depends on the lane only, so the compiler would hoist ~30 registers of index
+    // arithmetic out of the tile loop and keep them live through the pair math, which is register-bound; an opaque copy
+    // of the lane id makes it recompute them per tile (a few dozen integer instructions) instead.
+    int lane_v = lane;
+    asm volatile("" : "+v"(lane_v));
+    {
+      int r_cell[kRowRounds], r_nx[kRowRounds], r_pl[kRowRounds];
+      uint4 w0[kRowRounds], w1[kRowRounds];
 #pragma unroll
-    for (int j = 0; j < kProbesPerLane; j++) {
-      int q = threadIdx.x + j * kBlockD;
-      int pl = (q < kQueueCap) ? q / kProbesPerPoint : 0;
-      int o = q - pl * kProbesPerPoint;
-      int dz = o / 9, dy = (o - dz * 9) / 3, dx = o - dz * 9 - dy * 3;
-      int nxyz = tp[pl].nxyz;
-      bool in_box = q < kQueueCap && dx < (nxyz & 0xff) && dy < ((nxyz >> 8) & 0xff) && dz < (nxyz >> 16);
-      p_pl[j] = pl;
-      p_cell[j] = in_box ? tp[pl].cell0 + dx + dy * dimx + dz * dimxy : -1;
+      for (int j = 0; j < kRowRounds; j++) {
+        int q = lane_v + j * 64;
+        int pl = (q < kRowProbes) ? q / kRowsPerPoint : 0;
+        int o = q - pl * kRowsPerPoint;
+        int dz = o / 3, dy = o - dz * 3;
+        int nxyz = tp[pl].nxyz;
+        bool in_box = q < kRowProbes && dy < ((nxyz >> 8) & 0xff) && dz < (nxyz >> 16);
+        r_pl[j] = pl;
+        r_nx[j] = in_box ? (nxyz & 0xff) : 0;
+        r_cell[j] = in_box ? tp[pl].cell0 + dy * dimx + dz * dimxy : 0;
+      }
+      // all word loads first so the L2 round trips overlap; the second word is needed only when the row straddles a
+      // 32-cell boundary (out-of-box probes read word 0 and are masked by nx == 0)
+#pragma unroll
+      for (int j = 0; j < kRowRounds; j++) {
+        int wi = r_cell[j] >> 5;
+        w0[j] = words[wi];
+        w1[j] = ((r_cell[j] & 31) + r_nx[j] > 32) ? words[wi + 1] : make_uint4(0u, 0u, 0u, 0u);
+      }
+#pragma unroll
+      for (int j = 0; j < kRowRounds; j++) {
+        int sh = r_cell[j] & 31;
+#pragma unroll
+        for (int i = 0; i < 3; i++) {
+          int b = sh + i;
+          bool second = b >= 32;
+          uint32_t occ = second ? w1[j].x : w0[j].x, val = second ? w1[j].y : w0[j].y, pre = second ? w1[j].z : w0[j].z;
+          uint32_t bit = 1u << (b & 31);
+          // points_per_voxel >= min_points_per_voxel_ and accepted eigenvalues (VoxelGrid.cpp:465)
+          bool ok = i < r_nx[j] && (val & bit);
+          unsigned rank = pre + __popc(occ & (bit - 1u));
+          c_ent[j * 3 + i] = ((unsigned)r_pl[j]) | (rank << 6);
+          if (ok) c_mask |= 1u << (j * 3 + i);
+        }
+      }
     }
+    unsigned total_c;
+    {
+      unsigned pos = wave_excl_scan(__popc(c_mask), lane, &total_c);
 #pragma unroll
-    for (int j = 0; j < kProbesPerLane; j++) p_w[j] = words[(p_cell[j] < 0 ? 0 : p_cell[j]) >> 5];
-    double p_c[kProbesPerLane][3];
-#pragma unroll
-    for (int j = 0; j < kProbesPerLane; j++) {
-      uint32_t bit = 1u << (p_cell[j] & 31);
-      // points_per_voxel >= min_points_per_voxel_ and accepted eigenvalues (VoxelGrid.cpp:465)
-      bool ok = p_cell[j] >= 0 && (p_w[j].y & bit);
-      unsigned rank = ok ? p_w[j].z + __popc(p_w[j].x & (bit - 1u)) : 0u;
-      hit_rank[j] = ((unsigned)p_pl[j]) | (rank << 6);
-      if (ok) hit_mask |= 1u << j;
-      const double *R = rec + (size_t)rank * kRecDoubles;
-      p_c[j][0] = R[0]; p_c[j][1] = R[1]; p_c[j][2] = R[2];
+      for (int k = 0; k < kRowRounds * 3; k++)
+        if (c_mask & (1u << k)) cand[pos++] = c_ent[k];
     }
+    wave_sync();
+    // ---- phase A2: candidates -> pairs (radius test on the centroid distance).  A lane owns a contiguous chunk of the
+    // candidate list, so one scan per round keeps the order; a round covers 64 x 4 candidates (a tile has ~160, the worst
+    // case 432 takes two rounds)
+    unsigned total = 0;
+    for (unsigned cbase = 0; cbase < total_c; cbase += 64 * kCandPerLane) {
+      const unsigned left = min(total_c - cbase, (unsigned)(64 * kCandPerLane));
+      const unsigned per = (left + 63) / 64;  // <= kCandPerLane
+      const unsigned c0 = cbase + lane * per, c_end = cbase + left;
+      unsigned p_ent[kCandPerLane];
+      unsigned p_mask = 0;
+      double pc[kCandPerLane][3];
 #pragma unroll
-    for (int j = 0; j < kProbesPerLane; j++) {
-      double cx = p_c[j][0] - (double)tp[p_pl[j]].tx, cy = p_c[j][1] - (double)tp[p_pl[j]].ty, cz = p_c[j][2] - (double)tp[p_pl[j]].tz;
-      double d2 = cx * cx + cy * cy + cz * cz;
-      if (!(d2 <= P.r2max)) hit_mask &= ~(1u << j);  // sqrt(d2) < radius (VoxelGrid.cpp:470-472)
+      for (int k = 0; k < kCandPerLane; k++) {
+        unsigned ci = c0 + k;
+        bool live = (unsigned)k < per && ci < c_end;
+        unsigned e = live ? cand[ci] : 0u;
+        p_ent[k] = e;
+        if (live) p_mask |= 1u << k;
+        const double *R = rec + (size_t)(e >> 6) * kRecDoubles;
+        if (live) { pc[k][0] = R[0]; pc[k][1] = R[1]; pc[k][2] = R[2]; }
+        else { pc[k][0] = pc[k][1] = pc[k][2] = 0.0; }
+      }
+#pragma unroll
+      for (int k = 0; k < kCandPerLane; k++) {
+        const TilePoint &t = tp[p_ent[k] & 63u];
+        double cx = pc[k][0] - (double)t.tx, cy = pc[k][1] - (double)t.ty, cz = pc[k][2] - (double)t.tz;
+        double d2 = cx * cx + cy * cy + cz * cz;
+        if (!(d2 <= P.r2max)) p_mask &= ~(1u << k);  // sqrt(d2) < radius (VoxelGrid.cpp:470-472)
+      }
+      unsigned round_total;
+      unsigned pos = total + wave_excl_scan(__popc(p_mask), lane, &round_total);
+#pragma unroll
+      for (int k = 0; k < kCandPerLane; k++)
+        if (p_mask & (1u << k)) queue[pos++] = p_ent[k];
+      total += round_total;
     }
-    // deterministic compaction: exclusive scan of the per-lane hit counts over the block
-    unsigned cnt = __popc(hit_mask), incl = cnt;
-#pragma unroll
-    for (int off = 1; off < 64; off <<= 1) {
-      unsigned v = __shfl_up(incl, off, 64);
-      if (lane >= off) incl += v;
-    }
-    if (lane == 63) wave_tot[wave] = incl;
-    __syncthreads();
-    unsigned base = 0, total = 0;
-#pragma unroll
-    for (int w = 0; w < kBlockD / 64; w++) {
-      unsigned t = wave_tot[w];
-      if (w < wave) base += t;
-      total += t;
-    }
-    unsigned pos = base + incl - cnt;
-#pragma unroll
-    for (int j = 0; j < kProbesPerLane; j++)
-      if (hit_mask & (1u << j)) queue[pos++] = hit_rank[j];
-    __syncthreads();
+    wave_sync();
     // ---- phase B: dense pair math
-    for (unsigned qi = threadIdx.x; qi < total; qi += kBlockD) {
+    for (unsigned qi = lane; qi < total; qi += 64) {
       unsigned e = queue[qi];
       const unsigned pl = e & 63u;
       const double *R = rec + (size_t)(e >> 6) * kRecDoubles;
-      double pg[8], ph[15];
+      double pg[8];
       const double *tm = terms + pl * kTermStride;
 #pragma unroll
       for (int k = 0; k < 8; k++) pg[k] = tm[k];
-      if (KIND != 1) {
-#pragma unroll
-        for (int k = 0; k < 15; k++) ph[k] = tm[8 + k];
-      }
-      pair_update<KIND>(P, R, tp[pl].tx, tp[pl].ty, tp[pl].tz, pg, ph, acc);
+      // the 15 Hessian terms stay in LDS and are read where they are used: 30 fewer live registers in the pair math
+      pair_update<KIND>(P, R, tp[pl].tx, tp[pl].ty, tp[pl].tz, pg, tm + 8, acc);
     }
-    if (threadIdx.x == 0) pairs += total;
-    __syncthreads();  // tp / terms / queue are rewritten by the next tile
+    pairs += total;
+    wave_sync();  // tp / terms / queues are rewritten by the next tile
   }
-  // block reduction through LDS in a fixed order (bitwise reproducible): transpose the 28 per-lane accumulators,
-  // 8 x 32 lanes add 32 rows each, then 32 lanes add the 8 partial rows
+  // block reduction through LDS in a fixed order (bitwise reproducible): transpose the 28 per-lane accumulators (two
+  // rounds of 128 lanes), 8 x 32 lanes add 32 rows each, then 32 lanes add the 8 partial rows
+  __syncthreads();  // the transposition area aliases the other waves' tile slices: every wave must have left its loop
   double *red = reinterpret_cast<double *>(lds);
-  double *red2 = reinterpret_cast<double *>(lds + (kLdsRed > kLdsTileEnd ? kLdsRed : kLdsTileEnd));
+  double *red2 = reinterpret_cast<double *>(lds + kLdsRed2);
+  double *wcnt = red2 + 8 * 32;  // [kWaves][2]: pairs, points per wave
+  if (lane == 0) { wcnt[wave * 2] = (double)pairs; wcnt[wave * 2 + 1] = (double)npts; }
 #pragma unroll
-  for (int k = 0; k < 28; k++) red[threadIdx.x * kRedStride + k] = acc[k];
-  __syncthreads();
-  {
-    int k = threadIdx.x & 31, part = threadIdx.x >> 5;
-    double v = 0.0;
-    if (k < 28) {
-      const double *r = red + (size_t)(part * 32) * kRedStride + k;
-#pragma unroll 8
-      for (int c = 0; c < 32; c++) v += r[c * kRedStride];
+  for (int round = 0; round < kBlockD / kRedLanes; round++) {
+    if ((int)(threadIdx.x / kRedLanes) == round) {
+#pragma unroll
+      for (int k = 0; k < 28; k++) red[(threadIdx.x % kRedLanes) * kRedStride + k] = acc[k];
     }
-    red2[part * 32 + k] = v;
+    __syncthreads();
+    if (threadIdx.x < kRedLanes) {
+      int k = threadIdx.x & 31, part = threadIdx.x >> 5;  // 4 parts of 32 rows per round
+      double v = 0.0;
+      if (k < 28) {
+        const double *r = red + (size_t)(part * 32) * kRedStride + k;
+#pragma unroll 8
+        for (int c = 0; c < 32; c++) v += r[c * kRedStride];
+      }
+      red2[(round * (kRedLanes / 32) + part) * 32 + k] = v;
+    }
+    __syncthreads();
   }
-  // slot 28 of every partial row carries the pair count (thread 0 holds it); rows 28..31 of red2 part 0 are unused sums
-  __syncthreads();
-  if (threadIdx.x == 0) red2[28] = (double)pairs;
-  __syncthreads();
   if (threadIdx.x < kOutDoubles) {
     double v = 0.0;
     if (threadIdx.x < 28) {
 #pragma unroll
       for (int part = 0; part < 8; part++) v += red2[part * 32 + threadIdx.x];
     } else if (threadIdx.x == 28) {
-      v = red2[28];
+      for (int w = 0; w < kWaves; w++) v += wcnt[w * 2];       // (point, voxel) pairs of this workgroup
     } else if (threadIdx.x == 29) {
-      size_t mine = 0;  // points owned by this workgroup (tiles blockIdx.x, + gridDim.x, ...)
-      for (size_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) mine += min((size_t)kTilePts, n - tile * kTilePts);
-      v = (double)mine;
+      for (int w = 0; w < kWaves; w++) v += wcnt[w * 2 + 1];   // source points of this workgroup
     }
     partials[(size_t)blockIdx.x * kOutDoubles + threadIdx.x] = v;  // one 256-byte row per workgroup, written once
   }
@@ -355,9 +449,9 @@ void ndt_make_pass_params(const lsa_ndt *h, const float T[16], const double p[6]
   for (int a = 0; a < 3; a++) { P->min_b[a] = h->vi.map.min_b[a]; P->dim[a] = h->vi.map.dim[a]; }
 }
 
-unsigned ndt_pass_grid(const lsa_ndt *h, size_t n) {
-  size_t blocks = (n + 63) / 64;  // one 64-point tile per workgroup until the chip is full, then grid-stride
-  size_t cap = (size_t)h->ctx->num_cus * 4;
+unsigned ndt_pass_grid(const lsa_ndt *h, size_t n, int kind) {
+  size_t blocks = (n + kWaves * kTilePts - 1) / (kWaves * kTilePts);  // one 16-point tile per wave until the chip is full, then grid-stride
+  size_t cap = (size_t)h->ctx->num_cus * pass_waves(kind);  // the resident set: every workgroup runs at once
   if (blocks > cap) blocks = cap;
   if (blocks < 1) blocks = 1;
   return (unsigned)blocks;
@@ -366,7 +460,7 @@ unsigned ndt_pass_grid(const lsa_ndt *h, size_t n) {
 // enqueue one pass: partial kernel + second-stage reduction into h->d_out (device). No sync.
 int ndt_enqueue_pass(lsa_ndt *h, const PassParams &P, int kind, bool reduce) {
   lsa_context *ctx = h->ctx;
-  unsigned g = ndt_pass_grid(h, h->n_source);
+  unsigned g = ndt_pass_grid(h, h->n_source, kind);
   int rc;
   if ((rc = h->partials.reserve(ctx, (size_t)g * kOutDoubles, 1.0))) return rc;
   if ((rc = h->d_out.reserve(ctx, kOutDoubles))) return rc;
@@ -385,11 +479,11 @@ int ndt_enqueue_pass(lsa_ndt *h, const PassParams &P, int kind, bool reduce) {
 // kernel (~8 us) from every pass.  The summation order is the one k_reduce_partials uses, so both paths give the same bits.
 constexpr unsigned kHostReduceMaxBlocks = 512;
 
-bool ndt_pass_host_reduce(const lsa_ndt *h) { return !h->allreduce && ndt_pass_grid(h, h->n_source) <= kHostReduceMaxBlocks; }
+bool ndt_pass_host_reduce(const lsa_ndt *h, int kind) { return !h->allreduce && ndt_pass_grid(h, h->n_source, kind) <= kHostReduceMaxBlocks; }
 
 int ndt_enqueue_pass_host(lsa_ndt *h, const PassParams &P, int kind, unsigned *grid_out) {
   lsa_context *ctx = h->ctx;
-  unsigned g = ndt_pass_grid(h, h->n_source);
+  unsigned g = ndt_pass_grid(h, h->n_source, kind);
   int rc;
   if ((rc = h->h_partials.reserve(ctx, (size_t)kHostReduceMaxBlocks * kOutDoubles))) return rc;
   const uint4 *words = h->words.p;
