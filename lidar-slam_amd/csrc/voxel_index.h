@@ -50,7 +50,10 @@ struct DevParams {
 };
 
 struct VoxelIndex {
-  DevBuf<uint32_t> bits, prefix, blocksums;
+  DevBuf<uint32_t> bits, prefix;
+  DevBuf<unsigned long long> scan_state;  // decoupled look-back states, one per 2048-word tile
+  DevBuf<unsigned> tickets;               // [1] scan tile ticket (self-resetting); [0] spare
+  unsigned scan_epoch = 0;
   DevBuf<int32_t> cell_of_rank, cnt, cell_idx;
   DevBuf<long long> acc;
   DevBuf<float> scratch;  // bbox partials
@@ -66,7 +69,7 @@ struct VoxelIndex {
   CellMap map{};
   FixScales fs{};
   void release() {
-    bits.release(); prefix.release(); blocksums.release(); cell_of_rank.release(); cnt.release(); cell_idx.release();
+    bits.release(); prefix.release(); scan_state.release(); tickets.release(); cell_of_rank.release(); cnt.release(); cell_idx.release();
     acc.release(); scratch.release(); dparams.release(); h_params.release();
     if (ev_done) { (void)hipEventDestroy(ev_done); ev_done = nullptr; }
     W_cap = 0; acc_rows = 0; clean = false;
@@ -74,7 +77,8 @@ struct VoxelIndex {
 };
 
 // Enqueue the whole index build for `n` points with the given rule set (mode 0 PCL / 1 NDT) and leaf:
-//   bbox -> grid definition (device) -> mark bitmap -> popcount scan (+ inverse map) -> per-cell sums (ns = 4 or 10).
+//   bbox -> grid definition (device) -> mark bitmap -> single-pass popcount scan (+ inverse map) -> per-cell sums
+//   (ns = 4 or 10): five launches.
 // No host synchronisation.  Buffers are sized for n; the bitmap uses the capacity left by earlier calls (the device flags
 // VI_CAPACITY if it does not fit).
 int vi_enqueue(lsa_context *ctx, VoxelIndex &vi, const float4 *d_pts, size_t n, int mode, const float leaf[3], int ns);

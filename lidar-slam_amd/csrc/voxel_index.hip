@@ -214,63 +214,34 @@ __global__ __launch_bounds__(kBlock) void k_mark(const float4 *__restrict__ pts,
   }
 }
 
-__global__ __launch_bounds__(kBlock) void k_scan_block_sums(const uint32_t *__restrict__ bits, const DevParams *__restrict__ dp, uint32_t *__restrict__ blocksums) {
-  if (dp->status != VI_OK || blockIdx.x >= dp->nsb) return;
-  const size_t W = dp->W;
-  size_t base = (size_t)blockIdx.x * kScanTile;
-  unsigned s = 0;
-  for (int k = 0; k < kScanTile / kBlock; k++) {
-    size_t i = base + (size_t)k * kBlock + threadIdx.x;
-    if (i < W) s += __popc(bits[i]);
-  }
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
-  __shared__ unsigned sw[kBlock / 64];
-  if ((threadIdx.x & 63) == 0) sw[threadIdx.x >> 6] = s;
-  __syncthreads();
+// ---- popcount prefix scan of the bitmap, single pass -------------------------------------------------------------
+// One launch instead of three (tile sums -> scan of the sums -> apply): decoupled look-back.  A workgroup takes a
+// ticket (its tile index, so tiles are started in order and the look-back can never wait on a tile that has not been
+// scheduled), publishes its tile's popcount as an AGGREGATE, and reads its predecessors' states 64 at a time until it
+// meets one that already carries an inclusive PREFIX.  A state word = {epoch : 30, flag : 2, value : 32}; the epoch
+// makes words left by earlier launches invalid without clearing the array.
+constexpr unsigned long long kFlagAgg = 1ull, kFlagPrefix = 2ull;
+__device__ __forceinline__ unsigned long long scan_word(unsigned epoch, unsigned long long flag, unsigned value) {
+  return ((unsigned long long)epoch << 34) | (flag << 32) | (unsigned long long)value;
+}
+
+__global__ __launch_bounds__(kBlock) void k_scan(const uint32_t *__restrict__ bits, DevParams *__restrict__ dp, unsigned long long *__restrict__ state,
+                                                 unsigned *__restrict__ ticket, unsigned epoch, uint32_t *__restrict__ prefix,
+                                                 int32_t *__restrict__ cell_of_rank) {
+  __shared__ unsigned s_tile, s_excl;
+  __shared__ unsigned wt[kBlock / 64];
   if (threadIdx.x == 0) {
-    unsigned t = 0;
-    for (int w = 0; w < kBlock / 64; w++) t += sw[w];
-    blocksums[blockIdx.x] = t;
+    unsigned t = atomicAdd(ticket, 1u);
+    if (t == gridDim.x - 1) *ticket = 0u;  // every ticket of this launch has been handed out: reset for the next one
+    s_tile = t;
   }
-}
-
-// single block: exclusive scan of blocksums[nsb] in place; the total (= #occupied cells) goes to dp->V
-__global__ __launch_bounds__(1024) void k_scan_top(uint32_t *__restrict__ blocksums, DevParams *__restrict__ dp) {
-  if (dp->status != VI_OK) return;
-  const int nb = (int)dp->nsb;
-  __shared__ unsigned s[1024];
-  __shared__ unsigned carry;
-  if (threadIdx.x == 0) carry = 0;
   __syncthreads();
-  for (int base = 0; base < nb; base += 1024) {
-    int i = base + threadIdx.x;
-    unsigned v = (i < nb) ? blocksums[i] : 0;
-    s[threadIdx.x] = v;
-    __syncthreads();
-    for (int off = 1; off < 1024; off <<= 1) {
-      unsigned t = (threadIdx.x >= (unsigned)off) ? s[threadIdx.x - off] : 0;
-      __syncthreads();
-      s[threadIdx.x] += t;
-      __syncthreads();
-    }
-    unsigned incl = s[threadIdx.x];
-    unsigned c = carry;
-    if (i < nb) blocksums[i] = c + incl - v;
-    __syncthreads();
-    if (threadIdx.x == 1023) carry = c + incl;
-    __syncthreads();
-  }
-  if (threadIdx.x == 0) dp->V = carry;
-}
-
-__global__ __launch_bounds__(kBlock) void k_scan_apply(const uint32_t *__restrict__ bits, const DevParams *__restrict__ dp, const uint32_t *__restrict__ blocksums,
-                                                       uint32_t *__restrict__ prefix, int32_t *__restrict__ cell_of_rank) {
-  if (dp->status != VI_OK || blockIdx.x >= dp->nsb) return;
+  const unsigned tile = s_tile;
+  if (dp->status != VI_OK || tile >= dp->nsb) return;
   const size_t W = dp->W;
   // thread t owns 8 consecutive words (two 16-byte loads; the bitmap capacity is a multiple of the tile, and words past
   // W are zero), so the in-block scan is one value per thread: wave shuffle scan + one barrier for the 4 wave totals
-  size_t base = (size_t)blockIdx.x * kScanTile + (size_t)threadIdx.x * 8;
+  size_t base = (size_t)tile * kScanTile + (size_t)threadIdx.x * 8;
   const uint4 *src = reinterpret_cast<const uint4 *>(bits + base);
   uint4 lo = src[0], hi = src[1];
   uint32_t wv[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
@@ -287,10 +258,43 @@ __global__ __launch_bounds__(kBlock) void k_scan_apply(const uint32_t *__restric
     unsigned v = __shfl_up(incl, off, 64);
     if (lane >= off) incl += v;
   }
-  __shared__ unsigned wt[kBlock / 64];
   if (lane == 63) wt[wave] = incl;
   __syncthreads();
-  unsigned run = blocksums[blockIdx.x] + incl - local;
+  unsigned agg = 0;
+#pragma unroll
+  for (int w = 0; w < kBlock / 64; w++) agg += wt[w];
+  if (wave == 0) {
+    if (lane == 0) __hip_atomic_store(state + tile, scan_word(epoch, tile == 0 ? kFlagPrefix : kFlagAgg, agg), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    unsigned excl = 0;
+    int j = (int)tile - 1;  // nearest predecessor not yet accounted for
+    while (j >= 0) {        // wave-uniform
+      int idx = j - lane;
+      unsigned long long w = 0;
+      bool ready;
+      do {
+        ready = true;
+        if (idx >= 0) {
+          w = __hip_atomic_load(state + idx, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
+          ready = ((unsigned)(w >> 34) == epoch) && (((w >> 32) & 3ull) != 0ull);
+        }
+      } while (!__all(ready));
+      unsigned long long pmask = __ballot(idx >= 0 && ((w >> 32) & 3ull) == kFlagPrefix);
+      int stop = pmask ? (__ffsll((long long)pmask) - 1) : 63;  // nearest predecessor that already holds a prefix
+      unsigned v = (idx >= 0 && lane <= stop) ? (unsigned)w : 0u;
+#pragma unroll
+      for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+      excl += __shfl(v, 0, 64);
+      if (pmask) break;
+      j -= 64;
+    }
+    if (lane == 0) {
+      if (tile != 0) __hip_atomic_store(state + tile, scan_word(epoch, kFlagPrefix, excl + agg), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+      s_excl = excl;
+      if (tile == dp->nsb - 1) dp->V = excl + agg;  // #occupied cells
+    }
+  }
+  __syncthreads();
+  unsigned run = s_excl + incl - local;
   for (int w = 0; w < wave; w++) run += wt[w];
   unsigned pf[8];
 #pragma unroll
@@ -440,8 +444,18 @@ int vi_enqueue(lsa_context *ctx, VoxelIndex &vi, const float4 *d_pts, size_t n, 
     vi.W_cap = 4096;
     if ((rc = vi.bits.reserve(ctx, vi.W_cap))) return rc;
     if ((rc = vi.prefix.reserve(ctx, vi.W_cap))) return rc;
-    if ((rc = vi.blocksums.reserve(ctx, vi.W_cap / kScanTile + 2))) return rc;
+    if ((rc = vi.scan_state.reserve(ctx, vi.W_cap / kScanTile + 2))) return rc;
+    LSA_HIP(ctx, hipMemsetAsync(vi.scan_state.p, 0, vi.scan_state.cap * sizeof(unsigned long long), ctx->stream));
+    vi.scan_epoch = 0;
     vi.clean = false;
+  }
+  if (!vi.tickets.p) {
+    if ((rc = vi.tickets.reserve(ctx, 2))) return rc;
+    LSA_HIP(ctx, hipMemsetAsync(vi.tickets.p, 0, 2 * sizeof(unsigned), ctx->stream));
+  }
+  if (++vi.scan_epoch >= (1u << 30)) {  // epoch wrap: invalidate every state word the old way
+    LSA_HIP(ctx, hipMemsetAsync(vi.scan_state.p, 0, vi.scan_state.cap * sizeof(unsigned long long), ctx->stream));
+    vi.scan_epoch = 1;
   }
   if (!vi.clean) {
     LSA_HIP(ctx, hipMemsetAsync(vi.bits.p, 0, vi.W_cap * sizeof(uint32_t), ctx->stream));
@@ -460,9 +474,8 @@ int vi_enqueue(lsa_context *ctx, VoxelIndex &vi, const float4 *d_pts, size_t n, 
   hipLaunchKernelGGL(k_bbox_partial, dim3(nb), dim3(kBlock), 0, ctx->stream, d_pts, n, vi.scratch.p);
   hipLaunchKernelGGL(k_bbox_final_params, dim3(1), dim3(kBlock), 0, ctx->stream, vi.scratch.p, (int)nb, req, vi.dparams.p);
   hipLaunchKernelGGL(k_mark, dim3(lsa_div_up(n, kTile)), dim3(kBlock), 0, ctx->stream, d_pts, n, dp, vi.bits.p, vi.cell_idx.p);
-  hipLaunchKernelGGL(k_scan_block_sums, dim3(nsb_cap), dim3(kBlock), 0, ctx->stream, vi.bits.p, dp, vi.blocksums.p);
-  hipLaunchKernelGGL(k_scan_top, dim3(1), dim3(1024), 0, ctx->stream, vi.blocksums.p, vi.dparams.p);
-  hipLaunchKernelGGL(k_scan_apply, dim3(nsb_cap), dim3(kBlock), 0, ctx->stream, vi.bits.p, dp, vi.blocksums.p, vi.prefix.p, vi.cell_of_rank.p);
+  hipLaunchKernelGGL(k_scan, dim3(nsb_cap), dim3(kBlock), 0, ctx->stream, vi.bits.p, vi.dparams.p, vi.scan_state.p, vi.tickets.p + 1, vi.scan_epoch,
+                     vi.prefix.p, vi.cell_of_rank.p);
   unsigned g = lsa_div_up(n, kTile);
   if (ns == 4)
     hipLaunchKernelGGL(k_accum<4>, dim3(g), dim3(kBlock), 0, ctx->stream, d_pts, vi.cell_idx.p, n, dp, vi.bits.p, vi.prefix.p, vi.acc.p, vi.cnt.p);
@@ -499,12 +512,14 @@ int vi_grow(lsa_context *ctx, VoxelIndex &vi) {
   const DevParams &p = vi.h_params.p[0];
   size_t need = (size_t)p.W + 1;
   size_t want = need + need / 4;
-  want = (want + kScanTile - 1) / kScanTile * kScanTile;  // whole scan tiles: k_scan_apply reads / writes 16-byte vectors
+  want = (want + kScanTile - 1) / kScanTile * kScanTile;  // whole scan tiles: k_scan reads / writes 16-byte vectors
   LSA_HIP(ctx, hipStreamSynchronize(ctx->stream));
   int rc;
   if ((rc = vi.bits.reserve(ctx, want))) return rc;
   if ((rc = vi.prefix.reserve(ctx, want))) return rc;
-  if ((rc = vi.blocksums.reserve(ctx, want / kScanTile + 2))) return rc;
+  if ((rc = vi.scan_state.reserve(ctx, want / kScanTile + 2))) return rc;
+  LSA_HIP(ctx, hipMemsetAsync(vi.scan_state.p, 0, vi.scan_state.cap * sizeof(unsigned long long), ctx->stream));
+  vi.scan_epoch = 0;
   vi.W_cap = want;
   vi.clean = false;
   return LSA_OK;
