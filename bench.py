@@ -94,9 +94,12 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
-    world = int(os.environ.get("WORLD_SIZE", "1")) if args.gpus > 1 else 1
-    rank = int(os.environ.get("RANK", "0")) if args.gpus > 1 else 0
-    local_rank = int(os.environ.get("LOCAL_RANK", "0")) if args.gpus > 1 else 0
+    # LSA_BENCH_FORCE_DIST=1: take the multi-rank code path (process group, RCCL all-reduce per pass, barrier, max over
+    # ranks) even for a world of one, so a one-GPU box rehearses exactly what `--gpus N` under torch.distributed.run does
+    dist_mode = args.gpus > 1 or os.environ.get("LSA_BENCH_FORCE_DIST") == "1"
+    world = int(os.environ.get("WORLD_SIZE", "1")) if dist_mode else 1
+    rank = int(os.environ.get("RANK", "0")) if dist_mode else 0
+    local_rank = int(os.environ.get("LOCAL_RANK", "0")) if dist_mode else 0
     if args.gpus > 1 and world != args.gpus:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch with torch.distributed.run --nproc-per-node %d" % (args.gpus, world, args.gpus))
 
@@ -114,8 +117,9 @@ def main():
     one_gpu = os.environ.get("LSA_BENCH_ONE_GPU") == "1"
     dev_index = 0 if one_gpu else local_rank
     torch.cuda.set_device(dev_index)
-    if world > 1:
+    if dist_mode:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29517")
         if one_gpu:
             dist.init_process_group("gloo", rank=rank, world_size=world)
         else:
@@ -163,7 +167,7 @@ def main():
         truths.append((P0inv @ poses[k]).astype(np.float32))
     d_filt2 = [torch.empty((max(s.shape[0] for s in d_scans), 4), dtype=torch.float32, device=dev) for _ in range(2)]
     d_filt = d_filt2[0]
-    if world > 1:
+    if dist_mode:
         ndt.set_allreduce(lsa_dist.make_gloo_staged_allreduce() if one_gpu else lsa_dist.make_rccl_allreduce())
 
     results = {}
@@ -203,7 +207,7 @@ def main():
             in_flight[0] = i + 1
         else:
             in_flight[0] = -1
-        if world > 1:
+        if dist_mode:
             lo, hi = lsa_dist.shard_bounds(m, rank, world)
             rc |= f_match(hn, fp + 16 * lo, hi - lo, guess_p[k], out_p[k], stats_r[k])
         else:
@@ -218,7 +222,7 @@ def main():
 
     def sync_all():
         torch.cuda.synchronize()
-        if world > 1:
+        if dist_mode:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -226,7 +230,7 @@ def main():
     # DVFS state; spin the same work (untimed, results discarded) for a fixed wall time first, then do the W warm-ups
     t_ramp = time.perf_counter()
     i_ramp = 0
-    if world > 1:
+    if dist_mode:
         # every step contains collectives, so all ranks must run the SAME number of ramp steps: count-based, not timed
         for i_ramp in range(int(args.ramp_seconds * 2000)):
             step(i_ramp, more=False)
@@ -243,7 +247,7 @@ def main():
     sync_all()
     elapsed = time.perf_counter() - t0
     collect()
-    if world > 1:
+    if dist_mode:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if one_gpu else dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -252,7 +256,7 @@ def main():
     roofline = None
     split = {}
     if rank == 0:
-        if world > 1:
+        if dist_mode:
             ndt.set_allreduce(None)
         k = 0
         reps = 50
@@ -368,7 +372,7 @@ def main():
         print(json.dumps(line), flush=True)
 
     ndt.close(); frame_filter.close(); map_filter.close(); ctx_f.close()
-    if world > 1:
+    if dist_mode:
         dist.barrier()
         dist.destroy_process_group()
     ctx.close()
