@@ -92,6 +92,7 @@ def main():
     ap.add_argument("--ramp-seconds", type=float, default=1.5, help="untimed clock-ramp spin before the W warm-up steps")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="bound on the CPU-baseline sample (rank 0, N = 1)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-large", action="store_true", help="skip the cfg5-sized roofline probe of the pass kernel")
     args = ap.parse_args()
 
     # LSA_BENCH_FORCE_DIST=1: take the multi-rank code path (process group, RCCL all-reduce per pass, barrier, max over
@@ -303,6 +304,35 @@ def main():
                     "alg_bytes_per_launch": int(alg_bytes), "source_points": M, "kbar": round(kbar, 3),
                     "note": "pass is L2-resident / f64-issue bound at this size, not HBM bound (DESIGN.md)"}
 
+    # ---- the same kernel at BASELINE.json configs[4] size (2,097,152-point source against a 2 M-point target): the size at
+    # which the HBM roofline is a meaningful yardstick for it (at cfg2 size one launch moves < 2 MB).  Extra key, rank 0.
+    roofline_cfg5 = None
+    if rank == 0 and world == 1 and not args.no_large:
+        from lidar_slam_amd import synth as _synth
+        P0i = np.linalg.inv(poses[0])
+        parts = [_synth.transform_points(P0i @ poses[i], scans[i]) for i in range(17)]
+        tgt5 = np.ascontiguousarray(np.concatenate(parts, 0))[:2000000]
+        src5 = _synth.gen_scan(_synth.Scene(seed=1), poses[8], seed=55, beams=128, az_steps=16384, max_range=120.0, clamp=True)
+        d_t5 = torch.from_numpy(tgt5).to(dev)
+        d_s5 = torch.from_numpy(src5).to(dev)
+        torch.cuda.synchronize()
+        ndt5 = registration.NDTRegistrationHip(ctx, 1.0, 0.1, 0.0, 30, 0.55)
+        ndt5.SetInputTarget(d_t5)
+        ndt5.set_source(d_s5)
+        g5 = (P0i @ poses[8]).astype(np.float32)
+        p5 = np.zeros(6)
+        capi.lib().lsa_matrix_to_pose(capi.fptr(capi.colmajor(g5)), capi.dptr(p5))
+        (_, _, _, pairs5, npts5), ms5 = ndt5.derivatives_timed(g5, p5, kind=0, repeat=20)
+        M5, kbar5 = int(npts5), pairs5 / max(1.0, float(npts5))
+        alg5 = M5 * (16.0 + 4.0 * 27.0 + 48.0 * kbar5)
+        roofline_cfg5 = {"workload": "cfg5: k_ndt_pass<0>, 2,097,152-point source vs 2 M-point target (res 1.0 m)", "bound": "hbm",
+                         "achieved": round(alg5 / (ms5 * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(alg5 / (ms5 * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "us_per_launch": round(ms5 * 1e3, 1),
+                         "alg_bytes_per_launch": int(alg5), "source_points": M5, "kbar": round(kbar5, 3),
+                         "pairs_per_s": round(pairs5 / (ms5 * 1e-3), 0)}
+        ndt5.close()
+        del d_t5, d_s5
+
     # ---- CPU baseline: the oracle (single thread) on a bounded sample of the same scans; also the pose check
     cpu_baseline = None
     pose_rmse = None
@@ -363,6 +393,7 @@ def main():
                 **split,
             },
             "roofline": roofline,
+            "roofline_cfg5": roofline_cfg5,
             "cpu_baseline": cpu_baseline,
             "pose_rmse_vs_oracle": pose_rmse,
         }

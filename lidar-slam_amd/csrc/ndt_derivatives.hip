@@ -217,9 +217,19 @@ __global__ __launch_bounds__(kBlockD, pass_waves(KIND)) void k_ndt_pass(const fl
           if (lsa_finite3(tx, ty, tz)) {
             // radiusSearch cell box (VoxelGrid.cpp:438-455), relative to real_min, clipped to the occupied bounds
             float r = P.res;
-            int hx = (int)floorf(lsa_fdiv(lsa_fadd(tx, r), r)) - P.min_b[0], lx = (int)floorf(lsa_fdiv(lsa_fsub(tx, r), r)) - P.min_b[0];
-            int hy = (int)floorf(lsa_fdiv(lsa_fadd(ty, r), r)) - P.min_b[1], ly = (int)floorf(lsa_fdiv(lsa_fsub(ty, r), r)) - P.min_b[1];
-            int hz = (int)floorf(lsa_fdiv(lsa_fadd(tz, r), r)) - P.min_b[2], lz = (int)floorf(lsa_fdiv(lsa_fsub(tz, r), r)) - P.min_b[2];
+            int hx, lx, hy, ly, hz, lz;
+            if (P.res_pow2) {
+              // a power-of-two leaf (the YAML default 1.0): x / r == x * (1 / r) exactly, so the six correctly rounded
+              // f32 divisions (~12 instructions each) collapse to multiplications without changing a single bit
+              float ir = P.inv_res;
+              hx = (int)floorf(lsa_fmul(lsa_fadd(tx, r), ir)) - P.min_b[0]; lx = (int)floorf(lsa_fmul(lsa_fsub(tx, r), ir)) - P.min_b[0];
+              hy = (int)floorf(lsa_fmul(lsa_fadd(ty, r), ir)) - P.min_b[1]; ly = (int)floorf(lsa_fmul(lsa_fsub(ty, r), ir)) - P.min_b[1];
+              hz = (int)floorf(lsa_fmul(lsa_fadd(tz, r), ir)) - P.min_b[2]; lz = (int)floorf(lsa_fmul(lsa_fsub(tz, r), ir)) - P.min_b[2];
+            } else {
+              hx = (int)floorf(lsa_fdiv(lsa_fadd(tx, r), r)) - P.min_b[0]; lx = (int)floorf(lsa_fdiv(lsa_fsub(tx, r), r)) - P.min_b[0];
+              hy = (int)floorf(lsa_fdiv(lsa_fadd(ty, r), r)) - P.min_b[1]; ly = (int)floorf(lsa_fdiv(lsa_fsub(ty, r), r)) - P.min_b[1];
+              hz = (int)floorf(lsa_fdiv(lsa_fadd(tz, r), r)) - P.min_b[2]; lz = (int)floorf(lsa_fdiv(lsa_fsub(tz, r), r)) - P.min_b[2];
+            }
             hx = min(hx, P.dim[0] - 1); hy = min(hy, P.dim[1] - 1); hz = min(hz, P.dim[2] - 1);
             lx = max(lx, 0); ly = max(ly, 0); lz = max(lz, 0);
             // with radius == leaf the box is at most 3 cells wide per axis
@@ -273,16 +283,16 @@ __global__ __launch_bounds__(kBlockD, pass_waves(KIND)) void k_ndt_pass(const fl
       }
 #pragma unroll
       for (int j = 0; j < kRowRounds; j++) {
-        int sh = r_cell[j] & 31;
+        // the row's bits as one 64-bit window over {word, next word}: prefix(next) = prefix(word) + popc(occ(word)), so
+        // rank(cell) = prefix(word) + popc(occ64 below the cell) holds on either side of the 32-cell boundary
+        const int sh = r_cell[j] & 31;
+        const unsigned long long occ = ((unsigned long long)w1[j].x << 32) | w0[j].x;
+        const unsigned long long val = (((unsigned long long)w1[j].y << 32) | w0[j].y) >> sh;
 #pragma unroll
         for (int i = 0; i < 3; i++) {
-          int b = sh + i;
-          bool second = b >= 32;
-          uint32_t occ = second ? w1[j].x : w0[j].x, val = second ? w1[j].y : w0[j].y, pre = second ? w1[j].z : w0[j].z;
-          uint32_t bit = 1u << (b & 31);
           // points_per_voxel >= min_points_per_voxel_ and accepted eigenvalues (VoxelGrid.cpp:465)
-          bool ok = i < r_nx[j] && (val & bit);
-          unsigned rank = pre + __popc(occ & (bit - 1u));
+          bool ok = i < r_nx[j] && ((val >> i) & 1ull);
+          unsigned rank = w0[j].z + (unsigned)__popcll(occ & ((1ull << (sh + i)) - 1ull));
           c_ent[j * 3 + i] = ((unsigned)r_pl[j]) | (rank << 6);
           if (ok) c_mask |= 1u << (j * 3 + i);
         }
@@ -440,6 +450,11 @@ void ndt_make_pass_params(const lsa_ndt *h, const float T[16], const double p[6]
   q[14][0] = -sx * sz + cx * sy * cz; q[14][1] = -cx * sy * sz - sx * cz; q[14][2] = 0;
   P->d1 = h->d1; P->d2 = h->d2;
   P->res = h->resolution;
+  {
+    int e = 0;
+    P->res_pow2 = (std::frexp(h->resolution, &e) == 0.5f) ? 1 : 0;  // mantissa 0.5: an exact power of two
+    P->inv_res = 1.0f / h->resolution;
+  }
   {  // exact squared-distance threshold: the largest double x with sqrt(x) < radius (sqrt is monotone)
     double r = (double)h->resolution, t = r * r;
     while (std::sqrt(t) >= r) t = std::nextafter(t, 0.0);

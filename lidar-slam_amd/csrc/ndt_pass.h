@@ -11,6 +11,8 @@ struct PassParams {
   double d1, d2;     // gauss_d1_, gauss_d2_
   double r2max;      // largest double x with sqrt(x) < (double)res: `sqrt(d2) < radius` == `d2 <= r2max`, no sqrt per probe
   float res;         // resolution_ = search radius = leaf
+  float inv_res;     // 1 / res, used only when res_pow2 (then x / res == x * inv_res bit for bit)
+  int res_pow2;
   int min_b[3];      // real_min_b*
   int dim[3];        // real_max_b* - real_min_b* + 1
 };
