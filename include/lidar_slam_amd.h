@@ -221,6 +221,27 @@ void lsa_matrix_to_pose(const float T[16], double p[6]);
 void lsa_ndt_gauss_constants(float res, float outlier_ratio, double *d1, double *d2);
 
 /* ---------------------------------------------------------------------------------------------
+ * Position-only initialisation — replaces Matching::generateGauss2DMapCells / resetMapRange / getInitialYawAngle
+ * (src/matching/matching.cpp:344-422, :267-307; `init_type: OnlyPosition`, config/matching/matching.yaml:4): a 2-D grid
+ * of per-cell height statistics over (local map - origin), and the best of 270 yaw hypotheses of a scan against it.
+ * ------------------------------------------------------------------------------------------- */
+typedef struct lsa_yaw_init lsa_yaw_init;
+/* grid_resolution: matching.yaml `grid_resolution` (clamped to >= 0.1 as InitGridMapResolution does, :137-138) */
+int lsa_yaw_init_create(lsa_yaw_init **out, lsa_context *ctx, double grid_resolution);
+void lsa_yaw_init_destroy(lsa_yaw_init *y);
+/* SetInitPose -> generateGauss2DMapCells (:325-342): origin = local_map_origion_ = the position ResetLocalMap was given */
+int lsa_yaw_init_set_local_map(lsa_yaw_init *y, const void *pts, size_t n, size_t stride, const float origin[3]);
+int lsa_yaw_init_set_local_map_device(lsa_yaw_init *y, const float *d_xyzw, size_t n, const float origin[3]);
+/* getInitialYawAngle(current_cloud) (:267-307). probs270 (optional) receives the 270 hypothesis scores. */
+int lsa_yaw_init_get_initial_yaw(lsa_yaw_init *y, const void *scan, size_t n, size_t stride, double *yaw,
+                                 double *probs270);
+int lsa_yaw_init_get_initial_yaw_device(lsa_yaw_init *y, const float *d_scan_xyzw, size_t n, double *yaw,
+                                        double *probs270);
+/* introspection for the parity tests: local_map_width_/height_, map_min/max_xyz_; cell k = cell_x * height + cell_y */
+int lsa_yaw_init_grid_info(lsa_yaw_init *y, int32_t wh[2], float min_xyz[3], float max_xyz[3]);
+int lsa_yaw_init_cells(lsa_yaw_init *y, float *mu, float *sigma, int32_t *point_cnt, size_t cap);
+
+/* ---------------------------------------------------------------------------------------------
  * ICP registration.
  *   LSA_ICP_MODE_MANUAL (0) replaces ICPRegistrationManual (icp_registration_manual.cpp:12-179): point-to-point
  *     Gauss-Newton, fixed max_iter iterations, exact 1-NN correspondences gated by squared-distance <=

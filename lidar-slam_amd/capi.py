@@ -124,6 +124,15 @@ def lib():
     L.lsa_icp_scan_match_device.argtypes = [vp, vp, sz, PF, PF]
     L.lsa_icp_get_fitness_score.argtypes = [vp, PF]
     L.lsa_icp_set_criteria.argtypes = [vp, f, f]
+    L.lsa_yaw_init_create.argtypes = [PVP, vp, C.c_double]
+    L.lsa_yaw_init_destroy.argtypes = [vp]
+    L.lsa_yaw_init_destroy.restype = None
+    L.lsa_yaw_init_set_local_map.argtypes = [vp, vp, sz, sz, PF]
+    L.lsa_yaw_init_set_local_map_device.argtypes = [vp, vp, sz, PF]
+    L.lsa_yaw_init_get_initial_yaw.argtypes = [vp, vp, sz, sz, PD, PD]
+    L.lsa_yaw_init_get_initial_yaw_device.argtypes = [vp, vp, sz, PD, PD]
+    L.lsa_yaw_init_grid_info.argtypes = [vp, C.POINTER(C.c_int32), PF, PF]
+    L.lsa_yaw_init_cells.argtypes = [vp, PF, PF, C.POINTER(C.c_int32), sz]
     L.lsa_box_filter_create.argtypes = [PVP, vp, PF]
     L.lsa_box_filter_destroy.argtypes = [vp]
     L.lsa_box_filter_destroy.restype = None

@@ -143,6 +143,18 @@ int orc_box_filter(const void *pts, size_t n, size_t stride, size_t w_off, const
 int orc_icp_manual(const void *tgt, size_t nt, size_t tstride, const void *src, size_t ns, size_t sstride,
                    float max_correspond_dis, int max_iter, const float guess[16], float out_pose[16]);
 
+/* ---- Matching's position-only initialisation (yaw_oracle.c; S/matching/matching.cpp:267-307,344-422; restated, UNPINNED) */
+typedef struct orc_yaw orc_yaw;
+/* generateGauss2DMapCells over (map - origin); grid_resolution as in the YAML (clamped to >= 0.1, :137-138) */
+orc_yaw *orc_yaw_build(const void *map, size_t n, size_t stride, const float origin[3], double grid_resolution);
+void orc_yaw_free(orc_yaw *y);
+void orc_yaw_info(const orc_yaw *y, int wh[2], float mn[3], float mx[3]);
+/* cell k = cell_x * height + cell_y */
+void orc_yaw_cells(const orc_yaw *y, float *mu, float *sigma, int *cnt);
+void orc_yaw_rotation(int i, float R[9]);
+/* getInitialYawAngle; probs270 (optional) receives the 270 scores */
+double orc_yaw_angle(const orc_yaw *y, const void *scan, size_t n, size_t stride, double *probs270);
+
 /* ---- PCL-semantics pieces (pcl_oracle.c; third-party PCL 1.7, absent from the tree: UNPINNED) -------------- */
 /* symmetric 3x3 eigen-decomposition, eigenvalues ascending, eigenvectors in columns (row-major storage):
  * what Eigen::SelfAdjointEigenSolver<Matrix3d> returns up to rounding and sign. cyclic Jacobi. */

@@ -118,6 +118,13 @@ class Oracle:
         L.orc_icp_manual.argtypes = [vp, sz, sz, vp, sz, sz, f, i, PF, PF]
         L.orc_icp_manual.restype = i
         L.orc_ndt_set_mode.argtypes = [vp, i]
+        L.orc_yaw_build.argtypes = [vp, sz, sz, PF, d]
+        L.orc_yaw_build.restype = vp
+        L.orc_yaw_free.argtypes = [vp]
+        L.orc_yaw_info.argtypes = [vp, PI, PF, PF]
+        L.orc_yaw_cells.argtypes = [vp, PF, PF, PI]
+        L.orc_yaw_angle.argtypes = [vp, vp, sz, sz, PD]
+        L.orc_yaw_angle.restype = d
         L.orc_box_filter.argtypes = [vp, sz, sz, sz, PF, PF, PF, sz, C.POINTER(sz)]
         L.orc_box_filter.restype = i
         L.orc_eig3_jacobi.argtypes = [PD, PD, PD]
@@ -349,3 +356,38 @@ def icp_pcl(tgt8, src8, guess, euclid_eps=0.01, max_correspond_dis=2.0, trans_ep
                          euclid_eps, max_correspond_dis, trans_eps, max_iter, _fp(_colmajor(guess)), _fp(out), _dp(st))
     assert rc == 0
     return out.reshape(4, 4).T.copy(), dict(iterations=int(st[0]), converged=int(st[1]), correspondences=int(st[2]), mse=st[3])
+
+
+class OracleYawInit:
+    """Matching::generateGauss2DMapCells + getInitialYawAngle (S/matching/matching.cpp:267-307,344-422)."""
+
+    def __init__(self, map8, origin, grid_resolution=0.8):
+        self.o = Oracle()
+        map8 = np.ascontiguousarray(map8, dtype=np.float32)
+        og = np.ascontiguousarray(origin, dtype=np.float32)
+        self.h = self.o.L.orc_yaw_build(map8.ctypes.data, map8.shape[0], POINT_STRIDE, _fp(og), float(grid_resolution))
+
+    def __del__(self):
+        try:
+            self.o.L.orc_yaw_free(self.h)
+        except Exception:
+            pass
+
+    def info(self):
+        wh = np.zeros(2, dtype=np.int32)
+        mn, mx = np.zeros(3, dtype=np.float32), np.zeros(3, dtype=np.float32)
+        self.o.L.orc_yaw_info(self.h, _ip(wh), _fp(mn), _fp(mx))
+        return int(wh[0]), int(wh[1]), mn, mx
+
+    def cells(self):
+        w, h, _, _ = self.info()
+        mu, sg, cnt = np.zeros(w * h, dtype=np.float32), np.zeros(w * h, dtype=np.float32), np.zeros(w * h, dtype=np.int32)
+        if w * h:
+            self.o.L.orc_yaw_cells(self.h, _fp(mu), _fp(sg), _ip(cnt))
+        return mu.reshape(w, h), sg.reshape(w, h), cnt.reshape(w, h)
+
+    def yaw(self, scan8):
+        scan8 = np.ascontiguousarray(scan8, dtype=np.float32)
+        probs = np.zeros(270)
+        a = self.o.L.orc_yaw_angle(self.h, scan8.ctypes.data, scan8.shape[0], POINT_STRIDE, _dp(probs))
+        return a, probs
