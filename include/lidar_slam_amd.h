@@ -250,9 +250,13 @@ int lsa_yaw_init_cells(lsa_yaw_init *y, float *mu, float *sigma, int32_t *point_
  *     third-party PCL 1.7 (not in the tree; parity UNPINNED): 1-NN correspondences gated at max_correspond_dis,
  *     SVD (Umeyama) increment, DefaultConvergenceCriteria with euclid_eps / trans_eps (lsa_icp_set_criteria; defaults
  *     0.01 / 0.01 = config/mapping/front_end.yaml:31-35), GetFitnessScore = mean squared nearest-point distance.
- *   mode 1 is reserved for a point-to-plane extension (not in the reference; BASELINE.json config 3) and is rejected.
+ *   LSA_ICP_MODE_PLANE (1) is a build EXTENSION, not reference code (BASELINE.json configs[2] asks for point-to-plane ICP;
+ *     both plugins of the reference are point-to-point): the ICPMANUAL Gauss-Newton skeleton with the residual
+ *     n . (p' - q), pairs gated at distance <= max_correspond_dis, normals = smallest-eigenvalue eigenvector of the
+ *     covariance of the target points in the neighbour's voxel (lsa_icp_set_normal_leaf, default 1.0 m, >= 6 points).
  * ------------------------------------------------------------------------------------------- */
 #define LSA_ICP_MODE_MANUAL 0
+#define LSA_ICP_MODE_PLANE 1
 #define LSA_ICP_MODE_PCL 2
 typedef struct lsa_icp lsa_icp;
 typedef struct {
@@ -265,6 +269,8 @@ int lsa_icp_create(lsa_icp **out, lsa_context *ctx, float max_correspond_dis, in
 /* ICPRegistration::SetRegistrationParam's setEuclideanFitnessEpsilon / setTransformationEpsilon (icp_registration.cpp:30-33) */
 int lsa_icp_set_criteria(lsa_icp *icp, float euclid_eps, float trans_eps);
 int lsa_icp_get_stats(lsa_icp *icp, lsa_icp_stats *stats);
+/* plane mode: edge of the voxels the target normals are estimated in (call before SetInputTarget) */
+int lsa_icp_set_normal_leaf(lsa_icp *icp, float leaf);
 void lsa_icp_destroy(lsa_icp *icp);
 int lsa_icp_set_input_target(lsa_icp *icp, const void *pts, size_t n, size_t stride);
 int lsa_icp_set_input_target_device(lsa_icp *icp, const float *d_xyzw, size_t n);

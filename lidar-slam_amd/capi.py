@@ -26,7 +26,7 @@ class LsaError(RuntimeError):
 
 
 NDT_MODE_MANUAL, NDT_MODE_PCL = 0, 1
-ICP_MODE_MANUAL, ICP_MODE_PCL = 0, 2
+ICP_MODE_MANUAL, ICP_MODE_PLANE, ICP_MODE_PCL = 0, 1, 2
 
 
 class IcpStats(C.Structure):
@@ -124,6 +124,7 @@ def lib():
     L.lsa_icp_scan_match_device.argtypes = [vp, vp, sz, PF, PF]
     L.lsa_icp_get_fitness_score.argtypes = [vp, PF]
     L.lsa_icp_set_criteria.argtypes = [vp, f, f]
+    L.lsa_icp_set_normal_leaf.argtypes = [vp, f]
     L.lsa_yaw_init_create.argtypes = [PVP, vp, C.c_double]
     L.lsa_yaw_init_destroy.argtypes = [vp]
     L.lsa_yaw_init_destroy.restype = None

@@ -21,6 +21,15 @@
 //   MSE change < 1e-12).  One kernel per iteration applies the pending increment, finds the neighbour and reduces the 17
 //   sums the fit needs (n, sum p, sum q, sum q p^T, sum d^2) in f64; the 3x3 SVD runs on the host.
 //   GetFitnessScore = pcl::Registration::getFitnessScore: mean squared distance to the nearest target point.
+//
+// mode 1 (LSA_ICP_MODE_PLANE) is a BUILD EXTENSION, not reference code: BASELINE.json configs[2] asks for point-to-plane
+// ICP while both plugins of the reference are point-to-point.  It keeps the ICPRegistrationManual skeleton (fixed number
+// of Gauss-Newton iterations, f32 pose, t += d[0:3], R *= exp(d[3:6]), skipped when det H == 0) with the scalar residual
+// r = n . (p' - q) and the row J = n^T [I | -R hat(p)]; pairs are gated at squared distance <= max_correspond_dis^2; the
+// normal of a target point is the smallest-eigenvalue eigenvector of the covariance of the target points in its voxel
+// (leaf `normal_leaf`, >= 6 points, the NDT grid's machinery), looked up once per SetInputTarget for every cell-sorted
+// target point.  Its oracle is oracle/icp_oracle.c orc_icp_plane; parity is definable only between the two.
+#include "eig3_dev.h"
 #include "nn_grid_dev.h"
 
 #include <cmath>
@@ -28,6 +37,12 @@
 namespace {
 constexpr int kBlock = 256;
 constexpr int kOut = 32;
+// The neighbour grid's cell is a THIRD of the gate distance and a query may walk kGateRings = 4 rings: a neighbour within
+// the gate lies at most ceil(gate / cell) = 3 rings out (+1 ring of slack for the f32 cell rounding), so the gated
+// answer is exact, while the ring search usually stops after ring 1 or 2 because the best distance is already proven.
+// (With cell = gate, every query scanned 27 cells of ~75 points each: 7 ms per 30-iteration ScanMatch; now ~5x less.)
+constexpr int kGateRings = 4;
+constexpr float kCellPerGate = 1.0f / 3.0f;
 
 struct IcpParams {
   float T[12];   // row-major 3x4 current pose
@@ -47,7 +62,7 @@ __global__ __launch_bounds__(kBlock) void k_icp_pass(const float4 *__restrict__ 
     float qy = lsa_fadd(lsa_fadd(lsa_fadd(lsa_fmul(P.T[4], s.x), lsa_fmul(P.T[5], s.y)), lsa_fmul(P.T[6], s.z)), P.T[7]);
     float qz = lsa_fadd(lsa_fadd(lsa_fadd(lsa_fmul(P.T[8], s.x), lsa_fmul(P.T[9], s.y)), lsa_fmul(P.T[10], s.z)), P.T[11]);
     if (!lsa_finite3(qx, qy, qz)) continue;
-    NNHit hit = nn_nearest(G, qx, qy, qz, /*gate <= cell^2: one ring*/ 1);
+    NNHit hit = nn_nearest(G, qx, qy, qz, kGateRings);
     float best = hit.d2, bx = hit.x, by = hit.y, bz = hit.z;
     unsigned best_id = hit.id;
     if (best_id == 0xffffffffu || best > P.gate) continue;  // :147
@@ -99,6 +114,112 @@ __global__ __launch_bounds__(kBlock) void k_icp_pass(const float4 *__restrict__ 
   }
 }
 
+// ---- point-to-plane extension --------------------------------------------------------------------------------------
+// per occupied voxel of the normal grid: population covariance from the corner-relative fixed-point sums -> Jacobi ->
+// eigenvector of the smallest eigenvalue; w = 1 marks a usable normal (>= 6 points)
+__global__ __launch_bounds__(kBlock) void k_plane_normals(const long long *__restrict__ acc, const int32_t *__restrict__ cnt, size_t nocc, FixScales fs,
+                                                          float4 *__restrict__ normals) {
+  size_t r = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= nocc) return;
+  const long long *a = acc + r * 10;
+  int ni = cnt[r];
+  float4 out = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (ni >= 6) {
+    double n = (double)ni;
+    double md[3] = {((double)a[0] * fs.inv_s1) / n, ((double)a[1] * fs.inv_s1) / n, ((double)a[2] * fs.inv_s1) / n};
+    double c[6];
+    c[0] = (double)a[3] * fs.inv_s2 / n - md[0] * md[0];
+    c[1] = (double)a[4] * fs.inv_s2 / n - md[0] * md[1];
+    c[2] = (double)a[5] * fs.inv_s2 / n - md[0] * md[2];
+    c[3] = (double)a[6] * fs.inv_s2 / n - md[1] * md[1];
+    c[4] = (double)a[7] * fs.inv_s2 / n - md[1] * md[2];
+    c[5] = (double)a[8] * fs.inv_s2 / n - md[2] * md[2];
+    double ev[3], V[3][3];
+    eig3_jacobi(c, ev, V);
+    out = make_float4((float)V[0][0], (float)V[1][0], (float)V[2][0], 1.0f);
+  }
+  normals[r] = out;
+}
+
+// one normal per cell-sorted target point: the voxel of the point in the normal grid -> rank -> normal
+__global__ __launch_bounds__(kBlock) void k_slot_normals(const float4 *__restrict__ sorted, size_t n, CellMap nm, const uint32_t *__restrict__ nbits,
+                                                         const uint32_t *__restrict__ nprefix, const float4 *__restrict__ normals, float4 *__restrict__ slot_normals) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  float4 p = sorted[i];
+  int ijk[3];
+  lsa_cell_ijk(nm, p.x, p.y, p.z, ijk);
+  int cell = lsa_cell_linear(nm, ijk);
+  float4 out = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (cell >= 0) {
+    uint32_t w = nbits[cell >> 5], bit = 1u << (cell & 31);
+    if (w & bit) out = normals[nprefix[cell >> 5] + __popc(w & (bit - 1u))];
+  }
+  slot_normals[i] = out;
+}
+
+// out32: [1..6] B = -sum J r, [7..27] H = sum J^T J upper triangle, [28] #pairs, [29] #finite source points
+__global__ __launch_bounds__(kBlock) void k_plane_pass(const float4 *__restrict__ src, size_t n, IcpParams P, NNView G, const float4 *__restrict__ slot_normals,
+                                                       double *__restrict__ partials) {
+  double acc[27];
+#pragma unroll
+  for (int k = 0; k < 27; k++) acc[k] = 0.0;
+  unsigned ncorr = 0, npts = 0;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    float4 s = src[i];
+    if (!lsa_finite3(s.x, s.y, s.z)) continue;
+    npts++;
+    float qx = lsa_fadd(lsa_fadd(lsa_fadd(lsa_fmul(P.T[0], s.x), lsa_fmul(P.T[1], s.y)), lsa_fmul(P.T[2], s.z)), P.T[3]);
+    float qy = lsa_fadd(lsa_fadd(lsa_fadd(lsa_fmul(P.T[4], s.x), lsa_fmul(P.T[5], s.y)), lsa_fmul(P.T[6], s.z)), P.T[7]);
+    float qz = lsa_fadd(lsa_fadd(lsa_fadd(lsa_fmul(P.T[8], s.x), lsa_fmul(P.T[9], s.y)), lsa_fmul(P.T[10], s.z)), P.T[11]);
+    if (!lsa_finite3(qx, qy, qz)) continue;
+    NNHit hit = nn_nearest(G, qx, qy, qz, kGateRings);
+    if (hit.id == 0xffffffffu || hit.d2 > P.gate) continue;  // P.gate = max_correspond_dis^2 in this mode
+    float4 nv = slot_normals[hit.slot];
+    if (nv.w == 0.0f) continue;
+    ncorr++;
+    float e0 = lsa_fsub(qx, hit.x), e1 = lsa_fsub(qy, hit.y), e2 = lsa_fsub(qz, hit.z);
+    float r = lsa_fadd(lsa_fadd(lsa_fmul(nv.x, e0), lsa_fmul(nv.y, e1)), lsa_fmul(nv.z, e2));
+    float J[6] = {nv.x, nv.y, nv.z, 0.f, 0.f, 0.f};
+    // A = -R * hat(p) in f32 as the manual plugin forms it; J[3 + c] = n . A[:, c]
+    float A[3][3];
+#pragma unroll
+    for (int rr = 0; rr < 3; rr++) {
+      float nr0 = -P.T[rr * 4 + 0], nr1 = -P.T[rr * 4 + 1], nr2 = -P.T[rr * 4 + 2];
+      // row rr of (-R) times hat(p) = [[0,-z,y],[z,0,-x],[-y,x,0]], summed left to right like the oracle
+      A[rr][0] = lsa_fadd(lsa_fadd(lsa_fmul(nr0, 0.0f), lsa_fmul(nr1, s.z)), lsa_fmul(nr2, -s.y));
+      A[rr][1] = lsa_fadd(lsa_fadd(lsa_fmul(nr0, -s.z), lsa_fmul(nr1, 0.0f)), lsa_fmul(nr2, s.x));
+      A[rr][2] = lsa_fadd(lsa_fadd(lsa_fmul(nr0, s.y), lsa_fmul(nr1, -s.x)), lsa_fmul(nr2, 0.0f));
+    }
+#pragma unroll
+    for (int c = 0; c < 3; c++) J[3 + c] = lsa_fadd(lsa_fadd(lsa_fmul(nv.x, A[0][c]), lsa_fmul(nv.y, A[1][c])), lsa_fmul(nv.z, A[2][c]));
+    int k = 6;
+#pragma unroll
+    for (int a = 0; a < 6; a++) {
+      acc[a] -= (double)J[a] * (double)r;
+#pragma unroll
+      for (int b = a; b < 6; b++) acc[k++] += (double)J[a] * (double)J[b];
+    }
+  }
+  __shared__ double sm[kBlock / 64][kOut];
+  int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int k = 0; k < 27; k++) {
+    double v = lsa_wave_sum(acc[k]);
+    if (lane == 0) sm[wave][1 + k] = v;
+  }
+  {
+    double vc = lsa_wave_sum((double)ncorr), vn = lsa_wave_sum((double)npts);
+    if (lane == 0) { sm[wave][0] = 0.0; sm[wave][28] = vc; sm[wave][29] = vn; sm[wave][30] = 0.0; sm[wave][31] = 0.0; }
+  }
+  __syncthreads();
+  if (threadIdx.x < kOut) {
+    double v = 0.0;
+    for (int w = 0; w < kBlock / 64; w++) v += sm[w][threadIdx.x];
+    partials[(size_t)blockIdx.x * kOut + threadIdx.x] = v;
+  }
+}
+
 struct T12 { float v[12]; };
 
 // PCL-mode iteration: work[i] = T * in[i] (the pending increment, f32 like IterativeClosestPoint::transformCloud), then
@@ -119,7 +240,7 @@ __global__ __launch_bounds__(kBlock) void k_pcl_pass(const float4 *__restrict__ 
     work[i] = make_float4(px, py, pz, s.w);
     if (!lsa_finite3(px, py, pz)) continue;
     npts++;
-    NNHit hit = nn_nearest(G, px, py, pz, /*gate <= cell: one ring*/ 1);
+    NNHit hit = nn_nearest(G, px, py, pz, kGateRings);
     if (hit.id == 0xffffffffu || (double)hit.d2 > gate2) continue;  // distance[0] > max_dist_sqr
     ncorr++;
     acc[0] += (double)hit.d2;
@@ -227,6 +348,9 @@ struct lsa_icp {
   int mode = 0;
   float euclid_eps = 0.01f, trans_eps = 0.01f;  // PCL mode (config/mapping/front_end.yaml:31-35)
   NNGrid grid;
+  VoxelIndex vi_n;                                  // plane mode: voxel grid the normals come from
+  DevBuf<float4> cell_normals, slot_normals;        // per occupied voxel / per cell-sorted target point
+  float normal_leaf = 1.0f;
   DevBuf<float4> d_target, d_source_own, d_work;
   DevBuf<double> partials, d_out;
   PinnedBuf<double> h_out;
@@ -264,9 +388,32 @@ int icp_build(lsa_icp *h, const float4 *d_pts, size_t n) {
   h->has_target = false;
   h->has_result = false;
   // manual mode gates the SQUARED distance at max_corr (sic) -> cell sqrt(max_corr); PCL mode gates the distance
-  float cell = (h->mode == LSA_ICP_MODE_PCL) ? h->max_corr : std::sqrt(h->max_corr);
+  float cell = ((h->mode == LSA_ICP_MODE_MANUAL) ? std::sqrt(h->max_corr) : h->max_corr) * kCellPerGate;
   int rc = nn_grid_build(h->ctx, h->grid, d_pts, n, cell, "ICP SetInputTarget");
   if (rc) return rc;
+  if (h->mode == LSA_ICP_MODE_PLANE) {
+    lsa_context *ctx = h->ctx;
+    VoxelIndex &vi = h->vi_n;
+    const float leaf[3] = {h->normal_leaf, h->normal_leaf, h->normal_leaf};
+    int status = VI_OK;
+    for (int attempt = 0; attempt < 2; attempt++) {
+      if ((rc = vi_enqueue(ctx, vi, d_pts, n, /*cells floor(x / leaf)*/ 1, leaf, 10))) return rc;
+      if ((rc = vi_fetch(ctx, vi))) return rc;
+      if ((rc = vi_wait(ctx, vi, &status))) return rc;
+      if (status != VI_CAPACITY) break;
+      if ((rc = vi_grow(ctx, vi))) return rc;
+    }
+    if (status != VI_OK) return lsa_fail(ctx, LSA_ERR_RANGE, "ICP SetInputTarget: normal grid status %d", status);
+    size_t V = vi.nocc;
+    if ((rc = h->cell_normals.reserve(ctx, V + 1, 1.25))) return rc;
+    if ((rc = h->slot_normals.reserve(ctx, n, 1.25))) return rc;
+    hipLaunchKernelGGL(k_plane_normals, dim3(lsa_div_up(V, kBlock)), dim3(kBlock), 0, ctx->stream, vi.acc.p, vi.cnt.p, V, vi.fs, h->cell_normals.p);
+    // non-finite target points are absent from the sorted array; its first start[V_nn] entries are the finite ones
+    hipLaunchKernelGGL(k_slot_normals, dim3(lsa_div_up(n, kBlock)), dim3(kBlock), 0, ctx->stream, h->grid.sorted.p, h->grid.n_sorted, vi.map, vi.bits.p,
+                       vi.prefix.p, h->cell_normals.p, h->slot_normals.p);
+    LSA_HIP(ctx, hipGetLastError());
+    LSA_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  }
   h->n_target = n;
   h->has_target = true;
   return LSA_OK;
@@ -308,8 +455,13 @@ int icp_match_manual(lsa_icp *h, const float4 *d_src, size_t n, const float pred
       for (int c = 0; c < 3; c++) P.T[r * 4 + c] = R[r * 3 + c];
       P.T[r * 4 + 3] = t[r];
     }
-    P.gate = h->max_corr;
-    hipLaunchKernelGGL(k_icp_pass, dim3(g), dim3(kBlock), 0, ctx->stream, d_src, n, P, G, h->partials.p);
+    if (h->mode == LSA_ICP_MODE_PLANE) {
+      P.gate = h->max_corr * h->max_corr;
+      hipLaunchKernelGGL(k_plane_pass, dim3(g), dim3(kBlock), 0, ctx->stream, d_src, n, P, G, h->slot_normals.p, h->partials.p);
+    } else {
+      P.gate = h->max_corr;
+      hipLaunchKernelGGL(k_icp_pass, dim3(g), dim3(kBlock), 0, ctx->stream, d_src, n, P, G, h->partials.p);
+    }
     if ((rc = icp_fetch_sums(h, g))) return rc;
     const double *o = h->h_out.p;
     float H[36], B[6];
@@ -481,7 +633,7 @@ int icp_match_pcl(lsa_icp *h, const float4 *d_src, size_t n, const float predict
 
 int icp_match(lsa_icp *h, const float4 *d_src, size_t n, const float predict[16], float result[16]) {
   if (!h->has_target) return lsa_fail(h->ctx, LSA_ERR_NO_TARGET, "ICP ScanMatch before SetInputTarget");
-  int rc = (h->mode == LSA_ICP_MODE_PCL) ? icp_match_pcl(h, d_src, n, predict, result) : icp_match_manual(h, d_src, n, predict, result);
+  int rc = (h->mode == LSA_ICP_MODE_PCL) ? icp_match_pcl(h, d_src, n, predict, result) : icp_match_manual(h, d_src, n, predict, result);  // manual + plane share the GN loop
   if (rc) return rc;
   h->d_last_src = d_src; h->n_last_src = n;
   memcpy(h->last_T, result, sizeof(h->last_T));
@@ -493,8 +645,8 @@ int icp_match(lsa_icp *h, const float4 *d_src, size_t n, const float predict[16]
 extern "C" int lsa_icp_create(lsa_icp **out, lsa_context *ctx, float max_correspond_dis, int max_iter, int mode) {
   if (!out || !ctx) { lsa_set_global_error("lsa_icp_create: null argument"); return LSA_ERR_INVALID; }
   *out = nullptr;
-  if (mode != LSA_ICP_MODE_MANUAL && mode != LSA_ICP_MODE_PCL)
-    return lsa_fail(ctx, LSA_ERR_INVALID, "lsa_icp_create: mode %d is not available in this build (0 = ICPMANUAL, 2 = ICP / PCL semantics)", mode);
+  if (mode != LSA_ICP_MODE_MANUAL && mode != LSA_ICP_MODE_PCL && mode != LSA_ICP_MODE_PLANE)
+    return lsa_fail(ctx, LSA_ERR_INVALID, "lsa_icp_create: unknown mode %d (0 = ICPMANUAL, 1 = point-to-plane extension, 2 = ICP / PCL semantics)", mode);
   if (!(max_correspond_dis > 0) || max_iter < 0) return lsa_fail(ctx, LSA_ERR_INVALID, "lsa_icp_create: bad parameters");
   lsa_icp *h = new lsa_icp();
   h->ctx = ctx; h->max_corr = max_correspond_dis; h->max_iter = max_iter; h->mode = mode;
@@ -508,6 +660,14 @@ extern "C" int lsa_icp_set_criteria(lsa_icp *h, float euclid_eps, float trans_ep
   return LSA_OK;
 }
 
+extern "C" int lsa_icp_set_normal_leaf(lsa_icp *h, float leaf) {
+  if (!h) return LSA_ERR_INVALID;
+  if (!(leaf > 0)) return lsa_fail(h->ctx, LSA_ERR_INVALID, "lsa_icp_set_normal_leaf: leaf must be > 0");
+  h->normal_leaf = leaf;
+  h->has_target = false;  // the normals belong to the old leaf
+  return LSA_OK;
+}
+
 extern "C" int lsa_icp_get_stats(lsa_icp *h, lsa_icp_stats *st) {
   if (!h || !st) return LSA_ERR_INVALID;
   *st = h->stats;
@@ -518,7 +678,7 @@ extern "C" void lsa_icp_destroy(lsa_icp *h) {
   if (!h) return;
   (void)hipSetDevice(h->ctx->device);
   (void)hipStreamSynchronize(h->ctx->stream);
-  h->grid.release(); h->d_target.release(); h->d_source_own.release(); h->d_work.release();
+  h->grid.release(); h->vi_n.release(); h->cell_normals.release(); h->slot_normals.release(); h->d_target.release(); h->d_source_own.release(); h->d_work.release();
   h->partials.release(); h->d_out.release(); h->h_out.release(); h->h_stage.release();
   delete h;
 }

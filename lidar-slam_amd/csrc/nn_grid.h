@@ -18,7 +18,8 @@ struct NNGrid {
   DevBuf<float4> sorted;
   DevBuf<double> fit_partials;   // nn_fitness: per-workgroup {sum d2, count}
   PinnedBuf<double> fit_host;
-  size_t n = 0;
+  size_t n = 0;         // points handed to the build
+  size_t n_sorted = 0;  // finite points = entries of sorted[]
   float cell = 0;
   bool built = false;
   void release() { vi.release(); cnt.release(); start.release(); fill.release(); sorted.release(); fit_partials.release(); fit_host.release(); n = 0; built = false; }

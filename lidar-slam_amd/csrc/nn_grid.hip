@@ -134,6 +134,7 @@ int nn_grid_build(lsa_context *ctx, NNGrid &g, const float4 *d_pts, size_t n, fl
   LSA_HIP(ctx, hipGetLastError());
   LSA_HIP(ctx, hipStreamSynchronize(ctx->stream));
   g.n = n;
+  g.n_sorted = (size_t)vi.h_params.p[0].n_finite;
   g.cell = cell;
   g.built = true;
   return LSA_OK;

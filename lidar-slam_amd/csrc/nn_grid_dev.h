@@ -9,6 +9,7 @@ struct NNHit {
   float d2;       // f32 squared distance, +inf when nothing was found
   unsigned id;    // original index of the neighbour, 0xffffffff when nothing was found
   float x, y, z;  // the neighbour
+  unsigned slot;  // its position in the cell-sorted array (index of per-slot side tables)
 };
 
 __device__ __forceinline__ void nn_visit_cell(const NNView &g, int ix, int iy, int iz, float qx, float qy, float qz, NNHit &h) {
@@ -23,7 +24,7 @@ __device__ __forceinline__ void nn_visit_cell(const NNView &g, int ix, int iy, i
     float ex = lsa_fsub(qx, t.x), ey = lsa_fsub(qy, t.y), ez = lsa_fsub(qz, t.z);
     float d = lsa_fadd(lsa_fadd(lsa_fmul(ex, ex), lsa_fmul(ey, ey)), lsa_fmul(ez, ez));  // FLANN L2_Simple, f32
     unsigned id = __float_as_uint(t.w);
-    if (d < h.d2 || (d == h.d2 && id < h.id)) { h.d2 = d; h.id = id; h.x = t.x; h.y = t.y; h.z = t.z; }
+    if (d < h.d2 || (d == h.d2 && id < h.id)) { h.d2 = d; h.id = id; h.x = t.x; h.y = t.y; h.z = t.z; h.slot = k; }
   }
 }
 
@@ -34,7 +35,7 @@ __device__ __forceinline__ void nn_visit_cell(const NNView &g, int ix, int iy, i
 __device__ __forceinline__ NNHit nn_nearest(const NNView &g, float qx, float qy, float qz, int max_ring) {
   const CellMap &m = g.map;
   NNHit h;
-  h.d2 = INFINITY; h.id = 0xffffffffu; h.x = h.y = h.z = 0.0f;
+  h.d2 = INFINITY; h.id = 0xffffffffu; h.x = h.y = h.z = 0.0f; h.slot = 0u;
   // unclamped cell coordinates relative to the grid corner (mode-1 rule: floor(x / leaf) - min_b), saturated so that
   // the ring arithmetic cannot overflow
   float fx = floorf(lsa_fdiv(qx, m.leaf[0])), fy = floorf(lsa_fdiv(qy, m.leaf[1])), fz = floorf(lsa_fdiv(qz, m.leaf[2]));

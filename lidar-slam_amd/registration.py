@@ -145,7 +145,7 @@ class ICPRegistrationHip(RegistrationInterface):
     """ICPRegistrationManual(max_correspond_dis, max_iter) or (node) with the YAML keys of
     config/mapping/front_end.yaml:37-39 (reference: src/models/registration/icp_registration_manual.cpp:12-67)."""
 
-    def __init__(self, ctx, max_correspond_dis=2.0, max_iter=30, node=None, mode=0, euclid_eps=0.01, trans_eps=0.01):
+    def __init__(self, ctx, max_correspond_dis=2.0, max_iter=30, node=None, mode=0, euclid_eps=0.01, trans_eps=0.01, normal_leaf=1.0):
         """mode 0 = ICPRegistrationManual; mode capi.ICP_MODE_PCL = ICPRegistration(euclid_eps, max_correspond_dis,
         trans_eps, max_iter) (icp_registration.cpp:20-33; YAML node 'ICP', config/mapping/front_end.yaml:31-35)."""
         if node is not None:
@@ -157,6 +157,8 @@ class ICPRegistrationHip(RegistrationInterface):
         ctx.check(capi.lib().lsa_icp_create(C.byref(h), ctx.h, max_correspond_dis, max_iter, mode))
         self.h = h
         ctx.check(capi.lib().lsa_icp_set_criteria(h, euclid_eps, trans_eps))
+        if mode == capi.ICP_MODE_PLANE:  # build extension (BASELINE.json configs[2]); not a reference plugin
+            ctx.check(capi.lib().lsa_icp_set_normal_leaf(h, normal_leaf))
         self._keep = None
         self._src_keep = None
 

@@ -174,3 +174,139 @@ int orc_icp_manual(const void *tgt, size_t nt, size_t tstride, const void *src, 
   memcpy(out_pose, T, sizeof(T));
   return 0;
 }
+
+/* ======================================================================================================================
+ * Point-to-plane ICP — a BUILD EXTENSION, not reference code: BASELINE.json configs[2] asks for "point-to-plane ICP" but
+ * both ICP plugins of the reference are point-to-point (SURVEY.md 8a note).  It reuses the ICPRegistrationManual skeleton
+ * above (fixed max_iter Gauss-Newton iterations, f32 pose, t += d[0:3], R *= exp(d[3:6]), skip when det H == 0) with the
+ * scalar residual r = n . (p' - q) and the row J = n^T [I | -R hat(p)].  Defined here and in csrc/icp.hip identically:
+ *   - correspondence: exact 1-NN in the target, kept when the squared distance <= max_correspond_dis^2;
+ *   - normal of a target point = eigenvector of the smallest eigenvalue of the population covariance of the target
+ *     points in its voxel (cells floor(x / normal_leaf)), voxels with fewer than 6 points give no normal (pair dropped);
+ *   - J and r are formed in f32, the normal equations are accumulated in f64, the 6x6 solve is the manual plugin's f32 LU.
+ * Parity for this mode is only definable between these two restatements.
+ * ==================================================================================================================== */
+void orc_eig3_jacobi(const double a[9], double evals[3], double evecs[9]);
+
+typedef struct { int lo[3], dim[3]; float leaf; float *normal; /* 4 per cell: nx, ny, nz, valid */ } normal_grid;
+
+static int ng_cell(const normal_grid *g, const float *p) {
+  int c[3];
+  for (int a = 0; a < 3; a++) {
+    c[a] = (int)floorf(p[a] / g->leaf) - g->lo[a];
+    if (c[a] < 0 || c[a] >= g->dim[a]) return -1;
+  }
+  return c[0] + c[1] * g->dim[0] + c[2] * g->dim[0] * g->dim[1];
+}
+
+static normal_grid *ng_build(const void *pts, size_t n, size_t stride, float leaf) {
+  normal_grid *g = (normal_grid *)calloc(1, sizeof(normal_grid));
+  g->leaf = leaf;
+  int mn[3] = {2147483647, 2147483647, 2147483647}, mx[3] = {-2147483647, -2147483647, -2147483647};
+  size_t nf = 0;
+  for (size_t i = 0; i < n; i++) {
+    const float *p = P(pts, stride, i);
+    if (!isfinite(p[0]) || !isfinite(p[1]) || !isfinite(p[2])) continue;
+    nf++;
+    for (int a = 0; a < 3; a++) { int c = (int)floorf(p[a] / leaf); if (c < mn[a]) mn[a] = c; if (c > mx[a]) mx[a] = c; }
+  }
+  if (!nf) { g->dim[0] = g->dim[1] = g->dim[2] = 0; return g; }
+  for (int a = 0; a < 3; a++) { g->lo[a] = mn[a]; g->dim[a] = mx[a] - mn[a] + 1; }
+  size_t nc = (size_t)g->dim[0] * g->dim[1] * g->dim[2];
+  double *sum = (double *)calloc(nc * 9, sizeof(double)); /* sx sy sz sxx sxy sxz syy syz szz, about the cell corner */
+  int *cnt = (int *)calloc(nc, sizeof(int));
+  g->normal = (float *)calloc(nc * 4, sizeof(float));
+  for (size_t i = 0; i < n; i++) {
+    const float *p = P(pts, stride, i);
+    if (!isfinite(p[0]) || !isfinite(p[1]) || !isfinite(p[2])) continue;
+    int c = ng_cell(g, p);
+    int ci[3] = {c % g->dim[0], (c / g->dim[0]) % g->dim[1], c / (g->dim[0] * g->dim[1])};
+    double d[3];
+    for (int a = 0; a < 3; a++) d[a] = (double)p[a] - (double)(ci[a] + g->lo[a]) * (double)leaf;
+    double *s = sum + (size_t)c * 9;
+    s[0] += d[0]; s[1] += d[1]; s[2] += d[2];
+    s[3] += d[0] * d[0]; s[4] += d[0] * d[1]; s[5] += d[0] * d[2]; s[6] += d[1] * d[1]; s[7] += d[1] * d[2]; s[8] += d[2] * d[2];
+    cnt[c]++;
+  }
+  for (size_t c = 0; c < nc; c++) {
+    if (cnt[c] < 6) continue;
+    double m = (double)cnt[c];
+    const double *s = sum + c * 9;
+    double mu[3] = {s[0] / m, s[1] / m, s[2] / m};
+    double C[9] = {s[3] / m - mu[0] * mu[0], s[4] / m - mu[0] * mu[1], s[5] / m - mu[0] * mu[2],
+                   0, s[6] / m - mu[1] * mu[1], s[7] / m - mu[1] * mu[2], 0, 0, s[8] / m - mu[2] * mu[2]};
+    C[3] = C[1]; C[6] = C[2]; C[7] = C[5];
+    double ev[3], V[9];
+    orc_eig3_jacobi(C, ev, V);
+    g->normal[c * 4] = (float)V[0]; g->normal[c * 4 + 1] = (float)V[3]; g->normal[c * 4 + 2] = (float)V[6]; /* column 0 */
+    g->normal[c * 4 + 3] = 1.0f;
+  }
+  free(sum); free(cnt);
+  return g;
+}
+
+static void ng_free(normal_grid *g) { if (g) { free(g->normal); free(g); } }
+
+int orc_icp_plane(const void *tgt, size_t nt, size_t tstride, const void *src, size_t ns, size_t sstride,
+                  float max_correspond_dis, int max_iter, float normal_leaf, const float guess[16], float out_pose[16], double stats[2]) {
+  float T[16];
+  memcpy(T, guess, sizeof(T));
+  float R[9], t[3];
+  for (int r = 0; r < 3; r++) { for (int c = 0; c < 3; c++) R[r * 3 + c] = T[c * 4 + r]; t[r] = T[12 + r]; }
+  float cell = max_correspond_dis > 0.05f ? max_correspond_dis : 0.05f;
+  nn_grid *g = nt ? nn_build(tgt, nt, tstride, cell) : NULL;
+  normal_grid *ng = ng_build(tgt, nt, tstride, normal_leaf);
+  float gate = max_correspond_dis * max_correspond_dis;
+  double ncorr = 0;
+  for (int it = 0; it < max_iter; it++) {
+    double Hd[36], Bd[6];
+    memset(Hd, 0, sizeof(Hd)); memset(Bd, 0, sizeof(Bd));
+    ncorr = 0;
+    for (size_t i = 0; i < ns; i++) {
+      const float *p = P(src, sstride, i);
+      if (!isfinite(p[0]) || !isfinite(p[1]) || !isfinite(p[2])) continue;
+      float q[3];
+      orc_transform_point(T, p, q);
+      if (!isfinite(q[0]) || !isfinite(q[1]) || !isfinite(q[2])) continue;
+      float sqd;
+      int id = g ? nn_query(g, q, gate, &sqd) : -1;
+      if (id < 0) continue;
+      const float *c = P(tgt, tstride, (size_t)id);
+      int nc = ng_cell(ng, c);
+      if (nc < 0 || ng->normal[(size_t)nc * 4 + 3] == 0.0f) continue;
+      const float *nv = ng->normal + (size_t)nc * 4;
+      float e[3] = {q[0] - c[0], q[1] - c[1], q[2] - c[2]};
+      float r = (nv[0] * e[0] + nv[1] * e[1]) + nv[2] * e[2];
+      float hat[9] = {0, -p[2], p[1], p[2], 0, -p[0], -p[1], p[0], 0};
+      float A[3][3];
+      for (int rr = 0; rr < 3; rr++)
+        for (int cc = 0; cc < 3; cc++)
+          A[rr][cc] = ((-R[rr * 3 + 0]) * hat[0 * 3 + cc] + (-R[rr * 3 + 1]) * hat[1 * 3 + cc]) + (-R[rr * 3 + 2]) * hat[2 * 3 + cc];
+      float J[6] = {nv[0], nv[1], nv[2], 0, 0, 0};
+      for (int cc = 0; cc < 3; cc++) J[3 + cc] = (nv[0] * A[0][cc] + nv[1] * A[1][cc]) + nv[2] * A[2][cc];
+      for (int a = 0; a < 6; a++) {
+        for (int b = 0; b < 6; b++) Hd[a * 6 + b] += (double)J[a] * (double)J[b];
+        Bd[a] -= (double)J[a] * (double)r;
+      }
+      ncorr += 1;
+    }
+    float H[36], B[6], Hi[36];
+    for (int k = 0; k < 36; k++) H[k] = (float)Hd[k];
+    for (int k = 0; k < 6; k++) B[k] = (float)Bd[k];
+    float det = lu6_inverse(H, Hi);
+    if (det == 0.0f) continue;
+    float d[6];
+    for (int a = 0; a < 6; a++) { float s = 0; for (int b = 0; b < 6; b++) s += Hi[a * 6 + b] * B[b]; d[a] = s; }
+    t[0] += d[0]; t[1] += d[1]; t[2] += d[2];
+    float dR[9], Rn[9];
+    so3_exp_f32(d + 3, dR);
+    for (int r2 = 0; r2 < 3; r2++) for (int c2 = 0; c2 < 3; c2++)
+      Rn[r2 * 3 + c2] = (R[r2 * 3 + 0] * dR[0 * 3 + c2] + R[r2 * 3 + 1] * dR[1 * 3 + c2]) + R[r2 * 3 + 2] * dR[2 * 3 + c2];
+    memcpy(R, Rn, sizeof(R));
+    for (int r2 = 0; r2 < 3; r2++) { for (int c2 = 0; c2 < 3; c2++) T[c2 * 4 + r2] = R[r2 * 3 + c2]; T[12 + r2] = t[r2]; }
+  }
+  nn_free(g); ng_free(ng);
+  memcpy(out_pose, T, sizeof(T));
+  if (stats) { stats[0] = max_iter; stats[1] = ncorr; }
+  return 0;
+}

@@ -143,6 +143,12 @@ int orc_box_filter(const void *pts, size_t n, size_t stride, size_t w_off, const
 int orc_icp_manual(const void *tgt, size_t nt, size_t tstride, const void *src, size_t ns, size_t sstride,
                    float max_correspond_dis, int max_iter, const float guess[16], float out_pose[16]);
 
+/* Point-to-plane ICP: build extension (BASELINE.json configs[2]; not in the reference), defined in icp_oracle.c.
+ * stats: [iterations, correspondences of the last iteration] */
+int orc_icp_plane(const void *tgt, size_t nt, size_t tstride, const void *src, size_t ns, size_t sstride,
+                  float max_correspond_dis, int max_iter, float normal_leaf, const float guess[16], float out_pose[16],
+                  double stats[2]);
+
 /* ---- Matching's position-only initialisation (yaw_oracle.c; S/matching/matching.cpp:267-307,344-422; restated, UNPINNED) */
 typedef struct orc_yaw orc_yaw;
 /* generateGauss2DMapCells over (map - origin); grid_resolution as in the YAML (clamped to >= 0.1, :137-138) */

@@ -118,6 +118,8 @@ class Oracle:
         L.orc_icp_manual.argtypes = [vp, sz, sz, vp, sz, sz, f, i, PF, PF]
         L.orc_icp_manual.restype = i
         L.orc_ndt_set_mode.argtypes = [vp, i]
+        L.orc_icp_plane.argtypes = [vp, sz, sz, vp, sz, sz, f, i, f, PF, PF, PD]
+        L.orc_icp_plane.restype = i
         L.orc_yaw_build.argtypes = [vp, sz, sz, PF, d]
         L.orc_yaw_build.restype = vp
         L.orc_yaw_free.argtypes = [vp]
@@ -391,3 +393,16 @@ class OracleYawInit:
         probs = np.zeros(270)
         a = self.o.L.orc_yaw_angle(self.h, scan8.ctypes.data, scan8.shape[0], POINT_STRIDE, _dp(probs))
         return a, probs
+
+
+def icp_plane(tgt8, src8, guess, max_correspond_dis=2.0, max_iter=30, normal_leaf=1.0):
+    """Point-to-plane ICP (build extension, BASELINE.json configs[2]). Returns (T, #correspondences of the last iteration)."""
+    o = Oracle()
+    tgt8 = np.ascontiguousarray(tgt8, dtype=np.float32)
+    src8 = np.ascontiguousarray(src8, dtype=np.float32)
+    out = np.zeros(16, dtype=np.float32)
+    st = np.zeros(2)
+    rc = o.L.orc_icp_plane(tgt8.ctypes.data, tgt8.shape[0], POINT_STRIDE, src8.ctypes.data, src8.shape[0], POINT_STRIDE,
+                           max_correspond_dis, max_iter, normal_leaf, _fp(_colmajor(guess)), _fp(out), _dp(st))
+    assert rc == 0
+    return out.reshape(4, 4).T.copy(), int(st[1])

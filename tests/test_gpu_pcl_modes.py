@@ -152,4 +152,23 @@ def test_icp_pcl_too_few_correspondences(ctx, clouds):
     assert st["converged"] == 0 and st["iterations"] == 0
     icp.close()
     with pytest.raises(RuntimeError):
-        registration.ICPRegistrationHip(ctx, 2.0, 30, mode=1)   # point-to-plane: not in the reference, not built
+        registration.ICPRegistrationHip(ctx, 2.0, 30, mode=7)   # unknown mode
+
+
+def test_icp_point_to_plane_extension(ctx, clouds, scan_pair):
+    """BASELINE.json configs[2] (point-to-plane ICP) is a build extension: no reference plugin does it, so parity is
+    between csrc/icp.hip and oracle/icp_oracle.c orc_icp_plane only; the truth check shows it is the better estimator."""
+    import oracle_py
+    tgt, src, T1 = clouds
+    guess = np.eye(4, dtype=np.float32)
+    for iters in (1, 5, 30):
+        Tr, ncorr_r = oracle_py.icp_plane(tgt, src, guess, 2.0, iters, 1.0)
+        icp = registration.ICPRegistrationHip(ctx, 2.0, iters, mode=capi.ICP_MODE_PLANE, normal_leaf=1.0)
+        icp.SetInputTarget(tgt)
+        _, T = icp.ScanMatch(src, guess)
+        st = icp.last_stats
+        assert st["correspondences"] == ncorr_r, (st, ncorr_r)
+        assert np.linalg.norm(T[:3, 3] - Tr[:3, 3]) <= 1e-4 and rot_angle(T, Tr) <= 1e-5, (T, Tr)
+        icp.close()
+    p2p = oracle_py.icp_manual(tgt, src, guess)
+    assert np.linalg.norm(T[:3, 3] - T1[:3, 3]) < 0.5 * np.linalg.norm(p2p[:3, 3] - T1[:3, 3])   # 3 cm vs 10 cm on this pair
