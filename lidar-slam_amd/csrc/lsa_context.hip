@@ -1,6 +1,8 @@
 // lsa_context.hip — context lifecycle, error text, host-side packing helpers.
 #include "lsa_common.h"
 
+#include <mutex>
+
 #include <cstdlib>
 
 static thread_local std::string g_global_err;
@@ -20,8 +22,13 @@ int lsa_fail(lsa_context *ctx, int code, const char *fmt, ...) {
   va_start(ap, fmt);
   vsnprintf(buf, sizeof(buf), fmt, ap);
   va_end(ap);
-  if (ctx) ctx->err = buf;
-  g_global_err = buf;
+  {
+    // the async frame filter reports failures from its helper thread: serialise the two string assignments
+    static std::mutex mu;
+    std::lock_guard<std::mutex> lock(mu);
+    if (ctx) ctx->err = buf;
+    g_global_err = buf;
+  }
   return code;
 }
 

@@ -122,6 +122,65 @@ class VoxelFilterHip : public CloudFilterInterface {
   int status_ = LSA_OK;
 };
 
+// BoxFilter(YAML::Node node) with node["box_filter_size"] = [min_x, max_x, min_y, max_y, min_z, max_z] (box_filter.cpp:14-73)
+class BoxFilterHip : public CloudFilterInterface {
+ public:
+  BoxFilterHip(const std::shared_ptr<Context> &ctx, const std::vector<float> &box_filter_size) : ctx_(ctx) {
+    if (box_filter_size.size() != 6) throw std::invalid_argument("box_filter_size needs 6 values");
+    report("lsa_box_filter_create", ctx_->get(), lsa_box_filter_create(&f_, ctx_->get(), box_filter_size.data()));
+  }
+  ~BoxFilterHip() override { lsa_box_filter_destroy(f_); }
+  bool Filter(const CloudData::CLOUD_PTR &in, CloudData::CLOUD_PTR &out) override {  // :27-37 (clears, then fills the output)
+    std::vector<PointXYZI> tmp(in->points.size());
+    size_t n_out = 0;
+    status_ = lsa_box_filter_apply(f_, in->points.data(), in->points.size(), sizeof(PointXYZI), LSA_POINTXYZI_W_OFF, tmp.data(), tmp.size(),
+                                   sizeof(PointXYZI), LSA_POINTXYZI_W_OFF, &n_out);
+    if (status_ != LSA_OK) return report("BoxFilterHip::Filter", ctx_->get(), status_);
+    tmp.resize(n_out);
+    out->points.swap(tmp);
+    return true;
+  }
+  void SetSize(const std::vector<float> &size) { if (size.size() == 6) status_ = lsa_box_filter_set_size(f_, size.data()); }      // :39-54
+  void SetOrigin(const std::vector<float> &origin) { if (origin.size() == 3) status_ = lsa_box_filter_set_origin(f_, origin.data()); }  // :56-60
+  std::vector<float> GetEdge() {                                                                                                  // :70-73
+    std::vector<float> e(6);
+    status_ = lsa_box_filter_get_edge(f_, e.data());
+    return e;
+  }
+  int last_status() const { return status_; }
+
+ private:
+  std::shared_ptr<Context> ctx_;
+  lsa_box_filter *f_ = nullptr;
+  int status_ = LSA_OK;
+};
+
+// Matching's position-only initialisation (matching.cpp:267-307, 344-422): generateGauss2DMapCells + getInitialYawAngle
+class YawInitHip {
+ public:
+  YawInitHip(const std::shared_ptr<Context> &ctx, double grid_resolution = 0.8) : ctx_(ctx) {
+    report("lsa_yaw_init_create", ctx_->get(), lsa_yaw_init_create(&y_, ctx_->get(), grid_resolution));
+  }
+  ~YawInitHip() { lsa_yaw_init_destroy(y_); }
+  bool SetLocalMap(const CloudData::CLOUD_PTR &local_map, float x, float y, float z) {   // ResetLocalMap(x, y, z) + SetInitPose
+    const float origin[3] = {x, y, z};
+    status_ = lsa_yaw_init_set_local_map(y_, local_map->points.data(), local_map->points.size(), sizeof(PointXYZI), origin);
+    return report("YawInitHip::SetLocalMap", ctx_->get(), status_);
+  }
+  double getInitialYawAngle(const CloudData::CLOUD_PTR &current_cloud) {
+    double yaw = 0.0;
+    status_ = lsa_yaw_init_get_initial_yaw(y_, current_cloud->points.data(), current_cloud->points.size(), sizeof(PointXYZI), &yaw, nullptr);
+    report("YawInitHip::getInitialYawAngle", ctx_->get(), status_);
+    return yaw;
+  }
+  int last_status() const { return status_; }
+
+ private:
+  std::shared_ptr<Context> ctx_;
+  lsa_yaw_init *y_ = nullptr;
+  int status_ = LSA_OK;
+};
+
 // ---------------------------------------------------------------------------------------------- registration
 class RegistrationInterface {
  public:

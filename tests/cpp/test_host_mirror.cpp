@@ -168,6 +168,34 @@ int main() {
     std::printf("icp(pcl): %d iterations, x = %.4f, |dt| %.2e |dR| %.2e vs oracle, fitness %.6f\n", st.iterations, pip(0, 3), dt, dr, ifit);
   }
 
+  // ---- BoxFilter + position-only initialisation (Matching's helpers) against their oracles
+  {
+    std::vector<float> size = {-30.f, 30.f, -10.f, 12.f, -2.f, 1.f}, origin = {2.5f, -1.f, 0.25f};
+    BoxFilterHip box(ctx, size);
+    box.SetOrigin(origin);
+    std::vector<float> edge = box.GetEdge();
+    CHECK(edge[0] == size[0] + origin[0] && edge[5] == size[5] + origin[2], "BoxFilter edge = size + origin");
+    CloudData::CLOUD_PTR cropped(new Cloud());
+    box.Filter(scan0, cropped);
+    std::vector<float> oc(scan0->size() * 4);
+    size_t on = 0;
+    orc_box_filter(scan0->points.data(), scan0->size(), 32, 16, size.data(), origin.data(), oc.data(), scan0->size(), &on);
+    CHECK(cropped->size() == on && on > 0 && on < scan0->size(), "BoxFilter kept %zu, oracle %zu", cropped->size(), on);
+    bool same = cropped->size() == on;
+    for (size_t i = 0; same && i < on; i++) same = cropped->points[i].x == oc[4 * i] && cropped->points[i].y == oc[4 * i + 1] && cropped->points[i].z == oc[4 * i + 2];
+    CHECK(same, "BoxFilter output differs from the oracle");
+
+    YawInitHip yi(ctx, 0.8);
+    yi.SetLocalMap(map, 0.f, 0.f, 0.f);
+    double yaw = yi.getInitialYawAngle(scan1);
+    const float zero[3] = {0.f, 0.f, 0.f};
+    orc_yaw *oy = orc_yaw_build(map->points.data(), map->size(), 32, zero, 0.8);
+    double oyaw = orc_yaw_angle(oy, scan1->points.data(), scan1->size(), 32, nullptr);
+    orc_yaw_free(oy);
+    CHECK(yaw == oyaw, "initial yaw %g vs oracle %g", yaw, oyaw);
+    std::printf("box filter: %zu -> %zu points; initial yaw %.4f rad (oracle %.4f)\n", scan0->size(), cropped->size(), yaw, oyaw);
+  }
+
   std::printf(g_fail ? "FAILED (%d)\n" : "ALL OK\n", g_fail);
   return g_fail ? 1 : 0;
 }
