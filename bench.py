@@ -276,11 +276,20 @@ def main():
         # PCIe-inclusive rate through the host-pointer boundary (what a PCL caller sees): pack 32-B PointXYZI -> 16 B,
         # H2D, filter, D2H, H2D, align.  Reported for DESIGN.md; it is never the headline `value`.
         raw8 = synth.to_xyzi32(scans[TEST_SCANS[k]])
-        t0 = time.perf_counter()
-        for _ in range(20):
+        _, f8 = frame_filter.Filter(raw8)      # untimed: first use of the host path allocates its pinned staging buffers
+        ndt.ScanMatch(f8, guesses[k])
+        tf_, ta_ = [], []
+        for _ in range(30):
+            t0 = time.perf_counter()
             _, f8 = frame_filter.Filter(raw8)
+            t1 = time.perf_counter()
             ndt.ScanMatch(f8, guesses[k])
-        split["host_boundary_ms_per_scan"] = (time.perf_counter() - t0) * 1e3 / 20
+            tf_.append(t1 - t0)
+            ta_.append(time.perf_counter() - t1)
+        # medians: the first calls through the host path still pay one-off runtime set-up (copy queues, staging buffers)
+        split["host_boundary_filter_ms"] = float(np.median(tf_)) * 1e3
+        split["host_boundary_align_ms"] = float(np.median(ta_)) * 1e3
+        split["host_boundary_ms_per_scan"] = split["host_boundary_filter_ms"] + split["host_boundary_align_ms"]
         ndt.set_source(f)
         L = capi.lib()
         p = np.zeros(6)

@@ -100,6 +100,7 @@ extern "C" void lsa_ndt_destroy(lsa_ndt *h) {
   ndt_fitness_release(h);
   h->nn.release();
   h->vi.release(); h->d_target.release(); h->rec.release(); h->state.release(); h->vbits.release(); h->words.release(); h->d_small.release();
+  h->dense.release();
   h->d_source_own.release(); h->h_stage.release(); h->partials.release(); h->d_out.release(); h->h_out.release(); h->h_partials.release();
   delete h;
 }

@@ -35,9 +35,15 @@ constexpr int pass_waves(int kind) { return kind == 1 ? LSA_PASS_WAVES_GRAD : LS
 
 template <int KIND>
 __device__ __forceinline__ void pair_update(const PassParams &P, const double *__restrict__ R, float tx, float ty, float tz,
-                                            const double pg[8], const double *ph /* LDS, read at the point of use */, double acc[28]) {
-  // R: centroid(3), C = icov (xx,xy,xz,yy,yz,zz), w.  The radius test (VoxelGrid.cpp:470-472) was done by the probe phase.
+                                            const double pg[8], const double *ph /* LDS, read at the point of use */, double acc[28],
+                                            unsigned &accepted) {
+  // R: centroid(3), C = icov (xx,xy,xz,yy,yz,zz), w.
   double d0 = (double)tx - R[0], d1 = (double)ty - R[1], d2 = (double)tz - R[2];  // x_trans - centroid (:434)
+  // the exact radius test of radiusSearch (VoxelGrid.cpp:470-472), on the squared f64 distance against the host-computed
+  // threshold.  The dense-table probe only pre-filters in f32 with a safety margin; the bitmap probe has already applied
+  // this very test, for which it is a no-op.
+  if (!(d0 * d0 + d1 * d1 + d2 * d2 <= P.r2max)) return;
+  accepted++;
   double C00 = R[3], C01 = R[4], C02 = R[5], C11 = R[6], C12 = R[7], C22 = R[8];
   double u0 = C00 * d0 + C01 * d1 + C02 * d2;
   double u1 = C01 * d0 + C11 * d1 + C12 * d2;
@@ -132,11 +138,12 @@ struct TilePoint {
   float tx, ty, tz;  // transformed point
   int cell0;         // linear index of the box's low corner
   int nxyz;          // box extent packed nx | ny << 8 | nz << 16 (0 = point contributes nothing)
+  float rx, ry, rz;  // transformed point relative to the low corner of the box's first cell (f32; dense-table pre-filter)
 };
 
 // per-wave LDS slice
 constexpr int kLdsTp = 0;
-constexpr int kLdsTerms = 512;                                                           // 16 * 20 B, rounded up
+constexpr int kLdsTerms = 512;                                                           // 16 * 32 B
 constexpr int kLdsCand = kLdsTerms + kTilePts * kTermStride * 8;                         // + 3072
 constexpr int kLdsQueue = kLdsCand + kQueueCap * 4;                                      // + 1728
 constexpr int kLdsSlice = ((kLdsQueue + kQueueCap * 4 + 255) / 256) * 256;               // 7168
@@ -168,9 +175,15 @@ __device__ __forceinline__ unsigned wave_excl_scan(unsigned cnt, int lane, unsig
   return incl - cnt;
 }
 
-template <int KIND>
+// DENSE: the probe reads a dense per-cell table {centroid - cell corner (f32 x 3), record rank or -1} (16 B per cell,
+// built when the cell box is small enough, ndt_grid.hip) instead of the bitmap words: one 48-B row load answers "valid?",
+// "which record?" and "roughly how far?" for 3 cells, so the candidate stage (A2: a dependent centroid load from the
+// record table + a second compaction) disappears; the f32 distance is only a pre-filter with a safety margin, the exact
+// f64 test runs in the pair step on the record's centroid it loads anyway.  ~20 % fewer instructions per tile and one
+// L2 round trip less on the critical path.  The bitmap path stays for cell boxes too large for a dense table.
+template <int KIND, bool DENSE>
 __global__ __launch_bounds__(kBlockD, pass_waves(KIND)) void k_ndt_pass(const float4 *__restrict__ src, size_t n, PassParams P, const uint4 *__restrict__ words,
-                                                      const double *__restrict__ rec, double *__restrict__ partials) {
+                                                      const float4 *__restrict__ dense, const double *__restrict__ rec, double *__restrict__ partials) {
   __shared__ __align__(16) unsigned char lds[kLdsBytes];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   unsigned char *slice = lds + wave * kLdsSlice;
@@ -181,7 +194,8 @@ __global__ __launch_bounds__(kBlockD, pass_waves(KIND)) void k_ndt_pass(const fl
   double acc[28];
 #pragma unroll
   for (int k = 0; k < 28; k++) acc[k] = 0.0;
-  unsigned long long pairs = 0, npts = 0;  // wave totals (meaningful in lane 0)
+  unsigned long long npts = 0;  // wave total (meaningful in lane 0)
+  unsigned accepted = 0;        // (point, voxel) pairs this lane accepted
   const int ppl = lane & (kTilePts - 1), part4 = lane / kTilePts;  // phase 0: 4 lanes per point
   const int dimx = P.dim[0], dimxy = P.dim[0] * P.dim[1];
   const size_t ntiles = (n + kTilePts - 1) / kTilePts;
@@ -207,7 +221,7 @@ __global__ __launch_bounds__(kBlockD, pass_waves(KIND)) void k_ndt_pass(const fl
       if (inext < n) s_next = src[inext];
       if (part4 == 0) {
         TilePoint t;
-        t.nxyz = 0; t.cell0 = 0; t.tx = t.ty = t.tz = 0.f;
+        t.nxyz = 0; t.cell0 = 0; t.tx = t.ty = t.tz = 0.f; t.rx = t.ry = t.rz = 0.f;
         if (i < n) {
           // pcl::transformPointCloud: x' = m00*x + m01*y + m02*z + m03, f32, left to right, no FMA
           float tx = lsa_fadd(lsa_fadd(lsa_fadd(lsa_fmul(P.T[0], s.x), lsa_fmul(P.T[1], s.y)), lsa_fmul(P.T[2], s.z)), P.T[3]);
@@ -237,6 +251,9 @@ __global__ __launch_bounds__(kBlockD, pass_waves(KIND)) void k_ndt_pass(const fl
             if (nx > 0 && ny > 0 && nz > 0) {
               t.cell0 = lx + ly * dimx + lz * dimxy;
               t.nxyz = nx | (ny << 8) | (nz << 16);
+              if (DENSE) {
+                t.rx = tx - (float)(lx + P.min_b[0]) * r; t.ry = ty - (float)(ly + P.min_b[1]) * r; t.rz = tz - (float)(lz + P.min_b[2]) * r;
+              }
             }
           }
         }
@@ -250,6 +267,56 @@ __global__ __launch_bounds__(kBlockD, pass_waves(KIND)) void k_ndt_pass(const fl
       if (lane == 0) npts += min((size_t)kTilePts, n - tile * kTilePts);
     }
     wave_sync();
+    unsigned total = 0;
+    if constexpr (DENSE) {
+      // ---- phase A (dense table): row probes -> pairs, pre-filtered on the f32 distance
+      unsigned c_ent[kRowRounds * 3];
+      unsigned c_mask = 0;
+      int lane_v = lane;  // opaque copy: keeps ~30 registers of lane-only index arithmetic from being hoisted out of the tile loop
+      asm volatile("" : "+v"(lane_v));
+      int r_cell[kRowRounds], r_nx[kRowRounds], r_pl[kRowRounds];
+      float r_y[kRowRounds], r_z[kRowRounds];
+      float4 e0[kRowRounds], e1[kRowRounds], e2[kRowRounds];
+#pragma unroll
+      for (int j = 0; j < kRowRounds; j++) {
+        int q = lane_v + j * 64;
+        int pl = (q < kRowProbes) ? q / kRowsPerPoint : 0;
+        int o = q - pl * kRowsPerPoint;
+        int dz = o / 3, dy = o - dz * 3;
+        int nxyz = tp[pl].nxyz;
+        bool in_box = q < kRowProbes && dy < ((nxyz >> 8) & 0xff) && dz < (nxyz >> 16);
+        r_pl[j] = pl;
+        r_nx[j] = in_box ? (nxyz & 0xff) : 0;
+        r_cell[j] = in_box ? tp[pl].cell0 + dy * dimx + dz * dimxy : 0;
+        r_y[j] = tp[pl].ry - (float)dy * P.res;
+        r_z[j] = tp[pl].rz - (float)dz * P.res;
+      }
+      // all row loads first so the L2 round trips overlap (the table is padded by two cells past the last row)
+#pragma unroll
+      for (int j = 0; j < kRowRounds; j++) {
+        const float4 *row = dense + r_cell[j];
+        e0[j] = row[0]; e1[j] = row[1]; e2[j] = row[2];
+      }
+#pragma unroll
+      for (int j = 0; j < kRowRounds; j++) {
+        const float rx = tp[r_pl[j]].rx;
+        const float4 ev[3] = {e0[j], e1[j], e2[j]};
+#pragma unroll
+        for (int i = 0; i < 3; i++) {
+          float dx = (rx - (float)i * P.res) - ev[i].x, dy = r_y[j] - ev[i].y, dz = r_z[j] - ev[i].z;
+          float d2 = dx * dx + dy * dy + dz * dz;
+          int rank = __float_as_int(ev[i].w);  // -1: unoccupied, too few points or rejected eigenvalues (VoxelGrid.cpp:465)
+          bool ok = i < r_nx[j] && rank >= 0 && d2 <= P.r2f_pre;
+          c_ent[j * 3 + i] = ((unsigned)r_pl[j]) | ((unsigned)rank << 6);
+          if (ok) c_mask |= 1u << (j * 3 + i);
+        }
+      }
+      unsigned pos = wave_excl_scan(__popc(c_mask), lane, &total);
+#pragma unroll
+      for (int k = 0; k < kRowRounds * 3; k++)
+        if (c_mask & (1u << k)) queue[pos++] = c_ent[k];
+      wave_sync();
+    } else {
     // ---- phase A1: row probes -> candidates (valid voxels inside the box)
     unsigned c_ent[kRowRounds * 3];
     unsigned c_mask = 0;
@@ -309,7 +376,6 @@ __global__ __launch_bounds__(kBlockD, pass_waves(KIND)) void k_ndt_pass(const fl
     // ---- phase A2: candidates -> pairs (radius test on the centroid distance).  A lane owns a contiguous chunk of the
     // candidate list, so one scan per round keeps the order; a round covers 64 x 4 candidates (a tile has ~160, the worst
     // case 432 takes two rounds)
-    unsigned total = 0;
     for (unsigned cbase = 0; cbase < total_c; cbase += 64 * kCandPerLane) {
       const unsigned left = min(total_c - cbase, (unsigned)(64 * kCandPerLane));
       const unsigned per = (left + 63) / 64;  // <= kCandPerLane
@@ -343,6 +409,7 @@ __global__ __launch_bounds__(kBlockD, pass_waves(KIND)) void k_ndt_pass(const fl
       total += round_total;
     }
     wave_sync();
+    }
     // ---- phase B: dense pair math
     for (unsigned qi = lane; qi < total; qi += 64) {
       unsigned e = queue[qi];
@@ -353,9 +420,8 @@ __global__ __launch_bounds__(kBlockD, pass_waves(KIND)) void k_ndt_pass(const fl
 #pragma unroll
       for (int k = 0; k < 8; k++) pg[k] = tm[k];
       // the 15 Hessian terms stay in LDS and are read where they are used: 30 fewer live registers in the pair math
-      pair_update<KIND>(P, R, tp[pl].tx, tp[pl].ty, tp[pl].tz, pg, tm + 8, acc);
+      pair_update<KIND>(P, R, tp[pl].tx, tp[pl].ty, tp[pl].tz, pg, tm + 8, acc, accepted);
     }
-    pairs += total;
     wave_sync();  // tp / terms / queues are rewritten by the next tile
   }
   // block reduction through LDS in a fixed order (bitwise reproducible): transpose the 28 per-lane accumulators (two
@@ -364,7 +430,12 @@ __global__ __launch_bounds__(kBlockD, pass_waves(KIND)) void k_ndt_pass(const fl
   double *red = reinterpret_cast<double *>(lds);
   double *red2 = reinterpret_cast<double *>(lds + kLdsRed2);
   double *wcnt = red2 + 8 * 32;  // [kWaves][2]: pairs, points per wave
-  if (lane == 0) { wcnt[wave * 2] = (double)pairs; wcnt[wave * 2 + 1] = (double)npts; }
+  {
+    unsigned wave_pairs = accepted;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) wave_pairs += __shfl_down(wave_pairs, off, 64);
+    if (lane == 0) { wcnt[wave * 2] = (double)wave_pairs; wcnt[wave * 2 + 1] = (double)npts; }
+  }
 #pragma unroll
   for (int round = 0; round < kBlockD / kRedLanes; round++) {
     if ((int)(threadIdx.x / kRedLanes) == round) {
@@ -451,6 +522,18 @@ void ndt_make_pass_params(const lsa_ndt *h, const float T[16], const double p[6]
   P->d1 = h->d1; P->d2 = h->d2;
   P->res = h->resolution;
   {
+    // dense-table pre-filter: accept when the f32 squared distance <= r^2 + margin.  The margin covers the f32 rounding
+    // of the cell corner ((float)(index) * res), of the stored centroid offset and of the subtraction chain: a few ulps
+    // of the largest coordinate of the cell box times 2 r, doubled; false positives are re-tested exactly in f64
+    double r = (double)h->resolution, cmax = 0.0;
+    for (int a = 0; a < 3; a++) {
+      cmax = std::fmax(cmax, std::fabs((double)h->vi.map.min_b[a]) * r);
+      cmax = std::fmax(cmax, std::fabs((double)(h->vi.map.min_b[a] + h->vi.map.dim[a])) * r);
+    }
+    double margin = 16.0 * r * (cmax + 4.0 * r) * 1.1920929e-07 + 1e-6;
+    P->r2f_pre = (float)(r * r + margin);
+  }
+  {
     int e = 0;
     P->res_pow2 = (std::frexp(h->resolution, &e) == 0.5f) ? 1 : 0;  // mantissa 0.5: an exact power of two
     P->inv_res = 1.0f / h->resolution;
@@ -472,6 +555,21 @@ unsigned ndt_pass_grid(const lsa_ndt *h, size_t n, int kind) {
   return (unsigned)blocks;
 }
 
+namespace {
+template <bool DENSE>
+void launch_pass_t(lsa_ndt *h, const PassParams &P, int kind, unsigned g, const uint4 *words, const double *rec, double *dst) {
+  hipStream_t st = h->ctx->stream;
+  const float4 *dense = h->dense.p;
+  if (kind == 0) hipLaunchKernelGGL((k_ndt_pass<0, DENSE>), dim3(g), dim3(kBlockD), 0, st, h->d_source, h->n_source, P, words, dense, rec, dst);
+  else if (kind == 1) hipLaunchKernelGGL((k_ndt_pass<1, DENSE>), dim3(g), dim3(kBlockD), 0, st, h->d_source, h->n_source, P, words, dense, rec, dst);
+  else hipLaunchKernelGGL((k_ndt_pass<2, DENSE>), dim3(g), dim3(kBlockD), 0, st, h->d_source, h->n_source, P, words, dense, rec, dst);
+}
+void launch_pass(lsa_ndt *h, const PassParams &P, int kind, unsigned g, const uint4 *words, const double *rec, double *dst) {
+  if (h->use_dense) launch_pass_t<true>(h, P, kind, g, words, rec, dst);
+  else launch_pass_t<false>(h, P, kind, g, words, rec, dst);
+}
+}  // namespace
+
 // enqueue one pass: partial kernel + second-stage reduction into h->d_out (device). No sync.
 int ndt_enqueue_pass(lsa_ndt *h, const PassParams &P, int kind, bool reduce) {
   lsa_context *ctx = h->ctx;
@@ -481,9 +579,7 @@ int ndt_enqueue_pass(lsa_ndt *h, const PassParams &P, int kind, bool reduce) {
   if ((rc = h->d_out.reserve(ctx, kOutDoubles))) return rc;
   const uint4 *words = h->words.p;
   const double *rec = h->rec.p;
-  if (kind == 0) hipLaunchKernelGGL(k_ndt_pass<0>, dim3(g), dim3(kBlockD), 0, ctx->stream, h->d_source, h->n_source, P, words, rec, h->partials.p);
-  else if (kind == 1) hipLaunchKernelGGL(k_ndt_pass<1>, dim3(g), dim3(kBlockD), 0, ctx->stream, h->d_source, h->n_source, P, words, rec, h->partials.p);
-  else hipLaunchKernelGGL(k_ndt_pass<2>, dim3(g), dim3(kBlockD), 0, ctx->stream, h->d_source, h->n_source, P, words, rec, h->partials.p);
+  launch_pass(h, P, kind, g, words, rec, h->partials.p);
   if (reduce) hipLaunchKernelGGL(k_reduce_partials, dim3(1), dim3(1024), 0, ctx->stream, h->partials.p, (int)g, h->d_out.p);
   LSA_HIP(ctx, hipGetLastError());
   return LSA_OK;
@@ -504,9 +600,7 @@ int ndt_enqueue_pass_host(lsa_ndt *h, const PassParams &P, int kind, unsigned *g
   const uint4 *words = h->words.p;
   const double *rec = h->rec.p;
   double *dst = h->h_partials.p;  // pinned + mapped: the same pointer is valid on the device
-  if (kind == 0) hipLaunchKernelGGL(k_ndt_pass<0>, dim3(g), dim3(kBlockD), 0, ctx->stream, h->d_source, h->n_source, P, words, rec, dst);
-  else if (kind == 1) hipLaunchKernelGGL(k_ndt_pass<1>, dim3(g), dim3(kBlockD), 0, ctx->stream, h->d_source, h->n_source, P, words, rec, dst);
-  else hipLaunchKernelGGL(k_ndt_pass<2>, dim3(g), dim3(kBlockD), 0, ctx->stream, h->d_source, h->n_source, P, words, rec, dst);
+  launch_pass(h, P, kind, g, words, rec, dst);
   LSA_HIP(ctx, hipGetLastError());
   *grid_out = g;
   return LSA_OK;

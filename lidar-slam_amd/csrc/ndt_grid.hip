@@ -187,6 +187,21 @@ __global__ __launch_bounds__(kBlock) void k_pack_words(const uint32_t *__restric
   words[i] = make_uint4(bits[i], vbits[i], prefix[i], 0u);
 }
 
+// dense probe table of the pass kernel: one 16-B entry per CELL of the box (not per occupied cell): the centroid relative
+// to the cell's low corner in f32 and the record rank; cells without a usable voxel keep the 0xFF fill (rank -1)
+__global__ __launch_bounds__(kBlock) void k_dense_fill(const double *__restrict__ rec, const int32_t *__restrict__ state, const int32_t *__restrict__ cell_of_rank,
+                                                       size_t nocc, CellMap m, float4 *__restrict__ dense) {
+  size_t r = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= nocc || state[r] != 1) return;
+  int cell = cell_of_rank[r];
+  int ijk[3];
+  lsa_cell_unravel(m, cell, ijk);
+  const double *R = rec + r * kRecDoubles;
+  // the corner exactly as the pass kernel forms it: (float)(absolute cell index) * res, in f32
+  float cx = (float)ijk[0] * m.leaf[0], cy = (float)ijk[1] * m.leaf[1], cz = (float)ijk[2] * m.leaf[2];
+  dense[cell] = make_float4((float)(R[0] - (double)cx), (float)(R[1] - (double)cy), (float)(R[2] - (double)cz), __int_as_float((int)r));
+}
+
 __global__ __launch_bounds__(kBlock) void k_count_valid(const int32_t *__restrict__ state, size_t nocc, unsigned *__restrict__ out) {
   size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   unsigned v = (i < nocc && state[i] == 1) ? 1u : 0u;
@@ -223,6 +238,15 @@ int ndt_build_grid(lsa_ndt *h, const float4 *d_pts, size_t n) {
                      h->rec.p, h->state.p, h->vbits.p, h->mode == LSA_NDT_MODE_PCL ? 1 : 0);
   hipLaunchKernelGGL(k_pack_words, dim3(lsa_div_up(vi.W, kBlock)), dim3(kBlock), 0, ctx->stream, vi.bits.p, h->vbits.p, vi.prefix.p, vi.W, h->words.p);
   hipLaunchKernelGGL(k_count_valid, dim3(lsa_div_up(V, kBlock)), dim3(kBlock), 0, ctx->stream, h->state.p, V, (unsigned *)h->d_small.p);
+  // dense probe table when the cell box is small enough (16 B per cell): 16 Mi cells = 256 MiB
+  constexpr long long kDenseMaxCells = 16ll << 20;
+  h->use_dense = vi.map.ncells <= kDenseMaxCells;
+  if (h->use_dense) {
+    size_t nc = (size_t)vi.map.ncells + 2;  // a row load reads 3 entries from any in-box cell
+    if ((rc = h->dense.reserve(ctx, nc, 1.1))) return rc;
+    LSA_HIP(ctx, hipMemsetAsync(h->dense.p, 0xFF, nc * sizeof(float4), ctx->stream));
+    hipLaunchKernelGGL(k_dense_fill, dim3(lsa_div_up(V, kBlock)), dim3(kBlock), 0, ctx->stream, h->rec.p, h->state.p, vi.cell_of_rank.p, V, vi.map, h->dense.p);
+  }
   LSA_HIP(ctx, hipGetLastError());
   unsigned nvalid = 0;
   if ((rc = h->h_out.reserve(ctx, kOutDoubles))) return rc;

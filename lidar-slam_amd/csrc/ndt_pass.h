@@ -13,6 +13,7 @@ struct PassParams {
   float res;         // resolution_ = search radius = leaf
   float inv_res;     // 1 / res, used only when res_pow2 (then x / res == x * inv_res bit for bit)
   int res_pow2;
+  float r2f_pre;     // dense-table probe: f32 squared-distance pre-filter threshold (r^2 + rounding margin)
   int min_b[3];      // real_min_b*
   int dim[3];        // real_max_b* - real_min_b* + 1
 };
