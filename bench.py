@@ -147,11 +147,14 @@ def main():
     local_map = np.ascontiguousarray(np.concatenate(parts, axis=0))
     d_map = torch.from_numpy(local_map).to(dev)
     torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    d_map_f = map_filter.filter_device(d_map)
-    ndt.SetInputTarget(d_map_f.contiguous())
-    torch.cuda.synchronize()
-    set_target_ms = (time.perf_counter() - t0) * 1e3
+    # per key-frame work: 0.3 m map filter (1.4 M points) + voxel table; the first call sizes the buffers, the second is
+    # the steady-state cost a key-frame pays
+    for _ in range(2):
+        t0 = time.perf_counter()
+        d_map_f = map_filter.filter_device(d_map)
+        ndt.SetInputTarget(d_map_f.contiguous())
+        torch.cuda.synchronize()
+        set_target_ms = (time.perf_counter() - t0) * 1e3
     ginfo = ndt.grid_info()
 
     # ---- test scans resident in HBM + constant-velocity guesses (front_end.cpp:238-240) from the true trajectory

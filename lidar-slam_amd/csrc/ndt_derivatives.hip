@@ -146,7 +146,7 @@ constexpr int kLdsTp = 0;
 constexpr int kLdsTerms = 512;                                                           // 16 * 32 B
 constexpr int kLdsCand = kLdsTerms + kTilePts * kTermStride * 8;                         // + 3072
 constexpr int kLdsQueue = kLdsCand + kQueueCap * 4;                                      // + 1728
-constexpr int kLdsSlice = ((kLdsQueue + kQueueCap * 4 + 255) / 256) * 256;               // 7168
+constexpr int kLdsSlice = ((kLdsQueue + (kQueueCap + 1) * 4 + 255) / 256) * 256;         // 7168 (queue + one dump slot)
 constexpr int kLdsTiles = kLdsSlice * kWaves;                                            // 28672
 constexpr int kLdsRed = kRedLanes * kRedStride * 8;                                      // 29696 (aliases the slices after the loops)
 constexpr int kLdsRed2 = (kLdsRed > kLdsTiles ? kLdsRed : kLdsTiles);
@@ -312,9 +312,13 @@ __global__ __launch_bounds__(kBlockD, pass_waves(KIND)) void k_ndt_pass(const fl
         }
       }
       unsigned pos = wave_excl_scan(__popc(c_mask), lane, &total);
+      // branch-free scatter: rejected entries go to a dump slot one past the queue
 #pragma unroll
-      for (int k = 0; k < kRowRounds * 3; k++)
-        if (c_mask & (1u << k)) queue[pos++] = c_ent[k];
+      for (int k = 0; k < kRowRounds * 3; k++) {
+        bool keep = (c_mask >> k) & 1u;
+        unsigned slot = keep ? pos + __popc(c_mask & ((1u << k) - 1u)) : (unsigned)kQueueCap;
+        queue[slot] = c_ent[k];
+      }
       wave_sync();
     } else {
     // ---- phase A1: row probes -> candidates (valid voxels inside the box)
