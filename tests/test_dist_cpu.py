@@ -95,3 +95,16 @@ def test_sharded_registration_two_ranks_gloo(scan_pair, oracle, tmp_path):
     assert np.max(np.abs(r0["T"] - T_ref)) <= 1e-6
     assert np.max(np.abs(r0["p"] - st_ref["final_p"])) <= 1e-8
     assert abs(float(r0["tp"]) - st_ref["trans_probability"]) <= 1e-9 * abs(st_ref["trans_probability"])
+
+
+def test_shard_pays_break_even():
+    """The shard-or-not rule every rank evaluates (dist.shard_pays): KITTI-sized filtered scans stay unsharded, cfg5-sized
+    sources are sharded; the break-even shrinks with the rank count and the rule is monotone in the point count."""
+    from lidar_slam_amd import dist as lsa_dist
+    assert not lsa_dist.shard_pays(7512, 1) and not lsa_dist.shard_pays(10 ** 7, 1)
+    for world in (2, 4, 8):
+        assert not lsa_dist.shard_pays(7512, world)          # bench.py's cfg2 source
+        assert not lsa_dist.shard_pays(132465, world)        # cfg4's 132 k-point source: 22 us of kernel vs 28 us of collective
+        assert lsa_dist.shard_pays(2097152, world)           # cfg5
+    be = [min(m for m in range(10000, 1000000, 1000) if lsa_dist.shard_pays(m, w)) for w in (2, 4, 8)]
+    assert be[0] > be[1] > be[2] and 250000 < be[2] < 350000
