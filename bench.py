@@ -181,8 +181,13 @@ def main():
     # N > 1: shard the source over the ranks (one all-reduce per pass) only where that pays; a KITTI-sized filtered scan
     # is faster replicated (dist.shard_pays).  LSA_BENCH_SHARD=1 / 0 forces either mode.
     allreduce_cb = None
+    native_rccl = None
     if dist_mode:
         allreduce_cb = lsa_dist.make_gloo_staged_allreduce() if one_gpu else lsa_dist.make_rccl_allreduce()
+        # LSA_BENCH_NATIVE_RCCL=1: the all-reduce is issued by the library itself (lsa_rccl_*, no Python per pass) instead
+        # of through torch.distributed.  Opt-in: the default stays on the torch path the multi-rank rehearsals exercise.
+        if os.environ.get("LSA_BENCH_NATIVE_RCCL") == "1" and not one_gpu:
+            native_rccl = lsa_dist.NativeRccl(ctx, rank, world)
     m_probe = int(frame_filter.filter_device(d_scans[0], d_filt).shape[0])
     force = os.environ.get("LSA_BENCH_SHARD")
     shard_policy = dist_mode and (force == "1" or (force != "0" and lsa_dist.shard_pays(m_probe, world)))
@@ -191,7 +196,10 @@ def main():
     def set_mode(shard):
         shard_now[0] = bool(shard)
         if dist_mode:
-            ndt.set_allreduce(allreduce_cb if shard else None)
+            if native_rccl is not None and shard:
+                native_rccl.attach(ndt)
+            else:
+                ndt.set_allreduce(allreduce_cb if shard else None)
 
     results = {}
 
@@ -455,6 +463,8 @@ def main():
         print(json.dumps(line), flush=True)
 
     ndt.close(); frame_filter.close(); map_filter.close(); ctx_f.close()
+    if native_rccl is not None:
+        native_rccl.close()
     if dist_mode:
         dist.barrier()
         dist.destroy_process_group()

@@ -204,6 +204,17 @@ int lsa_ndt_derivatives_timed(lsa_ndt *ndt, const float T[16], const double p[6]
 typedef int (*lsa_allreduce_fn)(void *user, void *device_buf, size_t n_doubles, void *hip_stream);
 int lsa_ndt_set_allreduce(lsa_ndt *ndt, lsa_allreduce_fn fn, void *user);
 
+/* Convenience for C / C++ hosts: the same exchange step through RCCL called by the library itself (librccl is dlopen()ed
+ * on first use — no link-time dependency, none at all for single-GPU use).  Protocol, one process per GPU: rank 0 calls
+ * lsa_rccl_get_unique_id and ships the 128 bytes to the other ranks by any means (MPI, a socket, torch.distributed's
+ * store); every rank calls lsa_rccl_comm_create (collective), then lsa_ndt_set_allreduce_rccl on its NDT handle. */
+typedef struct lsa_rccl_comm lsa_rccl_comm;
+int lsa_rccl_get_unique_id(void *id128);
+int lsa_rccl_comm_create(lsa_rccl_comm **out, lsa_context *ctx, const void *id128, int rank, int world);
+void lsa_rccl_comm_destroy(lsa_rccl_comm *comm);
+int lsa_ndt_set_allreduce_rccl(lsa_ndt *ndt, lsa_rccl_comm *comm);   /* comm == NULL clears it */
+int lsa_rccl_allreduce_f64(lsa_rccl_comm *comm, void *device_buf, size_t n_doubles);  /* in place, on the context's stream */
+
 /* ---- host-side Newton / More-Thuente driver with a caller-supplied pass evaluator ---------- */
 /* The same driver lsa_ndt_scan_match runs, exposed so the multi-process path can be exercised
  * without a GPU (tests: world_size-2 gloo).  eval must fill out32 as lsa_ndt_derivatives does,

@@ -124,6 +124,12 @@ def lib():
     L.lsa_icp_scan_match_device.argtypes = [vp, vp, sz, PF, PF]
     L.lsa_icp_get_fitness_score.argtypes = [vp, PF]
     L.lsa_icp_set_criteria.argtypes = [vp, f, f]
+    L.lsa_rccl_get_unique_id.argtypes = [vp]
+    L.lsa_rccl_comm_create.argtypes = [PVP, vp, vp, i, i]
+    L.lsa_rccl_comm_destroy.argtypes = [vp]
+    L.lsa_rccl_comm_destroy.restype = None
+    L.lsa_ndt_set_allreduce_rccl.argtypes = [vp, vp]
+    L.lsa_rccl_allreduce_f64.argtypes = [vp, vp, sz]
     L.lsa_icp_set_normal_leaf.argtypes = [vp, f]
     L.lsa_yaw_init_create.argtypes = [PVP, vp, C.c_double]
     L.lsa_yaw_init_destroy.argtypes = [vp]

@@ -56,6 +56,48 @@ def make_rccl_allreduce(group=None):
     return fn
 
 
+class NativeRccl:
+    """The exchange step through RCCL called by the library itself (lsa_rccl_*, csrc/rccl_native.cpp): no Python in the
+    per-pass path.  The 128-byte RCCL unique id is created on rank 0 and shipped with torch.distributed's object
+    broadcast (any transport would do); lsa_rccl_comm_create is collective."""
+
+    def __init__(self, ctx, rank, world, group=None):
+        import ctypes as C
+        import torch.distributed as dist
+        from . import capi
+        self.ctx = ctx
+        L = capi.lib()
+        ident = [None]
+        if rank == 0:
+            buf = (C.c_char * 128)()
+            rc = L.lsa_rccl_get_unique_id(C.cast(buf, C.c_void_p))
+            if rc:
+                raise capi.LsaError(rc, L.lsa_last_global_error().decode())
+            ident[0] = bytes(buf)
+        if world > 1:
+            dist.broadcast_object_list(ident, src=0, group=group)
+        self._id = (C.c_char * 128).from_buffer_copy(ident[0])
+        h = C.c_void_p()
+        ctx.check(L.lsa_rccl_comm_create(C.byref(h), ctx.h, C.cast(self._id, C.c_void_p), rank, world))
+        self.h = h
+
+    def attach(self, ndt):
+        from . import capi
+        self.ctx.check(capi.lib().lsa_ndt_set_allreduce_rccl(ndt.h, self.h))
+
+    def allreduce_(self, tensor):
+        """In-place sum of a float64 CUDA tensor on the context's stream (self-test / other 32-double blocks)."""
+        from . import capi
+        self.ctx.check(capi.lib().lsa_rccl_allreduce_f64(self.h, tensor.data_ptr(), tensor.numel()))
+        return tensor
+
+    def close(self):
+        from . import capi
+        if self.h and self.ctx.h:
+            capi.lib().lsa_rccl_comm_destroy(self.h)
+        self.h = None
+
+
 def make_gloo_staged_allreduce(group=None):
     """Rehearsal variant for boxes with fewer GPUs than ranks: stage the 32 doubles through the host and all-reduce
     them with gloo.  Same call protocol as make_rccl_allreduce()."""

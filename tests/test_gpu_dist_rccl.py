@@ -38,6 +38,19 @@ lo, hi = lsa_dist.shard_bounds(d_s.shape[0], 0, 1)
 _, T_rccl = ndt.ScanMatch(d_s[lo:hi], guess)
 st_rccl = dict(ndt.last_stats)
 ndt.set_allreduce(None)
+# the same exchange step through the library's own RCCL call (lsa_rccl_*, no Python in the per-pass path)
+native = lsa_dist.NativeRccl(ctx, 0, 1)
+t = torch.arange(32, dtype=torch.float64, device="cuda") + 0.5
+torch.cuda.synchronize()
+native.allreduce_(t)
+torch.cuda.synchronize()
+assert torch.equal(t.cpu(), torch.arange(32, dtype=torch.float64) + 0.5)     # the sum over one rank
+native.attach(ndt)
+_, T_native = ndt.ScanMatch(d_s[lo:hi], guess)
+st_native = dict(ndt.last_stats)
+capi.lib().lsa_ndt_set_allreduce_rccl(ndt.h, None)
+native.close()
+assert np.array_equal(T_single, T_native) and st_native["passes"] == st_single["passes"] and st_native["score"] == st_single["score"]
 assert np.array_equal(T_single, T_rccl), (T_single, T_rccl)
 assert st_single["passes"] == st_rccl["passes"] and st_single["score"] == st_rccl["score"]
 ndt.close(); ctx.close()
