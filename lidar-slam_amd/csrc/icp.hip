@@ -42,6 +42,7 @@ constexpr int kOut = 32;
 // answer is exact, while the ring search usually stops after ring 1 or 2 because the best distance is already proven.
 // (With cell = gate, every query scanned 27 cells of ~75 points each: 7 ms per 30-iteration ScanMatch; now ~5x less.)
 constexpr int kGateRings = 4;
+constexpr int kSub = 4;  // lanes per query (nn_nearest_sub): the per-lane chain of dependent cell visits is the bottleneck
 constexpr float kCellPerGate = 1.0f / 3.0f;
 
 struct IcpParams {
@@ -54,15 +55,17 @@ __global__ __launch_bounds__(kBlock) void k_icp_pass(const float4 *__restrict__ 
 #pragma unroll
   for (int k = 0; k < 27; k++) acc[k] = 0.0;
   unsigned ncorr = 0, npts = 0;
-  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+  const int sub = threadIdx.x & (kSub - 1);  // kSub adjacent lanes share one source point's neighbour search
+  for (size_t i = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) / kSub; i < n; i += (size_t)gridDim.x * blockDim.x / kSub) {
     float4 s = src[i];
     if (!lsa_finite3(s.x, s.y, s.z)) continue;  // pcl::isFinite(ori_point) (:141)
-    npts++;
+    if (sub == 0) npts++;
     float qx = lsa_fadd(lsa_fadd(lsa_fadd(lsa_fmul(P.T[0], s.x), lsa_fmul(P.T[1], s.y)), lsa_fmul(P.T[2], s.z)), P.T[3]);
     float qy = lsa_fadd(lsa_fadd(lsa_fadd(lsa_fmul(P.T[4], s.x), lsa_fmul(P.T[5], s.y)), lsa_fmul(P.T[6], s.z)), P.T[7]);
     float qz = lsa_fadd(lsa_fadd(lsa_fadd(lsa_fmul(P.T[8], s.x), lsa_fmul(P.T[9], s.y)), lsa_fmul(P.T[10], s.z)), P.T[11]);
     if (!lsa_finite3(qx, qy, qz)) continue;
-    NNHit hit = nn_nearest(G, qx, qy, qz, kGateRings);
+    NNHit hit = nn_nearest_sub<kSub>(G, qx, qy, qz, kGateRings, sub);
+    if (sub != 0) continue;  // lane 0 of the group carries the point into the sums
     float best = hit.d2, bx = hit.x, by = hit.y, bz = hit.z;
     unsigned best_id = hit.id;
     if (best_id == 0xffffffffu || best > P.gate) continue;  // :147
@@ -165,15 +168,17 @@ __global__ __launch_bounds__(kBlock) void k_plane_pass(const float4 *__restrict_
 #pragma unroll
   for (int k = 0; k < 27; k++) acc[k] = 0.0;
   unsigned ncorr = 0, npts = 0;
-  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+  const int sub = threadIdx.x & (kSub - 1);  // kSub adjacent lanes share one source point's neighbour search
+  for (size_t i = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) / kSub; i < n; i += (size_t)gridDim.x * blockDim.x / kSub) {
     float4 s = src[i];
     if (!lsa_finite3(s.x, s.y, s.z)) continue;
-    npts++;
+    if (sub == 0) npts++;
     float qx = lsa_fadd(lsa_fadd(lsa_fadd(lsa_fmul(P.T[0], s.x), lsa_fmul(P.T[1], s.y)), lsa_fmul(P.T[2], s.z)), P.T[3]);
     float qy = lsa_fadd(lsa_fadd(lsa_fadd(lsa_fmul(P.T[4], s.x), lsa_fmul(P.T[5], s.y)), lsa_fmul(P.T[6], s.z)), P.T[7]);
     float qz = lsa_fadd(lsa_fadd(lsa_fadd(lsa_fmul(P.T[8], s.x), lsa_fmul(P.T[9], s.y)), lsa_fmul(P.T[10], s.z)), P.T[11]);
     if (!lsa_finite3(qx, qy, qz)) continue;
-    NNHit hit = nn_nearest(G, qx, qy, qz, kGateRings);
+    NNHit hit = nn_nearest_sub<kSub>(G, qx, qy, qz, kGateRings, sub);
+    if (sub != 0) continue;  // lane 0 of the group carries the point into the sums
     if (hit.id == 0xffffffffu || hit.d2 > P.gate) continue;  // P.gate = max_correspond_dis^2 in this mode
     float4 nv = slot_normals[hit.slot];
     if (nv.w == 0.0f) continue;
@@ -231,16 +236,18 @@ __global__ __launch_bounds__(kBlock) void k_pcl_pass(const float4 *__restrict__ 
 #pragma unroll
   for (int k = 0; k < 16; k++) acc[k] = 0.0;
   unsigned ncorr = 0, npts = 0;
-  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+  const int sub = threadIdx.x & (kSub - 1);  // kSub adjacent lanes share one source point's neighbour search
+  for (size_t i = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) / kSub; i < n; i += (size_t)gridDim.x * blockDim.x / kSub) {
     float4 s = in[i];
-    if (!lsa_finite3(s.x, s.y, s.z)) { work[i] = s; continue; }
+    if (!lsa_finite3(s.x, s.y, s.z)) { if (sub == 0) work[i] = s; continue; }
     float px = lsa_fadd(lsa_fadd(lsa_fadd(lsa_fmul(T.v[0], s.x), lsa_fmul(T.v[1], s.y)), lsa_fmul(T.v[2], s.z)), T.v[3]);
     float py = lsa_fadd(lsa_fadd(lsa_fadd(lsa_fmul(T.v[4], s.x), lsa_fmul(T.v[5], s.y)), lsa_fmul(T.v[6], s.z)), T.v[7]);
     float pz = lsa_fadd(lsa_fadd(lsa_fadd(lsa_fmul(T.v[8], s.x), lsa_fmul(T.v[9], s.y)), lsa_fmul(T.v[10], s.z)), T.v[11]);
-    work[i] = make_float4(px, py, pz, s.w);
+    if (sub == 0) work[i] = make_float4(px, py, pz, s.w);
     if (!lsa_finite3(px, py, pz)) continue;
-    npts++;
-    NNHit hit = nn_nearest(G, px, py, pz, kGateRings);
+    if (sub == 0) npts++;
+    NNHit hit = nn_nearest_sub<kSub>(G, px, py, pz, kGateRings, sub);
+    if (sub != 0) continue;  // lane 0 of the group carries the point into the sums
     if (hit.id == 0xffffffffu || (double)hit.d2 > gate2) continue;  // distance[0] > max_dist_sqr
     ncorr++;
     acc[0] += (double)hit.d2;
@@ -420,7 +427,7 @@ int icp_build(lsa_icp *h, const float4 *d_pts, size_t n) {
 }
 
 unsigned icp_grid_size(const lsa_icp *h, size_t n) {
-  unsigned g = (unsigned)std::min<size_t>((n + kBlock - 1) / kBlock, (size_t)h->ctx->num_cus * 8);
+  unsigned g = (unsigned)std::min<size_t>((n * kSub + kBlock - 1) / kBlock, (size_t)h->ctx->num_cus * 8);
   return g < 1 ? 1 : g;
 }
 
