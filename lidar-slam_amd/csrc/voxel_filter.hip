@@ -2,8 +2,8 @@
 // (reference: lidar_localization/src/models/cloud_filter/voxel_filter.cpp:36-41 -> pcl::VoxelGrid::filter).
 //
 // Pipeline on the device (no sort: ranks of the occupancy bitmap are already in PCL's output order):
-//   bbox reduce -> [host: PCL min_b/div_b rules] -> mark bitmap -> popcount scan -> fixed-point accumulate
-//   -> finalize (mean of x,y,z,intensity per voxel).
+//   bbox reduce -> grid definition by PCL's min_b / div_b rules (on the device) -> mark bitmap -> single-pass popcount
+//   scan -> fixed-point accumulate -> finalize (mean of x,y,z,intensity per voxel; also zeroes what the build touched).
 // Algorithmic HBM bytes (SURVEY.md 8d formula A): 16*N read + 16*V written; this implementation re-reads
 // the points once per streaming pass (bbox, mark, accumulate: 3 x 16*N + 2 x 4*N cell ids).
 #include "voxel_index_dev.h"
@@ -38,9 +38,9 @@ struct lsa_voxel_filter {
 namespace {
 constexpr int kBlock = 256;
 
-__global__ __launch_bounds__(kBlock) void k_filter_finalize(const long long *__restrict__ acc, const int32_t *__restrict__ cnt,
+__global__ __launch_bounds__(kBlock) void k_filter_finalize(long long *__restrict__ acc, int32_t *__restrict__ cnt,
                                                             const int32_t *__restrict__ cell_of_rank, const DevParams *__restrict__ dp,
-                                                            float4 *__restrict__ out, DevParams *__restrict__ host_mirror) {
+                                                            float4 *__restrict__ out, DevParams *__restrict__ host_mirror, uint32_t *__restrict__ bits) {
   // the grid definition + voxel count + status go straight into host-mapped pinned memory (no copy kernel): the host
   // reads them after the completion event
   if (blockIdx.x == 0 && threadIdx.x == 0) *host_mirror = *dp;
@@ -49,16 +49,22 @@ __global__ __launch_bounds__(kBlock) void k_filter_finalize(const long long *__r
   if (r >= dp->V) return;  // the grid is sized for the point count; the occupied-cell count only exists on the device
   const CellMap m = dp->map;
   const FixScales fs = dp->fs;
-  const long long *a = acc + r * 4;
+  long long *a = acc + r * 4;
   double n = (double)cnt[r];
   double o[3];
-  lsa_cell_origin(m, cell_of_rank[r], o);
+  const int cell = cell_of_rank[r];
+  lsa_cell_origin(m, cell, o);
   float4 v;
   v.x = (float)(o[0] + ((double)a[0] * fs.inv_s1) / n);
   v.y = (float)(o[1] + ((double)a[1] * fs.inv_s1) / n);
   v.z = (float)(o[2] + ((double)a[2] * fs.inv_s1) / n);
   v.w = (float)(((double)a[3] * fs.inv_sw) / n);
   out[r] = v;
+  // leave the index clean for the next scan (was a separate clean-up launch): this cell's sums, its count and its
+  // bitmap word (cells sharing the word all store the same zero)
+  a[0] = 0; a[1] = 0; a[2] = 0; a[3] = 0;
+  cnt[r] = 0;
+  bits[cell >> 5] = 0u;
 }
 
 int filter_device(lsa_voxel_filter *f, const float4 *d_in, size_t n, float4 *d_out, size_t *n_out) {
@@ -72,11 +78,11 @@ int filter_device(lsa_voxel_filter *f, const float4 *d_in, size_t n, float4 *d_o
   for (int attempt = 0; attempt < 2; attempt++) {
     if ((rc = vi_enqueue(ctx, vi, d_in, n, /*mode PCL*/ 0, f->leaf, 4))) return rc;
     hipLaunchKernelGGL(k_filter_finalize, dim3(lsa_div_up(n, kBlock)), dim3(kBlock), 0, ctx->stream, vi.acc.p, vi.cnt.p, vi.cell_of_rank.p, vi.dparams.p,
-                       d_out, vi.h_params.p);
+                       d_out, vi.h_params.p, vi.bits.p);
     LSA_HIP(ctx, hipGetLastError());
     if ((rc = vi_mark_done(ctx, vi))) return rc;
-    if ((rc = vi_cleanup(ctx, vi, n))) return rc;  // behind the completion event: off the caller's critical path
     if ((rc = vi_wait(ctx, vi, &status))) return rc;
+    vi.clean = (status == VI_OK);  // the finalize kernel zeroed what this build touched
     if (status != VI_CAPACITY) break;
     if ((rc = vi_grow(ctx, vi))) return rc;  // first call / bigger extent than ever seen: size the bitmap and redo
   }
@@ -94,10 +100,9 @@ int filter_enqueue(lsa_voxel_filter *f, const float4 *d_in, size_t n, float4 *d_
   int rc;
   if ((rc = vi_enqueue(ctx, vi, d_in, n, /*mode PCL*/ 0, f->leaf, 4))) return rc;
   hipLaunchKernelGGL(k_filter_finalize, dim3(lsa_div_up(n, kBlock)), dim3(kBlock), 0, ctx->stream, vi.acc.p, vi.cnt.p, vi.cell_of_rank.p, vi.dparams.p, d_out,
-                     vi.h_params.p);
+                     vi.h_params.p, vi.bits.p);
   LSA_HIP(ctx, hipGetLastError());
-  if ((rc = vi_mark_done(ctx, vi))) return rc;
-  return vi_cleanup(ctx, vi, n);
+  return vi_mark_done(ctx, vi);  // filter_wait() marks the index clean once the status is known
 }
 }  // namespace
 
@@ -154,6 +159,7 @@ extern "C" int lsa_voxel_filter_wait(lsa_voxel_filter *f, size_t *n_out) {
   int status = VI_OK;
   int rc = vi_wait(f->ctx, f->vi, &status);
   if (rc) return rc;
+  f->vi.clean = (status == VI_OK);  // the finalize kernel zeroed what this build touched
   if (status == VI_CAPACITY) {  // rare: extent larger than ever seen; size the bitmap and run the synchronous path
     if ((rc = vi_grow(f->ctx, f->vi))) return rc;
     return filter_device(f, f->p_in, f->p_n, f->p_out, n_out);
