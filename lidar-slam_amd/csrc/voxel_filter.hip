@@ -98,7 +98,10 @@ int filter_enqueue(lsa_voxel_filter *f, const float4 *d_in, size_t n, float4 *d_
   lsa_context *ctx = f->ctx;
   VoxelIndex &vi = f->vi;
   int rc;
-  if ((rc = vi_enqueue(ctx, vi, d_in, n, /*mode PCL*/ 0, f->leaf, 4))) return rc;
+  vi.background = true;  // the async entry point exists to overlap the caller's registration
+  rc = vi_enqueue(ctx, vi, d_in, n, /*mode PCL*/ 0, f->leaf, 4);
+  vi.background = false;
+  if (rc) return rc;
   hipLaunchKernelGGL(k_filter_finalize, dim3(lsa_div_up(n, kBlock)), dim3(kBlock), 0, ctx->stream, vi.acc.p, vi.cnt.p, vi.cell_of_rank.p, vi.dparams.p, d_out,
                      vi.h_params.p, vi.bits.p);
   LSA_HIP(ctx, hipGetLastError());

@@ -64,6 +64,7 @@ struct VoxelIndex {
   size_t acc_rows = 0;    // rows of acc / cnt known to be zero ("clean") on entry
   int acc_ns = 0;
   bool clean = false;     // bits[0..W_cap), acc, cnt are all zero
+  bool background = false;  // this build overlaps another stream's latency-critical work: prefer few, fat workgroups
   // host copies after vi_fetch()
   size_t W = 0, nocc = 0;
   CellMap map{};

@@ -5,6 +5,7 @@
 #include "voxel_index_dev.h"
 
 #include <cfloat>
+#include <cstdlib>
 #include <cmath>
 
 namespace {
@@ -155,28 +156,34 @@ __global__ __launch_bounds__(kBlock) void k_bbox_final_params(const float *__res
 // DISTINCT cell of the tile leaves the CU.  (Global atomics execute at the memory side at ~1e10/s and serialise on a
 // shared word; LDS atomics are two orders of magnitude cheaper.)  A point that cannot be placed because the table is
 // full falls back to direct global atomics, so correctness never depends on the tile's diversity.
-constexpr int kTile = 2048;      // points per workgroup
-constexpr int kHashCap = 1024;   // LDS slots (power of two)
+// Tile geometry: points per workgroup TILE and LDS slots CAP (power of two, = TILE / 2).  Big tiles de-duplicate best
+// (2 M-point maps); a KITTI scan (131 k points) cut into 2048-point tiles is only 64 workgroups on a 256-CU chip and each
+// kernel is a latency chain, so small inputs use 512-point tiles: four times the workgroups, a quarter of the chain.
+constexpr int kTileBig = 2048, kTileSmall = 512;
+constexpr size_t kSmallInput = 512 * 1024;  // points; below this the small tile is used
 
 __device__ __forceinline__ unsigned lds_hash(int cell) { return ((unsigned)cell * 2654435761u) >> 22; }  // top 10 bits
 
 // returns the slot of `cell` in keys[] (inserting it if new), or -1 if the table is full
+template <int CAP>
 __device__ __forceinline__ int lds_insert(int *keys, int cell) {
-  unsigned h = lds_hash(cell) & (kHashCap - 1);
-  for (int probe = 0; probe < kHashCap; probe++) {
+  unsigned h = lds_hash(cell) & (CAP - 1);
+  for (int probe = 0; probe < CAP; probe++) {
     int old = keys[h];
     if (old == cell) return (int)h;
     if (old == -1) {
       old = atomicCAS(&keys[h], -1, cell);
       if (old == -1 || old == cell) return (int)h;
     }
-    h = (h + 1) & (kHashCap - 1);
+    h = (h + 1) & (CAP - 1);
   }
   return -1;
 }
 
+template <int TILE>
 __global__ __launch_bounds__(kBlock) void k_mark(const float4 *__restrict__ pts, size_t n, const DevParams *__restrict__ dp, uint32_t *__restrict__ bits,
                                                  int32_t *__restrict__ cell_idx) {
+  constexpr int kTile = TILE, kHashCap = TILE / 2;
   if (dp->status != VI_OK) return;
   const CellMap m = dp->map;
   __shared__ int keys[kHashCap];
@@ -202,7 +209,7 @@ __global__ __launch_bounds__(kBlock) void k_mark(const float4 *__restrict__ pts,
       cell = lsa_cell_linear(m, ijk);
     }
     cell_idx[i] = cell;
-    if (cell >= 0 && lds_insert(keys, cell) < 0) atomicOr(bits + (cell >> 5), 1u << (cell & 31));
+    if (cell >= 0 && lds_insert<kHashCap>(keys, cell) < 0) atomicOr(bits + (cell >> 5), 1u << (cell & 31));
   }
   __syncthreads();
   // one fire-and-forget atomic per distinct cell of the tile (no read-before-write: a dependent load per slot would
@@ -336,10 +343,11 @@ __device__ __forceinline__ unsigned cell_rank(const uint32_t *__restrict__ bits,
 }
 
 // per-cell fixed-point sums: LDS pre-aggregation per tile, then one set of global atomics per distinct cell
-template <int NS>
+template <int NS, int TILE>
 __global__ __launch_bounds__(kBlock) void k_accum(const float4 *__restrict__ pts, const int32_t *__restrict__ cell_idx, size_t n,
                                                   const DevParams *__restrict__ dp, const uint32_t *__restrict__ bits, const uint32_t *__restrict__ prefix,
                                                   long long *__restrict__ acc, int32_t *__restrict__ cnt) {
+  constexpr int kTile = TILE, kHashCap = TILE / 2;
   if (dp->status != VI_OK) return;
   const CellMap m = dp->map;
   const FixScales fs = dp->fs;
@@ -369,7 +377,7 @@ __global__ __launch_bounds__(kBlock) void k_accum(const float4 *__restrict__ pts
     float4 p = pv[k];
     unsigned long long v[NS];
     point_terms<NS>(m, fs, cell, p, v);
-    int slot = lds_insert(keys, cell);
+    int slot = lds_insert<kHashCap>(keys, cell);
     if (slot >= 0) {
 #pragma unroll
       for (int j = 0; j < NS; j++) atomicAdd(&sums[slot][j], v[j]);
@@ -473,14 +481,19 @@ int vi_enqueue(lsa_context *ctx, VoxelIndex &vi, const float4 *d_pts, size_t n, 
   const DevParams *dp = vi.dparams.p;
   hipLaunchKernelGGL(k_bbox_partial, dim3(nb), dim3(kBlock), 0, ctx->stream, d_pts, n, vi.scratch.p);
   hipLaunchKernelGGL(k_bbox_final_params, dim3(1), dim3(kBlock), 0, ctx->stream, vi.scratch.p, (int)nb, req, vi.dparams.p);
-  hipLaunchKernelGGL(k_mark, dim3(lsa_div_up(n, kTile)), dim3(kBlock), 0, ctx->stream, d_pts, n, dp, vi.bits.p, vi.cell_idx.p);
+  // a build that runs UNDER another latency-critical stream (the async frame filter under the registration of the
+  // previous scan) keeps the big tile: measured, 256 filter workgroups instead of 64 make the filter 10 % faster alone
+  // but the overlapped pipeline 6 % slower, because they take CUs from the pass kernels
+  const bool small = n < kSmallInput && !vi.background;
+  if (small) hipLaunchKernelGGL(k_mark<kTileSmall>, dim3(lsa_div_up(n, kTileSmall)), dim3(kBlock), 0, ctx->stream, d_pts, n, dp, vi.bits.p, vi.cell_idx.p);
+  else hipLaunchKernelGGL(k_mark<kTileBig>, dim3(lsa_div_up(n, kTileBig)), dim3(kBlock), 0, ctx->stream, d_pts, n, dp, vi.bits.p, vi.cell_idx.p);
   hipLaunchKernelGGL(k_scan, dim3(nsb_cap), dim3(kBlock), 0, ctx->stream, vi.bits.p, vi.dparams.p, vi.scan_state.p, vi.tickets.p + 1, vi.scan_epoch,
                      vi.prefix.p, vi.cell_of_rank.p);
-  unsigned g = lsa_div_up(n, kTile);
-  if (ns == 4)
-    hipLaunchKernelGGL(k_accum<4>, dim3(g), dim3(kBlock), 0, ctx->stream, d_pts, vi.cell_idx.p, n, dp, vi.bits.p, vi.prefix.p, vi.acc.p, vi.cnt.p);
-  else
-    hipLaunchKernelGGL(k_accum<10>, dim3(g), dim3(kBlock), 0, ctx->stream, d_pts, vi.cell_idx.p, n, dp, vi.bits.p, vi.prefix.p, vi.acc.p, vi.cnt.p);
+  unsigned g = lsa_div_up(n, small ? kTileSmall : kTileBig);
+#define LSA_LAUNCH_ACCUM(NS_, TILE_) hipLaunchKernelGGL((k_accum<NS_, TILE_>), dim3(g), dim3(kBlock), 0, ctx->stream, d_pts, vi.cell_idx.p, n, dp, vi.bits.p, vi.prefix.p, vi.acc.p, vi.cnt.p)
+  if (ns == 4) { if (small) LSA_LAUNCH_ACCUM(4, kTileSmall); else LSA_LAUNCH_ACCUM(4, kTileBig); }
+  else { if (small) LSA_LAUNCH_ACCUM(10, kTileSmall); else LSA_LAUNCH_ACCUM(10, kTileBig); }
+#undef LSA_LAUNCH_ACCUM
   LSA_HIP(ctx, hipGetLastError());
   return LSA_OK;
 }
