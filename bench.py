@@ -203,56 +203,44 @@ def main():
 
     results = {}
 
-    # the timed step talks to the C-ABI directly (two calls per scan, like front_end.cpp's Filter + ScanMatch) with
-    # every buffer preallocated, so interpreter overhead stays in the microseconds
+    # The timed region is ONE call into the C-ABI per run: lsa_pipeline_scan_match walks `count` scans through
+    # Filter -> ScanMatch with the filter of scan k+1 enqueued (own context / HIP stream) before the registration of scan
+    # k, i.e. the loop front_end_node's C++ would run; every scan is filtered once and registered once.
     import ctypes as C
     L = capi.lib()
+    L.lsa_pipeline_scan_match.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t), C.POINTER(C.c_float),
+                                          C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_float), C.POINTER(capi.NdtStats), C.POINTER(C.c_size_t)]
     ns = len(d_scans)
-    in_ptrs = [C.c_void_p(t.data_ptr()) for t in d_scans]
-    in_n = [C.c_size_t(t.shape[0]) for t in d_scans]
-    filt_ptrs = [t.data_ptr() for t in d_filt2]
-    guess_c = [capi.colmajor(g) for g in guesses]
-    guess_p = [capi.fptr(g) for g in guess_c]
-    out_c = [np.zeros(16, dtype=np.float32) for _ in range(ns)]
-    out_p = [capi.fptr(o) for o in out_c]
-    stats_c = [capi.NdtStats() for _ in range(ns)]
-    stats_r = [C.byref(s) for s in stats_c]
-    n_out = C.c_size_t(0)
-    n_out_r = C.byref(n_out)
-    m_of = [0] * ns
-    f_async, f_wait, f_match = L.lsa_voxel_filter_apply_device_async, L.lsa_voxel_filter_wait, L.lsa_ndt_scan_match_device
+    guess_cm = np.stack([capi.colmajor(g) for g in guesses]).astype(np.float32)   # (ns, 16) column-major poses
     hf, hn = frame_filter.h, ndt.h
-    in_flight = [-1]
+    last_run = {}
 
-    def step(i, more=True):
+    def run_scans(count):
+        """count scans through the pipeline; scan i of the run is test scan (i + off) % ns."""
         # independent-streams mode: every rank walks its own scan stream (offset by its rank); sharded mode: all ranks walk
         # the same stream and each takes its shard of every scan
         off = 0 if shard_now[0] else rank
-        k = (i + off) % ns
-        fp = filt_ptrs[i & 1]
-        rc = 0
-        if in_flight[0] != i:      # first step of a run: nothing was prefetched
-            rc = f_async(hf, in_ptrs[k], in_n[k], fp)
-        rc |= f_wait(hf, n_out_r)
-        m = n_out.value
-        if more:                   # prefetch: filter of the next scan overlaps this scan's registration
-            k1 = (i + 1 + off) % ns
-            rc |= f_async(hf, in_ptrs[k1], in_n[k1], filt_ptrs[(i + 1) & 1])
-            in_flight[0] = i + 1
-        else:
-            in_flight[0] = -1
-        if shard_now[0]:
-            lo, hi = lsa_dist.shard_bounds(m, rank, world)
-            rc |= f_match(hn, fp + 16 * lo, hi - lo, guess_p[k], out_p[k], stats_r[k])
-        else:
-            rc |= f_match(hn, fp, m, guess_p[k], out_p[k], stats_r[k])
-        if rc:
-            ctx_f.check(rc if rc < 0 else -3)
-        m_of[k] = m
+        idx = [(i + off) % ns for i in range(count)]
+        ptrs = (C.c_void_p * count)(*[d_scans[k].data_ptr() for k in idx])
+        nn = (C.c_size_t * count)(*[d_scans[k].shape[0] for k in idx])
+        pred = np.ascontiguousarray(guess_cm[idx])
+        out = np.zeros((count, 16), dtype=np.float32)
+        st = (capi.NdtStats * count)()
+        nf = (C.c_size_t * count)()
+        r, w = (rank, world) if shard_now[0] else (0, 1)
+
+        def call():
+            rc = L.lsa_pipeline_scan_match(hf, hn, count, ptrs, nn, capi.fptr(pred), d_filt2[0].data_ptr(), d_filt2[1].data_ptr(), r, w,
+                                           capi.fptr(out), st, nf)
+            if rc:
+                ctx_f.check(rc)
+        last_run.update(idx=idx, out=out, st=st, nf=nf)
+        return call
 
     def collect():
-        for k in range(ns):
-            results[k] = (capi.from_colmajor(out_c[k]), stats_c[k].as_dict(), m_of[k])
+        idx, out, st, nf = last_run["idx"], last_run["out"], last_run["st"], last_run["nf"]
+        for i in range(max(0, len(idx) - ns), len(idx)):   # the last visit of every test scan
+            results[idx[i]] = (capi.from_colmajor(out[i]), st[i].as_dict(), int(nf[i]))
 
     def sync_all():
         torch.cuda.synchronize()
@@ -264,23 +252,17 @@ def main():
         """W untimed warm-ups (after a clock ramp), then exactly `steps` timed steps between barriers; max over ranks."""
         set_mode(shard)
         # clock ramp: a step is ~0.1 ms of latency-bound kernels, so W steps alone end before the GPU has left its idle
-        # DVFS state; spin the same work (untimed, results discarded) first, then do the W warm-ups
-        if dist_mode:
-            # steps may contain collectives, so all ranks run the SAME number of ramp steps: count-based, not timed
-            for i_ramp in range(int(ramp_seconds * 2000)):
-                step(i_ramp, more=False)
-        else:
-            t_ramp = time.perf_counter()
-            i_ramp = 0
-            while time.perf_counter() - t_ramp < ramp_seconds:
-                step(i_ramp, more=False)
-                i_ramp += 1
-        for i in range(warmup):
-            step(i, more=(i + 1 < warmup))
+        # DVFS state; spin the same work (untimed, results discarded) first, then do the W warm-ups.  Steps may contain
+        # collectives, so all ranks run the SAME number of ramp steps: count-based, not timed.
+        n_ramp = int(ramp_seconds * 8000)
+        if n_ramp:
+            run_scans(n_ramp)()
+        if warmup:
+            run_scans(warmup)()
+        timed = run_scans(steps)
         sync_all()
         t0 = time.perf_counter()
-        for i in range(steps):
-            step(i, more=(i + 1 < steps))
+        timed()
         sync_all()
         dt = time.perf_counter() - t0
         if dist_mode:

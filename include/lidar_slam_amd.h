@@ -232,6 +232,19 @@ void lsa_matrix_to_pose(const float T[16], double p[6]);
 void lsa_ndt_gauss_constants(float res, float outlier_ratio, double *d1, double *d2);
 
 /* ---------------------------------------------------------------------------------------------
+ * Batch of scans through the per-scan hot path: for k in [0, count): filtered_k = Filter(scan_k) (front_end.cpp:106-107),
+ * result_k = ScanMatch(filtered_k, predict_k) (:225) — with the two stages software-pipelined inside the library: the
+ * filter of scan k+1 runs on the filter's context (create it on its OWN lsa_context, i.e. its own HIP stream) while the
+ * registration of scan k runs on the NDT's.  Every scan is filtered once and registered once; the results are those of
+ * the sequential calls.  d_filtered_a / _b: two device buffers of max(n_points) float4 each.  rank / world: (0, 1) on one
+ * GPU; with world > 1 the rank registers its contiguous shard of every filtered scan and the NDT handle must carry the
+ * all-reduce (lsa_ndt_set_allreduce / _rccl).  stats and n_filtered may be NULL.
+ * ------------------------------------------------------------------------------------------- */
+int lsa_pipeline_scan_match(lsa_voxel_filter *frame_filter, lsa_ndt *ndt, size_t count, const float *const *d_scans_xyzw,
+                            const size_t *n_points, const float *predict_poses, float *d_filtered_a, float *d_filtered_b,
+                            int rank, int world, float *result_poses, lsa_ndt_stats *stats, size_t *n_filtered);
+
+/* ---------------------------------------------------------------------------------------------
  * Position-only initialisation — replaces Matching::generateGauss2DMapCells / resetMapRange / getInitialYawAngle
  * (src/matching/matching.cpp:344-422, :267-307; `init_type: OnlyPosition`, config/matching/matching.yaml:4): a 2-D grid
  * of per-cell height statistics over (local map - origin), and the best of 270 yaw hypotheses of a scan against it.

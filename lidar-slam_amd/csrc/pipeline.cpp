@@ -1,0 +1,33 @@
+// pipeline.cpp — lsa_pipeline_scan_match: a batch of scans through frame filter -> NDT ScanMatch with the two stages
+// software-pipelined inside the library (the filter of scan k+1 is enqueued on the filter's context before the
+// registration of scan k starts on the NDT's context), i.e. the loop a C++ caller such as front_end_node would write
+// around lsa_voxel_filter_apply_device_async / _wait and lsa_ndt_scan_match_device, without a foreign-function call per
+// stage.  Results are exactly those of the sequential calls: every scan is filtered once and registered once.
+#include "lsa_common.h"
+
+extern "C" int lsa_pipeline_scan_match(lsa_voxel_filter *frame_filter, lsa_ndt *ndt, size_t count, const float *const *d_scans_xyzw,
+                                       const size_t *n_points, const float *predict_poses, float *d_filtered_a, float *d_filtered_b, int rank,
+                                       int world, float *result_poses, lsa_ndt_stats *stats, size_t *n_filtered) {
+  if (!frame_filter || !ndt || (count && (!d_scans_xyzw || !n_points || !predict_poses || !result_poses || !d_filtered_a || !d_filtered_b)))
+    return LSA_ERR_INVALID;
+  if (world < 1 || rank < 0 || rank >= world) return LSA_ERR_INVALID;
+  if (count == 0) return LSA_OK;
+  float *buf[2] = {d_filtered_a, d_filtered_b};
+  int rc = lsa_voxel_filter_apply_device_async(frame_filter, d_scans_xyzw[0], n_points[0], buf[0]);
+  if (rc) return rc;
+  for (size_t k = 0; k < count; k++) {
+    size_t m = 0;
+    if ((rc = lsa_voxel_filter_wait(frame_filter, &m))) return rc;
+    if (k + 1 < count && (rc = lsa_voxel_filter_apply_device_async(frame_filter, d_scans_xyzw[k + 1], n_points[k + 1], buf[(k + 1) & 1]))) return rc;
+    // multi-GPU: this rank's contiguous shard of the filtered source; the all-reduce callback installed on
+    // the NDT handle sums the per-rank normal equations
+    size_t lo = (m * (size_t)rank) / (size_t)world, hi = (m * (size_t)(rank + 1)) / (size_t)world;
+    rc = lsa_ndt_scan_match_device(ndt, buf[k & 1] + 4 * lo, hi - lo, predict_poses + 16 * k, result_poses + 16 * k, stats ? stats + k : nullptr);
+    if (rc) {  // leave no filter in flight behind an error
+      if (k + 1 < count) { size_t dummy; (void)lsa_voxel_filter_wait(frame_filter, &dummy); }
+      return rc;
+    }
+    if (n_filtered) n_filtered[k] = m;
+  }
+  return LSA_OK;
+}

@@ -33,7 +33,7 @@ struct FixScales {
   double sw, inv_sw;  // intensity / static weight
 };
 
-enum { VI_OK = 0, VI_CAPACITY = 1, VI_RANGE = 2, VI_EMPTY = 3 };
+enum { VI_OK = 0, VI_CAPACITY = 1, VI_RANGE = 2, VI_EMPTY = 3, VI_SPEC_MISS = 4 };
 
 struct DevParams {
   CellMap map;
@@ -41,6 +41,9 @@ struct DevParams {
   unsigned long long W;         // bitmap words in use
   unsigned long long W_cap;     // bitmap words allocated (input)
   unsigned long long n_finite;
+  unsigned long long n_cap;     // largest point count the fixed-point scales `fs` are safe for
+  int spec_miss;                // a speculative build met a finite point outside the reused cell box (result invalid)
+  int expand;                   // input: define the cell box with a margin around the bounding box (filter mode only)
   unsigned nsb;                 // scan blocks in use
   unsigned V;                   // occupied cells (written by the scan)
   int status;                   // VI_*
@@ -65,6 +68,12 @@ struct VoxelIndex {
   int acc_ns = 0;
   bool clean = false;     // bits[0..W_cap), acc, cnt are all zero
   bool background = false;  // this build overlaps another stream's latency-critical work: prefer few, fat workgroups
+  // speculative reuse of the previous grid definition (VoxelFilter only, see vi_enqueue)
+  bool spec_valid = false, last_allow_spec = false, last_was_spec = false;
+  int spec_mode = 0;
+  float spec_leaf[3] = {0, 0, 0};
+  unsigned long long spec_n_cap = 0;
+  size_t spec_W_cap = 0;
   // host copies after vi_fetch()
   size_t W = 0, nocc = 0;
   CellMap map{};
@@ -82,7 +91,11 @@ struct VoxelIndex {
 //   (ns = 4 or 10): five launches.
 // No host synchronisation.  Buffers are sized for n; the bitmap uses the capacity left by earlier calls (the device flags
 // VI_CAPACITY if it does not fit).
-int vi_enqueue(lsa_context *ctx, VoxelIndex &vi, const float4 *d_pts, size_t n, int mode, const float leaf[3], int ns);
+// allow_spec (VoxelFilter): consecutive lidar scans have the same extent, and PCL's output ORDER (ascending i + j*dx +
+// k*dx*dy) and values do not depend on where the cell box starts or how large it is, only on floor(x * inv_leaf) — so a
+// build may reuse the previous build's grid definition (defined with a margin) and skip the two bounding-box launches;
+// k_mark flags any finite point that falls outside (spec_miss) and the caller then rebuilds exactly.
+int vi_enqueue(lsa_context *ctx, VoxelIndex &vi, const float4 *d_pts, size_t n, int mode, const float leaf[3], int ns, bool allow_spec = false);
 // Enqueue the D2H copy of the grid definition + result count, record the completion event (call after the caller's own
 // finalize kernel).  vi_wait() blocks on that event only and refreshes vi.map / vi.fs / vi.W / vi.nocc.
 // Returns VI_* in *status.  On VI_CAPACITY the caller calls vi_grow() and re-enqueues.

@@ -61,6 +61,7 @@ struct ReqParams {  // the request travels as a kernel argument: no H2D copy on 
   int mode;
   float leaf[3];
   unsigned long long W_cap;
+  int expand;  // define the cell box with a margin so that the next scans can reuse it (vi_enqueue allow_spec)
 };
 
 __global__ __launch_bounds__(kBlock) void k_bbox_final_params(const float *__restrict__ partial, int nb, ReqParams req, DevParams *__restrict__ dp) {
@@ -117,6 +118,20 @@ __global__ __launch_bounds__(kBlock) void k_bbox_final_params(const float *__res
       int max_b = (int)floorf(lsa_fmul(mx[a], m.inv[a]));
       m.dim[a] = max_b - m.min_b[a] + 1;
     }
+    if (req.expand && status == VI_OK) {
+      // margin of max(2 cells, 5 % of the extent) per side: neither the output order nor the values depend on min_b /
+      // dims (the order is lexicographic in (k, j, i), the sums are taken against absolute cell corners), only the
+      // overflow verdict above does, and that used the exact box.  Keep the exact box if the padded one would overflow.
+      int mb[3], dm[3];
+      double nc = 1.0;
+      for (int a = 0; a < 3; a++) {
+        int pad = max(2, m.dim[a] / 20);
+        mb[a] = m.min_b[a] - pad; dm[a] = m.dim[a] + 2 * pad;
+        nc *= (double)dm[a];
+      }
+      if (nc <= (double)INT32_MAX && (unsigned long long)((nc + 31.0) / 32.0) <= req.W_cap)
+        for (int a = 0; a < 3; a++) { m.min_b[a] = mb[a]; m.dim[a] = dm[a]; }
+    }
   } else {
     // reference VoxelGrid::findBoundaries (VoxelGrid.cpp:366-372): real_min/real_max = floor(min|max / leaf).  The
     // reference additionally pads its DENSE allocation to multiples of 16x16x8 cells (:379-392); every lookup is clipped
@@ -136,7 +151,8 @@ __global__ __launch_bounds__(kBlock) void k_bbox_final_params(const float *__res
   if (status == VI_OK && W > req.W_cap) status = VI_CAPACITY;
   // fixed-point scales: |d| <= leaf (+ slop) < 2 * leaf, N <= n_finite summands, |intensity| < 1024 => no int64 overflow
   double leaf_max = fmax(fmax((double)m.leaf[0], (double)m.leaf[1]), (double)m.leaf[2]);
-  int bits_n = ceil_log2_dev((double)nfin + 1.0), bits_d = ceil_log2_dev(2.0 * leaf_max);
+  // with `expand` the scales leave room for twice the points, so that later (speculative) builds can reuse them
+  int bits_n = ceil_log2_dev((req.expand ? 2.0 : 1.0) * (double)nfin + 1.0), bits_d = ceil_log2_dev(2.0 * leaf_max);
   int k1 = min(62 - bits_n - bits_d, 44), k2 = min(62 - bits_n - 2 * bits_d, 44), kw = min(62 - bits_n - 10, 40);
   FixScales fs;
   fs.s1 = ldexp(1.0, k1); fs.inv_s1 = ldexp(1.0, -k1);
@@ -148,6 +164,9 @@ __global__ __launch_bounds__(kBlock) void k_bbox_final_params(const float *__res
   dp->nsb = (unsigned)((W + kScanTile - 1) / kScanTile);
   dp->V = 0;
   dp->status = status;
+  dp->n_cap = (bits_n >= 62) ? ~0ull : ((1ull << bits_n) - 1ull);
+  dp->spec_miss = 0;
+  dp->expand = req.expand;
 }
 
 // ---- LDS tile hashing ---------------------------------------------------------------------------------------
@@ -181,7 +200,7 @@ __device__ __forceinline__ int lds_insert(int *keys, int cell) {
 }
 
 template <int TILE>
-__global__ __launch_bounds__(kBlock) void k_mark(const float4 *__restrict__ pts, size_t n, const DevParams *__restrict__ dp, uint32_t *__restrict__ bits,
+__global__ __launch_bounds__(kBlock) void k_mark(const float4 *__restrict__ pts, size_t n, DevParams *__restrict__ dp, uint32_t *__restrict__ bits,
                                                  int32_t *__restrict__ cell_idx) {
   constexpr int kTile = TILE, kHashCap = TILE / 2;
   if (dp->status != VI_OK) return;
@@ -207,6 +226,7 @@ __global__ __launch_bounds__(kBlock) void k_mark(const float4 *__restrict__ pts,
       int ijk[3];
       lsa_cell_ijk(m, p.x, p.y, p.z, ijk);
       cell = lsa_cell_linear(m, ijk);
+      if (cell < 0) dp->spec_miss = 1;  // only possible when the grid definition was reused from an earlier build
     }
     cell_idx[i] = cell;
     if (cell >= 0 && lds_insert<kHashCap>(keys, cell) < 0) atomicOr(bits + (cell >> 5), 1u << (cell & 31));
@@ -434,7 +454,7 @@ inline unsigned stream_grid(lsa_context *ctx, size_t n) {
 
 }  // namespace
 
-int vi_enqueue(lsa_context *ctx, VoxelIndex &vi, const float4 *d_pts, size_t n, int mode, const float leaf[3], int ns) {
+int vi_enqueue(lsa_context *ctx, VoxelIndex &vi, const float4 *d_pts, size_t n, int mode, const float leaf[3], int ns, bool allow_spec) {
   int rc;
   unsigned nb = stream_grid(ctx, n);
   if ((rc = vi.scratch.reserve(ctx, (size_t)nb * 8 + 8))) return rc;
@@ -477,10 +497,23 @@ int vi_enqueue(lsa_context *ctx, VoxelIndex &vi, const float4 *d_pts, size_t n, 
   req.mode = mode;
   for (int a = 0; a < 3; a++) req.leaf[a] = leaf[a];
   req.W_cap = vi.W_cap;
+  // only for small inputs: there the two bounding-box launches are ~10 of ~50 us; on a 2 M-point map they are noise, the
+  // extent moves with the vehicle, and a miss costs a whole second build
+  req.expand = (allow_spec && mode == 0 && n < kSmallInput) ? 1 : 0;
+  // reuse the previous build's grid definition (still in vi.dparams on the device) when it is known to be good for
+  // this request: same rule set and leaf, scales valid for n, bitmap capacity unchanged
+  const bool spec = req.expand && vi.spec_valid && vi.spec_mode == mode && vi.spec_leaf[0] == leaf[0] && vi.spec_leaf[1] == leaf[1] &&
+                    vi.spec_leaf[2] == leaf[2] && (unsigned long long)n <= vi.spec_n_cap && vi.spec_W_cap == vi.W_cap;
+  vi.last_allow_spec = req.expand != 0;
+  vi.last_was_spec = spec;
+  vi.spec_mode = mode;
+  for (int a = 0; a < 3; a++) vi.spec_leaf[a] = leaf[a];
   unsigned nsb_cap = (unsigned)((vi.W_cap + kScanTile - 1) / kScanTile);
-  const DevParams *dp = vi.dparams.p;
-  hipLaunchKernelGGL(k_bbox_partial, dim3(nb), dim3(kBlock), 0, ctx->stream, d_pts, n, vi.scratch.p);
-  hipLaunchKernelGGL(k_bbox_final_params, dim3(1), dim3(kBlock), 0, ctx->stream, vi.scratch.p, (int)nb, req, vi.dparams.p);
+  DevParams *dp = vi.dparams.p;
+  if (!spec) {
+    hipLaunchKernelGGL(k_bbox_partial, dim3(nb), dim3(kBlock), 0, ctx->stream, d_pts, n, vi.scratch.p);
+    hipLaunchKernelGGL(k_bbox_final_params, dim3(1), dim3(kBlock), 0, ctx->stream, vi.scratch.p, (int)nb, req, vi.dparams.p);
+  }
   // a build that runs UNDER another latency-critical stream (the async frame filter under the registration of the
   // previous scan) keeps the big tile: measured, 256 filter workgroups instead of 64 make the filter 10 % faster alone
   // but the overlapped pipeline 6 % slower, because they take CUs from the pass kernels
@@ -517,6 +550,11 @@ int vi_wait(lsa_context *ctx, VoxelIndex &vi, int *status) {
   vi.W = (size_t)p.W;
   vi.nocc = (p.status == VI_OK) ? p.V : 0;
   *status = p.status;
+  // the device-side definition can be reused by the next build if this one was good and was defined with a margin
+  vi.spec_valid = vi.last_allow_spec && p.status == VI_OK && !p.spec_miss && p.expand;
+  vi.spec_n_cap = p.n_cap;
+  vi.spec_W_cap = vi.W_cap;
+  if (p.spec_miss) *status = VI_SPEC_MISS;
   return LSA_OK;
 }
 
@@ -524,7 +562,7 @@ int vi_grow(lsa_context *ctx, VoxelIndex &vi) {
   // called after a VI_CAPACITY report: h_params holds the grid the device wanted
   const DevParams &p = vi.h_params.p[0];
   size_t need = (size_t)p.W + 1;
-  size_t want = need + need / 4;
+  size_t want = need + (p.expand ? need : need / 4);  // room for the speculative margin (1.1^3 of the cells + 4 cells per axis)
   want = (want + kScanTile - 1) / kScanTile * kScanTile;  // whole scan tiles: k_scan reads / writes 16-byte vectors
   LSA_HIP(ctx, hipStreamSynchronize(ctx->stream));
   int rc;

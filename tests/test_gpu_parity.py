@@ -285,3 +285,69 @@ def test_device_resident_path(ctx, oracle, scan_pair):
     _, Td = n_d.ScanMatch(d_src.contiguous(), g)
     assert np.array_equal(Th, Td)
     n_h.close(); n_d.close(); f.close()
+
+
+def test_voxel_filter_speculative_grid_reuse(oracle, scan_pair):
+    """Consecutive scans reuse the previous grid definition (no bounding-box launches); a scan that pokes out of it must
+    be detected and rebuilt: every result equals the oracle's, whatever the history of the handle."""
+    ctx = capi.Context(0)
+    f = cloud_filter.VoxelFilterHip(ctx, 0.5, 0.5, 0.5)
+    s0, s1, _, _ = scan_pair
+    rng = np.random.RandomState(5)
+    history = [s0, s1, s0[::2], s1 * np.float32([1.0, 1.0, 1.0, 1.0]),
+               s0 + np.float32([30.0, -12.0, 1.5, 0.0]),          # shifted far outside the margin: miss -> exact rebuild
+               s0 + np.float32([30.5, -12.0, 1.5, 0.0]),          # inside the new definition again
+               np.concatenate([s1, np.float32([[400.0, 0.0, 0.0, 1.0]])]),   # one far outlier
+               s1[:50], s0]
+    for k, pts in enumerate(history):
+        p8 = synth.to_xyzi32(pts)
+        ref, _ = oracle.voxel_filter(p8, 0.5)
+        _, out = f.Filter(p8)
+        assert out.shape[0] == ref.shape[0], (k, out.shape, ref.shape)
+        assert np.allclose(out[:, [0, 1, 2, 4]], ref, rtol=2e-6, atol=2e-5), k
+    f.close()
+    ctx.close()
+
+
+def test_pipeline_batch_equals_sequential_calls(oracle, scene):
+    """lsa_pipeline_scan_match (filter of scan k+1 under the registration of scan k, inside the library) returns exactly
+    what Filter + ScanMatch called scan by scan return."""
+    import ctypes as C
+    import torch
+    ctx, ctx_f = capi.Context(0), capi.Context(0)
+    poses = synth.trajectory(6)
+    scans = [synth.gen_scan(scene, poses[i], seed=900 + i, beams=32, az_steps=900) for i in range(6)]
+    d_scans = [torch.from_numpy(np.ascontiguousarray(s)).cuda() for s in scans]
+    P0i = np.linalg.inv(poses[0])
+    tgt = np.concatenate([synth.transform_points(P0i @ poses[i], scans[i]) for i in range(2)], 0)
+    ndt = registration.NDTRegistrationHip(ctx)
+    ndt.SetInputTarget(synth.to_xyzi32(tgt))
+    ff = cloud_filter.VoxelFilterHip(ctx_f, 0.5, 0.5, 0.5)
+    guesses = [(P0i @ poses[max(0, i - 1)]).astype(np.float32) for i in range(6)]
+    torch.cuda.synchronize()
+    seq = []
+    for i in range(6):
+        f = ff.filter_device(d_scans[i]).clone()
+        torch.cuda.synchronize()
+        _, T = ndt.ScanMatch(f, guesses[i])
+        seq.append((T, f.shape[0], ndt.last_stats["passes"]))
+    L = capi.lib()
+    L.lsa_pipeline_scan_match.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t), C.POINTER(C.c_float),
+                                          C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_float), C.POINTER(capi.NdtStats), C.POINTER(C.c_size_t)]
+    n = 6
+    ptrs = (C.c_void_p * n)(*[t.data_ptr() for t in d_scans])
+    nn = (C.c_size_t * n)(*[t.shape[0] for t in d_scans])
+    pred = np.ascontiguousarray(np.stack([capi.colmajor(g) for g in guesses]).astype(np.float32))
+    out = np.zeros((n, 16), dtype=np.float32)
+    st = (capi.NdtStats * n)()
+    nf = (C.c_size_t * n)()
+    cap = max(t.shape[0] for t in d_scans)
+    bufs = [torch.empty((cap, 4), dtype=torch.float32, device="cuda") for _ in range(2)]
+    rc = L.lsa_pipeline_scan_match(ff.h, ndt.h, n, ptrs, nn, capi.fptr(pred), bufs[0].data_ptr(), bufs[1].data_ptr(), 0, 1, capi.fptr(out), st, nf)
+    assert rc == 0
+    for i in range(6):
+        assert int(nf[i]) == seq[i][1] and st[i].passes == seq[i][2]
+        assert np.array_equal(capi.from_colmajor(out[i]), seq[i][0])
+    # argument checking
+    assert L.lsa_pipeline_scan_match(ff.h, ndt.h, n, ptrs, nn, capi.fptr(pred), bufs[0].data_ptr(), bufs[1].data_ptr(), 2, 2, capi.fptr(out), st, nf) != 0
+    ndt.close(); ff.close(); ctx.close(); ctx_f.close()
