@@ -156,6 +156,11 @@ void lsa_ndt_destroy(lsa_ndt *ndt);
 #define LSA_NDT_MODE_PCL 1
 int lsa_ndt_set_mode(lsa_ndt *ndt, int mode);
 
+/* The derivative pass probes the target through a dense per-cell table (16 B per CELL of the target's bounding box) when
+ * that box has at most max_cells cells (default 16 Mi = 256 MiB), otherwise through the occupancy bitmap (0.5 B per cell);
+ * same results either way.  0 forces the bitmap.  Call before SetInputTarget. */
+int lsa_ndt_set_dense_limit(lsa_ndt *ndt, long long max_cells);
+
 /* SetInputTarget(input_target) (ndt_registration_manual.cpp:48-54 -> NormalDistributionsTransform::setInputTarget
  * -> VoxelGrid::setInput, VoxelGrid.cpp:326-358).  The target is copied to the device; the caller's
  * buffer is not retained. */

@@ -93,6 +93,13 @@ extern "C" int lsa_ndt_set_mode(lsa_ndt *h, int mode) {
   return LSA_OK;
 }
 
+extern "C" int lsa_ndt_set_dense_limit(lsa_ndt *h, long long max_cells) {
+  if (!h) return LSA_ERR_INVALID;
+  h->dense_max_cells = max_cells < 0 ? 0 : max_cells;
+  h->has_target = false;  // the probe structure is chosen when the table is built
+  return LSA_OK;
+}
+
 extern "C" void lsa_ndt_destroy(lsa_ndt *h) {
   if (!h) return;
   (void)hipSetDevice(h->ctx->device);

@@ -7,6 +7,8 @@
 //   product and the intensity -> one finalize thread per occupied cell.
 // The reference keeps a DENSE grid of ~232 B per cell (160 k cells at KITTI size, 861 k for the 2 M-pt map);
 // here the lookup structure is 12 B per 32 cells plus 80 B per OCCUPIED cell, which stays in the 4 MiB per-XCD L2.
+#include <cstdlib>
+
 #include "eig3_dev.h"
 #include "ndt_internal.h"
 
@@ -238,9 +240,8 @@ int ndt_build_grid(lsa_ndt *h, const float4 *d_pts, size_t n) {
                      h->rec.p, h->state.p, h->vbits.p, h->mode == LSA_NDT_MODE_PCL ? 1 : 0);
   hipLaunchKernelGGL(k_pack_words, dim3(lsa_div_up(vi.W, kBlock)), dim3(kBlock), 0, ctx->stream, vi.bits.p, h->vbits.p, vi.prefix.p, vi.W, h->words.p);
   hipLaunchKernelGGL(k_count_valid, dim3(lsa_div_up(V, kBlock)), dim3(kBlock), 0, ctx->stream, h->state.p, V, (unsigned *)h->d_small.p);
-  // dense probe table when the cell box is small enough (16 B per cell): 16 Mi cells = 256 MiB
-  constexpr long long kDenseMaxCells = 16ll << 20;
-  h->use_dense = vi.map.ncells <= kDenseMaxCells;
+  // dense probe table when the cell box is small enough (16 B per cell; default limit 16 Mi cells = 256 MiB)
+  h->use_dense = vi.map.ncells <= h->dense_max_cells;
   if (h->use_dense) {
     size_t nc = (size_t)vi.map.ncells + 2;  // a row load reads 3 entries from any in-box cell
     if ((rc = h->dense.reserve(ctx, nc, 1.1))) return rc;

@@ -28,7 +28,8 @@ struct lsa_ndt {
   DevBuf<uint32_t> vbits;       // valid bitmap
   DevBuf<uint4> words;          // {occ bits, valid bits, prefix, 0} per 32 cells
   DevBuf<float4> dense;         // dense probe table {centroid - cell corner (f32 x3), record rank or -1} per cell (+2 pad)
-  bool use_dense = false;       // built when the cell box has <= kDenseMaxCells cells
+  bool use_dense = false;       // built when the cell box has <= dense_max_cells cells
+  long long dense_max_cells = 16ll << 20;  // lsa_ndt_set_dense_limit
   DevBuf<double> d_small;
   bool has_target = false;
   size_t n_target = 0, n_valid = 0;

@@ -351,3 +351,39 @@ def test_pipeline_batch_equals_sequential_calls(oracle, scene):
     # argument checking
     assert L.lsa_pipeline_scan_match(ff.h, ndt.h, n, ptrs, nn, capi.fptr(pred), bufs[0].data_ptr(), bufs[1].data_ptr(), 2, 2, capi.fptr(out), st, nf) != 0
     ndt.close(); ff.close(); ctx.close(); ctx_f.close()
+
+
+def test_bitmap_probe_path_matches_dense_table_path(oracle, scan_pair):
+    """Targets whose cell box is too large for the dense probe table fall back to the bitmap probe; forced here on a small
+    target: both structures must select the same (point, voxel) pairs and give the same sums and the same ScanMatch."""
+    import oracle_py
+    ctx = capi.Context(0)
+    s0, s1, _, _ = scan_pair
+    tgt = synth.to_xyzi32(s0)
+    filt, _ = oracle.voxel_filter(synth.to_xyzi32(s1), 0.5)
+    src = synth.to_xyzi32(filt)
+    T = synth.pose_matrix(0.4, 0.02, 0.0, 0.001, -0.002, 0.01).astype(np.float32)
+    p = oracle.matrix_to_pose(T)
+    res = {}
+    for name, limit in (("dense", 16 << 20), ("bitmap", 0)):
+        n = registration.NDTRegistrationHip(ctx)
+        ctx.check(capi.lib().lsa_ndt_set_dense_limit(n.h, limit))
+        n.SetInputTarget(tgt)
+        n.set_source(src)
+        out = [n.derivatives(T, p, kind) for kind in (0, 1, 2)]
+        _, Tm = n.ScanMatch(src, np.eye(4, dtype=np.float32))
+        res[name] = (out, Tm, dict(n.last_stats))
+        n.close()
+    for kind in range(3):
+        a, b = res["dense"][0][kind], res["bitmap"][0][kind]
+        assert int(a[3]) == int(b[3]) and int(a[4]) == int(b[4])                       # same pairs, same points
+        assert abs(a[0] - b[0]) <= 1e-12 * max(1.0, abs(a[0]))
+        assert np.max(np.abs(a[1] - b[1])) <= 1e-11 * max(1.0, np.max(np.abs(a[1])))
+        assert np.max(np.abs(a[2] - b[2])) <= 1e-11 * max(1.0, np.max(np.abs(a[2])))
+    assert res["dense"][2]["passes"] == res["bitmap"][2]["passes"]
+    assert np.max(np.abs(res["dense"][1] - res["bitmap"][1])) <= 1e-6
+    o = oracle_py.OracleNDT()
+    o.set_input_target(tgt)
+    Tr, _ = o.scan_match(src, np.eye(4, dtype=np.float32))
+    assert np.linalg.norm(res["bitmap"][1][:3, 3] - Tr[:3, 3]) <= 1e-4
+    ctx.close()
