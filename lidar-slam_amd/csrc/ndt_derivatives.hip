@@ -5,16 +5,17 @@
 //  :391-445 computeDerivatives, :448-482 computePointDerivatives, :485-520 updateDerivatives, :875-899 updateHessian,
 //  :901-936 computeHessian; VoxelGrid.cpp:432-480 radiusSearch; pcl::transformPointCloud, f32).
 //
-// Per 64-point tile: f32 rigid transform (bit-identical to PCL's, no FMA contraction), block-cooperative probe of the
-// <= 3x3x3 cell neighbourhood through the {occupancy, valid, prefix} words, compaction of the hits into an LDS pair
-// queue, then dense f64 pair math on the gathered 80-byte voxel records exploiting the symmetry of C^-1 (21 unique
-// Hessian entries + 6 gradient + score = 28 values), wave shuffle reduction -> LDS -> one 32-double partial per
-// workgroup, then a fixed-order second-stage reduction (no atomics: bitwise reproducible run to run).
-// No MFMA: the largest contraction is 6x6.
+// Per 16-point tile, owned by ONE wave: f32 rigid transform (bit-identical to PCL's, no FMA contraction), row probes of the
+// <= 3x3x3 cell neighbourhood (dense per-cell table, or the {occupancy, valid, prefix} bitmap words for huge cell boxes),
+// scan-based compaction of the hits into an LDS pair queue, then dense f64 pair math on the gathered 80-byte voxel
+// records exploiting the symmetry of C^-1 (21 unique Hessian entries + 6 gradient + score = 28 values), LDS transpose
+// reduction -> one 32-double partial per workgroup, then a fixed-order second-stage reduction (no atomics: bitwise
+// reproducible run to run).  No MFMA: the largest contraction is 6x6.
 //
-// Algorithmic bytes per pass (SURVEY.md 8d formula C, with this implementation's record size):
-//   16*M (points) + 27*16*M (cell words, worst case) + 80*Kbar*M (records); the word table and the records are
-//   L2 / Infinity-Cache resident at every BASELINE.json size, so the pass is latency / f64-issue bound, not HBM bound.
+// Algorithmic bytes per pass (SURVEY.md 8d formula C, with this implementation's sizes):
+//   16*M (points) + 27*16*M (dense probe entries, worst case) + 80*Kbar*M (records); the probe table and the records are
+//   L2 / Infinity-Cache resident at every BASELINE.json size (PMC: HBM traffic = the source cloud), so the pass is
+//   latency bound at KITTI size and VALU-issue bound at 2 M points, not HBM bound.
 #include "ndt_internal.h"
 #include "ndt_pass.h"
 

@@ -1,5 +1,5 @@
-// voxel_index.hip — sparse voxel index: bbox reduce, grid definition on the device, occupancy bitmap, popcount prefix
-// scan, fixed-point per-cell accumulation.  HBM-bound streaming kernels over packed float4 points (16 B/point, one
+// voxel_index.hip — sparse voxel index: bbox reduce, grid definition on the device (or reused from the previous build),
+// occupancy bitmap, single-pass popcount prefix scan, fixed-point per-cell accumulation.  HBM-bound streaming kernels over packed float4 points (16 B/point, one
 // global_load_dwordx4 per lane); at KITTI size (131 k points = 2.1 MB = 0.3 us of HBM time) they are launch-latency
 // bound, which is why the pipeline is enqueued back to back with no host round trip in between.
 #include "voxel_index_dev.h"
