@@ -374,6 +374,7 @@ def main():
     # ---- CPU baseline: the oracle (single thread) on a bounded sample of the same scans; also the pose check
     cpu_baseline = None
     pose_rmse = None
+    pose_rmse_pcl = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         sys.path.insert(0, os.path.join(ROOT, "oracle"))
         import oracle_py
@@ -399,6 +400,30 @@ def main():
         if errs:
             e = np.array(errs)
             pose_rmse = {"t_m": float(np.sqrt(np.mean(e[:, 0] ** 2))), "r_rad": float(np.sqrt(np.mean(e[:, 1] ** 2))), "scans": len(errs)}
+        # the metric says "RMSE vs PCL": PCL itself is absent, so the closest statement available is the
+        # PCL-SEMANTICS mode of the HIP path (the "NDT" plugin's arithmetic) against the oracle's restatement of it, on the
+        # same scans (both unpinned against real PCL)
+        ndt_p = registration.NDTRegistrationHip(ctx, pcl_mode=True, **NDT_PARAMS)
+        ndt_p.SetInputTarget(d_map_f.contiguous())
+        ondt_p = oracle_py.OracleNDT(fast=True, pcl_mode=True, **NDT_PARAMS)
+        ondt_p.set_input_target(synth.to_xyzi32(d_map_f.cpu().numpy()))
+        errs_p, capped = [], []
+        for k in range(len(TEST_SCANS)):
+            filt, _ = o.voxel_filter(synth.to_xyzi32(scans[TEST_SCANS[k]]), 0.5)
+            f8 = synth.to_xyzi32(filt)
+            Tref, st_ref = ondt_p.scan_match(f8, guesses[k])
+            _, Tg = ndt_p.ScanMatch(f8, guesses[k])
+            hit_cap = st_ref["iterations"] > NDT_PARAMS["max_iter"] or ndt_p.last_stats["iterations"] > NDT_PARAMS["max_iter"]
+            (capped if hit_cap else errs_p).append(pose_err(Tg, Tref))
+        ndt_p.close()
+        e = np.array(errs_p) if errs_p else np.zeros((0, 2))
+        c = np.array(capped) if capped else np.zeros((0, 2))
+        pose_rmse_pcl = {"t_m": float(np.sqrt(np.mean(e[:, 0] ** 2))) if len(e) else None,
+                         "r_rad": float(np.sqrt(np.mean(e[:, 1] ** 2))) if len(e) else None, "scans": len(errs_p),
+                         "scans_at_iteration_cap": len(capped), "max_t_m_at_iteration_cap": float(c[:, 0].max()) if len(c) else None,
+                         "note": "HIP PCL-semantics mode vs the oracle's PCL-semantics restatement (real PCL is not available). With PCL's "
+                                 "zero-seeded covariances the fixed 0.1 step does not settle within max_iter on some scans; those runs "
+                                 "are a 32-iteration limit cycle in which 1e-12 differences are amplified, so they are counted apart"}
 
     if rank == 0:
         st_list = [results[k][1] for k in sorted(results)]
@@ -438,6 +463,7 @@ def main():
             "multi_gpu_alt": alt,
             "cpu_baseline": cpu_baseline,
             "pose_rmse_vs_oracle": pose_rmse,
+            "pose_rmse_pcl_mode_vs_oracle": pose_rmse_pcl,
         }
         if gt_err:
             ge = np.array(gt_err)
