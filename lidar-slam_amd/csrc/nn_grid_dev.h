@@ -28,12 +28,53 @@ __device__ __forceinline__ void nn_visit_cell(const NNView &g, int ix, int iy, i
   }
 }
 
+// visit the points of one occupied cell given its bitmap word (already loaded)
+__device__ __forceinline__ void nn_visit_bit(const NNView &g, int cell, uint32_t w, float qx, float qy, float qz, NNHit &h) {
+  uint32_t bit = 1u << (cell & 31);
+  unsigned rank = g.prefix[cell >> 5] + __popc(w & (bit - 1u));
+  unsigned a = g.start[rank], b = g.start[rank + 1];
+  for (unsigned k = a; k < b; k++) {
+    float4 t = g.sorted[k];
+    float ex = lsa_fsub(qx, t.x), ey = lsa_fsub(qy, t.y), ez = lsa_fsub(qz, t.z);
+    float d = lsa_fadd(lsa_fadd(lsa_fmul(ex, ex), lsa_fmul(ey, ey)), lsa_fmul(ez, ez));  // FLANN L2_Simple, f32
+    unsigned id = __float_as_uint(t.w);
+    if (d < h.d2 || (d == h.d2 && id < h.id)) { h.d2 = d; h.id = id; h.x = t.x; h.y = t.y; h.z = t.z; h.slot = k; }
+  }
+}
+
+// visit the occupied cells among x in [xa, xb] (clipped by the caller) of row (iy, iz); only_ends: just xa and xb.
+// Cells of a row are consecutive bits, so an EMPTY stretch costs one or two bitmap words instead of a load per cell —
+// what a query with no neighbour nearby spends its time on.
+__device__ __forceinline__ void nn_visit_row(const NNView &g, int xa, int xb, int iy, int iz, bool only_ends, float qx, float qy, float qz, NNHit &h) {
+  const CellMap &m = g.map;
+  const int base = iy * m.dim[0] + iz * m.dim[0] * m.dim[1];
+  const int ca = base + xa, cb = base + xb;
+  for (int wi = ca >> 5; wi <= (cb >> 5); wi++) {
+    uint32_t w = g.bits[wi];
+    if (!w) continue;
+    int lo = max(ca, wi << 5) & 31, hi = min(cb, (wi << 5) + 31) & 31;
+    uint32_t mask = (hi == 31 ? 0xffffffffu : ((1u << (hi + 1)) - 1u)) & ~((1u << lo) - 1u);
+    if (only_ends) {
+      uint32_t ends = 0u;
+      if ((ca >> 5) == wi) ends |= 1u << (ca & 31);
+      if ((cb >> 5) == wi) ends |= 1u << (cb & 31);
+      mask &= ends;
+    }
+    uint32_t bitsel = w & mask;
+    while (bitsel) {
+      int b = __ffs(bitsel) - 1;
+      bitsel &= bitsel - 1;
+      nn_visit_bit(g, (wi << 5) + b, w, qx, qy, qz, h);
+    }
+  }
+}
+
 // Exact nearest neighbour of a FINITE query.  max_ring bounds the search: with a gate g a caller that only accepts
 // neighbours within the gate passes max_ring = ceil(g / cell) + 1 (anything farther out is farther than the gate);
 // INT_MAX searches until the answer is proven.  Every wave-divergent loop below has a trip count bounded by the grid
 // dimensions, so all lanes finish.
 //
-// SUB lanes (1, 2, 4 or 8 ADJACENT lanes, same query in each) share one search: the cells of a ring are dealt round-robin
+// SUB lanes (1, 2, 4 or 8 ADJACENT lanes, same query in each) share one search: the (y, z) rows of a ring are dealt round-robin
 // to the SUB lanes and the partial results are merged after every ring, so the dependent bitmap -> prefix -> start ->
 // points chain a single lane would walk for 27-125 cells is cut SUB-fold.  All SUB lanes return the same hit.
 template <int SUB>
@@ -58,17 +99,19 @@ __device__ __forceinline__ NNHit nn_nearest_sub(const NNView &g, float qx, float
   for (int rho = rho0; rho <= rho_end; rho++) {
     int z0 = c2 - rho, z1 = c2 + rho, y0 = c1 - rho, y1 = c1 + rho, x0 = c0 - rho, x1 = c0 + rho;
     int zc0 = max(z0, 0), zc1 = min(z1, m.dim[2] - 1), yc0 = max(y0, 0), yc1 = min(y1, m.dim[1] - 1), xc0 = max(x0, 0), xc1 = min(x1, m.dim[0] - 1);
-    int turn = 0;  // round-robin over the SUB lanes, identical sequence in each of them
+    int turn = 0;  // rows are dealt round-robin to the SUB lanes, identical sequence in each of them
     for (int iz = zc0; iz <= zc1; iz++)
       for (int iy = yc0; iy <= yc1; iy++) {
-        if (iz == z0 || iz == z1 || iy == y0 || iy == y1) {
-          for (int ix = xc0; ix <= xc1; ix++)
-            if (SUB == 1 || ((turn++) & (SUB - 1)) == sub) nn_visit_cell(g, ix, iy, iz, qx, qy, qz, h);
+        if (SUB != 1 && ((turn++) & (SUB - 1)) != sub) continue;
+        const bool shell = iz == z0 || iz == z1 || iy == y0 || iy == y1;  // a face row: every x of the ring's extent
+        if (shell) {
+          if (xc0 <= xc1) nn_visit_row(g, xc0, xc1, iy, iz, false, qx, qy, qz, h);
         } else {
-          if (x0 >= 0 && x0 < m.dim[0])
-            if (SUB == 1 || ((turn++) & (SUB - 1)) == sub) nn_visit_cell(g, x0, iy, iz, qx, qy, qz, h);
-          if (x1 != x0 && x1 >= 0 && x1 < m.dim[0])
-            if (SUB == 1 || ((turn++) & (SUB - 1)) == sub) nn_visit_cell(g, x1, iy, iz, qx, qy, qz, h);
+          // an inner row contributes only the two end cells x0, x1 (when inside the grid)
+          const bool in0 = x0 >= 0 && x0 < m.dim[0], in1 = x1 >= 0 && x1 < m.dim[0] && x1 != x0;
+          if (in0 && in1) nn_visit_row(g, x0, x1, iy, iz, true, qx, qy, qz, h);
+          else if (in0) nn_visit_row(g, x0, x0, iy, iz, true, qx, qy, qz, h);
+          else if (in1) nn_visit_row(g, x1, x1, iy, iz, true, qx, qy, qz, h);
         }
       }
     if (SUB > 1) {  // merge across the SUB lanes (xor butterfly: every lane ends with the group's best)
