@@ -360,7 +360,7 @@ struct lsa_icp {
   float normal_leaf = 1.0f;
   DevBuf<float4> d_target, d_source_own, d_work;
   DevBuf<double> partials, d_out;
-  PinnedBuf<double> h_out;
+  PinnedBuf<double> h_out, h_partials;
   PinnedBuf<float> h_stage;
   bool has_target = false;
   size_t n_target = 0;
@@ -431,9 +431,30 @@ unsigned icp_grid_size(const lsa_icp *h, size_t n) {
   return g < 1 ? 1 : g;
 }
 
-// launches the block reduction of `g` partial rows and brings the 32 doubles to the host
+// Where the pass kernels write their workgroup rows: up to kHostRows rows go straight into host-mapped pinned memory and
+// the host adds them (fixed order) — no reduction launch, no copy; larger grids use the device reduction.
+constexpr unsigned kHostRows = 512;
+double *icp_partials_dst(lsa_icp *h, unsigned g) { return g <= kHostRows ? h->h_partials.p : h->partials.p; }
+
+// brings the 32 sums of `g` partial rows to h->h_out
 int icp_fetch_sums(lsa_icp *h, unsigned g) {
   lsa_context *ctx = h->ctx;
+  LSA_HIP(ctx, hipGetLastError());
+  if (g <= kHostRows) {
+    LSA_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    // rows b, b + 32, ... accumulate in ascending b, then a 32-way tree: the order k_reduce32 uses
+    double sm[32][kOut];
+    for (int r = 0; r < 32; r++) for (int c = 0; c < kOut; c++) sm[r][c] = 0.0;
+    for (unsigned b = 0; b < g; b++) {
+      const double *row = h->h_partials.p + (size_t)b * kOut;
+      double *dst = sm[b & 31];
+      for (int c = 0; c < kOut; c++) dst[c] += row[c];
+    }
+    for (int st = 16; st > 0; st >>= 1)
+      for (int r = 0; r < st; r++) for (int c = 0; c < kOut; c++) sm[r][c] += sm[r + st][c];
+    memcpy(h->h_out.p, sm[0], kOut * sizeof(double));
+    return LSA_OK;
+  }
   hipLaunchKernelGGL(k_reduce32, dim3(1), dim3(1024), 0, ctx->stream, h->partials.p, (int)g, h->d_out.p);
   LSA_HIP(ctx, hipGetLastError());
   LSA_HIP(ctx, hipMemcpyAsync(h->h_out.p, h->d_out.p, kOut * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
@@ -455,6 +476,7 @@ int icp_match_manual(lsa_icp *h, const float4 *d_src, size_t n, const float pred
   if ((rc = h->partials.reserve(ctx, (size_t)g * kOut, 1.0))) return rc;
   if ((rc = h->d_out.reserve(ctx, kOut))) return rc;
   if ((rc = h->h_out.reserve(ctx, kOut))) return rc;
+  if ((rc = h->h_partials.reserve(ctx, (size_t)kHostRows * kOut))) return rc;
   NNView G = nn_view(h->grid);
   for (int it = 0; it < h->max_iter; it++) {
     IcpParams P;
@@ -464,10 +486,10 @@ int icp_match_manual(lsa_icp *h, const float4 *d_src, size_t n, const float pred
     }
     if (h->mode == LSA_ICP_MODE_PLANE) {
       P.gate = h->max_corr * h->max_corr;
-      hipLaunchKernelGGL(k_plane_pass, dim3(g), dim3(kBlock), 0, ctx->stream, d_src, n, P, G, h->slot_normals.p, h->partials.p);
+      hipLaunchKernelGGL(k_plane_pass, dim3(g), dim3(kBlock), 0, ctx->stream, d_src, n, P, G, h->slot_normals.p, icp_partials_dst(h, g));
     } else {
       P.gate = h->max_corr;
-      hipLaunchKernelGGL(k_icp_pass, dim3(g), dim3(kBlock), 0, ctx->stream, d_src, n, P, G, h->partials.p);
+      hipLaunchKernelGGL(k_icp_pass, dim3(g), dim3(kBlock), 0, ctx->stream, d_src, n, P, G, icp_partials_dst(h, g));
     }
     if ((rc = icp_fetch_sums(h, g))) return rc;
     const double *o = h->h_out.p;
@@ -603,6 +625,7 @@ int icp_match_pcl(lsa_icp *h, const float4 *d_src, size_t n, const float predict
   if ((rc = h->partials.reserve(ctx, (size_t)g * kOut, 1.0))) return rc;
   if ((rc = h->d_out.reserve(ctx, kOut))) return rc;
   if ((rc = h->h_out.reserve(ctx, kOut))) return rc;
+  if ((rc = h->h_partials.reserve(ctx, (size_t)kHostRows * kOut))) return rc;
   if ((rc = h->d_work.reserve(ctx, n ? n : 1, 1.25))) return rc;
   NNView G = nn_view(h->grid);
   float final_T[16], incr[16];
@@ -614,7 +637,7 @@ int icp_match_pcl(lsa_icp *h, const float4 *d_src, size_t n, const float predict
   int iterations = 0, converged = 0;
   const float4 *in = d_src;
   for (;;) {
-    hipLaunchKernelGGL(k_pcl_pass, dim3(g), dim3(kBlock), 0, ctx->stream, in, h->d_work.p, n, to_t12(incr), gate2, G, h->partials.p);
+    hipLaunchKernelGGL(k_pcl_pass, dim3(g), dim3(kBlock), 0, ctx->stream, in, h->d_work.p, n, to_t12(incr), gate2, G, icp_partials_dst(h, g));
     if ((rc = icp_fetch_sums(h, g))) return rc;
     in = h->d_work.p;
     const double *o = h->h_out.p;
@@ -686,7 +709,7 @@ extern "C" void lsa_icp_destroy(lsa_icp *h) {
   (void)hipSetDevice(h->ctx->device);
   (void)hipStreamSynchronize(h->ctx->stream);
   h->grid.release(); h->vi_n.release(); h->cell_normals.release(); h->slot_normals.release(); h->d_target.release(); h->d_source_own.release(); h->d_work.release();
-  h->partials.release(); h->d_out.release(); h->h_out.release(); h->h_stage.release();
+  h->partials.release(); h->d_out.release(); h->h_out.release(); h->h_partials.release(); h->h_stage.release();
   delete h;
 }
 
