@@ -64,7 +64,7 @@ __global__ __launch_bounds__(kBlock) void k_icp_pass(const float4 *__restrict__ 
     float qy = lsa_fadd(lsa_fadd(lsa_fadd(lsa_fmul(P.T[4], s.x), lsa_fmul(P.T[5], s.y)), lsa_fmul(P.T[6], s.z)), P.T[7]);
     float qz = lsa_fadd(lsa_fadd(lsa_fadd(lsa_fmul(P.T[8], s.x), lsa_fmul(P.T[9], s.y)), lsa_fmul(P.T[10], s.z)), P.T[11]);
     if (!lsa_finite3(qx, qy, qz)) continue;
-    NNHit hit = nn_nearest_sub<kSub>(G, qx, qy, qz, kGateRings, sub);
+    NNHit hit = nn_nearest_sub<kSub>(G, qx, qy, qz, kGateRings, sub, P.gate);
     if (sub != 0) continue;  // lane 0 of the group carries the point into the sums
     float best = hit.d2, bx = hit.x, by = hit.y, bz = hit.z;
     unsigned best_id = hit.id;
@@ -177,7 +177,7 @@ __global__ __launch_bounds__(kBlock) void k_plane_pass(const float4 *__restrict_
     float qy = lsa_fadd(lsa_fadd(lsa_fadd(lsa_fmul(P.T[4], s.x), lsa_fmul(P.T[5], s.y)), lsa_fmul(P.T[6], s.z)), P.T[7]);
     float qz = lsa_fadd(lsa_fadd(lsa_fadd(lsa_fmul(P.T[8], s.x), lsa_fmul(P.T[9], s.y)), lsa_fmul(P.T[10], s.z)), P.T[11]);
     if (!lsa_finite3(qx, qy, qz)) continue;
-    NNHit hit = nn_nearest_sub<kSub>(G, qx, qy, qz, kGateRings, sub);
+    NNHit hit = nn_nearest_sub<kSub>(G, qx, qy, qz, kGateRings, sub, P.gate);
     if (sub != 0) continue;  // lane 0 of the group carries the point into the sums
     if (hit.id == 0xffffffffu || hit.d2 > P.gate) continue;  // P.gate = max_correspond_dis^2 in this mode
     float4 nv = slot_normals[hit.slot];
@@ -246,7 +246,7 @@ __global__ __launch_bounds__(kBlock) void k_pcl_pass(const float4 *__restrict__ 
     if (sub == 0) work[i] = make_float4(px, py, pz, s.w);
     if (!lsa_finite3(px, py, pz)) continue;
     if (sub == 0) npts++;
-    NNHit hit = nn_nearest_sub<kSub>(G, px, py, pz, kGateRings, sub);
+    NNHit hit = nn_nearest_sub<kSub>(G, px, py, pz, kGateRings, sub, (float)gate2);
     if (sub != 0) continue;  // lane 0 of the group carries the point into the sums
     if (hit.id == 0xffffffffu || (double)hit.d2 > gate2) continue;  // distance[0] > max_dist_sqr
     ncorr++;

@@ -19,12 +19,20 @@ __device__ __forceinline__ void nn_visit_cell(const NNView &g, int ix, int iy, i
   if (!(w & bit)) return;
   unsigned rank = g.prefix[cell >> 5] + __popc(w & (bit - 1u));
   unsigned a = g.start[rank], b = g.start[rank + 1];
-  for (unsigned k = a; k < b; k++) {
-    float4 t = g.sorted[k];
-    float ex = lsa_fsub(qx, t.x), ey = lsa_fsub(qy, t.y), ez = lsa_fsub(qz, t.z);
-    float d = lsa_fadd(lsa_fadd(lsa_fmul(ex, ex), lsa_fmul(ey, ey)), lsa_fmul(ez, ez));  // FLANN L2_Simple, f32
-    unsigned id = __float_as_uint(t.w);
-    if (d < h.d2 || (d == h.d2 && id < h.id)) { h.d2 = d; h.id = id; h.x = t.x; h.y = t.y; h.z = t.z; h.slot = k; }
+  // four points per step, their loads issued together: a cell holds a handful of points and a load-compare-load chain
+  // would cost one memory round trip per point
+  for (unsigned k0 = a; k0 < b; k0 += 4) {
+    float4 t[4];
+#pragma unroll
+    for (int u = 0; u < 4; u++) t[u] = g.sorted[min(k0 + u, b - 1)];
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+      if (k0 + u >= b) break;
+      float ex = lsa_fsub(qx, t[u].x), ey = lsa_fsub(qy, t[u].y), ez = lsa_fsub(qz, t[u].z);
+      float d = lsa_fadd(lsa_fadd(lsa_fmul(ex, ex), lsa_fmul(ey, ey)), lsa_fmul(ez, ez));  // FLANN L2_Simple, f32
+      unsigned id = __float_as_uint(t[u].w);
+      if (d < h.d2 || (d == h.d2 && id < h.id)) { h.d2 = d; h.id = id; h.x = t[u].x; h.y = t[u].y; h.z = t[u].z; h.slot = k0 + u; }
+    }
   }
 }
 
@@ -33,12 +41,20 @@ __device__ __forceinline__ void nn_visit_bit(const NNView &g, int cell, uint32_t
   uint32_t bit = 1u << (cell & 31);
   unsigned rank = g.prefix[cell >> 5] + __popc(w & (bit - 1u));
   unsigned a = g.start[rank], b = g.start[rank + 1];
-  for (unsigned k = a; k < b; k++) {
-    float4 t = g.sorted[k];
-    float ex = lsa_fsub(qx, t.x), ey = lsa_fsub(qy, t.y), ez = lsa_fsub(qz, t.z);
-    float d = lsa_fadd(lsa_fadd(lsa_fmul(ex, ex), lsa_fmul(ey, ey)), lsa_fmul(ez, ez));  // FLANN L2_Simple, f32
-    unsigned id = __float_as_uint(t.w);
-    if (d < h.d2 || (d == h.d2 && id < h.id)) { h.d2 = d; h.id = id; h.x = t.x; h.y = t.y; h.z = t.z; h.slot = k; }
+  // four points per step, their loads issued together: a cell holds a handful of points and a load-compare-load chain
+  // would cost one memory round trip per point
+  for (unsigned k0 = a; k0 < b; k0 += 4) {
+    float4 t[4];
+#pragma unroll
+    for (int u = 0; u < 4; u++) t[u] = g.sorted[min(k0 + u, b - 1)];
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+      if (k0 + u >= b) break;
+      float ex = lsa_fsub(qx, t[u].x), ey = lsa_fsub(qy, t[u].y), ez = lsa_fsub(qz, t[u].z);
+      float d = lsa_fadd(lsa_fadd(lsa_fmul(ex, ex), lsa_fmul(ey, ey)), lsa_fmul(ez, ez));  // FLANN L2_Simple, f32
+      unsigned id = __float_as_uint(t[u].w);
+      if (d < h.d2 || (d == h.d2 && id < h.id)) { h.d2 = d; h.id = id; h.x = t[u].x; h.y = t[u].y; h.z = t[u].z; h.slot = k0 + u; }
+    }
   }
 }
 
@@ -77,8 +93,11 @@ __device__ __forceinline__ void nn_visit_row(const NNView &g, int xa, int xb, in
 // SUB lanes (1, 2, 4 or 8 ADJACENT lanes, same query in each) share one search: the (y, z) rows of a ring are dealt round-robin
 // to the SUB lanes and the partial results are merged after every ring, so the dependent bitmap -> prefix -> start ->
 // points chain a single lane would walk for 27-125 cells is cut SUB-fold.  All SUB lanes return the same hit.
+// gate_d2: squared distance beyond which the caller rejects the neighbour anyway (INFINITY: none).  Cells — and whole
+// rows — that cannot hold a point closer than min(gate_d2, best so far) are skipped without touching memory: the cube
+// of rings shrinks to the sphere that matters (about half the cells), which is what bounds a query with no neighbour.
 template <int SUB>
-__device__ __forceinline__ NNHit nn_nearest_sub(const NNView &g, float qx, float qy, float qz, int max_ring, int sub) {
+__device__ __forceinline__ NNHit nn_nearest_sub(const NNView &g, float qx, float qy, float qz, int max_ring, int sub, float gate_d2 = INFINITY) {
   const CellMap &m = g.map;
   NNHit h;
   h.d2 = INFINITY; h.id = 0xffffffffu; h.x = h.y = h.z = 0.0f; h.slot = 0u;
@@ -103,10 +122,20 @@ __device__ __forceinline__ NNHit nn_nearest_sub(const NNView &g, float qx, float
     for (int iz = zc0; iz <= zc1; iz++)
       for (int iy = yc0; iy <= yc1; iy++) {
         if (SUB != 1 && ((turn++) & (SUB - 1)) != sub) continue;
+        // lower bound of the distance from the query (anywhere inside its own cell) to this row / its cells
+        const float bound2 = fminf(gate_d2, h.d2);
+        const float my = fmaxf((float)(abs(iy - c1) - 1) * g.cell - 1e-3f, 0.0f), mz = fmaxf((float)(abs(iz - c2) - 1) * g.cell - 1e-3f, 0.0f);
+        const float ryz2 = my * my + mz * mz;
+        if (ryz2 > bound2) continue;
         const bool shell = iz == z0 || iz == z1 || iy == y0 || iy == y1;  // a face row: every x of the ring's extent
         if (shell) {
-          if (xc0 <= xc1) nn_visit_row(g, xc0, xc1, iy, iz, false, qx, qy, qz, h);
+          // x offsets beyond 1 + sqrt(bound2 - ryz2) / cell cannot matter
+          const int reach = 1 + (int)(sqrtf(bound2 - ryz2) / g.cell + 1.0f);
+          const int xa = (bound2 == INFINITY) ? xc0 : max(xc0, c0 - reach), xb = (bound2 == INFINITY) ? xc1 : min(xc1, c0 + reach);
+          if (xa <= xb) nn_visit_row(g, xa, xb, iy, iz, false, qx, qy, qz, h);
         } else {
+          const float mx = fmaxf((float)(rho - 1) * g.cell - 1e-3f, 0.0f);
+          if (ryz2 + mx * mx > bound2) continue;
           // an inner row contributes only the two end cells x0, x1 (when inside the grid)
           const bool in0 = x0 >= 0 && x0 < m.dim[0], in1 = x1 >= 0 && x1 < m.dim[0] && x1 != x0;
           if (in0 && in1) nn_visit_row(g, x0, x1, iy, iz, true, qx, qy, qz, h);
