@@ -87,3 +87,33 @@ def test_matrix_to_pose_matches_euler_chart(oracle, fx):
         if abs(ref[3]) > 3.0:
             flipped += 1
     assert flipped >= 2  # the [0, pi] first-angle chart (slightly negative roll -> roll + pi) is covered
+
+
+def test_oracle_regression_tripwire():
+    """The oracle still computes what it computed when tests/golden/oracle_regression.json was written (NOT a pin against
+    the reference — a tripwire against accidental edits of oracle/*.c; regenerate with make_oracle_regression.py when an
+    oracle change is intended)."""
+    import importlib.util
+    import json
+    import os
+    here = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    spec = importlib.util.spec_from_file_location("make_oracle_regression", os.path.join(here, "make_oracle_regression.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    now = mod.compute()
+    ref = json.load(open(os.path.join(here, "oracle_regression.json")))
+
+    def same(a, b, path=""):
+        if isinstance(a, dict):
+            assert a.keys() == b.keys(), path
+            for k in a:
+                same(a[k], b[k], path + "/" + k)
+        elif isinstance(a, list):
+            assert len(a) == len(b), path
+            for i, (x, y) in enumerate(zip(a, b)):
+                same(x, y, path + "[%d]" % i)
+        elif isinstance(a, float):
+            assert a == b or abs(a - b) <= 1e-9 * max(1.0, abs(b)), (path, a, b)   # libm differences across hosts only
+        else:
+            assert a == b, (path, a, b)
+    same(now, ref)
