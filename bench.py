@@ -102,6 +102,13 @@ def main():
     ap.add_argument("--no-large", action="store_true", help="skip the cfg5-sized roofline probe of the pass kernel")
     args = ap.parse_args()
 
+    # stdout carries exactly ONE line, the JSON result: RCCL prints a version banner on stdout when its first communicator
+    # comes up, gloo a "[Gloo] Rank ..." line, so everything any library writes to fd 1 is sent to stderr instead and the
+    # result goes to a private duplicate of the original stdout
+    sys.stdout.flush()
+    real_stdout = os.fdopen(os.dup(1), "w")
+    os.dup2(2, 1)
+
     # LSA_BENCH_FORCE_DIST=1: take the multi-rank code path (process group, RCCL all-reduce per pass, barrier, max over
     # ranks) even for a world of one, so a one-GPU box rehearses exactly what `--gpus N` under torch.distributed.run does
     dist_mode = args.gpus > 1 or os.environ.get("LSA_BENCH_FORCE_DIST") == "1"
@@ -468,7 +475,7 @@ def main():
         if gt_err:
             ge = np.array(gt_err)
             line["pose_rmse_vs_truth"] = {"t_m": float(np.sqrt(np.mean(ge[:, 0] ** 2))), "r_rad": float(np.sqrt(np.mean(ge[:, 1] ** 2)))}
-        print(json.dumps(line), flush=True)
+        print(json.dumps(line), file=real_stdout, flush=True)
 
     ndt.close(); frame_filter.close(); map_filter.close(); ctx_f.close()
     if native_rccl is not None:
