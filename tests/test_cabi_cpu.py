@@ -123,3 +123,14 @@ def test_host_gn_driver_line_search_branch(scan_pair, oracle):
     assert st["passes"] == st_ref["passes"]
     assert st["iterations"] == st_ref["iterations"]
     assert np.max(np.abs(T_got - T_ref)) <= 1e-6
+
+
+def test_public_header_is_plain_c(tmp_path):
+    """The boundary is a C ABI: include/lidar_slam_amd.h must compile as C99 (no C++ types, default arguments or
+    references) and as C++11, on its own."""
+    import subprocess
+    src = tmp_path / "hdr.c"
+    src.write_text('#include "lidar_slam_amd.h"\nint main(void) { return lsa_version() ? 0 : 0; }\n')
+    inc = os.path.join(os.path.dirname(HERE), "include")
+    subprocess.run(["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-I", inc, "-fsyntax-only", str(src)], check=True)
+    subprocess.run(["g++", "-std=c++11", "-Wall", "-Werror", "-I", inc, "-fsyntax-only", "-x", "c++", str(src)], check=True)
