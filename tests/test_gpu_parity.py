@@ -353,6 +353,68 @@ def test_pipeline_batch_equals_sequential_calls(oracle, scene):
     ndt.close(); ff.close(); ctx.close(); ctx_f.close()
 
 
+def test_concurrent_pipelines_on_one_gpu(scene):
+    """Three independent scan streams (own contexts / HIP streams / filter / registration handles), each driven by its own
+    host thread through lsa_pipeline_scan_match at the same time, return bit for bit what one stream returns alone: handles
+    share nothing but the device (bench.py's `concurrent_streams`)."""
+    import ctypes as C
+    import threading
+    import torch
+    poses = synth.trajectory(6)
+    scans = [synth.gen_scan(scene, poses[i], seed=940 + i, beams=32, az_steps=900) for i in range(6)]
+    d_scans = [torch.from_numpy(np.ascontiguousarray(s)).cuda() for s in scans]
+    P0i = np.linalg.inv(poses[0])
+    tgt = synth.to_xyzi32(np.concatenate([synth.transform_points(P0i @ poses[i], scans[i]) for i in range(2)], 0))
+    guesses = np.ascontiguousarray(np.stack([capi.colmajor((P0i @ poses[max(0, i - 1)]).astype(np.float32)) for i in range(6)]).astype(np.float32))
+    cap = max(t.shape[0] for t in d_scans)
+    L = capi.lib()
+    L.lsa_pipeline_scan_match.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t), C.POINTER(C.c_float),
+                                          C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_float), C.POINTER(capi.NdtStats), C.POINTER(C.c_size_t)]
+    reps = 40   # 240 scans per stream: long enough for the three streams to really overlap
+
+    class Pipe:
+        def __init__(self, sid):
+            self.ctx, self.ctx_f = capi.Context(0), capi.Context(0)
+            self.ndt = registration.NDTRegistrationHip(self.ctx)
+            self.ndt.SetInputTarget(tgt)
+            self.ff = cloud_filter.VoxelFilterHip(self.ctx_f, 0.5, 0.5, 0.5)
+            self.idx = [(i + sid) % 6 for i in range(6 * reps)]
+            n = len(self.idx)
+            self.ptrs = (C.c_void_p * n)(*[d_scans[k].data_ptr() for k in self.idx])
+            self.nn = (C.c_size_t * n)(*[d_scans[k].shape[0] for k in self.idx])
+            self.pred = np.ascontiguousarray(guesses[self.idx])
+            self.out = np.zeros((n, 16), dtype=np.float32)
+            self.st = (capi.NdtStats * n)()
+            self.nf = (C.c_size_t * n)()
+            self.bufs = [torch.empty((cap, 4), dtype=torch.float32, device="cuda") for _ in range(2)]
+            self.rc = None
+
+        def run(self):
+            self.rc = L.lsa_pipeline_scan_match(self.ff.h, self.ndt.h, len(self.idx), self.ptrs, self.nn, capi.fptr(self.pred), self.bufs[0].data_ptr(),
+                                                self.bufs[1].data_ptr(), 0, 1, capi.fptr(self.out), self.st, self.nf)
+
+        def close(self):
+            self.ndt.close(); self.ff.close(); self.ctx.close(); self.ctx_f.close()
+
+    torch.cuda.synchronize()
+    alone = Pipe(0)
+    alone.run()
+    assert alone.rc == 0
+    ref = {k: (alone.out[i].copy(), int(alone.nf[i]), alone.st[i].passes) for i, k in enumerate(alone.idx[:6])}
+    pipes = [Pipe(s) for s in range(3)]
+    th = [threading.Thread(target=p.run) for p in pipes]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    for p in pipes:
+        assert p.rc == 0
+        for i, k in enumerate(p.idx):
+            assert np.array_equal(p.out[i], ref[k][0]) and int(p.nf[i]) == ref[k][1] and p.st[i].passes == ref[k][2]
+        p.close()
+    alone.close()
+
+
 def test_bitmap_probe_path_matches_dense_table_path(oracle, scan_pair):
     """Targets whose cell box is too large for the dense probe table fall back to the bitmap probe; forced here on a small
     target: both structures must select the same (point, voxel) pairs and give the same sums and the same ScanMatch."""
