@@ -16,6 +16,8 @@
 //   16*M (points) + 27*16*M (dense probe entries, worst case) + 80*Kbar*M (records); the probe table and the records are
 //   L2 / Infinity-Cache resident at every BASELINE.json size (PMC: HBM traffic = the source cloud), so the pass is
 //   latency bound at KITTI size and VALU-issue bound at 2 M points, not HBM bound.
+#include <chrono>
+#include <cstring>
 #include "ndt_internal.h"
 #include "ndt_pass.h"
 
@@ -184,7 +186,8 @@ __device__ __forceinline__ unsigned wave_excl_scan(unsigned cnt, int lane, unsig
 // L2 round trip less on the critical path.  The bitmap path stays for cell boxes too large for a dense table.
 template <int KIND, bool DENSE>
 __global__ __launch_bounds__(kBlockD, pass_waves(KIND)) void k_ndt_pass(const float4 *__restrict__ src, size_t n, PassParams P, const uint4 *__restrict__ words,
-                                                      const float4 *__restrict__ dense, const double *__restrict__ rec, double *__restrict__ partials) {
+                                                      const float4 *__restrict__ dense, const double *__restrict__ rec, double *__restrict__ partials,
+                                                      unsigned long long key) {
   __shared__ __align__(16) unsigned char lds[kLdsBytes];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   unsigned char *slice = lds + wave * kLdsSlice;
@@ -470,7 +473,20 @@ __global__ __launch_bounds__(kBlockD, pass_waves(KIND)) void k_ndt_pass(const fl
     } else if (threadIdx.x == 29) {
       for (int w = 0; w < kWaves; w++) v += wcnt[w * 2 + 1];   // source points of this workgroup
     }
-    partials[(size_t)blockIdx.x * kOutDoubles + threadIdx.x] = v;  // one 256-byte row per workgroup, written once
+    // one 256-byte row per workgroup, written once.  key != 0 (rows go to host-mapped memory and the host picks them up
+    // without waiting for the stream): column 31 carries key ^ XOR of the other 31 words, so the host can tell a complete
+    // row of THIS pass from a stale or half-arrived one whatever order the stores land in.
+    unsigned long long w = (unsigned long long)__double_as_longlong(v);
+    if (key) {
+      unsigned long long x = threadIdx.x == kOutDoubles - 1 ? 0ull : w;
+#pragma unroll
+      for (int off = 1; off < 32; off <<= 1) x ^= __shfl_xor(x, off, 64);
+      if (threadIdx.x == kOutDoubles - 1) w = x ^ key;
+      __hip_atomic_store(reinterpret_cast<unsigned long long *>(partials) + (size_t)blockIdx.x * kOutDoubles + threadIdx.x, w, __ATOMIC_RELAXED,
+                         __HIP_MEMORY_SCOPE_SYSTEM);
+    } else {
+      partials[(size_t)blockIdx.x * kOutDoubles + threadIdx.x] = v;
+    }
   }
 }
 
@@ -562,16 +578,16 @@ unsigned ndt_pass_grid(const lsa_ndt *h, size_t n, int kind) {
 
 namespace {
 template <bool DENSE>
-void launch_pass_t(lsa_ndt *h, const PassParams &P, int kind, unsigned g, const uint4 *words, const double *rec, double *dst) {
+void launch_pass_t(lsa_ndt *h, const PassParams &P, int kind, unsigned g, const uint4 *words, const double *rec, double *dst, unsigned long long key) {
   hipStream_t st = h->ctx->stream;
   const float4 *dense = h->dense.p;
-  if (kind == 0) hipLaunchKernelGGL((k_ndt_pass<0, DENSE>), dim3(g), dim3(kBlockD), 0, st, h->d_source, h->n_source, P, words, dense, rec, dst);
-  else if (kind == 1) hipLaunchKernelGGL((k_ndt_pass<1, DENSE>), dim3(g), dim3(kBlockD), 0, st, h->d_source, h->n_source, P, words, dense, rec, dst);
-  else hipLaunchKernelGGL((k_ndt_pass<2, DENSE>), dim3(g), dim3(kBlockD), 0, st, h->d_source, h->n_source, P, words, dense, rec, dst);
+  if (kind == 0) hipLaunchKernelGGL((k_ndt_pass<0, DENSE>), dim3(g), dim3(kBlockD), 0, st, h->d_source, h->n_source, P, words, dense, rec, dst, key);
+  else if (kind == 1) hipLaunchKernelGGL((k_ndt_pass<1, DENSE>), dim3(g), dim3(kBlockD), 0, st, h->d_source, h->n_source, P, words, dense, rec, dst, key);
+  else hipLaunchKernelGGL((k_ndt_pass<2, DENSE>), dim3(g), dim3(kBlockD), 0, st, h->d_source, h->n_source, P, words, dense, rec, dst, key);
 }
-void launch_pass(lsa_ndt *h, const PassParams &P, int kind, unsigned g, const uint4 *words, const double *rec, double *dst) {
-  if (h->use_dense) launch_pass_t<true>(h, P, kind, g, words, rec, dst);
-  else launch_pass_t<false>(h, P, kind, g, words, rec, dst);
+void launch_pass(lsa_ndt *h, const PassParams &P, int kind, unsigned g, const uint4 *words, const double *rec, double *dst, unsigned long long key) {
+  if (h->use_dense) launch_pass_t<true>(h, P, kind, g, words, rec, dst, key);
+  else launch_pass_t<false>(h, P, kind, g, words, rec, dst, key);
 }
 }  // namespace
 
@@ -584,7 +600,7 @@ int ndt_enqueue_pass(lsa_ndt *h, const PassParams &P, int kind, bool reduce) {
   if ((rc = h->d_out.reserve(ctx, kOutDoubles))) return rc;
   const uint4 *words = h->words.p;
   const double *rec = h->rec.p;
-  launch_pass(h, P, kind, g, words, rec, h->partials.p);
+  launch_pass(h, P, kind, g, words, rec, h->partials.p, 0ull);
   if (reduce) hipLaunchKernelGGL(k_reduce_partials, dim3(1), dim3(1024), 0, ctx->stream, h->partials.p, (int)g, h->d_out.p);
   LSA_HIP(ctx, hipGetLastError());
   return LSA_OK;
@@ -597,7 +613,7 @@ constexpr unsigned kHostReduceMaxBlocks = 512;
 
 bool ndt_pass_host_reduce(const lsa_ndt *h, int kind) { return !h->allreduce && ndt_pass_grid(h, h->n_source, kind) <= kHostReduceMaxBlocks; }
 
-int ndt_enqueue_pass_host(lsa_ndt *h, const PassParams &P, int kind, unsigned *grid_out) {
+int ndt_enqueue_pass_host(lsa_ndt *h, const PassParams &P, int kind, unsigned *grid_out, unsigned long long *key_out) {
   lsa_context *ctx = h->ctx;
   unsigned g = ndt_pass_grid(h, h->n_source, kind);
   int rc;
@@ -605,25 +621,57 @@ int ndt_enqueue_pass_host(lsa_ndt *h, const PassParams &P, int kind, unsigned *g
   const uint4 *words = h->words.p;
   const double *rec = h->rec.p;
   double *dst = h->h_partials.p;  // pinned + mapped: the same pointer is valid on the device
-  launch_pass(h, P, kind, g, words, rec, dst);
+  // a fresh non-zero key per pass (odd multiplier: a bijection of the counter, so consecutive keys share no pattern)
+  unsigned long long key = (++h->pass_seq) * 0x9E3779B97F4A7C15ull;
+  if (!key) key = (++h->pass_seq) * 0x9E3779B97F4A7C15ull;
+  launch_pass(h, P, kind, g, words, rec, dst, key);
   LSA_HIP(ctx, hipGetLastError());
   *grid_out = g;
+  *key_out = key;
   return LSA_OK;
 }
 
-void ndt_reduce_partials_host(const double *partials, unsigned nb, double out32[32]) {
-  // sm[b % 32][col] accumulates rows b, b + 32, ... in ascending b (the order k_reduce_partials uses); the rows are
-  // read front to back once, because they sit in device-written pinned memory that is cold in the CPU caches
+// Host second stage.  sm[b % 32][col] accumulates rows b, b + 32, ... in ascending b (the order k_reduce_partials uses);
+// the rows are read front to back once, because they sit in device-written pinned memory that is cold in the CPU
+// caches.  key != 0: the rows are taken as they ARRIVE — each is accepted once its check word matches (the kernel may
+// still be running, nothing waits for the stream) — and a row that does not show up within the time limit makes the call
+// return false (the caller then waits for the stream the ordinary way and calls again).
+bool ndt_reduce_partials_host(const double *partials, unsigned nb, unsigned long long key, double limit_ms, double out32[32]) {
   double sm[32][32];
   for (int rl = 0; rl < 32; rl++)
     for (int col = 0; col < 32; col++) sm[rl][col] = 0.0;
+  std::chrono::steady_clock::time_point t0;
+  bool timing = false;
   for (unsigned b = 0; b < nb; b++) {
     const double *row = partials + (size_t)b * kOutDoubles;
+    double v[32];
+    if (key) {
+      const volatile unsigned long long *wr = reinterpret_cast<const volatile unsigned long long *>(row);
+      unsigned spins = 0;
+      for (;;) {
+        unsigned long long w[32], x = 0ull;
+        for (int col = 0; col < 32; col++) w[col] = wr[col];
+        for (int col = 0; col < 31; col++) x ^= w[col];
+        if ((x ^ key) == w[31]) {
+          memcpy(v, w, sizeof(v));
+          break;
+        }
+        if ((++spins & 63u) == 0u) {
+          if (!timing) { t0 = std::chrono::steady_clock::now(); timing = true; }
+          else if (std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count() > limit_ms) return false;
+        }
+        __builtin_ia32_pause();
+      }
+      v[31] = 0.0;
+    } else {
+      memcpy(v, row, sizeof(v));
+    }
     double *dst = sm[b & 31];
-    for (int col = 0; col < 32; col++) dst[col] += row[col];
+    for (int col = 0; col < 32; col++) dst[col] += v[col];
   }
   for (int st = 16; st > 0; st >>= 1)
     for (int rl = 0; rl < st; rl++)
       for (int col = 0; col < 32; col++) sm[rl][col] += sm[rl + st][col];
   for (int col = 0; col < 32; col++) out32[col] = sm[0][col];
+  return true;
 }

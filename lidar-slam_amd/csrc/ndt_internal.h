@@ -2,6 +2,7 @@
 #ifndef LSA_NDT_INTERNAL_H_
 #define LSA_NDT_INTERNAL_H_
 
+#include <cstdlib>
 #include "nn_grid.h"
 #include "voxel_index_dev.h"
 
@@ -48,6 +49,9 @@ struct lsa_ndt {
   DevBuf<double> d_out;         // kOutDoubles
   PinnedBuf<double> h_out;
   PinnedBuf<double> h_partials;  // host-mapped: small passes write their workgroup partials here directly
+  unsigned long long pass_seq = 0;  // numbers the host-reduced passes (row check words)
+  bool no_row_polling = getenv("LSA_NO_ROW_POLLING") != nullptr;  // diagnostics: wait for the stream per pass instead
+  unsigned unsynced = 0;            // host-reduced passes enqueued since the stream was last waited for
 
   // multi-GPU
   lsa_allreduce_fn allreduce = nullptr;

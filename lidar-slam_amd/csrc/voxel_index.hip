@@ -256,7 +256,9 @@ __global__ __launch_bounds__(kBlock) void k_mark(const float4 *__restrict__ pts,
 // ticket (its tile index, so tiles are started in order and the look-back can never wait on a tile that has not been
 // scheduled), publishes its tile's popcount as an AGGREGATE, and reads its predecessors' states 64 at a time until it
 // meets one that already carries an inclusive PREFIX.  A state word = {epoch : 30, flag : 2, value : 32}; the epoch
-// makes words left by earlier launches invalid without clearing the array.
+// makes words left by earlier launches invalid without clearing the array.  The word IS the message (no other memory
+// is handed from tile to tile), so the device-scope atomics are RELAXED: an acquire / release pair would add an L2
+// invalidate / write-back per tile on this eight-L2 part.
 constexpr unsigned long long kFlagAgg = 1ull, kFlagPrefix = 2ull;
 __device__ __forceinline__ unsigned long long scan_word(unsigned epoch, unsigned long long flag, unsigned value) {
   return ((unsigned long long)epoch << 34) | (flag << 32) | (unsigned long long)value;
@@ -301,7 +303,7 @@ __global__ __launch_bounds__(kBlock) void k_scan(const uint32_t *__restrict__ bi
 #pragma unroll
   for (int w = 0; w < kBlock / 64; w++) agg += wt[w];
   if (wave == 0) {
-    if (lane == 0) __hip_atomic_store(state + tile, scan_word(epoch, tile == 0 ? kFlagPrefix : kFlagAgg, agg), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    if (lane == 0) __hip_atomic_store(state + tile, scan_word(epoch, tile == 0 ? kFlagPrefix : kFlagAgg, agg), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     unsigned excl = 0;
     int j = (int)tile - 1;  // nearest predecessor not yet accounted for
     while (j >= 0) {        // wave-uniform
@@ -311,7 +313,7 @@ __global__ __launch_bounds__(kBlock) void k_scan(const uint32_t *__restrict__ bi
       do {
         ready = true;
         if (idx >= 0) {
-          w = __hip_atomic_load(state + idx, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
+          w = __hip_atomic_load(state + idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
           ready = ((unsigned)(w >> 34) == epoch) && (((w >> 32) & 3ull) != 0ull);
         }
       } while (!__all(ready));
@@ -325,7 +327,7 @@ __global__ __launch_bounds__(kBlock) void k_scan(const uint32_t *__restrict__ bi
       j -= 64;
     }
     if (lane == 0) {
-      if (tile != 0) __hip_atomic_store(state + tile, scan_word(epoch, kFlagPrefix, excl + agg), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+      if (tile != 0) __hip_atomic_store(state + tile, scan_word(epoch, kFlagPrefix, excl + agg), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       s_excl = excl;
       if (tile == dp->nsb - 1) dp->V = excl + agg;  // #occupied cells
     }
