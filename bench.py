@@ -94,7 +94,7 @@ def pose_err(Ta, Tb):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=2000)
+    ap.add_argument("--steps", type=int, default=10000)
     ap.add_argument("--warmup", type=int, default=100)
     ap.add_argument("--ramp-seconds", type=float, default=1.5, help="untimed clock-ramp spin before the W warm-up steps")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="bound on the CPU-baseline sample (rank 0, N = 1)")

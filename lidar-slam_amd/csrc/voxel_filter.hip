@@ -100,12 +100,11 @@ int filter_enqueue(lsa_voxel_filter *f, const float4 *d_in, size_t n, float4 *d_
   lsa_context *ctx = f->ctx;
   VoxelIndex &vi = f->vi;
   int rc;
-  vi.background = true;  // the async entry point exists to overlap the caller's registration
-  // no speculative grid reuse here: measured in the overlapped pipeline it is 2-4 % SLOWER although the filter alone is
-  // 7 us faster — without the two light bounding-box launches in front, the heavy mark / accumulate kernels collide with
-  // the first NDT pass of the scan being registered
-  rc = vi_enqueue(ctx, vi, d_in, n, /*mode PCL*/ 0, f->leaf, 4, /*allow_spec*/ false);
-  vi.background = false;
+  // Same fast variants as the synchronous call (512-point tiles, speculative reuse of the previous grid definition).
+  // While the registration still waited for its stream after every pass, a lighter background filter made the overlapped
+  // pipeline slower; since the passes hand their rows over without a stream wait it is the other way round (5 A/B pairs:
+  // +6 %).  A point outside the reused cell box is caught by filter_wait(), which rebuilds exactly.
+  rc = vi_enqueue(ctx, vi, d_in, n, /*mode PCL*/ 0, f->leaf, 4, /*allow_spec*/ true);
   if (rc) return rc;
   hipLaunchKernelGGL(k_filter_finalize, dim3(lsa_div_up(n, kBlock)), dim3(kBlock), 0, ctx->stream, vi.acc.p, vi.cnt.p, vi.cell_of_rank.p, vi.dparams.p, d_out,
                      vi.h_params.p, vi.bits.p);

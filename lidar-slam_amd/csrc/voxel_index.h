@@ -67,7 +67,6 @@ struct VoxelIndex {
   size_t acc_rows = 0;    // rows of acc / cnt known to be zero ("clean") on entry
   int acc_ns = 0;
   bool clean = false;     // bits[0..W_cap), acc, cnt are all zero
-  bool background = false;  // this build overlaps another stream's latency-critical work: prefer few, fat workgroups
   // speculative reuse of the previous grid definition (VoxelFilter only, see vi_enqueue)
   bool spec_valid = false, last_allow_spec = false, last_was_spec = false;
   int spec_mode = 0;

@@ -542,10 +542,7 @@ int vi_enqueue(lsa_context *ctx, VoxelIndex &vi, const float4 *d_pts, size_t n, 
     hipLaunchKernelGGL(k_bbox_partial, dim3(nb), dim3(kBlock), 0, ctx->stream, d_pts, n, vi.scratch.p);
     hipLaunchKernelGGL(k_bbox_final_params, dim3(1), dim3(kBlock), 0, ctx->stream, vi.scratch.p, (int)nb, req, vi.dparams.p);
   }
-  // a build that runs UNDER another latency-critical stream (the async frame filter under the registration of the
-  // previous scan) keeps the big tile: measured, 256 filter workgroups instead of 64 make the filter 10 % faster alone
-  // but the overlapped pipeline 6 % slower, because they take CUs from the pass kernels
-  const bool small = n < kSmallInput && !vi.background;
+  const bool small = n < kSmallInput;
   if (small) hipLaunchKernelGGL(k_mark<kTileSmall>, dim3(lsa_div_up(n, kTileSmall)), dim3(kBlock), 0, ctx->stream, d_pts, n, dp, vi.bits.p, vi.cell_idx.p);
   else hipLaunchKernelGGL(k_mark<kTileBig>, dim3(lsa_div_up(n, kTileBig)), dim3(kBlock), 0, ctx->stream, d_pts, n, dp, vi.bits.p, vi.cell_idx.p);
   hipLaunchKernelGGL(k_scan, dim3(nsb_cap), dim3(kBlock), 0, ctx->stream, vi.bits.p, vi.dparams.p, vi.scan_state.p, vi.tickets.p + 1, vi.scan_epoch,
