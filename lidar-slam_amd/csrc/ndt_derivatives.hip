@@ -606,10 +606,11 @@ int ndt_enqueue_pass(lsa_ndt *h, const PassParams &P, int kind, bool reduce) {
   return LSA_OK;
 }
 
-// Single-GPU, KITTI-sized passes (<= kHostReduceMaxBlocks workgroups): the workgroup partials are written straight into
-// host-mapped pinned memory and the fixed-order second stage runs on the host, which removes a kernel launch and a copy
-// kernel (~8 us) from every pass.  The summation order is the one k_reduce_partials uses, so both paths give the same bits.
-constexpr unsigned kHostReduceMaxBlocks = 512;
+// Single-GPU passes: the workgroup partials are written straight into host-mapped pinned memory and the fixed-order
+// second stage runs on the host as the rows arrive, which removes a kernel launch, a copy and the stream wait from every
+// pass (cfg2: ~10 us of ~25; cfg4, 768 rows: 44 -> 35 us per pass).  The summation order is the one k_reduce_partials
+// uses, so both paths give the same bits.  1024 rows covers every grid ndt_pass_grid() produces (<= 256 CUs x 4).
+constexpr unsigned kHostReduceMaxBlocks = 1024;
 
 bool ndt_pass_host_reduce(const lsa_ndt *h, int kind) { return !h->allreduce && ndt_pass_grid(h, h->n_source, kind) <= kHostReduceMaxBlocks; }
 
