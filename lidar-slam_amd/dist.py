@@ -24,17 +24,19 @@ def shard_bounds(n, rank, world):
     return lo, hi
 
 
-def shard_pays(m_points, world, collective_us=28.0, us_per_point=1.1e-4):
+def shard_pays(m_points, world, collective_us=28.0, us_per_point=1.1e-4, device_stage_us=10.0):
     """Should the source cloud of a pass be sharded over `world` ranks?
 
-    Sharding trades (1 - 1/world) of the pass kernel's point-proportional time for one all-reduce per pass.  Measured on
-    MI355X: the pass kernel costs ~8 us + 0.11 us per 1 000 source points, the 256-byte all-reduce through
-    torch.distributed ~28 us.  So a KITTI-sized filtered scan (7-25 k points) is faster REPLICATED (every rank computes the
-    whole pass, no collective) and only sources of several hundred thousand points are worth the exchange step:
-    world 2: > 509 k points, 4: > 339 k, 8: > 291 k.  Every rank evaluates the same rule on the same numbers."""
+    Sharding trades (1 - 1/world) of the pass kernel's point-proportional time for one all-reduce per pass — and for the
+    device second stage + copy + stream wait the collective needs, which an unsharded pass avoids by handing its workgroup
+    rows straight to the host.  Measured on MI355X: the pass kernel costs ~8 us + 0.11 us per 1 000 source
+    points, the 256-byte all-reduce through torch.distributed ~28 us, the device second stage ~10 us (cfg4: 44 vs 35 us per
+    pass).  So a KITTI-sized filtered scan (7-25 k points) is faster REPLICATED (every rank computes the whole pass, no
+    collective) and only sources of several hundred thousand points are worth the exchange step:
+    world 2: > 691 k points, 4: > 461 k, 8: > 395 k.  Every rank evaluates the same rule on the same numbers."""
     if world <= 1:
         return False
-    return us_per_point * float(m_points) * (1.0 - 1.0 / world) > collective_us
+    return us_per_point * float(m_points) * (1.0 - 1.0 / world) > collective_us + device_stage_us
 
 
 def make_rccl_allreduce(group=None):

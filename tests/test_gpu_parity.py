@@ -266,6 +266,28 @@ def test_voxel_filter_async_pipeline(ctx, scan_pair):
     f_async.close(); f_sync.close(); ctx2.close()
 
 
+def test_row_handover_equals_stream_wait(ctx, oracle, scan_pair, monkeypatch):
+    """A pass hands its workgroup rows to the host through check-worded rows that are added as they arrive; with
+    LSA_NO_ROW_POLLING the host waits for the stream first (the fallback a late row takes).  Same bits either way."""
+    s0, s1, _, _ = scan_pair
+    filt, _ = oracle.voxel_filter(synth.to_xyzi32(s1), 0.5)
+    src = synth.to_xyzi32(filt)
+    g = synth.pose_matrix(0.3, -0.1, 0.02, 0.002, -0.001, 0.015).astype(np.float32)
+    out = []
+    for wait in (False, True):
+        if wait:
+            monkeypatch.setenv("LSA_NO_ROW_POLLING", "1")
+        n = registration.NDTRegistrationHip(ctx)   # the switch is read when the handle is created
+        n.SetInputTarget(synth.to_xyzi32(s0))
+        ok, T = n.ScanMatch(src, g)
+        out.append((T, dict(n.last_stats), n.derivatives(g, oracle.matrix_to_pose(g), 0)))
+        n.close()
+    assert np.array_equal(out[0][0], out[1][0])
+    assert all(np.array_equal(out[0][1][k], out[1][1][k]) for k in out[0][1])
+    for a, b in zip(out[0][2], out[1][2]):
+        assert np.array_equal(np.asarray(a), np.asarray(b))
+
+
 def test_device_resident_path(ctx, oracle, scan_pair):
     """Same results when clouds are already resident in HBM (torch tensors as plain device memory)."""
     import torch
