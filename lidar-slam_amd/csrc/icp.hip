@@ -31,26 +31,30 @@
 // target point.  Its oracle is oracle/icp_oracle.c orc_icp_plane; parity is definable only between the two.
 #include "eig3_dev.h"
 #include "nn_grid_dev.h"
+#include "ndt_pass.h"
 
 #include <cmath>
 
 namespace {
 constexpr int kBlock = 256;
 constexpr int kOut = 32;
-// The neighbour grid's cell is a THIRD of the gate distance and a query may walk kGateRings = 4 rings: a neighbour within
-// the gate lies at most ceil(gate / cell) = 3 rings out (+1 ring of slack for the f32 cell rounding), so the gated
-// answer is exact, while the ring search usually stops after ring 1 or 2 because the best distance is already proven.
-// (With cell = gate, every query scanned 27 cells of ~75 points each: 7 ms per 30-iteration ScanMatch; now ~5x less.)
-constexpr int kGateRings = 4;
+// The neighbour grid's cell is HALF the gate distance and a query may walk kGateRings = 3 rings: a neighbour within the
+// gate lies at most ceil(gate / cell) = 2 rings out (+1 ring of slack for the f32 cell rounding), so the gated answer is
+// exact, while the search usually stops after the query's own cell and a few face neighbours because the best distance is
+// already proven (exact slab bounds, nn_grid_dev.h).  Measured per-iteration kernel time on the cfg2 pair, gate / cell =
+// 1, 1.5, 2, 2.5, 3: 57, 45, 43, 54, 67 us (bigger cells: more points per visited cell; smaller: more rings for the
+// queries that have no neighbour).
+constexpr int kGateRings = 3;
 constexpr int kSub = 4;  // lanes per query (nn_nearest_sub): the per-lane chain of dependent cell visits is the bottleneck
-constexpr float kCellPerGate = 1.0f / 3.0f;
+constexpr float kCellPerGate = 1.0f / 2.0f;
 
 struct IcpParams {
   float T[12];   // row-major 3x4 current pose
   float gate;    // max_correspond_distance_ compared with the SQUARED distance (sic)
 };
 
-__global__ __launch_bounds__(kBlock) void k_icp_pass(const float4 *__restrict__ src, size_t n, IcpParams P, NNView G, double *__restrict__ partials) {
+__global__ __launch_bounds__(kBlock) void k_icp_pass(const float4 *__restrict__ src, size_t n, IcpParams P, NNView G, unsigned *__restrict__ prev,
+                                                     double *__restrict__ partials, unsigned long long key) {
   double acc[27];
 #pragma unroll
   for (int k = 0; k < 27; k++) acc[k] = 0.0;
@@ -64,7 +68,8 @@ __global__ __launch_bounds__(kBlock) void k_icp_pass(const float4 *__restrict__ 
     float qy = lsa_fadd(lsa_fadd(lsa_fadd(lsa_fmul(P.T[4], s.x), lsa_fmul(P.T[5], s.y)), lsa_fmul(P.T[6], s.z)), P.T[7]);
     float qz = lsa_fadd(lsa_fadd(lsa_fadd(lsa_fmul(P.T[8], s.x), lsa_fmul(P.T[9], s.y)), lsa_fmul(P.T[10], s.z)), P.T[11]);
     if (!lsa_finite3(qx, qy, qz)) continue;
-    NNHit hit = nn_nearest_sub<kSub>(G, qx, qy, qz, kGateRings, sub, P.gate);
+    NNHit hit = nn_nearest_sub<kSub>(G, qx, qy, qz, kGateRings, sub, P.gate, prev[i]);
+    if (sub == 0) prev[i] = hit.id == 0xffffffffu ? 0xffffffffu : hit.slot;  // next iteration's seed (all kSub lanes have read theirs)
     if (sub != 0) continue;  // lane 0 of the group carries the point into the sums
     float best = hit.d2, bx = hit.x, by = hit.y, bz = hit.z;
     unsigned best_id = hit.id;
@@ -113,7 +118,7 @@ __global__ __launch_bounds__(kBlock) void k_icp_pass(const float4 *__restrict__ 
   if (threadIdx.x < kOut) {
     double v = 0.0;
     for (int w = 0; w < kBlock / 64; w++) v += sm[w][threadIdx.x];
-    partials[(size_t)blockIdx.x * kOut + threadIdx.x] = v;
+    lsa_store_row32(partials + (size_t)blockIdx.x * kOut, (int)threadIdx.x, v, key);
   }
 }
 
@@ -162,8 +167,9 @@ __global__ __launch_bounds__(kBlock) void k_slot_normals(const float4 *__restric
 }
 
 // out32: [1..6] B = -sum J r, [7..27] H = sum J^T J upper triangle, [28] #pairs, [29] #finite source points
-__global__ __launch_bounds__(kBlock) void k_plane_pass(const float4 *__restrict__ src, size_t n, IcpParams P, NNView G, const float4 *__restrict__ slot_normals,
-                                                       double *__restrict__ partials) {
+__global__ __launch_bounds__(kBlock) void k_plane_pass(const float4 *__restrict__ src, size_t n, IcpParams P, NNView G, unsigned *__restrict__ prev,
+                                                       const float4 *__restrict__ slot_normals,
+                                                       double *__restrict__ partials, unsigned long long key) {
   double acc[27];
 #pragma unroll
   for (int k = 0; k < 27; k++) acc[k] = 0.0;
@@ -177,7 +183,8 @@ __global__ __launch_bounds__(kBlock) void k_plane_pass(const float4 *__restrict_
     float qy = lsa_fadd(lsa_fadd(lsa_fadd(lsa_fmul(P.T[4], s.x), lsa_fmul(P.T[5], s.y)), lsa_fmul(P.T[6], s.z)), P.T[7]);
     float qz = lsa_fadd(lsa_fadd(lsa_fadd(lsa_fmul(P.T[8], s.x), lsa_fmul(P.T[9], s.y)), lsa_fmul(P.T[10], s.z)), P.T[11]);
     if (!lsa_finite3(qx, qy, qz)) continue;
-    NNHit hit = nn_nearest_sub<kSub>(G, qx, qy, qz, kGateRings, sub, P.gate);
+    NNHit hit = nn_nearest_sub<kSub>(G, qx, qy, qz, kGateRings, sub, P.gate, prev[i]);
+    if (sub == 0) prev[i] = hit.id == 0xffffffffu ? 0xffffffffu : hit.slot;  // next iteration's seed (all kSub lanes have read theirs)
     if (sub != 0) continue;  // lane 0 of the group carries the point into the sums
     if (hit.id == 0xffffffffu || hit.d2 > P.gate) continue;  // P.gate = max_correspond_dis^2 in this mode
     float4 nv = slot_normals[hit.slot];
@@ -221,7 +228,7 @@ __global__ __launch_bounds__(kBlock) void k_plane_pass(const float4 *__restrict_
   if (threadIdx.x < kOut) {
     double v = 0.0;
     for (int w = 0; w < kBlock / 64; w++) v += sm[w][threadIdx.x];
-    partials[(size_t)blockIdx.x * kOut + threadIdx.x] = v;
+    lsa_store_row32(partials + (size_t)blockIdx.x * kOut, (int)threadIdx.x, v, key);
   }
 }
 
@@ -231,7 +238,7 @@ struct T12 { float v[12]; };
 // the gated nearest neighbour and the sums of the rigid fit.
 // out32: [0] sum d2, [1..3] sum p (source side), [4..6] sum q (target side), [7..15] sum q_r * p_c, [28] #pairs, [29] #finite
 __global__ __launch_bounds__(kBlock) void k_pcl_pass(const float4 *__restrict__ in, float4 *__restrict__ work, size_t n, T12 T, double gate2, NNView G,
-                                                     double *__restrict__ partials) {
+                                                     unsigned *__restrict__ prev, double *__restrict__ partials, unsigned long long key) {
   double acc[16];
 #pragma unroll
   for (int k = 0; k < 16; k++) acc[k] = 0.0;
@@ -246,7 +253,8 @@ __global__ __launch_bounds__(kBlock) void k_pcl_pass(const float4 *__restrict__ 
     if (sub == 0) work[i] = make_float4(px, py, pz, s.w);
     if (!lsa_finite3(px, py, pz)) continue;
     if (sub == 0) npts++;
-    NNHit hit = nn_nearest_sub<kSub>(G, px, py, pz, kGateRings, sub, (float)gate2);
+    NNHit hit = nn_nearest_sub<kSub>(G, px, py, pz, kGateRings, sub, (float)gate2, prev[i]);
+    if (sub == 0) prev[i] = hit.id == 0xffffffffu ? 0xffffffffu : hit.slot;
     if (sub != 0) continue;  // lane 0 of the group carries the point into the sums
     if (hit.id == 0xffffffffu || (double)hit.d2 > gate2) continue;  // distance[0] > max_dist_sqr
     ncorr++;
@@ -276,7 +284,7 @@ __global__ __launch_bounds__(kBlock) void k_pcl_pass(const float4 *__restrict__ 
   if (threadIdx.x < kOut) {
     double v = 0.0;
     for (int w = 0; w < kBlock / 64; w++) v += sm[w][threadIdx.x];
-    partials[(size_t)blockIdx.x * kOut + threadIdx.x] = v;
+    lsa_store_row32(partials + (size_t)blockIdx.x * kOut, (int)threadIdx.x, v, key);
   }
 }
 
@@ -361,6 +369,9 @@ struct lsa_icp {
   DevBuf<float4> d_target, d_source_own, d_work;
   DevBuf<double> partials, d_out;
   PinnedBuf<double> h_out, h_partials;
+  unsigned long long pass_seq = 0, row_key = 0;  // check word of the rows of the pass in flight (0: plain rows)
+  unsigned unsynced = 0;
+  DevBuf<unsigned> prev;  // per source point: cell-sorted slot of the neighbour found one iteration ago (0xffffffff: none)
   PinnedBuf<float> h_stage;
   bool has_target = false;
   size_t n_target = 0;
@@ -435,24 +446,30 @@ unsigned icp_grid_size(const lsa_icp *h, size_t n) {
 // the host adds them (fixed order) — no reduction launch, no copy; larger grids use the device reduction.
 constexpr unsigned kHostRows = 512;
 double *icp_partials_dst(lsa_icp *h, unsigned g) { return g <= kHostRows ? h->h_partials.p : h->partials.p; }
+// host-bound rows carry a check word (lsa_store_row32) so that the host can add them as they arrive; 0 = plain rows
+unsigned long long icp_next_key(lsa_icp *h, unsigned g) {
+  if (g > kHostRows) return h->row_key = 0ull;
+  unsigned long long key = (++h->pass_seq) * 0x9E3779B97F4A7C15ull;
+  if (!key) key = (++h->pass_seq) * 0x9E3779B97F4A7C15ull;
+  return h->row_key = key;
+}
 
 // brings the 32 sums of `g` partial rows to h->h_out
 int icp_fetch_sums(lsa_icp *h, unsigned g) {
   lsa_context *ctx = h->ctx;
   LSA_HIP(ctx, hipGetLastError());
   if (g <= kHostRows) {
-    LSA_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    // rows b, b + 32, ... accumulate in ascending b, then a 32-way tree: the order k_reduce32 uses
-    double sm[32][kOut];
-    for (int r = 0; r < 32; r++) for (int c = 0; c < kOut; c++) sm[r][c] = 0.0;
-    for (unsigned b = 0; b < g; b++) {
-      const double *row = h->h_partials.p + (size_t)b * kOut;
-      double *dst = sm[b & 31];
-      for (int c = 0; c < kOut; c++) dst[c] += row[c];
+    // rows b, b + 32, ... accumulate in ascending b, then a 32-way tree (the order k_reduce32 uses), each row as soon as
+    // its check word matches; a row that is 20 ms late is waited for the ordinary way
+    if (!ndt_reduce_partials_host(h->h_partials.p, g, h->row_key, 20.0, h->h_out.p)) {
+      LSA_HIP(ctx, hipStreamSynchronize(ctx->stream));
+      h->unsynced = 0;
+      if (!ndt_reduce_partials_host(h->h_partials.p, g, h->row_key, 0.0, h->h_out.p))
+        return lsa_fail(ctx, LSA_ERR_HIP, "ICP pass: workgroup rows incomplete after the kernel finished");
+    } else if (++h->unsynced >= 256) {  // let the runtime retire its commands now and then
+      LSA_HIP(ctx, hipStreamSynchronize(ctx->stream));
+      h->unsynced = 0;
     }
-    for (int st = 16; st > 0; st >>= 1)
-      for (int r = 0; r < st; r++) for (int c = 0; c < kOut; c++) sm[r][c] += sm[r + st][c];
-    memcpy(h->h_out.p, sm[0], kOut * sizeof(double));
     return LSA_OK;
   }
   hipLaunchKernelGGL(k_reduce32, dim3(1), dim3(1024), 0, ctx->stream, h->partials.p, (int)g, h->d_out.p);
@@ -477,6 +494,8 @@ int icp_match_manual(lsa_icp *h, const float4 *d_src, size_t n, const float pred
   if ((rc = h->d_out.reserve(ctx, kOut))) return rc;
   if ((rc = h->h_out.reserve(ctx, kOut))) return rc;
   if ((rc = h->h_partials.reserve(ctx, (size_t)kHostRows * kOut))) return rc;
+  if ((rc = h->prev.reserve(ctx, n ? n : 1, 1.25))) return rc;
+  LSA_HIP(ctx, hipMemsetAsync(h->prev.p, 0xff, (n ? n : 1) * sizeof(unsigned), ctx->stream));  // no seeds: the first iteration searches cold
   NNView G = nn_view(h->grid);
   for (int it = 0; it < h->max_iter; it++) {
     IcpParams P;
@@ -486,10 +505,10 @@ int icp_match_manual(lsa_icp *h, const float4 *d_src, size_t n, const float pred
     }
     if (h->mode == LSA_ICP_MODE_PLANE) {
       P.gate = h->max_corr * h->max_corr;
-      hipLaunchKernelGGL(k_plane_pass, dim3(g), dim3(kBlock), 0, ctx->stream, d_src, n, P, G, h->slot_normals.p, icp_partials_dst(h, g));
+      hipLaunchKernelGGL(k_plane_pass, dim3(g), dim3(kBlock), 0, ctx->stream, d_src, n, P, G, h->prev.p, h->slot_normals.p, icp_partials_dst(h, g), icp_next_key(h, g));
     } else {
       P.gate = h->max_corr;
-      hipLaunchKernelGGL(k_icp_pass, dim3(g), dim3(kBlock), 0, ctx->stream, d_src, n, P, G, icp_partials_dst(h, g));
+      hipLaunchKernelGGL(k_icp_pass, dim3(g), dim3(kBlock), 0, ctx->stream, d_src, n, P, G, h->prev.p, icp_partials_dst(h, g), icp_next_key(h, g));
     }
     if ((rc = icp_fetch_sums(h, g))) return rc;
     const double *o = h->h_out.p;
@@ -627,6 +646,8 @@ int icp_match_pcl(lsa_icp *h, const float4 *d_src, size_t n, const float predict
   if ((rc = h->h_out.reserve(ctx, kOut))) return rc;
   if ((rc = h->h_partials.reserve(ctx, (size_t)kHostRows * kOut))) return rc;
   if ((rc = h->d_work.reserve(ctx, n ? n : 1, 1.25))) return rc;
+  if ((rc = h->prev.reserve(ctx, n ? n : 1, 1.25))) return rc;
+  LSA_HIP(ctx, hipMemsetAsync(h->prev.p, 0xff, (n ? n : 1) * sizeof(unsigned), ctx->stream));
   NNView G = nn_view(h->grid);
   float final_T[16], incr[16];
   memcpy(final_T, predict, sizeof(final_T));
@@ -637,7 +658,7 @@ int icp_match_pcl(lsa_icp *h, const float4 *d_src, size_t n, const float predict
   int iterations = 0, converged = 0;
   const float4 *in = d_src;
   for (;;) {
-    hipLaunchKernelGGL(k_pcl_pass, dim3(g), dim3(kBlock), 0, ctx->stream, in, h->d_work.p, n, to_t12(incr), gate2, G, icp_partials_dst(h, g));
+    hipLaunchKernelGGL(k_pcl_pass, dim3(g), dim3(kBlock), 0, ctx->stream, in, h->d_work.p, n, to_t12(incr), gate2, G, h->prev.p, icp_partials_dst(h, g), icp_next_key(h, g));
     if ((rc = icp_fetch_sums(h, g))) return rc;
     in = h->d_work.p;
     const double *o = h->h_out.p;
@@ -709,7 +730,7 @@ extern "C" void lsa_icp_destroy(lsa_icp *h) {
   (void)hipSetDevice(h->ctx->device);
   (void)hipStreamSynchronize(h->ctx->stream);
   h->grid.release(); h->vi_n.release(); h->cell_normals.release(); h->slot_normals.release(); h->d_target.release(); h->d_source_own.release(); h->d_work.release();
-  h->partials.release(); h->d_out.release(); h->h_out.release(); h->h_partials.release(); h->h_stage.release();
+  h->partials.release(); h->d_out.release(); h->h_out.release(); h->h_partials.release(); h->h_stage.release(); h->prev.release();
   delete h;
 }
 

@@ -473,20 +473,8 @@ __global__ __launch_bounds__(kBlockD, pass_waves(KIND)) void k_ndt_pass(const fl
     } else if (threadIdx.x == 29) {
       for (int w = 0; w < kWaves; w++) v += wcnt[w * 2 + 1];   // source points of this workgroup
     }
-    // one 256-byte row per workgroup, written once.  key != 0 (rows go to host-mapped memory and the host picks them up
-    // without waiting for the stream): column 31 carries key ^ XOR of the other 31 words, so the host can tell a complete
-    // row of THIS pass from a stale or half-arrived one whatever order the stores land in.
-    unsigned long long w = (unsigned long long)__double_as_longlong(v);
-    if (key) {
-      unsigned long long x = threadIdx.x == kOutDoubles - 1 ? 0ull : w;
-#pragma unroll
-      for (int off = 1; off < 32; off <<= 1) x ^= __shfl_xor(x, off, 64);
-      if (threadIdx.x == kOutDoubles - 1) w = x ^ key;
-      __hip_atomic_store(reinterpret_cast<unsigned long long *>(partials) + (size_t)blockIdx.x * kOutDoubles + threadIdx.x, w, __ATOMIC_RELAXED,
-                         __HIP_MEMORY_SCOPE_SYSTEM);
-    } else {
-      partials[(size_t)blockIdx.x * kOutDoubles + threadIdx.x] = v;
-    }
+    // one 256-byte row per workgroup, written once (check-worded when it goes straight to the host)
+    lsa_store_row32(partials + (size_t)blockIdx.x * kOutDoubles, (int)threadIdx.x, v, key);
   }
 }
 

@@ -31,6 +31,7 @@ struct NNView {
   const uint32_t *bits, *prefix, *start;
   const float4 *sorted;
   float cell;
+  unsigned n_sorted;  // points in sorted[]
 };
 
 // Build over n device points with the given cell edge (synchronises the context's stream once).
@@ -39,6 +40,6 @@ int nn_grid_build(lsa_context *ctx, NNGrid &g, const float4 *d_pts, size_t n, fl
 // transformed by the f32 column-major T, of the SQUARED f32 distance to the nearest point of the grid; pairs with
 // d2 > max_range are dropped; DBL_MAX (std::numeric_limits<double>::max()) when no pair is left.
 int nn_fitness(lsa_context *ctx, NNGrid &g, const float4 *d_src, size_t n, const float T[16], float max_range, double *out);
-inline NNView nn_view(const NNGrid &g) { return NNView{g.vi.map, g.vi.bits.p, g.vi.prefix.p, g.start.p, g.sorted.p, g.cell}; }
+inline NNView nn_view(const NNGrid &g) { return NNView{g.vi.map, g.vi.bits.p, g.vi.prefix.p, g.start.p, g.sorted.p, g.cell, (unsigned)g.n_sorted}; }
 
 #endif

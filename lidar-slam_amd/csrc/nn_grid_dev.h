@@ -12,15 +12,9 @@ struct NNHit {
   unsigned slot;  // its position in the cell-sorted array (index of per-slot side tables)
 };
 
-__device__ __forceinline__ void nn_visit_cell(const NNView &g, int ix, int iy, int iz, float qx, float qy, float qz, NNHit &h) {
-  const CellMap &m = g.map;
-  int cell = ix + iy * m.dim[0] + iz * m.dim[0] * m.dim[1];
-  uint32_t w = g.bits[cell >> 5], bit = 1u << (cell & 31);
-  if (!(w & bit)) return;
-  unsigned rank = g.prefix[cell >> 5] + __popc(w & (bit - 1u));
-  unsigned a = g.start[rank], b = g.start[rank + 1];
-  // four points per step, their loads issued together: a cell holds a handful of points and a load-compare-load chain
-  // would cost one memory round trip per point
+// compare the query with the points sorted[a, b) of one cell.  Four points per step, their loads issued together: a cell
+// holds a handful of points and a load-compare-load chain would cost one memory round trip per point.
+__device__ __forceinline__ void nn_visit_range(const NNView &g, unsigned a, unsigned b, float qx, float qy, float qz, NNHit &h) {
   for (unsigned k0 = a; k0 < b; k0 += 4) {
     float4 t[4];
 #pragma unroll
@@ -40,22 +34,7 @@ __device__ __forceinline__ void nn_visit_cell(const NNView &g, int ix, int iy, i
 __device__ __forceinline__ void nn_visit_bit(const NNView &g, int cell, uint32_t w, float qx, float qy, float qz, NNHit &h) {
   uint32_t bit = 1u << (cell & 31);
   unsigned rank = g.prefix[cell >> 5] + __popc(w & (bit - 1u));
-  unsigned a = g.start[rank], b = g.start[rank + 1];
-  // four points per step, their loads issued together: a cell holds a handful of points and a load-compare-load chain
-  // would cost one memory round trip per point
-  for (unsigned k0 = a; k0 < b; k0 += 4) {
-    float4 t[4];
-#pragma unroll
-    for (int u = 0; u < 4; u++) t[u] = g.sorted[min(k0 + u, b - 1)];
-#pragma unroll
-    for (int u = 0; u < 4; u++) {
-      if (k0 + u >= b) break;
-      float ex = lsa_fsub(qx, t[u].x), ey = lsa_fsub(qy, t[u].y), ez = lsa_fsub(qz, t[u].z);
-      float d = lsa_fadd(lsa_fadd(lsa_fmul(ex, ex), lsa_fmul(ey, ey)), lsa_fmul(ez, ez));  // FLANN L2_Simple, f32
-      unsigned id = __float_as_uint(t[u].w);
-      if (d < h.d2 || (d == h.d2 && id < h.id)) { h.d2 = d; h.id = id; h.x = t[u].x; h.y = t[u].y; h.z = t[u].z; h.slot = k0 + u; }
-    }
-  }
+  nn_visit_range(g, g.start[rank], g.start[rank + 1], qx, qy, qz, h);
 }
 
 // visit the occupied cells among x in [xa, xb] (clipped by the caller) of row (iy, iz); only_ends: just xa and xb.
@@ -97,17 +76,36 @@ __device__ __forceinline__ void nn_visit_row(const NNView &g, int xa, int xb, in
 // rows — that cannot hold a point closer than min(gate_d2, best so far) are skipped without touching memory: the cube
 // of rings shrinks to the sphere that matters (about half the cells), which is what bounds a query with no neighbour.
 template <int SUB>
-__device__ __forceinline__ NNHit nn_nearest_sub(const NNView &g, float qx, float qy, float qz, int max_ring, int sub, float gate_d2 = INFINITY) {
+__device__ __forceinline__ NNHit nn_nearest_sub(const NNView &g, float qx, float qy, float qz, int max_ring, int sub, float gate_d2 = INFINITY,
+                                                unsigned seed_slot = 0xffffffffu) {
   const CellMap &m = g.map;
   NNHit h;
   h.d2 = INFINITY; h.id = 0xffffffffu; h.x = h.y = h.z = 0.0f; h.slot = 0u;
+  // seed_slot: a point of the sorted array known to be a good guess (the neighbour found for this query one ICP iteration
+  // ago).  It is treated as already visited, which changes nothing in the answer — every cell that could hold a closer
+  // (or equally close, lower-index) point is still searched — but shrinks the sphere the search has to cover from the
+  // start; from the second iteration on most queries end after their own cell and a few face neighbours.
+  if (seed_slot < g.n_sorted) {
+    const float4 t = g.sorted[seed_slot];
+    const float ex = lsa_fsub(qx, t.x), ey = lsa_fsub(qy, t.y), ez = lsa_fsub(qz, t.z);
+    h.d2 = lsa_fadd(lsa_fadd(lsa_fmul(ex, ex), lsa_fmul(ey, ey)), lsa_fmul(ez, ez));
+    h.id = __float_as_uint(t.w); h.x = t.x; h.y = t.y; h.z = t.z; h.slot = seed_slot;
+  }
   // unclamped cell coordinates relative to the grid corner (mode-1 rule: floor(x / leaf) - min_b), saturated so that
   // the ring arithmetic cannot overflow
-  float fx = floorf(lsa_fdiv(qx, m.leaf[0])), fy = floorf(lsa_fdiv(qy, m.leaf[1])), fz = floorf(lsa_fdiv(qz, m.leaf[2]));
+  const float vx = lsa_fdiv(qx, m.leaf[0]), vy = lsa_fdiv(qy, m.leaf[1]), vz = lsa_fdiv(qz, m.leaf[2]);
+  float fx = floorf(vx), fy = floorf(vy), fz = floorf(vz);
   const float lim = 5.0e8f;
   int c0 = (int)fminf(fmaxf(fx, -lim), lim) - m.min_b[0];
   int c1 = (int)fminf(fmaxf(fy, -lim), lim) - m.min_b[1];
   int c2 = (int)fminf(fmaxf(fz, -lim), lim) - m.min_b[2];
+  // position of the query inside its own cell, in cells: [0, 1).  A point that the grid puts into cell i has
+  // floor(x / leaf) == i under the same f32 division, so along one axis it is at least (i - c - u) cells (i > c) or
+  // (c - i - 1 + u) cells (i < c) away from the query, up to the rounding of that division; kSlack (in metres, far above an
+  // ulp of any coordinate the grid accepts) is taken off every such bound.
+  const float ux = fminf(fmaxf(vx - fx, 0.0f), 1.0f), uy = fminf(fmaxf(vy - fy, 0.0f), 1.0f), uz = fminf(fmaxf(vz - fz, 0.0f), 1.0f);
+  const float kSlack = 1e-3f;
+  const float umin = fminf(fminf(fminf(ux, 1.0f - ux), fminf(uy, 1.0f - uy)), fminf(uz, 1.0f - uz));
   int out0 = c0 < 0 ? -c0 : (c0 > m.dim[0] - 1 ? c0 - (m.dim[0] - 1) : 0);
   int out1 = c1 < 0 ? -c1 : (c1 > m.dim[1] - 1 ? c1 - (m.dim[1] - 1) : 0);
   int out2 = c2 < 0 ? -c2 : (c2 > m.dim[2] - 1 ? c2 - (m.dim[2] - 1) : 0);
@@ -122,22 +120,30 @@ __device__ __forceinline__ NNHit nn_nearest_sub(const NNView &g, float qx, float
     for (int iz = zc0; iz <= zc1; iz++)
       for (int iy = yc0; iy <= yc1; iy++) {
         if (SUB != 1 && ((turn++) & (SUB - 1)) != sub) continue;
-        // lower bound of the distance from the query (anywhere inside its own cell) to this row / its cells
+        // lower bound of the distance from the query to this row / its cells (exact slab distances, see above)
         const float bound2 = fminf(gate_d2, h.d2);
-        const float my = fmaxf((float)(abs(iy - c1) - 1) * g.cell - 1e-3f, 0.0f), mz = fmaxf((float)(abs(iz - c2) - 1) * g.cell - 1e-3f, 0.0f);
+        const float gy = iy > c1 ? (float)(iy - c1) - uy : (iy < c1 ? (float)(c1 - iy - 1) + uy : 0.0f);
+        const float gz = iz > c2 ? (float)(iz - c2) - uz : (iz < c2 ? (float)(c2 - iz - 1) + uz : 0.0f);
+        const float my = fmaxf(gy * g.cell - kSlack, 0.0f), mz = fmaxf(gz * g.cell - kSlack, 0.0f);
         const float ryz2 = my * my + mz * mz;
         if (ryz2 > bound2) continue;
         const bool shell = iz == z0 || iz == z1 || iy == y0 || iy == y1;  // a face row: every x of the ring's extent
         if (shell) {
-          // x offsets beyond 1 + sqrt(bound2 - ryz2) / cell cannot matter
-          const int reach = 1 + (int)(sqrtf(bound2 - ryz2) / g.cell + 1.0f);
-          const int xa = (bound2 == INFINITY) ? xc0 : max(xc0, c0 - reach), xb = (bound2 == INFINITY) ? xc1 : min(xc1, c0 + reach);
+          // cells more than sqrt(bound2 - ryz2) away along x cannot matter: nl cells to the left of c0, nr to the right
+          int xa = xc0, xb = xc1;
+          if (bound2 != INFINITY) {
+            const float rc = (sqrtf(bound2 - ryz2) + kSlack) / g.cell;
+            const float tl = rc - ux, tr = rc - (1.0f - ux);
+            const int nl = tl < 0.0f ? 0 : (int)fminf(tl, 1.0e6f) + 1, nr = tr < 0.0f ? 0 : (int)fminf(tr, 1.0e6f) + 1;
+            xa = max(xc0, c0 - nl);
+            xb = min(xc1, c0 + nr);
+          }
           if (xa <= xb) nn_visit_row(g, xa, xb, iy, iz, false, qx, qy, qz, h);
         } else {
-          const float mx = fmaxf((float)(rho - 1) * g.cell - 1e-3f, 0.0f);
-          if (ryz2 + mx * mx > bound2) continue;
-          // an inner row contributes only the two end cells x0, x1 (when inside the grid)
-          const bool in0 = x0 >= 0 && x0 < m.dim[0], in1 = x1 >= 0 && x1 < m.dim[0] && x1 != x0;
+          // an inner row contributes only the two end cells x0, x1 (when inside the grid and close enough)
+          const float ml = fmaxf(((float)(rho - 1) + ux) * g.cell - kSlack, 0.0f), mr = fmaxf(((float)rho - ux) * g.cell - kSlack, 0.0f);
+          const bool in0 = x0 >= 0 && x0 < m.dim[0] && ryz2 + ml * ml <= bound2;
+          const bool in1 = x1 >= 0 && x1 < m.dim[0] && x1 != x0 && ryz2 + mr * mr <= bound2;
           if (in0 && in1) nn_visit_row(g, x0, x1, iy, iz, true, qx, qy, qz, h);
           else if (in0) nn_visit_row(g, x0, x0, iy, iz, true, qx, qy, qz, h);
           else if (in1) nn_visit_row(g, x1, x1, iy, iz, true, qx, qy, qz, h);
@@ -152,9 +158,12 @@ __device__ __forceinline__ NNHit nn_nearest_sub(const NNView &g, float qx, float
         if (o.d2 < h.d2 || (o.d2 == h.d2 && o.id < h.id)) h = o;
       }
     }
-    // every cell not visited yet lies at least rho * cell away from the query (minus slack for the f32 cell rounding)
-    float lb = (float)rho * g.cell - 1e-3f;
+    // every cell not visited yet differs from the query's by more than rho along some axis, i.e. lies at least
+    // (rho + umin) cells away
+    float lb = ((float)rho + umin) * g.cell - kSlack;
     if (h.id != 0xffffffffu && lb > 0.0f && h.d2 <= lb * lb) break;
+    // ... and nothing farther than the gate is wanted at all
+    if (lb > 0.0f && gate_d2 < lb * lb) break;
   }
   return h;
 }

@@ -73,6 +73,19 @@ __device__ __forceinline__ void lsa_cell_unravel(const CellMap &m, int cell, int
   ijk_abs[0] = i + m.min_b[0]; ijk_abs[1] = j + m.min_b[1]; ijk_abs[2] = k + m.min_b[2];
 }
 
+// Lanes 0..31 of a wave write one 32-double workgroup row.  key != 0: the row goes to host-mapped memory and the host
+// picks it up without waiting for the stream, so column 31 carries key ^ XOR of the other 31 words (it must hold no
+// payload): the host can tell a complete row of THIS pass from a stale or half-arrived one whatever order the stores land in.
+__device__ __forceinline__ void lsa_store_row32(double *__restrict__ row, int col, double v, unsigned long long key) {
+  if (!key) { row[col] = v; return; }
+  unsigned long long w = (unsigned long long)__double_as_longlong(v);
+  unsigned long long x = col == 31 ? 0ull : w;
+#pragma unroll
+  for (int off = 1; off < 32; off <<= 1) x ^= __shfl_xor(x, off, 64);
+  if (col == 31) w = x ^ key;
+  __hip_atomic_store(reinterpret_cast<unsigned long long *>(row) + col, w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
 __device__ __forceinline__ double lsa_wave_sum(double v) {
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
