@@ -91,12 +91,19 @@ __global__ __launch_bounds__(kBlock) void k_blocks_compact(const long long *__re
 
 struct T12s { float v[12]; };
 
+// kFitLanes adjacent lanes share one source point: each takes every kFitLanes-th leaf of the brute-force argmin and every
+// kFitLanes-th voxel of the winning leaf's box, and the partial results are merged with the reference's tie rules (the
+// comparison is on the ROUNDED f64 distance, lower leaf id on equality, so the f64 sqrt cannot be dropped — but it is only
+// taken for leaves whose squared distance does not already rule them out).  One lane per point walked ~1500 leaves and
+// up to 32 dependent bitmap -> prefix -> record chains alone: 182 us for 7.7 k points on 30 workgroups.
+constexpr int kFitLanes = 8;
 __global__ __launch_bounds__(kBlock) void k_fitness(const float4 *__restrict__ src, size_t n, T12s Tm, const LeafRec *__restrict__ leaves,
                                                     unsigned nleaves, CellMap m, const uint32_t *__restrict__ bits, const uint32_t *__restrict__ prefix,
                                                     const double *__restrict__ rec, double *__restrict__ partials) {
   __shared__ LeafRec tile[kBlock];
   __shared__ double sm[kBlock / 64][2];
-  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int sub = threadIdx.x & (kFitLanes - 1);
+  size_t i = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) / kFitLanes;
   bool live = i < n;
   float qx = 0, qy = 0, qz = 0;
   const float *T12 = Tm.v;
@@ -107,7 +114,7 @@ __global__ __launch_bounds__(kBlock) void k_fitness(const float4 *__restrict__ s
     qz = lsa_fadd(lsa_fadd(lsa_fadd(lsa_fmul(T12[8], s.x), lsa_fmul(T12[9], s.y)), lsa_fmul(T12[10], s.z)), T12[11]);
     live = lsa_finite3(qx, qy, qz);
   }
-  double best = DBL_MAX;
+  double best = DBL_MAX, best2_hi = DBL_MAX;  // best2_hi: a squared distance above it cannot reach `best` after the sqrt
   int best_id = INT_MAX;
   float bbox[6] = {0, 0, 0, 0, 0, 0};
   for (unsigned base = 0; base < nleaves; base += kBlock) {
@@ -116,19 +123,36 @@ __global__ __launch_bounds__(kBlock) void k_fitness(const float4 *__restrict__ s
     __syncthreads();
     unsigned cntl = min((unsigned)kBlock, nleaves - base);
     if (live) {
-      for (unsigned k = 0; k < cntl; k++) {
+      for (unsigned k = sub; k < cntl; k += kFitLanes) {
         const LeafRec &L = tile[k];
         double dx = L.c[0] - (double)qx, dy = L.c[1] - (double)qy, dz = L.c[2] - (double)qz;
-        double d = sqrt(dx * dx + dy * dy + dz * dz);
+        double d2 = dx * dx + dy * dy + dz * dz;
+        if (d2 > best2_hi) continue;
+        double d = sqrt(d2);
         if (d < best || (d == best && L.id < best_id)) {
           best = d; best_id = L.id;
+          best2_hi = d * d * (1.0 + 1e-14);
 #pragma unroll
           for (int a = 0; a < 6; a++) bbox[a] = L.box[a];
         }
       }
     }
   }
-  double dist = 0.0, cnt = 0.0;
+  // merge the kFitLanes partial winners (all lanes of a group end with the group's)
+#pragma unroll
+  for (int off = 1; off < kFitLanes; off <<= 1) {
+    double ob = __shfl_xor(best, off, 64);
+    int oid = __shfl_xor(best_id, off, 64);
+    float obox[6];
+#pragma unroll
+    for (int a = 0; a < 6; a++) obox[a] = __shfl_xor(bbox[a], off, 64);
+    if (ob < best || (ob == best && oid < best_id)) {
+      best = ob; best_id = oid;
+#pragma unroll
+      for (int a = 0; a < 6; a++) bbox[a] = obox[a];
+    }
+  }
+  double md = DBL_MAX;
   if (live && best_id != INT_MAX) {
     // nearestVoxel (VoxelGrid.cpp:483-521): voxels floor(lower / leaf) .. floor(upper / leaf) holding >= 1 point
     int lo[3], hi[3];
@@ -137,21 +161,26 @@ __global__ __launch_bounds__(kBlock) void k_fitness(const float4 *__restrict__ s
       hi[a] = (int)floorf(lsa_fdiv(bbox[3 + a], m.leaf[a])) - m.min_b[a];
       lo[a] = max(lo[a], 0); hi[a] = min(hi[a], m.dim[a] - 1);
     }
-    double md = DBL_MAX;
-    for (int ix = lo[0]; ix <= hi[0]; ix++)
-      for (int iy = lo[1]; iy <= hi[1]; iy++)
-        for (int iz = lo[2]; iz <= hi[2]; iz++) {
-          int cell = ix + iy * m.dim[0] + iz * m.dim[0] * m.dim[1];
-          uint32_t w = bits[cell >> 5], bit = 1u << (cell & 31);
-          if (!(w & bit)) continue;
-          unsigned rank = prefix[cell >> 5] + __popc(w & (bit - 1u));
-          const double *R = rec + (size_t)rank * kRecDoubles;
-          double dx = (double)qx - R[0], dy = (double)qy - R[1], dz = (double)qz - R[2];
-          double d = sqrt(dx * dx + dy * dy + dz * dz);
-          if (d < md) md = d;
-        }
-    if (md < DBL_MAX) { dist = md; cnt = 1.0; }  // distance < max_range (= DBL_MAX) (:954-957)
+    const int nx = hi[0] - lo[0] + 1, ny = hi[1] - lo[1] + 1, nz = hi[2] - lo[2] + 1;
+    if (nx > 0 && ny > 0 && nz > 0) {
+      const long long total = (long long)nx * ny * nz;
+      for (long long c = sub; c < total; c += kFitLanes) {
+        int iz = (int)(c % nz), iy = (int)((c / nz) % ny), ix = (int)(c / ((long long)nz * ny));
+        int cell = (lo[0] + ix) + (lo[1] + iy) * m.dim[0] + (lo[2] + iz) * m.dim[0] * m.dim[1];
+        uint32_t w = bits[cell >> 5], bit = 1u << (cell & 31);
+        if (!(w & bit)) continue;
+        unsigned rank = prefix[cell >> 5] + __popc(w & (bit - 1u));
+        const double *R = rec + (size_t)rank * kRecDoubles;
+        double dx = (double)qx - R[0], dy = (double)qy - R[1], dz = (double)qz - R[2];
+        double d = sqrt(dx * dx + dy * dy + dz * dz);
+        if (d < md) md = d;
+      }
+    }
   }
+#pragma unroll
+  for (int off = 1; off < kFitLanes; off <<= 1) md = fmin(md, __shfl_xor(md, off, 64));
+  double dist = 0.0, cnt = 0.0;
+  if (sub == 0 && live && best_id != INT_MAX && md < DBL_MAX) { dist = md; cnt = 1.0; }  // distance < max_range (= DBL_MAX) (:954-957)
   dist = lsa_wave_sum(dist);
   cnt = lsa_wave_sum(cnt);
   int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -267,7 +296,7 @@ int ndt_fitness(lsa_ndt *h, float *score) {
   T12s Tm;
   for (int r = 0; r < 3; r++)
     for (int c = 0; c < 4; c++) Tm.v[r * 4 + c] = h->last_T[c * 4 + r];
-  unsigned nb = lsa_div_up(n, kBlock);
+  unsigned nb = lsa_div_up(n * kFitLanes, kBlock);
   if ((rc = f->partials.reserve(ctx, (size_t)nb * 2 + 2, 1.25))) return rc;
   hipLaunchKernelGGL(k_fitness, dim3(nb), dim3(kBlock), 0, ctx->stream, h->d_source, n, Tm, f->leaves.p, f->nleaves, h->vi.map, h->vi.bits.p,
                      h->vi.prefix.p, h->rec.p, f->partials.p);

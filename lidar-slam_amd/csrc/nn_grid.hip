@@ -56,19 +56,21 @@ __global__ __launch_bounds__(kBlock) void k_scatter(const float4 *__restrict__ p
 }
 struct T12 { float v[12]; };
 
-// one lane per source point; the unbounded ring search ends as soon as the best distance is proven minimal, which for a
-// scan registered to its map is ring 1 or 2
+// four adjacent lanes per source point share its search (nn_nearest_sub); the unbounded ring search ends as soon as the
+// best distance is proven minimal, which for a scan registered to its map is the query's own cell or ring 1
+constexpr int kFitSub = 4;
 __global__ __launch_bounds__(kBlock) void k_nn_fitness(const float4 *__restrict__ src, size_t n, T12 T, float max_range, NNView G,
                                                        double *__restrict__ partials) {
   double sum = 0.0, cnt = 0.0;
-  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+  const int sub = threadIdx.x & (kFitSub - 1);
+  for (size_t i = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) / kFitSub; i < n; i += (size_t)gridDim.x * blockDim.x / kFitSub) {
     float4 s = src[i];
     float qx = lsa_fadd(lsa_fadd(lsa_fadd(lsa_fmul(T.v[0], s.x), lsa_fmul(T.v[1], s.y)), lsa_fmul(T.v[2], s.z)), T.v[3]);
     float qy = lsa_fadd(lsa_fadd(lsa_fadd(lsa_fmul(T.v[4], s.x), lsa_fmul(T.v[5], s.y)), lsa_fmul(T.v[6], s.z)), T.v[7]);
     float qz = lsa_fadd(lsa_fadd(lsa_fadd(lsa_fmul(T.v[8], s.x), lsa_fmul(T.v[9], s.y)), lsa_fmul(T.v[10], s.z)), T.v[11]);
     if (!lsa_finite3(qx, qy, qz)) continue;
-    NNHit h = nn_nearest(G, qx, qy, qz, 0x7fffffff);
-    if (h.id != 0xffffffffu && h.d2 <= max_range) { sum += (double)h.d2; cnt += 1.0; }
+    NNHit h = nn_nearest_sub<kFitSub>(G, qx, qy, qz, 0x7fffffff, sub);
+    if (sub == 0 && h.id != 0xffffffffu && h.d2 <= max_range) { sum += (double)h.d2; cnt += 1.0; }
   }
   __shared__ double sm[kBlock / 64][2];
   sum = lsa_wave_sum(sum);
@@ -88,7 +90,7 @@ int nn_fitness(lsa_context *ctx, NNGrid &g, const float4 *d_src, size_t n, const
   if (!g.built) return lsa_fail(ctx, LSA_ERR_NO_TARGET, "fitness: no neighbour grid");
   *out = 1.7976931348623157e308;
   if (!n) return LSA_OK;
-  unsigned nb = (unsigned)std::min<size_t>(lsa_div_up(n, kBlock), (size_t)ctx->num_cus * 8);
+  unsigned nb = (unsigned)std::min<size_t>(lsa_div_up(n * kFitSub, kBlock), (size_t)ctx->num_cus * 8);
   int rc;
   if ((rc = g.fit_partials.reserve(ctx, (size_t)nb * 2, 1.0))) return rc;
   if ((rc = g.fit_host.reserve(ctx, (size_t)nb * 2))) return rc;
