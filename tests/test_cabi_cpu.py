@@ -125,6 +125,40 @@ def test_host_gn_driver_line_search_branch(scan_pair, oracle):
     assert np.max(np.abs(T_got - T_ref)) <= 1e-6
 
 
+def test_newton_step_well_conditioned_and_rank_deficient():
+    """The Newton system is solved by Gaussian elimination when it is well conditioned and by the Jacobi SVD (Eigen's
+    JacobiSVD::solve semantics: minimum-norm solution, rank by 6 eps sigma_max) otherwise.  One iteration of lsa_gn_solve
+    on synthetic normal equations: the step direction must be pinv(H) (-g) in both regimes."""
+    rs = np.random.RandomState(11)
+    J = rs.normal(size=(40, 6)) * np.array([1, 1, 1, 30, 30, 30])
+    H_full = J.T @ J
+    H_sing = H_full.copy()
+    H_sing[5, :] = 0.0
+    H_sing[:, 5] = 0.0           # no information about yaw: LU meets a zero pivot, the SVD drops the direction
+    H_near = H_full.copy()
+    H_near[5, :] = H_near[4, :] * (1 + 1e-13)
+    H_near[:, 5] = H_near[:, 4] * (1 + 1e-13)   # numerically rank 5: pivot ratio far below 1e-10 -> SVD path
+    H_near[5, 5] = H_near[4, 4] * (1 + 1e-13) ** 2
+    g = rs.normal(size=6) * 50
+    guess = np.eye(4, dtype=np.float32)
+    for H in (H_full, H_sing, H_near):
+        gg = g.copy()
+        if H is H_sing:
+            gg[5] = 0.0
+
+        def evaluator(T, p, kind, H=H, gg=gg):
+            return registration.pack_out32(-1.0, gg, H, 10, 10)
+
+        T_got, st = registration.gn_solve(evaluator, 1.0, 0.1, 0.01, 1, 0.55, guess)
+        want = np.linalg.pinv(H, rcond=6 * np.finfo(float).eps) @ (-gg)
+        step = np.asarray(st["final_p"], dtype=np.float64)
+        assert np.linalg.norm(step) > 0
+        cosang = float(step @ want / (np.linalg.norm(step) * np.linalg.norm(want)))
+        assert abs(abs(cosang) - 1.0) < 1e-9, cosang
+        if H is H_sing:
+            assert step[5] == 0.0
+
+
 def test_public_header_is_plain_c(tmp_path):
     """The boundary is a C ABI: include/lidar_slam_amd.h must compile as C99 (no C++ types, default arguments or
     references) and as C++11, on its own."""
