@@ -37,6 +37,22 @@ __global__ __launch_bounds__(kBlock) void k_transform(const float4 *__restrict__
   out[i] = o;
 }
 
+// the same into a fixed-size slot of the local-map buffer: points [n, cap) of the slot become NaN, which every kernel
+// downstream (filter, voxel table, neighbour grid) skips
+__global__ __launch_bounds__(kBlock) void k_transform_slot(const float4 *__restrict__ in, size_t n, size_t cap, T12 T, float4 *__restrict__ out) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= cap) return;
+  float4 o = make_float4(NAN, NAN, NAN, 0.0f);
+  if (i < n) {
+    float4 s = in[i];
+    o.x = lsa_fadd(lsa_fadd(lsa_fadd(lsa_fmul(T.v[0], s.x), lsa_fmul(T.v[1], s.y)), lsa_fmul(T.v[2], s.z)), T.v[3]);
+    o.y = lsa_fadd(lsa_fadd(lsa_fadd(lsa_fmul(T.v[4], s.x), lsa_fmul(T.v[5], s.y)), lsa_fmul(T.v[6], s.z)), T.v[7]);
+    o.z = lsa_fadd(lsa_fadd(lsa_fadd(lsa_fmul(T.v[8], s.x), lsa_fmul(T.v[9], s.y)), lsa_fmul(T.v[10], s.z)), T.v[11]);
+    o.w = s.w;
+  }
+  out[i] = o;
+}
+
 __global__ __launch_bounds__(kBlock) void k_copy_w(const float4 *__restrict__ in, size_t n, float4 *__restrict__ out, int force_w_one) {
   size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
@@ -91,6 +107,7 @@ struct KeyFrame {
   DevBuf<float4> pts;
   size_t n = 0;
   float pose[16];
+  int slot = -1;  // which slot of the local-map buffer holds its transformed points
 };
 
 struct lsa_front_end {
@@ -104,36 +121,49 @@ struct lsa_front_end {
   PinnedBuf<float> h_stage;
   float init_pose[16], last_pose[16], predict_pose[16], step_pose[16], last_kf_pose[16];
   size_t map_points = 0, target_points = 0;
+  size_t slot_cap = 0;  // points per local-map slot
   long frames_seen = 0;
 };
 
 namespace {
-int fe_rebuild_map(lsa_front_end *fe) {
+// The local map buffer is `local_frame_num` slots of slot_cap points; a key-frame's transformed cloud lives in its slot
+// until the frame leaves the window (its pose never changes), so a new key-frame costs ONE transform launch — into the
+// slot of the frame it evicts — instead of re-transforming all 20.  The frames therefore sit in the buffer in slot order,
+// not in age order, with NaN padding behind each: the 0.3 m filter and the voxel table sum in exact fixed point, so their
+// results do not depend on the order of the points (and they skip non-finite ones).
+void fe_transform_into_slot(lsa_front_end *fe, KeyFrame *f) {
+  T12 T;
+  for (int r = 0; r < 3; r++)
+    for (int c = 0; c < 4; c++) T.v[r * 4 + c] = f->pose[c * 4 + r];
+  hipLaunchKernelGGL(k_transform_slot, dim3(lsa_div_up(fe->slot_cap, kBlock)), dim3(kBlock), 0, fe->ctx->stream, f->pts.p, f->n, fe->slot_cap, T,
+                     fe->d_map.p + (size_t)f->slot * fe->slot_cap);
+}
+
+int fe_rebuild_map(lsa_front_end *fe, KeyFrame *added) {
   lsa_context *ctx = fe->ctx;
-  size_t total = 0;
-  for (KeyFrame *f : fe->frames) total += f->n;
+  size_t sum = 0, biggest = 0;
+  for (KeyFrame *f : fe->frames) { sum += f->n; biggest = std::max(biggest, f->n); }
   int rc;
-  if ((rc = fe->d_map.reserve(ctx, total, 1.25))) return rc;
-  size_t off = 0;
-  for (KeyFrame *f : fe->frames) {
-    if (!f->n) continue;
-    T12 T;
-    for (int r = 0; r < 3; r++)
-      for (int c = 0; c < 4; c++) T.v[r * 4 + c] = f->pose[c * 4 + r];
-    hipLaunchKernelGGL(k_transform, dim3(lsa_div_up(f->n, kBlock)), dim3(kBlock), 0, ctx->stream, f->pts.p, f->n, T, fe->d_map.p + off, 0);
-    off += f->n;
+  if (biggest > fe->slot_cap || !fe->d_map.p) {  // first frame, or a cloud larger than any before: lay the buffer out anew
+    fe->slot_cap = biggest + biggest / 8 + 1;
+    if ((rc = fe->d_map.reserve(ctx, fe->slot_cap * (size_t)fe->cfg.local_frame_num))) return rc;
+    int k = 0;
+    for (KeyFrame *f : fe->frames) { f->slot = k++; fe_transform_into_slot(fe, f); }
+  } else {
+    fe_transform_into_slot(fe, added);
   }
+  const size_t total = fe->slot_cap * fe->frames.size();  // slots 0 .. size-1 are the occupied ones (see fe_add_key_frame)
   LSA_HIP(ctx, hipGetLastError());
-  fe->map_points = total;
+  fe->map_points = sum;
   if ((int)fe->frames.size() < 10 || !fe->cfg.use_map_filter) {  // front_end.cpp:394-396: few key-frames -> unfiltered map
-    fe->target_points = total;
+    fe->target_points = sum;
     return lsa_ndt_set_input_target_device(fe->ndt, (const float *)fe->d_map.p, total);
   }
   if ((rc = fe->d_map_f.reserve(ctx, total, 1.25))) return rc;
   size_t V = 0;
   rc = lsa_voxel_filter_apply_device(fe->map_filter, (const float *)fe->d_map.p, total, (float *)fe->d_map_f.p, &V);
   if (rc == LSA_ERR_RANGE) {  // PCL passes the input through
-    fe->target_points = total;
+    fe->target_points = sum;
     return lsa_ndt_set_input_target_device(fe->ndt, (const float *)fe->d_map.p, total);
   }
   if (rc) return rc;
@@ -147,11 +177,13 @@ int fe_add_key_frame(lsa_front_end *fe, const float4 *d_cloud, size_t n, const f
   if ((int)fe->frames.size() >= fe->cfg.local_frame_num && !fe->frames.empty()) {  // :364-372: slide the window
     kf = fe->frames.front();
     fe->frames.pop_front();
-  } else if (!fe->pool.empty()) {
+  } else if (!fe->pool.empty()) {  // (the evicted frame's object is reused and with it its slot of the map buffer)
     kf = fe->pool.back();
     fe->pool.pop_back();
+    kf->slot = (int)fe->frames.size();
   } else {
     kf = new KeyFrame();
+    kf->slot = (int)fe->frames.size();
   }
   int rc = kf->pts.reserve(ctx, n, 1.1);
   if (rc) { fe->pool.push_back(kf); return rc; }
@@ -163,7 +195,7 @@ int fe_add_key_frame(lsa_front_end *fe, const float4 *d_cloud, size_t n, const f
     fe->pool.push_back(fe->frames.front());
     fe->frames.pop_front();
   }
-  return fe_rebuild_map(fe);
+  return fe_rebuild_map(fe, kf);
 }
 
 int fe_update_device(lsa_front_end *fe, const float4 *d_cloud, size_t n, float pose_out[16], lsa_front_end_stats *stats) {
