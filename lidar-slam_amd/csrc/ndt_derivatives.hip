@@ -145,17 +145,23 @@ struct TilePoint {
 };
 
 // per-wave LDS slice
+// The point data of a tile (TilePoint + its 23 terms) is double-buffered (nb = 2) in the passes that carry pairs over
+// from one tile to the next (see phase B): the pairs a tile leaves after its last FULL round of 64 join the next tile's
+// first round, whose phase 0 writes the other buffer.  The gradient-only pass of the line search (KIND 1) keeps one buffer:
+// its pair math is cheap and the 14 KB it saves per workgroup is what lets a fourth workgroup share the CU.
 constexpr int kLdsTp = 0;
-constexpr int kLdsTerms = 512;                                                           // 16 * 32 B
-constexpr int kLdsCand = kLdsTerms + kTilePts * kTermStride * 8;                         // + 3072
-constexpr int kLdsQueue = kLdsCand + kQueueCap * 4;                                      // + 1728
-constexpr int kLdsSlice = ((kLdsQueue + (kQueueCap + 1) * 4 + 255) / 256) * 256;         // 7168 (queue + one dump slot)
-constexpr int kLdsTiles = kLdsSlice * kWaves;                                            // 28672
+constexpr int kQueueSlots = kQueueCap + 64;                                              // a tile's pairs behind < 64 carried ones
+constexpr int lds_terms(int nb) { return nb * 512; }                                     // after nb x 16 * 32 B of TilePoint
+constexpr int lds_cand(int nb) { return lds_terms(nb) + nb * kTilePts * kTermStride * 8; }  // + nb x 3072
+constexpr int lds_queue(int nb) { return lds_cand(nb) + kQueueCap * 4; }                 // + 1728
+constexpr int lds_slice(int nb) { return ((lds_queue(nb) + (kQueueSlots + 1) * 4 + 255) / 256) * 256; }  // 7424 / 11008 (queue + one dump slot)
+constexpr int lds_tiles(int nb) { return lds_slice(nb) * kWaves; }                       // 29696 / 44032
 constexpr int kLdsRed = kRedLanes * kRedStride * 8;                                      // 29696 (aliases the slices after the loops)
-constexpr int kLdsRed2 = (kLdsRed > kLdsTiles ? kLdsRed : kLdsTiles);
-constexpr int kLdsConst = kLdsRed2 + (8 * 32 + 2 * kWaves) * 8;                          // + second-stage [8][32] + per-wave counters
-constexpr int kLdsBytes = kLdsConst + 72 * 8;                                            // + the 69 angle-derivative constants
-static_assert(kTilePts * (int)sizeof(TilePoint) <= kLdsTerms, "tile points overflow their LDS slot");
+constexpr int lds_red2(int nb) { return kLdsRed > lds_tiles(nb) ? kLdsRed : lds_tiles(nb); }
+constexpr int lds_const(int nb) { return lds_red2(nb) + (8 * 32 + 2 * kWaves) * 8; }     // + second-stage [8][32] + per-wave counters
+constexpr int lds_bytes(int nb) { return lds_const(nb) + 72 * 8; }                       // + the 69 angle-derivative constants
+constexpr int pass_bufs(int kind) { return kind == 1 ? 1 : 2; }
+static_assert(kTilePts * (int)sizeof(TilePoint) <= 512, "tile points overflow their LDS slot");
 
 // wave-level ordering point for LDS hand-offs between lanes of ONE wave: LDS operations of a wave execute in order, so it
 // is enough to stop the compiler from moving accesses across it (this is what a workgroup barrier of a single-wave
@@ -188,7 +194,10 @@ template <int KIND, bool DENSE>
 __global__ __launch_bounds__(kBlockD, pass_waves(KIND)) void k_ndt_pass(const float4 *__restrict__ src, size_t n, PassParams P, const uint4 *__restrict__ words,
                                                       const float4 *__restrict__ dense, const double *__restrict__ rec, double *__restrict__ partials,
                                                       unsigned long long key) {
-  __shared__ __align__(16) unsigned char lds[kLdsBytes];
+  constexpr int NB = pass_bufs(KIND);
+  constexpr int kLdsSlice = lds_slice(NB), kLdsTerms = lds_terms(NB), kLdsCand = lds_cand(NB), kLdsQueue = lds_queue(NB), kLdsRed2 = lds_red2(NB),
+                kLdsConst = lds_const(NB);
+  __shared__ __align__(16) unsigned char lds[lds_bytes(NB)];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   unsigned char *slice = lds + wave * kLdsSlice;
   TilePoint *tp = reinterpret_cast<TilePoint *>(slice + kLdsTp);
@@ -216,7 +225,9 @@ __global__ __launch_bounds__(kBlockD, pass_waves(KIND)) void k_ndt_pass(const fl
     size_t i0 = tile0 * kTilePts + ppl;
     if (i0 < n) s_next = src[i0];
   }
-  for (size_t tile = tile0; tile < ntiles; tile += tstride) {
+  unsigned carried = 0;  // pairs at the front of the queue left over by the previous tile (< 64, wave-uniform)
+  int pbase = 0;         // which half of tp / terms this tile uses: 0 or kTilePts
+  for (size_t tile = tile0; tile < ntiles; tile += tstride, pbase ^= (NB == 2 ? kTilePts : 0)) {
     // ---- phase 0
     {
       size_t i = tile * kTilePts + ppl;
@@ -261,17 +272,17 @@ __global__ __launch_bounds__(kBlockD, pass_waves(KIND)) void k_ndt_pass(const fl
             }
           }
         }
-        tp[ppl] = t;
+        tp[pbase + ppl] = t;
       }
       // computePointDerivatives (:448-482): dot products of the source point with the angle-derivative vectors;
       // lane group g of a point owns terms 6g .. 6g+5 (KIND 1 needs only the 8 Jacobian terms)
       double x = s.x, y = s.y, z = s.z;
       const int k0 = part4 * 6, k1 = min(k0 + 6, (KIND == 1) ? 8 : kPointTerms);
-      for (int k = k0; k < k1; k++) terms[ppl * kTermStride + k] = x * jh[k * 3] + y * jh[k * 3 + 1] + z * jh[k * 3 + 2];
+      for (int k = k0; k < k1; k++) terms[(pbase + ppl) * kTermStride + k] = x * jh[k * 3] + y * jh[k * 3 + 1] + z * jh[k * 3 + 2];
       if (lane == 0) npts += min((size_t)kTilePts, n - tile * kTilePts);
     }
     wave_sync();
-    unsigned total = 0;
+    unsigned total = carried;  // the queue already holds the previous tile's left-over pairs
     if constexpr (DENSE) {
       // ---- phase A (dense table): row probes -> pairs, pre-filtered on the f32 distance
       unsigned c_ent[kRowRounds * 3];
@@ -287,13 +298,13 @@ __global__ __launch_bounds__(kBlockD, pass_waves(KIND)) void k_ndt_pass(const fl
         int pl = (q < kRowProbes) ? q / kRowsPerPoint : 0;
         int o = q - pl * kRowsPerPoint;
         int dz = o / 3, dy = o - dz * 3;
-        int nxyz = tp[pl].nxyz;
+        int nxyz = tp[pbase + pl].nxyz;
         bool in_box = q < kRowProbes && dy < ((nxyz >> 8) & 0xff) && dz < (nxyz >> 16);
         r_pl[j] = pl;
         r_nx[j] = in_box ? (nxyz & 0xff) : 0;
-        r_cell[j] = in_box ? tp[pl].cell0 + dy * dimx + dz * dimxy : 0;
-        r_y[j] = tp[pl].ry - (float)dy * P.res;
-        r_z[j] = tp[pl].rz - (float)dz * P.res;
+        r_cell[j] = in_box ? tp[pbase + pl].cell0 + dy * dimx + dz * dimxy : 0;
+        r_y[j] = tp[pbase + pl].ry - (float)dy * P.res;
+        r_z[j] = tp[pbase + pl].rz - (float)dz * P.res;
       }
       // all row loads first so the L2 round trips overlap (the table is padded by two cells past the last row)
 #pragma unroll
@@ -303,7 +314,7 @@ __global__ __launch_bounds__(kBlockD, pass_waves(KIND)) void k_ndt_pass(const fl
       }
 #pragma unroll
       for (int j = 0; j < kRowRounds; j++) {
-        const float rx = tp[r_pl[j]].rx;
+        const float rx = tp[pbase + r_pl[j]].rx;
         const float4 ev[3] = {e0[j], e1[j], e2[j]};
 #pragma unroll
         for (int i = 0; i < 3; i++) {
@@ -311,16 +322,18 @@ __global__ __launch_bounds__(kBlockD, pass_waves(KIND)) void k_ndt_pass(const fl
           float d2 = dx * dx + dy * dy + dz * dz;
           int rank = __float_as_int(ev[i].w);  // -1: unoccupied, too few points or rejected eigenvalues (VoxelGrid.cpp:465)
           bool ok = i < r_nx[j] && rank >= 0 && d2 <= P.r2f_pre;
-          c_ent[j * 3 + i] = ((unsigned)r_pl[j]) | ((unsigned)rank << 6);
+          c_ent[j * 3 + i] = ((unsigned)(pbase + r_pl[j])) | ((unsigned)rank << 6);  // point slot incl. its buffer half
           if (ok) c_mask |= 1u << (j * 3 + i);
         }
       }
-      unsigned pos = wave_excl_scan(__popc(c_mask), lane, &total);
+      unsigned fresh;
+      unsigned pos = carried + wave_excl_scan(__popc(c_mask), lane, &fresh);
+      total += fresh;
       // branch-free scatter: rejected entries go to a dump slot one past the queue
 #pragma unroll
       for (int k = 0; k < kRowRounds * 3; k++) {
         bool keep = (c_mask >> k) & 1u;
-        unsigned slot = keep ? pos + __popc(c_mask & ((1u << k) - 1u)) : (unsigned)kQueueCap;
+        unsigned slot = keep ? pos + __popc(c_mask & ((1u << k) - 1u)) : (unsigned)kQueueSlots;
         queue[slot] = c_ent[k];
       }
       wave_sync();
@@ -342,11 +355,11 @@ __global__ __launch_bounds__(kBlockD, pass_waves(KIND)) void k_ndt_pass(const fl
         int pl = (q < kRowProbes) ? q / kRowsPerPoint : 0;
         int o = q - pl * kRowsPerPoint;
         int dz = o / 3, dy = o - dz * 3;
-        int nxyz = tp[pl].nxyz;
+        int nxyz = tp[pbase + pl].nxyz;
         bool in_box = q < kRowProbes && dy < ((nxyz >> 8) & 0xff) && dz < (nxyz >> 16);
         r_pl[j] = pl;
         r_nx[j] = in_box ? (nxyz & 0xff) : 0;
-        r_cell[j] = in_box ? tp[pl].cell0 + dy * dimx + dz * dimxy : 0;
+        r_cell[j] = in_box ? tp[pbase + pl].cell0 + dy * dimx + dz * dimxy : 0;
       }
       // all word loads first so the L2 round trips overlap; the second word is needed only when the row straddles a
       // 32-cell boundary (out-of-box probes read word 0 and are masked by nx == 0)
@@ -368,7 +381,7 @@ __global__ __launch_bounds__(kBlockD, pass_waves(KIND)) void k_ndt_pass(const fl
           // points_per_voxel >= min_points_per_voxel_ and accepted eigenvalues (VoxelGrid.cpp:465)
           bool ok = i < r_nx[j] && ((val >> i) & 1ull);
           unsigned rank = w0[j].z + (unsigned)__popcll(occ & ((1ull << (sh + i)) - 1ull));
-          c_ent[j * 3 + i] = ((unsigned)r_pl[j]) | (rank << 6);
+          c_ent[j * 3 + i] = ((unsigned)(pbase + r_pl[j])) | (rank << 6);
           if (ok) c_mask |= 1u << (j * 3 + i);
         }
       }
@@ -418,19 +431,55 @@ __global__ __launch_bounds__(kBlockD, pass_waves(KIND)) void k_ndt_pass(const fl
     }
     wave_sync();
     }
-    // ---- phase B: dense pair math
-    for (unsigned qi = lane; qi < total; qi += 64) {
-      unsigned e = queue[qi];
+    // ---- phase B: dense pair math, in FULL rounds of 64 pairs.  A tile leaves 57 pairs on average (cfg5), so one round
+    // per tile ran at 76 % lane use and every fifth tile paid a second, nearly empty one; instead the pairs beyond the last
+    // full round stay at the front of the queue and join the next tile's (their point data sits in the other buffer
+    // half, which that tile does not touch).  Pairs are never carried twice: the previous tile's are at the front and go
+    // out with the first round, and if even carried + fresh stays below 64 while something was carried, the round is run
+    // partly filled.
+    {
+      total = (unsigned)__builtin_amdgcn_readfirstlane((int)total);  // wave-uniform by construction: keep the round bookkeeping scalar
+      const unsigned full = total >> 6;
+      unsigned left = total & 63u;
+      // (single-buffered pass: nothing may be carried, every tile is drained)
+      const bool drain = NB == 1 ? left != 0 : (full == 0 && carried != 0);  // < 64 in all, part of it a tile old: run it now
+      const unsigned rounds = drain ? full + 1u : full;
+      for (unsigned r = 0; r < rounds; r++) {
+        const unsigned qi = r * 64 + lane;
+        if (qi < total) {
+          unsigned e = queue[qi];
+          const unsigned pl = e & 63u;
+          const double *R = rec + (size_t)(e >> 6) * kRecDoubles;
+          double pg[8];
+          const double *tm = terms + pl * kTermStride;
+#pragma unroll
+          for (int k = 0; k < 8; k++) pg[k] = tm[k];
+          // the 15 Hessian terms stay in LDS and are read where they are used: 30 fewer live registers in the pair math
+          pair_update<KIND>(P, R, tp[pl].tx, tp[pl].ty, tp[pl].tz, pg, tm + 8, acc, accepted);
+        }
+      }
+      if (drain) left = 0;
+      if (full != 0 && left != 0) {  // move the left-over pairs (all of THIS tile) to the front of the queue
+        unsigned e = lane < left ? queue[full * 64 + lane] : 0u;
+        wave_sync();
+        if (lane < left) queue[lane] = e;
+      }
+      carried = left;
+    }
+    wave_sync();  // the other half of tp / terms and the queue behind the carried pairs are rewritten by the next tile
+  }
+  // the last tile's left-over pairs
+  if (carried) {
+    if (lane < carried) {
+      unsigned e = queue[lane];
       const unsigned pl = e & 63u;
       const double *R = rec + (size_t)(e >> 6) * kRecDoubles;
       double pg[8];
       const double *tm = terms + pl * kTermStride;
 #pragma unroll
       for (int k = 0; k < 8; k++) pg[k] = tm[k];
-      // the 15 Hessian terms stay in LDS and are read where they are used: 30 fewer live registers in the pair math
       pair_update<KIND>(P, R, tp[pl].tx, tp[pl].ty, tp[pl].tz, pg, tm + 8, acc, accepted);
     }
-    wave_sync();  // tp / terms / queues are rewritten by the next tile
   }
   // block reduction through LDS in a fixed order (bitwise reproducible): transpose the 28 per-lane accumulators (two
   // rounds of 128 lanes), 8 x 32 lanes add 32 rows each, then 32 lanes add the 8 partial rows
