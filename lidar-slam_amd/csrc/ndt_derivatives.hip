@@ -5,7 +5,7 @@
 //  :391-445 computeDerivatives, :448-482 computePointDerivatives, :485-520 updateDerivatives, :875-899 updateHessian,
 //  :901-936 computeHessian; VoxelGrid.cpp:432-480 radiusSearch; pcl::transformPointCloud, f32).
 //
-// Per 16-point tile, owned by ONE wave: f32 rigid transform (bit-identical to PCL's, no FMA contraction), row probes of the
+// Per 14-point tile, owned by ONE wave: f32 rigid transform (bit-identical to PCL's, no FMA contraction), row probes of the
 // <= 3x3x3 cell neighbourhood (dense per-cell table, or the {occupancy, valid, prefix} bitmap words for huge cell boxes),
 // scan-based compaction of the hits into an LDS pair queue, then dense f64 pair math on the gathered 80-byte voxel
 // records exploiting the symmetry of C^-1 (21 unique Hessian entries + 6 gradient + score = 28 values), LDS transpose
@@ -105,19 +105,23 @@ __device__ __forceinline__ void pair_update(const PassParams &P, const double *_
   }
 }
 
-// Each WAVE of a 256-lane workgroup walks its own tiles of 16 source points, in four phases per tile, without ever
+// Each WAVE of a 256-lane workgroup walks its own tiles of 14 source points, in four phases per tile, without ever
 // waiting for the other three waves (the only workgroup barrier is the one before the final reduction):
 //   0. 4 lanes per point: one transforms it (f32, PCL order) and publishes the clipped 3x3x3 cell box, and each of the
 //      four computes its share of the 23 point-derivative dot products (8 Jacobian + 15 Hessian terms,
 //      computePointDerivatives) into LDS -- once per POINT, not once per pair as the reference does;
 //   A1. ROW probes: the <= 3 cells of one (y, z) row of a box are consecutive linear indices, i.e. adjacent bits of one
-//      (rarely two) 16-B {occ, valid, prefix} words.  16 points x 9 rows = 144 row probes (<= 3 per lane) read the word
+//      (rarely two) 16-B {occ, valid, prefix} words.  14 points x 9 rows = 126 row probes (<= 2 per lane) read the word
 //      from L2, mask the valid bits and emit one CANDIDATE {point, record rank} per valid cell -- integer work only;
 //   A2. candidates (valid voxels inside the box, ~10 per point) load the 24-B centroid and take the radius test on the
 //      squared distance against a host-computed exact threshold (no f64 sqrt); survivors (Kbar ~ 2.5-5 per point) become
 //      PAIRS.  Both compactions place their output at offsets from wave-wide exclusive scans (no atomics), so the queue
 //      order -- and with it every f64 sum -- is reproducible run to run;
-//   B. the wave drains the pair queue: one (point, voxel) pair per lane per step, dense f64 pair math into 28 registers.
+//   B. the wave takes FULL rounds of 64 pairs off the queue (what is left joins the next tile's pairs): one (point,
+//      voxel) pair per lane per step, dense f64 pair math into 28 registers.
+// Tile size: 14 points = two probe rounds (16 points needed a third, three quarters empty) and 50 pairs per tile on
+// average at cfg5, which the carry-over packs into full rounds: 244 -> 216 us per pass against 16-point tiles drained
+// tile by tile.
 // Separating the cheap integer probe from the centroid test and that from the expensive pair math keeps the f64 pipes on
 // useful work (the reference computes a distance for all 27 cells of every point).  All hand-offs inside a tile go
 // through the wave's private LDS slice and need only wave-level ordering (LDS is in order per wave), so the 8 waves
@@ -126,11 +130,12 @@ __device__ __forceinline__ void pair_update(const PassParams &P, const double *_
 // >= 470 waves.  The 69 angle-derivative constants are touched only in phase 0, which keeps them out of the pair loop's
 // scalar registers.
 constexpr int kWaves = kBlockD / 64;
-constexpr int kTilePts = 16;                                             // points per wave tile, 4 lanes per point in phase 0
+constexpr int kTilePts = 14;                                             // points per wave tile, 4 lanes per point in phase 0 (56 lanes)
+constexpr int kTileSlots = 16;                                           // LDS slots per buffer half (power of two)
 constexpr int kRowsPerPoint = 9;
-constexpr int kRowProbes = kTilePts * kRowsPerPoint;                     // 144
+constexpr int kRowProbes = kTilePts * kRowsPerPoint;                     // 126
 constexpr int kRowRounds = (kRowProbes + 63) / 64;                       // 3
-constexpr int kQueueCap = kTilePts * 27;                                 // 432 candidates / pairs at most
+constexpr int kQueueCap = kTilePts * 27;                                 // 378 candidates / pairs at most
 constexpr int kCandPerLane = 4;                                          // A2 candidates per lane per round
 constexpr int kPointTerms = 23;   // pg[8] + ph[15]
 constexpr int kTermStride = 24;
@@ -152,7 +157,7 @@ struct TilePoint {
 constexpr int kLdsTp = 0;
 constexpr int kQueueSlots = kQueueCap + 64;                                              // a tile's pairs behind < 64 carried ones
 constexpr int lds_terms(int nb) { return nb * 512; }                                     // after nb x 16 * 32 B of TilePoint
-constexpr int lds_cand(int nb) { return lds_terms(nb) + nb * kTilePts * kTermStride * 8; }  // + nb x 3072
+constexpr int lds_cand(int nb) { return lds_terms(nb) + nb * kTileSlots * kTermStride * 8; }  // + nb x 3072
 constexpr int lds_queue(int nb) { return lds_cand(nb) + kQueueCap * 4; }                 // + 1728
 constexpr int lds_slice(int nb) { return ((lds_queue(nb) + (kQueueSlots + 1) * 4 + 255) / 256) * 256; }  // 7424 / 11008 (queue + one dump slot)
 constexpr int lds_tiles(int nb) { return lds_slice(nb) * kWaves; }                       // 29696 / 44032
@@ -161,7 +166,7 @@ constexpr int lds_red2(int nb) { return kLdsRed > lds_tiles(nb) ? kLdsRed : lds_
 constexpr int lds_const(int nb) { return lds_red2(nb) + (8 * 32 + 2 * kWaves) * 8; }     // + second-stage [8][32] + per-wave counters
 constexpr int lds_bytes(int nb) { return lds_const(nb) + 72 * 8; }                       // + the 69 angle-derivative constants
 constexpr int pass_bufs(int kind) { return kind == 1 ? 1 : 2; }
-static_assert(kTilePts * (int)sizeof(TilePoint) <= 512, "tile points overflow their LDS slot");
+static_assert(kTilePts <= kTileSlots && kTileSlots * (int)sizeof(TilePoint) <= 512, "tile points overflow their LDS slot");
 
 // wave-level ordering point for LDS hand-offs between lanes of ONE wave: LDS operations of a wave execute in order, so it
 // is enough to stop the compiler from moving accesses across it (this is what a workgroup barrier of a single-wave
@@ -209,7 +214,7 @@ __global__ __launch_bounds__(kBlockD, pass_waves(KIND)) void k_ndt_pass(const fl
   for (int k = 0; k < 28; k++) acc[k] = 0.0;
   unsigned long long npts = 0;  // wave total (meaningful in lane 0)
   unsigned accepted = 0;        // (point, voxel) pairs this lane accepted
-  const int ppl = lane & (kTilePts - 1), part4 = lane / kTilePts;  // phase 0: 4 lanes per point
+  const int part4 = lane / kTilePts, ppl = lane - part4 * kTilePts;  // phase 0: 4 lanes per point (part4 == 4: the spare lanes 56..63)
   const int dimx = P.dim[0], dimxy = P.dim[0] * P.dim[1];
   const size_t ntiles = (n + kTilePts - 1) / kTilePts;
   const size_t tile0 = (size_t)blockIdx.x * kWaves + wave, tstride = (size_t)gridDim.x * kWaves;
@@ -226,8 +231,8 @@ __global__ __launch_bounds__(kBlockD, pass_waves(KIND)) void k_ndt_pass(const fl
     if (i0 < n) s_next = src[i0];
   }
   unsigned carried = 0;  // pairs at the front of the queue left over by the previous tile (< 64, wave-uniform)
-  int pbase = 0;         // which half of tp / terms this tile uses: 0 or kTilePts
-  for (size_t tile = tile0; tile < ntiles; tile += tstride, pbase ^= (NB == 2 ? kTilePts : 0)) {
+  int pbase = 0;         // which half of tp / terms this tile uses: 0 or kTileSlots
+  for (size_t tile = tile0; tile < ntiles; tile += tstride, pbase ^= (NB == 2 ? kTileSlots : 0)) {
     // ---- phase 0
     {
       size_t i = tile * kTilePts + ppl;
@@ -606,7 +611,7 @@ void ndt_make_pass_params(const lsa_ndt *h, const float T[16], const double p[6]
 }
 
 unsigned ndt_pass_grid(const lsa_ndt *h, size_t n, int kind) {
-  size_t blocks = (n + kWaves * kTilePts - 1) / (kWaves * kTilePts);  // one 16-point tile per wave until the chip is full, then grid-stride
+  size_t blocks = (n + kWaves * kTilePts - 1) / (kWaves * kTilePts);  // one tile per wave until the chip is full, then grid-stride
   size_t cap = (size_t)h->ctx->num_cus * pass_waves(kind);  // the resident set: every workgroup runs at once
   if (blocks > cap) blocks = cap;
   if (blocks < 1) blocks = 1;
