@@ -352,22 +352,24 @@ def main():
 
     # ---- the same kernel at BASELINE.json configs[4] size (2,097,152-point source against a 2 M-point target): the size at
     # which the HBM roofline is a meaningful yardstick for it (at cfg2 size one launch moves < 2 MB).  Extra key, rank 0.
+    def make_cfg5():
+        """2 M-point target (17 scans in the map frame) and the 2,097,152-point 128-beam source of BASELINE.json configs[4]."""
+        P0i = np.linalg.inv(poses[0])
+        parts5 = [synth.transform_points(P0i @ poses[i], scans[i]) for i in range(17)]
+        tgt5 = np.ascontiguousarray(np.concatenate(parts5, 0))[:2000000]
+        src5 = synth.gen_scan(synth.Scene(seed=1), poses[8], seed=55, beams=128, az_steps=16384, max_range=120.0, clamp=True)
+        g5 = (P0i @ poses[8]).astype(np.float32)
+        p5 = np.zeros(6)
+        capi.lib().lsa_matrix_to_pose(capi.fptr(capi.colmajor(g5)), capi.dptr(p5))
+        return torch.from_numpy(tgt5).to(dev), torch.from_numpy(src5).to(dev), g5, p5
+
     roofline_cfg5 = None
     if rank == 0 and world == 1 and not args.no_large:
-        from lidar_slam_amd import synth as _synth
-        P0i = np.linalg.inv(poses[0])
-        parts = [_synth.transform_points(P0i @ poses[i], scans[i]) for i in range(17)]
-        tgt5 = np.ascontiguousarray(np.concatenate(parts, 0))[:2000000]
-        src5 = _synth.gen_scan(_synth.Scene(seed=1), poses[8], seed=55, beams=128, az_steps=16384, max_range=120.0, clamp=True)
-        d_t5 = torch.from_numpy(tgt5).to(dev)
-        d_s5 = torch.from_numpy(src5).to(dev)
+        d_t5, d_s5, g5, p5 = make_cfg5()
         torch.cuda.synchronize()
         ndt5 = registration.NDTRegistrationHip(ctx, 1.0, 0.1, 0.0, 30, 0.55)
         ndt5.SetInputTarget(d_t5)
         ndt5.set_source(d_s5)
-        g5 = (P0i @ poses[8]).astype(np.float32)
-        p5 = np.zeros(6)
-        capi.lib().lsa_matrix_to_pose(capi.fptr(capi.colmajor(g5)), capi.dptr(p5))
         (_, _, _, pairs5, npts5), ms5 = ndt5.derivatives_timed(g5, p5, kind=0, repeat=20)
         M5, kbar5 = int(npts5), pairs5 / max(1.0, float(npts5))
         alg5 = M5 * (16.0 + 4.0 * 27.0 + 48.0 * kbar5)
@@ -376,6 +378,40 @@ def main():
                          "frac": round(alg5 / (ms5 * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "us_per_launch": round(ms5 * 1e3, 1),
                          "alg_bytes_per_launch": int(alg5), "source_points": M5, "kbar": round(kbar5, 3),
                          "pairs_per_s": round(pairs5 / (ms5 * 1e-3), 0)}
+        ndt5.close()
+        del d_t5, d_s5
+
+    # ---- N > 1: the exchange step at the size it is meant for (BASELINE.json configs[3] / [4]): the 2,097,152-point source
+    # sharded over the ranks against the replicated 2 M-point target, ONE all-reduce of the 32-double block per pass.
+    # Whole passes (kernel + second stage + collective + result on the host), wall clock between barriers, max over ranks.
+    # Every rank executes exactly the same sequence of collectives.  Extra key; the headline stays the cfg2 metric.
+    cfg5_sharded = None
+    if dist_mode and world > 1 and not args.no_large:
+        d_t5, d_s5, g5, p5 = make_cfg5()
+        lo5, hi5 = lsa_dist.shard_bounds(int(d_s5.shape[0]), rank, world)
+        ndt5 = registration.NDTRegistrationHip(ctx, 1.0, 0.1, 0.0, 30, 0.55)
+        ndt5.SetInputTarget(d_t5)
+        ndt5.set_source(d_s5[lo5:hi5].contiguous())
+        if native_rccl is not None:
+            native_rccl.attach(ndt5)
+        else:
+            ndt5.set_allreduce(allreduce_cb)
+        k5 = 20
+        for _ in range(3):
+            out5 = ndt5.derivatives(g5, p5, 0)
+        sync_all()
+        t0 = time.perf_counter()
+        for _ in range(k5):
+            out5 = ndt5.derivatives(g5, p5, 0)
+        sync_all()
+        dt5 = time.perf_counter() - t0
+        t5 = torch.tensor([dt5], dtype=torch.float64, device="cpu" if one_gpu else dev)
+        dist.all_reduce(t5, op=dist.ReduceOp.MAX)
+        dt5 = float(t5.item())
+        if rank == 0:
+            cfg5_sharded = {"workload": "cfg5 pass (kind 0): 2,097,152-point source sharded over the ranks, 2 M-point target replicated, one all-reduce per pass",
+                            "ranks": world, "source_points_per_rank": int(hi5 - lo5), "us_per_pass": round(dt5 / k5 * 1e6, 1),
+                            "pairs_per_s": round(float(out5[3]) / (dt5 / k5), 0), "pairs": float(out5[3]), "source_points": float(out5[4])}
         ndt5.close()
         del d_t5, d_s5
 
@@ -536,6 +572,7 @@ def main():
             },
             "roofline": roofline,
             "roofline_cfg5": roofline_cfg5,
+            "cfg5_sharded": cfg5_sharded,
             "multi_gpu_alt": alt,
             "concurrent_streams": concurrent,
             "cpu_baseline": cpu_baseline,
