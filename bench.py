@@ -20,8 +20,10 @@ size of the filtered source (same rule on every rank; LSA_BENCH_SHARD=1 / 0 forc
   * independent scan streams (KITTI-sized scans, where a 28 us collective per 8 us pass would make N GPUs SLOWER than
     one): rank r registers its own stream of scans against its own copy of the local map, no data-path collective;
     value = N * steps / time, "weak".
-The mode that was NOT chosen is timed too (a quarter of the steps) and reported under `multi_gpu_alt`, so the
-scaling of the exchange step is on the line either way.
+The mode that was NOT chosen is timed too (a quarter of the steps, after the headline run) and reported under
+`multi_gpu_alt`, and `cfg5_sharded` times the exchange step at the size it is meant for (2,097,152-point source sharded
+over the ranks), so the scaling of the exchange step is on the line either way.  Barriers and the max over ranks run on
+a gloo group; the RCCL communicator is created only when a mode with an exchange step is about to run.
 """
 import argparse
 import json
@@ -136,10 +138,11 @@ def main():
     if dist_mode:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29517")
-        if one_gpu:
-            dist.init_process_group("gloo", rank=rank, world_size=world)
-        else:
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", dev_index))
+        # Control plane (barriers, the max over ranks of the elapsed time) on gloo; RCCL is brought up only where the data
+        # path has an exchange step (ensure_exchange() below), i.e. not before the headline run when the ranks walk
+        # independent scan streams: measured on one GPU, a process that has initialised an RCCL communicator runs the
+        # same collective-free pipeline 25 % slower (10.6 k vs 14 k scans/s), which would be booked as scaling loss.
+        dist.init_process_group("gloo", rank=rank, world_size=world)
     dev = torch.device("cuda", dev_index)
     # one non-default stream shared by torch (uploads, RCCL collectives) and the library (kernels, copies):
     # everything the hot path does is ordered on it, no cross-stream events needed
@@ -188,14 +191,25 @@ def main():
     d_filt = d_filt2[0]
     # N > 1: shard the source over the ranks (one all-reduce per pass) only where that pays; a KITTI-sized filtered scan
     # is faster replicated (dist.shard_pays).  LSA_BENCH_SHARD=1 / 0 forces either mode.
-    allreduce_cb = None
-    native_rccl = None
-    if dist_mode:
-        allreduce_cb = lsa_dist.make_gloo_staged_allreduce() if one_gpu else lsa_dist.make_rccl_allreduce()
-        # LSA_BENCH_NATIVE_RCCL=1: the all-reduce is issued by the library itself (lsa_rccl_*, no Python per pass) instead
-        # of through torch.distributed.  Opt-in: the default stays on the torch path the multi-rank rehearsals exercise.
-        if os.environ.get("LSA_BENCH_NATIVE_RCCL") == "1" and not one_gpu:
-            native_rccl = lsa_dist.NativeRccl(ctx, rank, world)
+    exchange = {"cb": None, "native": None, "ready": False}
+
+    def ensure_exchange():
+        """Bring up the data-path collective (collective call: every rank, same point of the program)."""
+        if exchange["ready"] or not dist_mode:
+            return
+        if one_gpu:
+            exchange["cb"] = lsa_dist.make_gloo_staged_allreduce()
+        else:
+            # one rank per GPU over RCCL, issued by the library itself on its own stream (lsa_rccl_*: ncclAllReduce behind the
+            # C-ABI, no Python per pass; the 128-byte unique id travels over the gloo group).  LSA_BENCH_NATIVE_RCCL=0 takes
+            # torch.distributed's "nccl" backend on a process group of its own instead: measured in the world-of-one
+            # rehearsal 154 us per sharded cfg2 step against 99 us.
+            if os.environ.get("LSA_BENCH_NATIVE_RCCL", "1") != "0":
+                exchange["native"] = lsa_dist.NativeRccl(ctx, rank, world)
+            else:
+                exchange["cb"] = lsa_dist.make_rccl_allreduce(group=dist.new_group(backend="nccl"))
+        exchange["ready"] = True
+
     m_probe = int(frame_filter.filter_device(d_scans[0], d_filt).shape[0])
     force = os.environ.get("LSA_BENCH_SHARD")
     shard_policy = dist_mode and (force == "1" or (force != "0" and lsa_dist.shard_pays(m_probe, world)))
@@ -204,10 +218,12 @@ def main():
     def set_mode(shard):
         shard_now[0] = bool(shard)
         if dist_mode:
-            if native_rccl is not None and shard:
-                native_rccl.attach(ndt)
+            if shard:
+                ensure_exchange()
+            if exchange["native"] is not None and shard:
+                exchange["native"].attach(ndt)
             else:
-                ndt.set_allreduce(allreduce_cb if shard else None)
+                ndt.set_allreduce(exchange["cb"] if shard else None)
 
     results = {}
 
@@ -274,11 +290,14 @@ def main():
         sync_all()
         dt = time.perf_counter() - t0
         if dist_mode:
-            t = torch.tensor([dt], dtype=torch.float64, device="cpu" if one_gpu else dev)
+            t = torch.tensor([dt], dtype=torch.float64)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             dt = float(t.item())
         return dt
 
+    # the headline run, in the mode the policy chose (the exchange step is brought up first only if that mode needs it)
+    elapsed = run_timed(shard_policy, args.steps, args.warmup, args.ramp_seconds)
+    collect()
     # N > 1: also time the mode the policy did NOT choose (a quarter of the steps) so the line shows both
     alt = None
     if dist_mode and world > 1:
@@ -288,8 +307,6 @@ def main():
         alt = {"mode": "every scan sharded over the ranks, one all-reduce per pass (strong scaling)" if not shard_policy
                else "one independent scan stream per rank, no collective (weak scaling)", "steps": k_alt,
                "value": round(units_alt / dt_alt, 2), "ms_per_step": round(dt_alt / k_alt * 1e3, 4)}
-    elapsed = run_timed(shard_policy, args.steps, args.warmup, args.ramp_seconds)
-    collect()
 
     # ---- component split + roofline of the dominant kernel (rank 0; HIP events on the library's stream)
     roofline = None
@@ -392,10 +409,11 @@ def main():
         ndt5 = registration.NDTRegistrationHip(ctx, 1.0, 0.1, 0.0, 30, 0.55)
         ndt5.SetInputTarget(d_t5)
         ndt5.set_source(d_s5[lo5:hi5].contiguous())
-        if native_rccl is not None:
-            native_rccl.attach(ndt5)
+        ensure_exchange()
+        if exchange["native"] is not None:
+            exchange["native"].attach(ndt5)
         else:
-            ndt5.set_allreduce(allreduce_cb)
+            ndt5.set_allreduce(exchange["cb"])
         k5 = 20
         for _ in range(3):
             out5 = ndt5.derivatives(g5, p5, 0)
@@ -405,7 +423,7 @@ def main():
             out5 = ndt5.derivatives(g5, p5, 0)
         sync_all()
         dt5 = time.perf_counter() - t0
-        t5 = torch.tensor([dt5], dtype=torch.float64, device="cpu" if one_gpu else dev)
+        t5 = torch.tensor([dt5], dtype=torch.float64)
         dist.all_reduce(t5, op=dist.ReduceOp.MAX)
         dt5 = float(t5.item())
         if rank == 0:
@@ -585,8 +603,8 @@ def main():
         print(json.dumps(line), file=real_stdout, flush=True)
 
     ndt.close(); frame_filter.close(); map_filter.close(); ctx_f.close()
-    if native_rccl is not None:
-        native_rccl.close()
+    if exchange["native"] is not None:
+        exchange["native"].close()
     if dist_mode:
         dist.barrier()
         dist.destroy_process_group()
