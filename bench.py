@@ -138,10 +138,11 @@ def main():
     if dist_mode:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29517")
-        # Control plane (barriers, the max over ranks of the elapsed time) on gloo; RCCL is brought up only where the data
-        # path has an exchange step (ensure_exchange() below), i.e. not before the headline run when the ranks walk
-        # independent scan streams: measured on one GPU, a process that has initialised an RCCL communicator runs the
-        # same collective-free pipeline 25 % slower (10.6 k vs 14 k scans/s), which would be booked as scaling loss.
+        # Control plane (barriers, the max over ranks of the elapsed time) on gloo; the data-path collective is brought up
+        # only where the path has an exchange step (ensure_exchange() below).  Measured on one GPU: with torch's "nccl"
+        # process group initialised, the SAME collective-free pipeline runs 25 % slower (10.6 k vs 14 k scans/s; its
+        # watchdog / heartbeat machinery, not RCCL — the library's own RCCL communicator costs nothing), which would be
+        # booked as scaling loss of the independent scan streams.
         dist.init_process_group("gloo", rank=rank, world_size=world)
     dev = torch.device("cuda", dev_index)
     # one non-default stream shared by torch (uploads, RCCL collectives) and the library (kernels, copies):
