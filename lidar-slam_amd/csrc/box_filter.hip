@@ -192,8 +192,7 @@ extern "C" int lsa_box_filter_apply(lsa_box_filter *f, const void *in_pts, size_
   if ((rc = f->h_stage.reserve(ctx, n * 4))) return rc;
   if ((rc = f->d_in.reserve(ctx, n, 1.25))) return rc;
   if ((rc = f->d_out.reserve(ctx, n, 1.25))) return rc;
-  lsa_pack_xyzw(in_pts, n, in_stride, in_w_off, f->h_stage.p);
-  LSA_HIP(ctx, hipMemcpyAsync(f->d_in.p, f->h_stage.p, n * sizeof(float4), hipMemcpyHostToDevice, ctx->stream));
+  if ((rc = lsa_upload_xyzw(ctx, in_pts, n, in_stride, in_w_off, f->h_stage.p, f->d_in.p))) return rc;
   size_t V = 0;
   if ((rc = box_device(f, f->d_in.p, n, f->d_out.p, &V))) return rc;
   if (V > out_cap) return lsa_fail(ctx, LSA_ERR_CAPACITY, "lsa_box_filter_apply: out_cap %zu < %zu points", out_cap, V);

@@ -298,8 +298,7 @@ extern "C" int lsa_front_end_update(lsa_front_end *fe, const void *cloud, size_t
   if ((rc = fe->h_stage.reserve(ctx, (n ? n : 1) * 4))) return rc;
   if ((rc = fe->d_in.reserve(ctx, n ? n : 1, 1.25))) return rc;
   LSA_HIP(ctx, hipStreamSynchronize(ctx->stream));
-  lsa_pack_xyzw(cloud, n, stride, w_off, fe->h_stage.p);
-  LSA_HIP(ctx, hipMemcpyAsync(fe->d_in.p, fe->h_stage.p, n * sizeof(float4), hipMemcpyHostToDevice, ctx->stream));
+  if ((rc = lsa_upload_xyzw(ctx, cloud, n, stride, w_off, fe->h_stage.p, fe->d_in.p))) return rc;
   return fe_update_device(fe, fe->d_in.p, n, pose_out, stats);
 }
 

@@ -397,9 +397,7 @@ int icp_upload(lsa_icp *h, const void *pts, size_t n, size_t stride, DevBuf<floa
   if ((rc = h->h_stage.reserve(ctx, n * 4))) return rc;
   if ((rc = dst.reserve(ctx, n, 1.25))) return rc;
   LSA_HIP(ctx, hipStreamSynchronize(ctx->stream));
-  lsa_pack_xyzw(pts, n, stride, SIZE_MAX, h->h_stage.p);
-  LSA_HIP(ctx, hipMemcpyAsync(dst.p, h->h_stage.p, n * sizeof(float4), hipMemcpyHostToDevice, ctx->stream));
-  return LSA_OK;
+  return lsa_upload_xyzw(ctx, pts, n, stride, SIZE_MAX, h->h_stage.p, dst.p);
 }
 
 int icp_build(lsa_icp *h, const float4 *d_pts, size_t n) {

@@ -36,17 +36,28 @@ void lsa_pack_xyzw(const void *pts, size_t n, size_t stride, size_t w_off, float
   const char *p = (const char *)pts;
   if (w_off != SIZE_MAX) {
     for (size_t i = 0; i < n; i++, p += stride) {
-      const float *q = (const float *)p;
-      out4[4 * i] = q[0]; out4[4 * i + 1] = q[1]; out4[4 * i + 2] = q[2];
-      out4[4 * i + 3] = *(const float *)(p + w_off);
+      memcpy(out4 + 4 * i, p, 12);  // x, y, z: one 16-byte move pair for the optimiser instead of three scalar ones
+      memcpy(out4 + 4 * i + 3, p + w_off, 4);
     }
   } else {
     for (size_t i = 0; i < n; i++, p += stride) {
-      const float *q = (const float *)p;
-      out4[4 * i] = q[0]; out4[4 * i + 1] = q[1]; out4[4 * i + 2] = q[2];
+      memcpy(out4 + 4 * i, p, 12);
       out4[4 * i + 3] = 1.0f;
     }
   }
+}
+
+// Host points -> device float4: packed into the pinned staging buffer and copied in a few chunks, each copy enqueued as
+// soon as its chunk is packed, so the PCIe transfer of chunk k runs under the packing of chunk k + 1 (a 131 k-point scan:
+// ~70 us of packing with ~40 us of copy behind it instead of after it).  The caller owns the ordering of h_stage reuse.
+int lsa_upload_xyzw(lsa_context *ctx, const void *pts, size_t n, size_t stride, size_t w_off, float *h_stage, float4 *d_dst) {
+  constexpr size_t kChunk = 32768;  // points: 512 KB per copy, few enough copies that their launch cost stays small
+  for (size_t off = 0; off < n; off += kChunk) {
+    const size_t m = n - off < kChunk ? n - off : kChunk;
+    lsa_pack_xyzw((const char *)pts + off * stride, m, stride, w_off, h_stage + 4 * off);
+    LSA_HIP(ctx, hipMemcpyAsync(d_dst + off, h_stage + 4 * off, m * sizeof(float4), hipMemcpyHostToDevice, ctx->stream));
+  }
+  return LSA_OK;
 }
 
 extern "C" int lsa_version(void) { return LSA_VERSION_MAJOR * 100 + LSA_VERSION_MINOR; }

@@ -16,9 +16,7 @@ int upload_points(lsa_ndt *h, const void *pts, size_t n, size_t stride, size_t w
   if ((rc = dst.reserve(ctx, n, 1.25))) return rc;
   // the staging buffer may still be feeding an earlier async copy
   LSA_HIP(ctx, hipStreamSynchronize(ctx->stream));
-  lsa_pack_xyzw(pts, n, stride, w_off, h->h_stage.p);
-  LSA_HIP(ctx, hipMemcpyAsync(dst.p, h->h_stage.p, n * sizeof(float4), hipMemcpyHostToDevice, ctx->stream));
-  return LSA_OK;
+  return lsa_upload_xyzw(ctx, pts, n, stride, w_off, h->h_stage.p, dst.p);
 }
 
 // one pass, synchronous: kernel(s) -> [all-reduce] -> D2H of 32 doubles

@@ -223,8 +223,7 @@ extern "C" int lsa_voxel_filter_apply(lsa_voxel_filter *f, const void *in_pts, s
   if ((rc = f->h_stage.reserve(ctx, n * 4))) return rc;
   if ((rc = f->d_in.reserve(ctx, n, 1.25))) return rc;
   if ((rc = f->d_out.reserve(ctx, n, 1.25))) return rc;
-  lsa_pack_xyzw(in_pts, n, in_stride, in_w_off, f->h_stage.p);
-  LSA_HIP(ctx, hipMemcpyAsync(f->d_in.p, f->h_stage.p, n * sizeof(float4), hipMemcpyHostToDevice, ctx->stream));
+  if ((rc = lsa_upload_xyzw(ctx, in_pts, n, in_stride, in_w_off, f->h_stage.p, f->d_in.p))) return rc;
   size_t V = 0;
   rc = filter_device(f, f->d_in.p, n, f->d_out.p, &V);
   if (rc == LSA_ERR_RANGE) {

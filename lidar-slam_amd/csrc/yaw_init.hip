@@ -233,9 +233,7 @@ int yaw_upload(lsa_yaw_init *h, const void *pts, size_t n, size_t stride) {
   if ((rc = h->h_stage.reserve(ctx, (n ? n : 1) * 4))) return rc;
   if ((rc = h->d_pts.reserve(ctx, n ? n : 1, 1.25))) return rc;
   LSA_HIP(ctx, hipStreamSynchronize(ctx->stream));
-  lsa_pack_xyzw(pts, n, stride, SIZE_MAX, h->h_stage.p);
-  LSA_HIP(ctx, hipMemcpyAsync(h->d_pts.p, h->h_stage.p, n * sizeof(float4), hipMemcpyHostToDevice, ctx->stream));
-  return LSA_OK;
+  return lsa_upload_xyzw(ctx, pts, n, stride, SIZE_MAX, h->h_stage.p, h->d_pts.p);
 }
 
 int yaw_build(lsa_yaw_init *h, const float4 *d_map, size_t n, const float origin[3]) {
