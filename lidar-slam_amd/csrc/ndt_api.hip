@@ -116,7 +116,7 @@ extern "C" void lsa_ndt_destroy(lsa_ndt *h) {
   (void)hipStreamSynchronize(h->ctx->stream);
   ndt_fitness_release(h);
   h->nn.release();
-  h->vi.release(); h->d_target.release(); h->rec.release(); h->state.release(); h->vbits.release(); h->words.release(); h->d_small.release();
+  h->vi.release(); h->d_target.release(); h->rec.release(); h->state.release(); h->vbits.release(); h->words.release(); h->d_small.release(); h->counts.release();
   h->dense.release();
   h->d_source_own.release(); h->h_stage.release(); h->partials.release(); h->d_out.release(); h->h_out.release(); h->h_partials.release();
   delete h;
@@ -241,6 +241,7 @@ extern "C" int lsa_ndt_grid_info(lsa_ndt *h, int64_t info[9]) {
   if (!h->has_target) return lsa_fail(h->ctx, LSA_ERR_NO_TARGET, "grid_info before SetInputTarget");
   for (int a = 0; a < 3; a++) { info[a] = h->vi.map.dim[a]; info[3 + a] = h->vi.map.min_b[a]; }
   info[6] = (int64_t)h->vi.nocc;
+  if ((rc = ndt_count_valid(h))) return rc;
   info[7] = (int64_t)h->n_valid;
   info[8] = (int64_t)h->n_target;
   return LSA_OK;
@@ -258,7 +259,7 @@ extern "C" int lsa_ndt_grid_dump(lsa_ndt *h, int32_t *cell_ints, double *cell_re
   if (cap < V) return lsa_fail(ctx, LSA_ERR_CAPACITY, "grid_dump: cap %zu < %zu cells", cap, V);
   std::vector<int32_t> cor(V), cnt(V), st(V);
   LSA_HIP(ctx, hipMemcpyAsync(cor.data(), h->vi.cell_of_rank.p, V * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
-  LSA_HIP(ctx, hipMemcpyAsync(cnt.data(), h->vi.cnt.p, V * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
+  LSA_HIP(ctx, hipMemcpyAsync(cnt.data(), h->counts.p, V * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
   LSA_HIP(ctx, hipMemcpyAsync(st.data(), h->state.p, V * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
   if (cell_rec) LSA_HIP(ctx, hipMemcpyAsync(cell_rec, h->rec.p, V * kRecDoubles * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
   LSA_HIP(ctx, hipStreamSynchronize(ctx->stream));

@@ -98,7 +98,7 @@ struct T12s { float v[12]; };
 // up to 32 dependent bitmap -> prefix -> record chains alone: 182 us for 7.7 k points on 30 workgroups.
 constexpr int kFitLanes = 8;
 __global__ __launch_bounds__(kBlock) void k_fitness(const float4 *__restrict__ src, size_t n, T12s Tm, const LeafRec *__restrict__ leaves,
-                                                    unsigned nleaves, CellMap m, const uint32_t *__restrict__ bits, const uint32_t *__restrict__ prefix,
+                                                    unsigned nleaves, CellMap m, const uint4 *__restrict__ words,
                                                     const double *__restrict__ rec, double *__restrict__ partials) {
   __shared__ LeafRec tile[kBlock];
   __shared__ double sm[kBlock / 64][2];
@@ -167,9 +167,10 @@ __global__ __launch_bounds__(kBlock) void k_fitness(const float4 *__restrict__ s
       for (long long c = sub; c < total; c += kFitLanes) {
         int iz = (int)(c % nz), iy = (int)((c / nz) % ny), ix = (int)(c / ((long long)nz * ny));
         int cell = (lo[0] + ix) + (lo[1] + iy) * m.dim[0] + (lo[2] + iz) * m.dim[0] * m.dim[1];
-        uint32_t w = bits[cell >> 5], bit = 1u << (cell & 31);
+        const uint4 wd = words[cell >> 5];  // {occupancy, valid, prefix}: the table's packed copy of the bitmap
+        const uint32_t w = wd.x, bit = 1u << (cell & 31);
         if (!(w & bit)) continue;
-        unsigned rank = prefix[cell >> 5] + __popc(w & (bit - 1u));
+        unsigned rank = wd.z + __popc(w & (bit - 1u));
         const double *R = rec + (size_t)rank * kRecDoubles;
         double dx = (double)qx - R[0], dy = (double)qy - R[1], dz = (double)qz - R[2];
         double d = sqrt(dx * dx + dy * dy + dz * dz);
@@ -298,8 +299,8 @@ int ndt_fitness(lsa_ndt *h, float *score) {
     for (int c = 0; c < 4; c++) Tm.v[r * 4 + c] = h->last_T[c * 4 + r];
   unsigned nb = lsa_div_up(n * kFitLanes, kBlock);
   if ((rc = f->partials.reserve(ctx, (size_t)nb * 2 + 2, 1.25))) return rc;
-  hipLaunchKernelGGL(k_fitness, dim3(nb), dim3(kBlock), 0, ctx->stream, h->d_source, n, Tm, f->leaves.p, f->nleaves, h->vi.map, h->vi.bits.p,
-                     h->vi.prefix.p, h->rec.p, f->partials.p);
+  hipLaunchKernelGGL(k_fitness, dim3(nb), dim3(kBlock), 0, ctx->stream, h->d_source, n, Tm, f->leaves.p, f->nleaves, h->vi.map, h->words.p,
+                     h->rec.p, f->partials.p);
   hipLaunchKernelGGL(k_fitness_final, dim3(1), dim3(kBlock), 0, ctx->stream, f->partials.p, (int)nb, f->small.p);
   LSA_HIP(ctx, hipGetLastError());
   LSA_HIP(ctx, hipMemcpyAsync(h->h_out.p, f->small.p, 2 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));

@@ -111,12 +111,13 @@ __device__ void inv3(const double m[3][3], double o[3][3]) {
 }
 
 // one thread per occupied cell (computeCentroidAndCovariance, VoxelGrid.cpp:273-323)
-__global__ __launch_bounds__(kBlock) void k_ndt_finalize(const long long *__restrict__ acc, const int32_t *__restrict__ cnt,
+__global__ __launch_bounds__(kBlock) void k_ndt_finalize(long long *__restrict__ acc, int32_t *__restrict__ cnt,
                                                          const int32_t *__restrict__ cell_of_rank, size_t nocc, CellMap m, FixScales fs,
-                                                         double *__restrict__ rec, int32_t *__restrict__ state, uint32_t *__restrict__ vbits, int pcl) {
+                                                         double *__restrict__ rec, int32_t *__restrict__ state, int32_t *__restrict__ counts,
+                                                         uint32_t *__restrict__ vbits, int pcl) {
   size_t r = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (r >= nocc) return;
-  const long long *a = acc + r * 10;
+  long long *a = acc + r * 10;
   int ni = cnt[r];
   double n = (double)ni;
   int cell = cell_of_rank[r];
@@ -180,13 +181,22 @@ __global__ __launch_bounds__(kBlock) void k_ndt_finalize(const long long *__rest
   }
   state[r] = st;
   if (st == 1) atomicOr(vbits + (cell >> 5), 1u << (cell & 31));
+  // leave the index clean for the next SetInputTarget (no memset of the sums / counts then: 6.6 MB for a 66 k-point map);
+  // the point count, which lsa_ndt_grid_dump reports, moves to its own array
+  counts[r] = ni;
+#pragma unroll
+  for (int k = 0; k < 10; k++) a[k] = 0;
+  cnt[r] = 0;
 }
 
-__global__ __launch_bounds__(kBlock) void k_pack_words(const uint32_t *__restrict__ bits, const uint32_t *__restrict__ vbits,
+// {occupancy, valid, prefix} per 32 cells in one 16-byte word; the index's own bitmap word is cleared on the way (the
+// packed copy is what every later reader uses), which completes the clean-up started in k_ndt_finalize
+__global__ __launch_bounds__(kBlock) void k_pack_words(uint32_t *__restrict__ bits, const uint32_t *__restrict__ vbits,
                                                        const uint32_t *__restrict__ prefix, size_t W, uint4 *__restrict__ words) {
   size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= W) return;
   words[i] = make_uint4(bits[i], vbits[i], prefix[i], 0u);
+  bits[i] = 0u;
 }
 
 // dense probe table of the pass kernel: one 16-B entry per CELL of the box (not per occupied cell): the centroid relative
@@ -213,6 +223,24 @@ __global__ __launch_bounds__(kBlock) void k_count_valid(const int32_t *__restric
 }
 }  // namespace
 
+int ndt_count_valid(lsa_ndt *h) {
+  if (h->n_valid_known) return LSA_OK;
+  lsa_context *ctx = h->ctx;
+  const size_t V = h->vi.nocc;
+  int rc;
+  if ((rc = h->d_small.reserve(ctx, 64)) || (rc = h->h_out.reserve(ctx, kOutDoubles))) return rc;
+  LSA_HIP(ctx, hipMemsetAsync(h->d_small.p, 0, 64 * sizeof(double), ctx->stream));
+  if (V) hipLaunchKernelGGL(k_count_valid, dim3(lsa_div_up(V, kBlock)), dim3(kBlock), 0, ctx->stream, h->state.p, V, (unsigned *)h->d_small.p);
+  LSA_HIP(ctx, hipGetLastError());
+  LSA_HIP(ctx, hipMemcpyAsync(h->h_out.p, h->d_small.p, sizeof(unsigned), hipMemcpyDeviceToHost, ctx->stream));
+  LSA_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  unsigned nvalid = 0;
+  memcpy(&nvalid, h->h_out.p, sizeof(unsigned));
+  h->n_valid = nvalid;
+  h->n_valid_known = true;
+  return LSA_OK;
+}
+
 int ndt_build_grid(lsa_ndt *h, const float4 *d_pts, size_t n) {
   lsa_context *ctx = h->ctx;
   VoxelIndex &vi = h->vi;
@@ -234,12 +262,12 @@ int ndt_build_grid(lsa_ndt *h, const float4 *d_pts, size_t n) {
   if ((rc = h->vbits.reserve(ctx, vi.W, 1.25))) return rc;
   if ((rc = h->words.reserve(ctx, vi.W, 1.25))) return rc;
   if ((rc = h->d_small.reserve(ctx, 64))) return rc;
+  if ((rc = h->counts.reserve(ctx, V + 1, 1.25))) return rc;
   LSA_HIP(ctx, hipMemsetAsync(h->vbits.p, 0, vi.W * sizeof(uint32_t), ctx->stream));
-  LSA_HIP(ctx, hipMemsetAsync(h->d_small.p, 0, 64 * sizeof(double), ctx->stream));
   hipLaunchKernelGGL(k_ndt_finalize, dim3(lsa_div_up(V, kBlock)), dim3(kBlock), 0, ctx->stream, vi.acc.p, vi.cnt.p, vi.cell_of_rank.p, V, vi.map, vi.fs,
-                     h->rec.p, h->state.p, h->vbits.p, h->mode == LSA_NDT_MODE_PCL ? 1 : 0);
+                     h->rec.p, h->state.p, h->counts.p, h->vbits.p, h->mode == LSA_NDT_MODE_PCL ? 1 : 0);
   hipLaunchKernelGGL(k_pack_words, dim3(lsa_div_up(vi.W, kBlock)), dim3(kBlock), 0, ctx->stream, vi.bits.p, h->vbits.p, vi.prefix.p, vi.W, h->words.p);
-  hipLaunchKernelGGL(k_count_valid, dim3(lsa_div_up(V, kBlock)), dim3(kBlock), 0, ctx->stream, h->state.p, V, (unsigned *)h->d_small.p);
+  vi.clean = true;  // sums, counts and bitmap words of this build are zero again
   // dense probe table when the cell box is small enough (16 B per cell; default limit 16 Mi cells = 256 MiB)
   h->use_dense = vi.map.ncells <= h->dense_max_cells;
   if (h->use_dense) {
@@ -249,12 +277,10 @@ int ndt_build_grid(lsa_ndt *h, const float4 *d_pts, size_t n) {
     hipLaunchKernelGGL(k_dense_fill, dim3(lsa_div_up(V, kBlock)), dim3(kBlock), 0, ctx->stream, h->rec.p, h->state.p, vi.cell_of_rank.p, V, vi.map, h->dense.p);
   }
   LSA_HIP(ctx, hipGetLastError());
-  unsigned nvalid = 0;
-  if ((rc = h->h_out.reserve(ctx, kOutDoubles))) return rc;
-  LSA_HIP(ctx, hipMemcpyAsync(h->h_out.p, h->d_small.p, sizeof(unsigned), hipMemcpyDeviceToHost, ctx->stream));
-  LSA_HIP(ctx, hipStreamSynchronize(ctx->stream));
-  memcpy(&nvalid, h->h_out.p, sizeof(unsigned));
-  h->n_valid = nvalid;
+  // Nothing after the bounding-box / count round trip above needs the host, so the call returns with the table still being
+  // finished on the stream (everything that uses it is ordered behind); the number of valid voxels is counted only when
+  // lsa_ndt_grid_info asks for it.  The input points are no longer read at this point.
+  h->n_valid_known = false;
   h->n_target = n;
   h->d_target_pts = d_pts;
   ndt_fitness_invalidate(h);

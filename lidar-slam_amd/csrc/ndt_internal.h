@@ -34,6 +34,8 @@ struct lsa_ndt {
   DevBuf<double> d_small;
   bool has_target = false;
   size_t n_target = 0, n_valid = 0;
+  bool n_valid_known = false;    // n_valid is counted on demand (ndt_count_valid)
+  DevBuf<int32_t> counts;        // points per occupied voxel (the index's own counts are zeroed again by the build)
   const float4 *d_target_pts = nullptr;  // the cloud the table was built from (ours, or the caller's device buffer)
   FitnessState *fitness = nullptr;       // lazily built leaf table for GetFitnessScore
   NNGrid nn;                             // PCL mode: lazily built point-level neighbour grid for GetFitnessScore
@@ -64,6 +66,7 @@ struct lsa_ndt {
 };
 
 int ndt_build_grid(lsa_ndt *h, const float4 *d_pts, size_t n);
+int ndt_count_valid(lsa_ndt *h);
 void ndt_fitness_invalidate(lsa_ndt *h);
 void ndt_fitness_release(lsa_ndt *h);
 
