@@ -171,6 +171,38 @@ def test_derivative_pass_matches_oracle(ctx, oracle, scan_pair, kind, same_table
     n.close()
 
 
+def test_derivative_pass_tile_and_round_boundaries(ctx, oracle, scan_pair):
+    """The pass kernel works in 14-point tiles and takes pairs off its queue in rounds of 64, carrying what a tile leaves over
+    into the next one.  Source sizes around the tile size and its multiples, on a dense target (several pairs per point, so
+    that the queue crosses 64 and 128 at different places), against the oracle on identical voxel tables: pair counts
+    exact, sums to 1e-11."""
+    import oracle_py
+    s0, s1, _, _ = scan_pair
+    tgt = synth.to_xyzi32(s0)
+    filt, _ = oracle.voxel_filter(synth.to_xyzi32(s1), 0.5)
+    src_all = synth.to_xyzi32(filt)
+    o = oracle_py.OracleNDT()
+    o.set_input_target(tgt)
+    n = registration.NDTRegistrationHip(ctx)
+    n.SetInputTarget(tgt)
+    o.override_cells(*n.grid_dump())
+    p = np.array([0.9, 0.04, 0.0, 0.002, -0.003, 0.02])
+    T = oracle.pose_to_matrix(p)
+    rng = np.random.RandomState(5)
+    for ns in (1, 2, 13, 14, 15, 27, 28, 29, 41, 42, 43, 55, 56, 57, 64, 70, 111, 112, 113, 14 * 4 * 3 - 1, 14 * 4 * 3, 14 * 4 * 3 + 1, 777):
+        src = src_all[rng.choice(src_all.shape[0], ns, replace=False)]
+        n.set_source(src)
+        for kind in (0, 1):
+            sref, gref, Href, pairs_ref = o.derivatives(src, T, p, compute_hessian=(kind == 0))
+            sc, g, H, pairs, npts = n.derivatives(T, p, kind)
+            assert int(pairs) == pairs_ref and int(npts) == ns, (ns, kind, pairs, pairs_ref)
+            assert abs(sc - sref) <= 1e-11 * max(abs(sref), 1e-300), (ns, kind)
+            assert np.max(np.abs(g - gref)) <= 1e-11 * max(np.max(np.abs(gref)), 1e-300), (ns, kind)
+            if kind == 0:
+                assert np.max(np.abs(H - 0.5 * (Href + Href.T))) <= 1e-11 * max(np.max(np.abs(Href)), 1e-300), ns
+    n.close()
+
+
 def test_derivative_pass_deterministic_and_linear(ctx, scan_pair, oracle):
     """Size-independent properties at full scan size (133 k source points, unfiltered):
     bitwise reproducibility, and additivity over a split of the source cloud (the multi-GPU invariant)."""
