@@ -1,5 +1,6 @@
 // nn_grid.hip — build of the exact nearest-neighbour grid (see nn_grid.h): sparse voxel index over the points, then a
 // counting sort of the points by occupied-cell rank.
+#include <cstdlib>
 #include "nn_grid_dev.h"
 
 namespace {
@@ -53,6 +54,14 @@ __global__ __launch_bounds__(kBlock) void k_scatter(const float4 *__restrict__ p
   float4 p = pts[i];
   p.w = __uint_as_float((unsigned)i);  // original index: deterministic tie-break, and what the kd-tree would return
   sorted[slot] = p;
+}
+// dense[cell] = {start[rank], #points} for every occupied cell (the table was zeroed before)
+__global__ __launch_bounds__(kBlock) void k_nn_dense_fill(const int32_t *__restrict__ cell_of_rank, const uint32_t *__restrict__ start, size_t V,
+                                                          uint2 *__restrict__ dense) {
+  size_t r = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= V) return;
+  unsigned a = start[r], b = start[r + 1];
+  dense[cell_of_rank[r]] = make_uint2(a, b - a);
 }
 struct T12 { float v[12]; };
 
@@ -133,6 +142,17 @@ int nn_grid_build(lsa_context *ctx, NNGrid &g, const float4 *d_pts, size_t n, fl
   hipLaunchKernelGGL(k_excl_scan, dim3(1), dim3(1024), 0, ctx->stream, g.cnt.p, V, g.start.p);
   hipLaunchKernelGGL(k_scatter, dim3(lsa_div_up(n, kBlock)), dim3(kBlock), 0, ctx->stream, d_pts, vi.cell_idx.p, n, vi.bits.p, vi.prefix.p, g.start.p,
                      g.fill.p, g.sorted.p);
+  {
+    const CellMap &m = vi.map;
+    const long long ncell = (long long)m.dim[0] * m.dim[1] * m.dim[2];
+    const char *lim = getenv("LSA_NN_DENSE_MAX_CELLS");  // diagnostics / tests: 0 forces the bitmap walk
+    g.use_dense = ncell > 0 && ncell <= (lim ? atoll(lim) : kNNDenseMaxCells);
+    if (g.use_dense) {
+      if ((rc = g.dense.reserve(ctx, (size_t)ncell, 1.25))) return rc;
+      LSA_HIP(ctx, hipMemsetAsync(g.dense.p, 0, (size_t)ncell * sizeof(uint2), ctx->stream));
+      hipLaunchKernelGGL(k_nn_dense_fill, dim3(lsa_div_up(V, kBlock)), dim3(kBlock), 0, ctx->stream, vi.cell_of_rank.p, g.start.p, V, g.dense.p);
+    }
+  }
   LSA_HIP(ctx, hipGetLastError());
   LSA_HIP(ctx, hipStreamSynchronize(ctx->stream));
   g.n = n;

@@ -83,6 +83,33 @@ def test_icp_matches_oracle(ctx, oracle, scan_pair, guess_kind):
     icp.close(); f03.close(); f05.close()
 
 
+def test_nn_phased_dense_search_equals_row_walk(ctx, oracle, scan_pair, monkeypatch):
+    """With a dense per-cell {first slot, count} table (cell boxes up to 16 Mi cells) the neighbour search lists a ring's
+    candidate cells per lane and fetches their entries together; without it (LSA_NN_DENSE_MAX_CELLS=0) it walks the bitmap
+    row by row.  Same neighbours, same bits: ICP poses after 5 iterations in all three modes, and the PCL fitness."""
+    s0, s1, _, _ = scan_pair
+    tgt, _ = oracle.voxel_filter(synth.to_xyzi32(s0), 0.3)
+    src, _ = oracle.voxel_filter(synth.to_xyzi32(s1), 0.5)
+    tgt, src = synth.to_xyzi32(tgt), synth.to_xyzi32(src)
+    guess = synth.pose_matrix(0.9, 0.03, 0.0, 0.001, -0.002, 0.018).astype(np.float32)
+    res = []
+    for walk in (False, True):
+        if walk:
+            monkeypatch.setenv("LSA_NN_DENSE_MAX_CELLS", "0")
+        out = []
+        for mode in (capi.ICP_MODE_MANUAL, capi.ICP_MODE_PLANE, capi.ICP_MODE_PCL):
+            icp = registration.ICPRegistrationHip(ctx, 2.0, 5, mode=mode)
+            icp.SetInputTarget(tgt)          # the grid (and its table) is built here
+            _, T = icp.ScanMatch(src, guess)
+            out.append(T)
+            if mode == capi.ICP_MODE_PCL:
+                out.append(np.float64(icp.GetFitnessScore()))
+            icp.close()
+        res.append(out)
+    for a, b in zip(res[0], res[1]):
+        assert np.array_equal(a, b)
+
+
 def test_icp_single_iteration_normal_equations(ctx, oracle, scan_pair):
     """One iteration isolates the NN + J^T J / J^T e kernel from the fixed-point iteration: poses after ONE update."""
     import oracle_py
