@@ -125,6 +125,12 @@ __device__ __forceinline__ NNHit nn_nearest_sub(const NNView &g, float qx, float
       // (The cube enumeration is O(rho^3) against the shell's O(rho^2): rings beyond kPhasedMaxRing — unbounded searches
       // of queries far from every point — take the row walk below.)
       constexpr int kSlots = 8;
+      // Rings 0 and 1 in ONE step when the query's own cell is in the grid: every dependent load costs ~1 us here (the
+      // table and the points are cold in this XCD's L2 at the start of a launch), and with a seed the cells of ring 1 that
+      // can matter are known before ring 0 has been looked at — so their entries are fetched with the own cell's.
+      const bool fused = rho == 0 && rho_end >= 1;
+      const int inner = rho;       // lowest Chebyshev distance this step covers
+      if (fused) rho = 1;          // ... and the highest; the termination test below then speaks for ring 1
       const int w = 2 * rho + 1, ww = w * w, ncube = ww * w;
       const float inv_w = 1.0f / (float)w, inv_ww = 1.0f / (float)ww;
       const float bound2 = fminf(gate_d2, h.d2);  // fixed for the ring: conservative
@@ -137,7 +143,7 @@ __device__ __forceinline__ NNHit nn_nearest_sub(const NNView &g, float qx, float
           const int tz = (int)(((float)t + 0.5f) * inv_ww), r2 = t - tz * ww, ty = (int)(((float)r2 + 0.5f) * inv_w), tx = r2 - ty * w;
           const int dx = tx - rho, dy = ty - rho, dz = tz - rho;
           const int ix = c0 + dx, iy = c1 + dy, iz = c2 + dz;
-          bool ok = t < ncube && max(abs(dx), max(abs(dy), abs(dz))) == rho && ix >= 0 && ix < m.dim[0] && iy >= 0 && iy < m.dim[1] && iz >= 0 &&
+          bool ok = t < ncube && max(abs(dx), max(abs(dy), abs(dz))) >= inner && ix >= 0 && ix < m.dim[0] && iy >= 0 && iy < m.dim[1] && iz >= 0 &&
                     iz < m.dim[2];
           const float gx = dx > 0 ? (float)dx - ux : (dx < 0 ? (float)(-dx - 1) + ux : 0.0f);
           const float gy = dy > 0 ? (float)dy - uy : (dy < 0 ? (float)(-dy - 1) + uy : 0.0f);
