@@ -495,7 +495,8 @@ def main():
         go(int(min(args.ramp_seconds, 0.5) * 8000)); go(max(1, args.warmup))
         dt_s = go(args.steps)
         # every stream must reproduce, bit for bit, what the single stream produced for the same scans
-        same = all(np.array_equal(capi.from_colmajor(p_.out[i]), results[p_.idx[i]][0]) for p_ in pipes for i in range(p_.count - ns, p_.count))
+        same = all(np.array_equal(capi.from_colmajor(p_.out[i]), results[p_.idx[i]][0]) for p_ in pipes for i in range(max(0, p_.count - ns), p_.count)
+                   if p_.idx[i] in results)
         concurrent = {"streams": S, "steps_per_stream": args.steps, "value": round(S * args.steps / dt_s, 2), "unit": "scans/s",
                       "ms_per_step_per_stream": round(dt_s / args.steps * 1e3, 4), "poses_identical_to_single_stream": bool(same),
                       "note": "S independent scan streams on one GPU, one host thread + one helper thread each; not applicable to a single sensor stream"}
