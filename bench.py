@@ -396,6 +396,15 @@ def main():
                          "frac": round(alg5 / (ms5 * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "us_per_launch": round(ms5 * 1e3, 1),
                          "alg_bytes_per_launch": int(alg5), "source_points": M5, "kbar": round(kbar5, 3),
                          "pairs_per_s": round(pairs5 / (ms5 * 1e-3), 0)}
+        # BASELINE.json configs[4] in full: the 30-iteration align of the 2 M-point scan (eps 0 -> runs to max_iter)
+        ndt5.ScanMatch(d_s5, g5)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        ndt5.ScanMatch(d_s5, g5)
+        torch.cuda.synchronize()
+        roofline_cfg5["align_ms"] = round((time.perf_counter() - t0) * 1e3, 3)
+        roofline_cfg5["align_iterations"] = int(ndt5.last_stats["iterations"])
+        roofline_cfg5["align_passes"] = int(ndt5.last_stats["passes"])
         ndt5.close()
         del d_t5, d_s5
 
