@@ -538,6 +538,27 @@ def main():
                           "note": "device-resident FrontEnd::Update loop incl. key-frame work (local map of <= 20 key-frames, 0.3 m map filter, voxel table)"}
         del d_all
 
+    # ---- BASELINE.json configs[2]: point-to-plane ICP (the second RegistrationInterface plugin, lsa_icp_* in its point-to-plane
+    # mode; 30 iterations, max correspondence distance 2 m, normals from the target's 1 m voxels) on the same scans against the
+    # same local map.  Extra key, rank 0.
+    icp_plane = None
+    if rank == 0 and world == 1 and not dist_mode:
+        icp = registration.ICPRegistrationHip(ctx, 2.0, 30, mode=capi.ICP_MODE_PLANE)
+        icp.SetInputTarget(d_map_f.contiguous())
+        t_icp, e_icp = [], []
+        for k in range(len(d_scans)):
+            f_k = frame_filter.filter_device(d_scans[k]).clone()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            _, T_icp = icp.ScanMatch(f_k, guesses[k])
+            t_icp.append(time.perf_counter() - t0)
+            e_icp.append(pose_err(T_icp, truths[k]))
+        e_icp = np.array(e_icp)
+        icp_plane = {"workload": "cfg3: point-to-plane ICP, 30 iterations, same scans / local map as the headline", "scans": len(t_icp),
+                     "ms_per_scan_match": round(float(np.median(t_icp)) * 1e3, 4), "value": round(1.0 / float(np.median(t_icp)), 1), "unit": "scans/s",
+                     "pose_rmse_vs_truth": {"t_m": float(np.sqrt(np.mean(e_icp[:, 0] ** 2))), "r_rad": float(np.sqrt(np.mean(e_icp[:, 1] ** 2)))}}
+        icp.close()
+
     # ---- CPU baseline: the oracle (single thread) on a bounded sample of the same scans; also the pose check
     cpu_baseline = None
     pose_rmse = None
@@ -631,6 +652,7 @@ def main():
             "multi_gpu_alt": alt,
             "concurrent_streams": concurrent,
             "front_end_loop": front_end_loop,
+            "icp_point_to_plane": icp_plane,
             "cpu_baseline": cpu_baseline,
             "pose_rmse_vs_oracle": pose_rmse,
             "pose_rmse_pcl_mode_vs_oracle": pose_rmse_pcl,
