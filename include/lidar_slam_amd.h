@@ -190,6 +190,10 @@ int lsa_ndt_grid_info(lsa_ndt *ndt, int64_t info[9]);
  * rec: centroid(3) icov sym (xx,xy,xz,yy,yz,zz) weight(1) -> 10 doubles per cell. cap in cells. */
 int lsa_ndt_grid_dump(lsa_ndt *ndt, int32_t *cell_ints, double *cell_rec, size_t cap, size_t *n_cells);
 
+/* Per-pass trace of the NEXT ScanMatch calls on this handle (rows as lsa_gn_solve_trace writes them); rows == NULL stops
+ * it.  The buffers must stay valid while the trace is set. */
+int lsa_ndt_set_trace(lsa_ndt *ndt, double *rows, int cap_rows, int *n_rows);
+
 /* One derivative pass of computeDerivatives / computeHessian (NormalDistributionsTransform.cpp:391-445,
  * :901-936) at rigid transform T (f32, column-major) and pose p (f64, for the angle derivatives).
  * kind 0: score + gradient + Hessian, 1: score + gradient, 2: Hessian only.
@@ -231,6 +235,11 @@ int lsa_gn_solve(lsa_pass_eval_fn eval, void *user, float res, float step_size, 
 int lsa_gn_solve_mode(lsa_pass_eval_fn eval, void *user, float res, float step_size, float trans_eps, int max_iter,
                       float outlier_ratio, int mode, const float predict_pose[16], float result_pose[16],
                       lsa_ndt_stats *stats);
+/* same, recording one row per derivative pass in the order the passes ran: {p(6), score, step length, pass kind} = 9
+ * doubles; *trace_n counts every pass, rows beyond trace_cap are dropped.  trace_rows == NULL: no trace. */
+int lsa_gn_solve_trace(lsa_pass_eval_fn eval, void *user, float res, float step_size, float trans_eps, int max_iter,
+                       float outlier_ratio, int mode, const float predict_pose[16], float result_pose[16],
+                       lsa_ndt_stats *stats, double *trace_rows, int trace_cap, int *trace_n);
 /* pose helpers of that driver (f32 rigid transform <-> the reference's (t, Euler XYZ) chart) */
 void lsa_pose_to_matrix(const double p[6], float T[16]);
 void lsa_matrix_to_pose(const float T[16], double p[6]);

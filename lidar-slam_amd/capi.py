@@ -17,6 +17,7 @@ LSA_OK = 0
 LSA_ERR_INVALID, LSA_ERR_NO_DEVICE, LSA_ERR_HIP, LSA_ERR_NO_TARGET, LSA_ERR_CAPACITY, LSA_ERR_COLLECTIVE, LSA_ERR_RANGE = -1, -2, -3, -4, -5, -6, -7
 POINT_STRIDE = 32
 W_OFF = 16
+NO_WEIGHT = C.c_size_t(-1).value  # SIZE_MAX: the cloud carries no intensity, every static weight is 1
 
 
 class LsaError(RuntimeError):
@@ -152,6 +153,8 @@ def lib():
     L.lsa_ndt_set_mode.argtypes = [vp, i]
     L.lsa_ndt_set_dense_limit.argtypes = [vp, C.c_longlong]
     L.lsa_gn_solve_mode.argtypes = [PASS_EVAL_FN, vp, f, f, f, i, f, i, PF, PF, C.POINTER(NdtStats)]
+    L.lsa_gn_solve_trace.argtypes = [PASS_EVAL_FN, vp, f, f, f, i, f, i, PF, PF, C.POINTER(NdtStats), PD, i, C.POINTER(C.c_int)]
+    L.lsa_ndt_set_trace.argtypes = [vp, PD, i, C.POINTER(C.c_int)]
     _lib = L
     return L
 
@@ -164,6 +167,14 @@ def declared_symbols():
     names = re.findall(r"\b(lsa_[a-z0-9_]+)\s*\(", txt)
     skip = {"lsa_allreduce_fn", "lsa_pass_eval_fn"}
     return sorted(set(n for n in names if n not in skip))
+
+
+def w_offset(cols):
+    """Byte offset of the intensity / static weight in a row of `cols` floats: (n,3) xyz rows have none (weight 1),
+    (n,4) rows are packed x,y,z,w, wider rows follow pcl::PointXYZI (intensity at 16)."""
+    if cols < 3:
+        raise ValueError("point rows need at least 3 floats, got %d" % cols)
+    return NO_WEIGHT if cols == 3 else (12 if cols == 4 else W_OFF)
 
 
 def colmajor(T):

@@ -41,7 +41,7 @@ class VoxelFilterHip(CloudFilterInterface):
         pts = np.ascontiguousarray(input_cloud, dtype=np.float32)
         n = pts.shape[0]
         stride = pts.strides[0]
-        w_off = capi.W_OFF if pts.shape[1] >= 5 else 12
+        w_off = capi.w_offset(pts.shape[1])
         out = np.zeros((max(n, 1), 8), dtype=np.float32)
         n_out = C.c_size_t(0)
         rc = capi.lib().lsa_voxel_filter_apply(self.h, pts.ctypes.data, n, stride, w_off, out.ctypes.data, n, capi.POINT_STRIDE, capi.W_OFF, C.byref(n_out))
@@ -104,7 +104,7 @@ class BoxFilterHip(CloudFilterInterface):
     def Filter(self, input_cloud, filtered_cloud=None):  # noqa: N802
         pts = np.ascontiguousarray(input_cloud, dtype=np.float32)
         n = pts.shape[0]
-        w_off = capi.W_OFF if pts.shape[1] >= 5 else 12
+        w_off = capi.w_offset(pts.shape[1])
         out = np.zeros((max(n, 1), 8), dtype=np.float32)
         n_out = C.c_size_t(0)
         self.ctx.check(capi.lib().lsa_box_filter_apply(self.h, pts.ctypes.data, n, pts.strides[0], w_off, out.ctypes.data, n, capi.POINT_STRIDE,

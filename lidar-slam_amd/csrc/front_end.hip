@@ -295,9 +295,9 @@ extern "C" int lsa_front_end_update(lsa_front_end *fe, const void *cloud, size_t
   lsa_context *ctx = fe->ctx;
   LSA_HIP(ctx, hipSetDevice(ctx->device));
   int rc;
+  LSA_HIP(ctx, hipStreamSynchronize(ctx->stream));  // before the reserves: they may free a buffer an earlier copy still reads
   if ((rc = fe->h_stage.reserve(ctx, (n ? n : 1) * 4))) return rc;
   if ((rc = fe->d_in.reserve(ctx, n ? n : 1, 1.25))) return rc;
-  LSA_HIP(ctx, hipStreamSynchronize(ctx->stream));
   if ((rc = lsa_upload_xyzw(ctx, cloud, n, stride, w_off, fe->h_stage.p, fe->d_in.p))) return rc;
   return fe_update_device(fe, fe->d_in.p, n, pose_out, stats);
 }

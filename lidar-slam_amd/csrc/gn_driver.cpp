@@ -183,6 +183,18 @@ struct Driver {
   int passes = 0, ls_iters = 0;
   double pairs_total = 0, npoints = 0;
   int rc = 0;
+  double *trace = nullptr;  // optional per-pass rows {p(6), score, step length, kind} (lsa_gn_solve_trace)
+  int trace_cap = 0, *trace_n = nullptr;
+
+  void trace_row(const double p[6], double step, int kind) {
+    if (!trace || !trace_n) return;
+    if (*trace_n < trace_cap) {
+      double *r = trace + (size_t)(*trace_n) * 9;
+      memcpy(r, p, 6 * sizeof(double));
+      r[6] = score; r[7] = step; r[8] = kind;
+    }
+    (*trace_n)++;
+  }
 
   bool pass(const double p[6], int kind) {
     double out[32];
@@ -222,6 +234,7 @@ struct Driver {
     for (int i = 0; i < 6; i++) x_t[i] = x[i] + dir[i] * a_t;
     lsa_pose_to_matrix(x_t, T);
     if (!pass(x_t, 0)) return NAN;
+    trace_row(x_t, a_t, 0);
     double phi_t = -score, d_phi_t = 0;
     for (int i = 0; i < 6; i++) d_phi_t += g[i] * dir[i];
     d_phi_t = -d_phi_t;
@@ -234,6 +247,7 @@ struct Driver {
       for (int i = 0; i < 6; i++) x_t[i] = x[i] + dir[i] * a_t;
       lsa_pose_to_matrix(x_t, T);
       if (!pass(x_t, 1)) return NAN;
+      trace_row(x_t, a_t, 1);
       double dd = 0;
       for (int i = 0; i < 6; i++) dd += g[i] * dir[i];
       if (mode == LSA_NDT_MODE_PCL) {  // pcl ndt.hpp assigns
@@ -256,6 +270,7 @@ struct Driver {
     }
     if (step_iterations) {
       if (!pass(x_t, 2)) return NAN;  // computeHessian (:749-751)
+      trace_row(x_t, a_t, 2);
     }
     ls_iters += step_iterations;
     return a_t;
@@ -316,10 +331,18 @@ extern "C" int lsa_gn_solve(lsa_pass_eval_fn eval, void *user, float res, float 
 
 extern "C" int lsa_gn_solve_mode(lsa_pass_eval_fn eval, void *user, float res, float step_size, float trans_eps, int max_iter,
                                  float outlier_ratio, int mode, const float predict_pose[16], float result_pose[16], lsa_ndt_stats *stats) {
+  return lsa_gn_solve_trace(eval, user, res, step_size, trans_eps, max_iter, outlier_ratio, mode, predict_pose, result_pose, stats, nullptr, 0, nullptr);
+}
+
+extern "C" int lsa_gn_solve_trace(lsa_pass_eval_fn eval, void *user, float res, float step_size, float trans_eps, int max_iter,
+                                  float outlier_ratio, int mode, const float predict_pose[16], float result_pose[16], lsa_ndt_stats *stats,
+                                  double *trace_rows, int trace_cap, int *trace_n) {
   (void)res; (void)outlier_ratio;  // the evaluator owns d1/d2; kept in the signature to mirror the plugin ctor
   if (!eval || !predict_pose || !result_pose) return LSA_ERR_INVALID;
   Driver d;
   d.eval = eval; d.user = user; d.mode = mode;
+  d.trace = trace_rows; d.trace_cap = trace_cap; d.trace_n = trace_n;
+  if (trace_n) *trace_n = 0;
   d.step_size = step_size; d.trans_eps = trans_eps; d.max_iter = max_iter;  // float -> double like the plugin (:14-22)
   memcpy(d.T, predict_pose, sizeof(d.T));  // final_transformation_ = guess (Registration.cpp:80, Normal...:323-328)
   double p[6], delta[6];
@@ -328,6 +351,7 @@ extern "C" int lsa_gn_solve_mode(lsa_pass_eval_fn eval, void *user, float res, f
   bool converged = false;
   double trans_probability = 0;
   if (!d.pass(p, 0)) return d.rc;  // :346
+  d.trace_row(p, 0.0, 0);
   while (!converged) {
     double negg[6];
     for (int i = 0; i < 6; i++) negg[i] = -d.g[i];

@@ -6,6 +6,9 @@
 #include <cstdlib>
 
 static thread_local std::string g_global_err;
+// ctx->err is written by whichever thread fails (the async frame filter reports from its helper thread) and read by the
+// caller's: both sides go through this mutex, and lsa_last_error hands out a per-thread copy
+static std::mutex g_err_mu;
 
 void lsa_set_global_error(const char *fmt, ...) {
   char buf[512];
@@ -23,12 +26,10 @@ int lsa_fail(lsa_context *ctx, int code, const char *fmt, ...) {
   vsnprintf(buf, sizeof(buf), fmt, ap);
   va_end(ap);
   {
-    // the async frame filter reports failures from its helper thread: serialise the two string assignments
-    static std::mutex mu;
-    std::lock_guard<std::mutex> lock(mu);
+    std::lock_guard<std::mutex> lock(g_err_mu);
     if (ctx) ctx->err = buf;
-    g_global_err = buf;
   }
+  g_global_err = buf;
   return code;
 }
 
@@ -51,6 +52,10 @@ void lsa_pack_xyzw(const void *pts, size_t n, size_t stride, size_t w_off, float
 // soon as its chunk is packed, so the PCIe transfer of chunk k runs under the packing of chunk k + 1 (a 131 k-point scan:
 // ~70 us of packing with ~40 us of copy behind it instead of after it).  The caller owns the ordering of h_stage reuse.
 int lsa_upload_xyzw(lsa_context *ctx, const void *pts, size_t n, size_t stride, size_t w_off, float *h_stage, float4 *d_dst) {
+  // an intensity offset that does not fit the row would read the next point (or past the buffer): (n,3) xyz rows have
+  // no intensity and must say so with w_off == SIZE_MAX
+  if (n && (stride < 12 || (w_off != SIZE_MAX && w_off + 4 > stride)))
+    return lsa_fail(ctx, LSA_ERR_INVALID, "point rows of %zu bytes cannot hold xyz + an intensity at offset %zu (pass SIZE_MAX for clouds without one)", stride, w_off);
   constexpr size_t kChunk = 32768;  // points: 512 KB per copy, few enough copies that their launch cost stays small
   for (size_t off = 0; off < n; off += kChunk) {
     const size_t m = n - off < kChunk ? n - off : kChunk;
@@ -64,7 +69,15 @@ extern "C" int lsa_version(void) { return LSA_VERSION_MAJOR * 100 + LSA_VERSION_
 
 extern "C" const char *lsa_last_global_error(void) { return g_global_err.c_str(); }
 
-extern "C" const char *lsa_last_error(const lsa_context *ctx) { return ctx ? ctx->err.c_str() : g_global_err.c_str(); }
+extern "C" const char *lsa_last_error(const lsa_context *ctx) {
+  if (!ctx) return g_global_err.c_str();
+  static thread_local std::string copy;
+  {
+    std::lock_guard<std::mutex> lock(g_err_mu);
+    copy = ctx->err;
+  }
+  return copy.c_str();
+}
 
 extern "C" int lsa_context_create(lsa_context **out, int device, void *hip_stream) {
   if (!out) { lsa_set_global_error("lsa_context_create: out is null"); return LSA_ERR_INVALID; }

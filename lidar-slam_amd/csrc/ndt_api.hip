@@ -12,10 +12,10 @@ namespace {
 int upload_points(lsa_ndt *h, const void *pts, size_t n, size_t stride, size_t w_off, DevBuf<float4> &dst) {
   lsa_context *ctx = h->ctx;
   int rc;
+  // the staging buffer may still be feeding an earlier async copy, and growing either buffer frees the old one: wait first
+  LSA_HIP(ctx, hipStreamSynchronize(ctx->stream));
   if ((rc = h->h_stage.reserve(ctx, n * 4))) return rc;
   if ((rc = dst.reserve(ctx, n, 1.25))) return rc;
-  // the staging buffer may still be feeding an earlier async copy
-  LSA_HIP(ctx, hipStreamSynchronize(ctx->stream));
   return lsa_upload_xyzw(ctx, pts, n, stride, w_off, h->h_stage.p, dst.p);
 }
 
@@ -74,7 +74,8 @@ int scan_match_common(lsa_ndt *h, const float predict_pose[16], float result_pos
   lsa_ndt_gauss_constants(h->resolution, h->outlier_ratio, &h->d1, &h->d2);
   lsa_ndt_stats st;
   memset(&st, 0, sizeof(st));
-  int rc = lsa_gn_solve_mode(eval_trampoline, h, h->resolution, h->step_size, h->trans_eps, h->max_iter, h->outlier_ratio, h->mode, predict_pose, result_pose, &st);
+  int rc = lsa_gn_solve_trace(eval_trampoline, h, h->resolution, h->step_size, h->trans_eps, h->max_iter, h->outlier_ratio, h->mode, predict_pose, result_pose, &st,
+                              h->trace_rows, h->trace_cap, h->trace_n);
   if (rc) return rc;
   memcpy(h->last_T, result_pose, sizeof(h->last_T));
   h->has_result = true;
@@ -225,6 +226,14 @@ extern "C" int lsa_ndt_get_fitness_score(lsa_ndt *h, float *score) {
     return LSA_OK;
   }
   return ndt_fitness(h, score);
+}
+
+extern "C" int lsa_ndt_set_trace(lsa_ndt *h, double *rows, int cap_rows, int *n_rows) {
+  if (!h) return LSA_ERR_INVALID;
+  if (rows && (!n_rows || cap_rows < 0)) return lsa_fail(h->ctx, LSA_ERR_INVALID, "lsa_ndt_set_trace: rows without a counter");
+  h->trace_rows = rows; h->trace_cap = rows ? cap_rows : 0; h->trace_n = rows ? n_rows : nullptr;
+  if (n_rows) *n_rows = 0;
+  return LSA_OK;
 }
 
 extern "C" int lsa_ndt_set_allreduce(lsa_ndt *h, lsa_allreduce_fn fn, void *user) {

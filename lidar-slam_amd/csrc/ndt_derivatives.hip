@@ -694,7 +694,7 @@ bool ndt_reduce_partials_host(const double *partials, unsigned nb, unsigned long
       for (;;) {
         unsigned long long w[32], x = 0ull;
         for (int col = 0; col < 32; col++) w[col] = wr[col];
-        for (int col = 0; col < 31; col++) x ^= w[col];
+        for (int col = 0; col < 31; col++) x ^= lsa_row_mix(w[col], col);
         if ((x ^ key) == w[31]) {
           memcpy(v, w, sizeof(v));
           break;

@@ -59,6 +59,10 @@ struct lsa_ndt {
   lsa_allreduce_fn allreduce = nullptr;
   void *allreduce_user = nullptr;
 
+  // diagnostics: per-pass trace of the Newton driver (lsa_ndt_set_trace)
+  double *trace_rows = nullptr;
+  int trace_cap = 0, *trace_n = nullptr;
+
   // last result (for GetFitnessScore)
   float last_T[16];
   bool has_result = false;

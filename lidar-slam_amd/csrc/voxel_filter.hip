@@ -220,6 +220,8 @@ extern "C" int lsa_voxel_filter_apply(lsa_voxel_filter *f, const void *in_pts, s
   if (in_stride < 12 || out_stride < 12) return lsa_fail(ctx, LSA_ERR_INVALID, "lsa_voxel_filter_apply: stride < 12");
   LSA_HIP(ctx, hipSetDevice(ctx->device));
   int rc;
+  // the staging buffer may still be feeding an earlier async copy, and growing a buffer frees the old one: wait first
+  LSA_HIP(ctx, hipStreamSynchronize(ctx->stream));
   if ((rc = f->h_stage.reserve(ctx, n * 4))) return rc;
   if ((rc = f->d_in.reserve(ctx, n, 1.25))) return rc;
   if ((rc = f->d_out.reserve(ctx, n, 1.25))) return rc;

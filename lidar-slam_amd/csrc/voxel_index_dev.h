@@ -74,12 +74,17 @@ __device__ __forceinline__ void lsa_cell_unravel(const CellMap &m, int cell, int
 }
 
 // Lanes 0..31 of a wave write one 32-double workgroup row.  key != 0: the row goes to host-mapped memory and the host
-// picks it up without waiting for the stream, so column 31 carries key ^ XOR of the other 31 words (it must hold no
-// payload): the host can tell a complete row of THIS pass from a stale or half-arrived one whatever order the stores land in.
+// picks it up without waiting for the stream, so column 31 carries key ^ XOR_c rotl(word_c, c + 1) over the other 31 words
+// (it must hold no payload): the host can tell a complete row of THIS pass from a stale or half-arrived one whatever order
+// the stores land in.  The rotation by the column index keeps equal or swapped stale columns from cancelling.
+__host__ __device__ __forceinline__ unsigned long long lsa_row_mix(unsigned long long w, int col) {
+  const int r = col + 1;  // 1..31
+  return (w << r) | (w >> (64 - r));
+}
 __device__ __forceinline__ void lsa_store_row32(double *__restrict__ row, int col, double v, unsigned long long key) {
   if (!key) { row[col] = v; return; }
   unsigned long long w = (unsigned long long)__double_as_longlong(v);
-  unsigned long long x = col == 31 ? 0ull : w;
+  unsigned long long x = col == 31 ? 0ull : lsa_row_mix(w, col);
 #pragma unroll
   for (int off = 1; off < 32; off <<= 1) x ^= __shfl_xor(x, off, 64);
   if (col == 31) w = x ^ key;

@@ -84,7 +84,7 @@ class FrontEndHip:
             rc = capi.lib().lsa_front_end_update_device(self.h, cloud.data_ptr(), cloud.shape[0], capi.fptr(out), C.byref(st))
         else:
             pts = np.ascontiguousarray(cloud, dtype=np.float32)
-            w_off = capi.W_OFF if pts.shape[1] >= 5 else 12
+            w_off = capi.w_offset(pts.shape[1])
             rc = capi.lib().lsa_front_end_update(self.h, pts.ctypes.data, pts.shape[0], pts.strides[0], w_off, capi.fptr(out), C.byref(st))
         self.ctx.check(rc)
         self.last_stats = dict(key_frame=st.key_frame, local_map_frames=st.local_map_frames, filtered_points=st.filtered_points,

@@ -52,23 +52,38 @@ class NDTRegistrationHip(RegistrationInterface):
             self.ctx.check(capi.lib().lsa_ndt_set_input_target_device(self.h, input_target.data_ptr(), input_target.shape[0]))
         else:
             pts = np.ascontiguousarray(input_target, dtype=np.float32)
-            w_off = capi.W_OFF if pts.shape[1] >= 5 else 12
-            self.ctx.check(capi.lib().lsa_ndt_set_input_target(self.h, pts.ctypes.data, pts.shape[0], pts.strides[0], w_off))
+            self.ctx.check(capi.lib().lsa_ndt_set_input_target(self.h, pts.ctypes.data, pts.shape[0], pts.strides[0], capi.w_offset(pts.shape[1])))
         return True
 
-    def ScanMatch(self, input_source, predict_pose):  # noqa: N802
+    def ScanMatch(self, input_source, predict_pose, trace=False):  # noqa: N802
+        """trace=True additionally records one row per derivative pass ({p(6), score, step length, kind}) in
+        last_stats["trace"] (lsa_ndt_set_trace; diagnostics for the parity tests)."""
         guess = capi.colmajor(predict_pose)
         out = np.zeros(16, dtype=np.float32)
         st = capi.NdtStats()
+        tr, ntr = None, C.c_int(0)
+        if trace:
+            tr = np.zeros((512, 9))
+            self.ctx.check(capi.lib().lsa_ndt_set_trace(self.h, capi.dptr(tr), 512, C.byref(ntr)))
+        try:
+            rc = self._scan_match(input_source, guess, out, st)
+        finally:
+            if trace:
+                capi.lib().lsa_ndt_set_trace(self.h, None, 0, None)
+        self.ctx.check(rc)
+        self.last_stats = st.as_dict()
+        if trace:
+            self.last_stats["trace"] = tr[: min(ntr.value, 512)].copy()
+        return True, capi.from_colmajor(out)
+
+    def _scan_match(self, input_source, guess, out, st):
         if _is_tensor(input_source):
             self._src_keep = input_source
             rc = capi.lib().lsa_ndt_scan_match_device(self.h, input_source.data_ptr(), input_source.shape[0], capi.fptr(guess), capi.fptr(out), C.byref(st))
         else:
             pts = np.ascontiguousarray(input_source, dtype=np.float32)
             rc = capi.lib().lsa_ndt_scan_match(self.h, pts.ctypes.data, pts.shape[0], pts.strides[0], capi.fptr(guess), capi.fptr(out), C.byref(st))
-        self.ctx.check(rc)
-        self.last_stats = st.as_dict()
-        return True, capi.from_colmajor(out)
+        return rc
 
     def GetFitnessScore(self):  # noqa: N802
         v = C.c_float(0)

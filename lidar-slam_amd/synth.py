@@ -55,9 +55,9 @@ class Scene:
         self.pole_top = -SENSOR_HEIGHT + 6.0
 
     # ------------------------------------------------------------------------------------------
-    def cast(self, T_world_sensor, az, elev, max_range):
+    def cast(self, T_world_sensor, az, elev, max_range, rng=None):
         """Ray-cast beams x azimuth columns. Returns t (n_az, beams) ranges (inf where nothing is hit)
-        and the unit directions in the sensor frame (n_az, beams, 3)."""
+        and the unit directions in the sensor frame (n_az, beams, 3).  rng: only scenes with foliage volumes draw from it."""
         R = T_world_sensor[:3, :3]
         o = T_world_sensor[:3, 3]
         ce, se = np.cos(elev), np.sin(elev)
@@ -86,7 +86,10 @@ class Scene:
                 return [slice(i0m, i1m + 1)]
             return [slice(i0m, n_az), slice(0, i1m + 1)]
 
-        for b in self.boxes:
+        foliage = getattr(self, "foliage", None)
+        n_solid = self.boxes.shape[0]
+        all_boxes = self.boxes if foliage is None else np.concatenate([self.boxes, foliage[:, :6]], axis=0)
+        for bi, b in enumerate(all_boxes):
             # azimuth interval of the box as seen from the sensor (sensor frame), from its 8 corners
             cs = np.array([[b[i], b[2 + j], b[4 + k]] for i in (0, 1) for j in (0, 1) for k in (0, 1)])
             cs_s = (cs - o) @ Rt.T
@@ -114,18 +117,31 @@ class Scene:
                 tmin = np.nanmax(np.minimum(t0, t1), axis=2)
                 tmax = np.nanmin(np.maximum(t0, t1), axis=2)
                 hit = (tmax >= tmin) & (tmax > 0)
-                tb = np.where(tmin > 0, tmin, tmax)
+                if bi >= n_solid:
+                    # foliage volume: a ray travelling through it returns from a depth drawn from an exponential free path
+                    # (density rho per metre), or passes through — a volumetric point distribution instead of a facet
+                    rho = foliage[bi - n_solid, 6]
+                    depth = rng.exponential(1.0 / rho, size=tmin.shape)
+                    t_in = np.maximum(tmin, 0.0)
+                    tb = t_in + depth
+                    hit &= tb < tmax
+                else:
+                    tb = np.where(tmin > 0, tmin, tmax)
                 tb[~hit] = np.inf
                 t[sl] = np.minimum(t[sl], tb)
-        for c in self.poles:
+        pole_r_all = getattr(self, "pole_radii", None)
+        pole_top_all = getattr(self, "pole_tops", None)
+        for pi_, c in enumerate(self.poles):
+            pole_r = self.pole_r if pole_r_all is None else pole_r_all[pi_]
+            pole_top = self.pole_top if pole_top_all is None else pole_top_all[pi_]
             oc = o[:2] - c
             dist = np.hypot(oc[0], oc[1])
-            if dist <= self.pole_r * 1.5:
+            if dist <= pole_r * 1.5:
                 sls = [slice(0, n_az)]
             else:
                 c_s = (np.array([c[0], c[1], o[2]]) - o) @ Rt.T
                 a_c = np.arctan2(c_s[1], c_s[0])
-                half = np.arcsin(min(1.0, self.pole_r / dist)) + 0.02
+                half = np.arcsin(min(1.0, pole_r / dist)) + 0.02
                 lo, hi = a_c - half, a_c + half
                 shift = np.floor((lo - az[0]) / (2.0 * np.pi)) * 2.0 * np.pi
                 sls = col_slices(lo - shift, hi - shift)
@@ -134,17 +150,107 @@ class Scene:
                 dxy = d[:, :, :2]
                 a = (dxy ** 2).sum(2)
                 bq = 2.0 * (dxy @ oc)
-                cq = oc @ oc - self.pole_r ** 2
+                cq = oc @ oc - pole_r ** 2
                 disc = bq * bq - 4.0 * a * cq
                 ok = disc > 0
                 with np.errstate(divide="ignore", invalid="ignore"):
                     tp = (-bq - np.sqrt(np.where(ok, disc, 0.0))) / (2.0 * a)
                 z = o[2] + tp * d[:, :, 2]
-                ok &= (tp > 0) & (z <= self.pole_top) & (z >= -SENSOR_HEIGHT)
+                ok &= (tp > 0) & (z <= pole_top) & (z >= -SENSOR_HEIGHT)
                 tp[~ok] = np.inf
                 t[sl] = np.minimum(t[sl], tp)
         t[t > max_range] = np.inf
         return t, d_s
+
+
+class DenseScene(Scene):
+    """A KITTI-residential-shaped bracket of the headline scene: detached houses set back 14-35 m
+    behind front gardens on both sides, a second row of buildings behind the gaps, a row of low-crowned trees on either
+    sidewalk (trunk + a crown that returns volumetrically), hedges along and across the property lines, bushes, fences and
+    parked cars.  An HDL-64E sees nothing above ~2 m + 3.5 % of the range, so what adds occupied voxels is LOW relief spread
+    over open ground, not tall facades: more occupied 1 m voxels, fatter voxel distributions and more neighbours per point
+    than the bare street canyon of `Scene`."""
+
+    def __init__(self, seed: int = 1, length: float = 260.0):
+        rng = np.random.RandomState(seed + 77)
+        boxes, foliage, poles, pole_r, pole_top = [], [], [], [], []
+        g = -SENSOR_HEIGHT
+
+        def bush(cx, cy, r, h, rho=1.2):
+            foliage.append([cx - r, cx + r, cy - r, cy + r, g, g + h, rho])
+
+        for side in (-1.0, 1.0):
+            x = -60.0
+            while x < length:
+                ln = rng.uniform(8.0, 18.0)          # house frontage
+                lot = ln + rng.uniform(4.0, 10.0)    # lot width incl. the gap to the next house
+                setback = rng.uniform(14.0, 22.0) if side < 0 else rng.uniform(18.0, 35.0)
+                h = rng.uniform(5.0, 10.0)
+                depth = rng.uniform(8.0, 12.0)
+                y0, y1 = (setback, setback + depth) if side > 0 else (-setback - depth, -setback)
+                boxes.append([x, x + ln, y0, y1, g, g + h])
+                # second row behind the gap
+                if rng.rand() < 0.6:
+                    sb2 = setback + depth + rng.uniform(10.0, 22.0)
+                    yy = (sb2, sb2 + 10.0) if side > 0 else (-sb2 - 10.0, -sb2)
+                    boxes.append([x + ln - 2.0, x + lot + 4.0, yy[0], yy[1], g, g + rng.uniform(5.0, 9.0)])
+                # porch / bay window
+                for _ in range(rng.randint(0, 3)):
+                    bx = rng.uniform(x, x + ln - 1.5)
+                    bw, bd, bz = rng.uniform(1.2, 3.0), rng.uniform(0.5, 1.5), rng.uniform(0.0, 1.0)
+                    yy = (setback - bd, setback) if side > 0 else (-setback, -setback + bd)
+                    boxes.append([bx, bx + bw, yy[0], yy[1], g + bz, g + bz + rng.uniform(1.5, 3.0)])
+                # hedge along the street side of the lot, hedges / fences between lots (across the street direction)
+                front = rng.uniform(7.0, 9.0)
+                if rng.rand() < 0.75:
+                    hy = side * front
+                    gap0 = rng.uniform(x + 1.0, x + lot - 4.0)    # driveway opening
+                    for (a, b) in ((x, gap0), (gap0 + 3.0, x + lot)):
+                        if b - a > 1.0:
+                            foliage.append([a, b, hy - 0.45, hy + 0.45, g, g + rng.uniform(0.9, 1.7), 1.8])
+                ya, yb = sorted((side * front, side * (setback + depth)))
+                if rng.rand() < 0.5:
+                    foliage.append([x + lot - 0.4, x + lot + 0.4, ya, yb, g, g + rng.uniform(1.0, 2.0), 1.8])
+                else:
+                    boxes.append([x + lot - 0.05, x + lot + 0.05, ya, yb, g, g + rng.uniform(0.9, 1.5)])
+                # front garden: bushes, a small tree or two, a car in the driveway
+                for _ in range(rng.randint(3, 9)):
+                    bush(rng.uniform(x, x + lot), side * rng.uniform(front + 1.0, setback - 0.5), rng.uniform(0.5, 1.5), rng.uniform(0.8, 2.4))
+                for _ in range(rng.randint(0, 3)):
+                    tx, ty = rng.uniform(x, x + lot), side * rng.uniform(front + 2.0, setback + depth + 8.0)
+                    poles.append([tx, ty]); pole_r.append(rng.uniform(0.1, 0.25))
+                    trunk = rng.uniform(1.2, 2.2)
+                    pole_top.append(g + trunk + 0.3)
+                    cr = rng.uniform(1.5, 3.0)
+                    foliage.append([tx - cr, tx + cr, ty - cr, ty + cr, g + trunk, g + trunk + rng.uniform(2.5, 5.0), 0.7])
+                if rng.rand() < 0.5:
+                    cx, cy = rng.uniform(x + 2.0, x + lot - 2.0), side * rng.uniform(front + 2.0, setback - 2.5)
+                    boxes.append([cx - 0.9, cx + 0.9, cy - 2.0, cy + 2.0, g, g + 1.5])
+                x += lot
+            # sidewalk trees with low crowns
+            x = -55.0 + rng.uniform(0.0, 5.0)
+            while x < length - 5.0:
+                ty = side * rng.uniform(5.2, 6.4)
+                poles.append([x, ty]); pole_r.append(rng.uniform(0.12, 0.3))
+                trunk = rng.uniform(1.7, 2.4)
+                pole_top.append(g + trunk + 0.3)
+                cr = rng.uniform(1.5, 2.6)
+                foliage.append([x - cr, x + cr, ty - cr, ty + cr, g + trunk, g + trunk + rng.uniform(3.0, 5.0), 0.6])
+                x += rng.uniform(7.0, 13.0)
+        boxes.append([-62.0, -60.0, -70.0, 70.0, g, 8.0])
+        boxes.append([length, length + 2.0, -70.0, 70.0, g, 8.0])
+        n_cars = int(16 * (length + 60.0) / 100.0)
+        for _ in range(n_cars):
+            cx = rng.uniform(-50.0, length - 10.0)
+            cy = rng.choice([-1.0, 1.0]) * rng.uniform(3.4, 4.4)
+            boxes.append([cx - 2.0, cx + 2.0, cy - 0.9, cy + 0.9, g, g + 1.5])
+        self.boxes = np.asarray(boxes, dtype=np.float64)
+        self.foliage = np.asarray(foliage, dtype=np.float64)   # [x0, x1, y0, y1, z0, z1, density per metre]
+        self.poles = np.asarray(poles, dtype=np.float64)
+        self.pole_radii = np.asarray(pole_r)
+        self.pole_tops = np.asarray(pole_top)
+        self.pole_r = 0.3
+        self.pole_top = g + 6.0
 
 
 def pose_matrix(x=0.0, y=0.0, z=0.0, roll=0.0, pitch=0.0, yaw=0.0):
@@ -167,7 +273,7 @@ def gen_scan(scene: Scene, T_world_sensor, seed: int, beams: int = 64, az_steps:
     rng = np.random.RandomState(seed)
     elev = np.deg2rad(np.linspace(-24.8, 2.0, beams))
     az = np.arange(az_steps) * (2.0 * np.pi / az_steps)
-    t, d_s = scene.cast(np.asarray(T_world_sensor, dtype=np.float64), az, elev, np.inf if clamp else max_range)
+    t, d_s = scene.cast(np.asarray(T_world_sensor, dtype=np.float64), az, elev, np.inf if clamp else max_range, rng=rng)
     t = t.reshape(-1)
     d_s = d_s.reshape(-1, 3)
     if clamp:
