@@ -190,6 +190,28 @@ int lsa_ndt_grid_info(lsa_ndt *ndt, int64_t info[9]);
  * rec: centroid(3) icov sym (xx,xy,xz,yy,yz,zz) weight(1) -> 10 doubles per cell. cap in cells. */
 int lsa_ndt_grid_dump(lsa_ndt *ndt, int32_t *cell_ints, double *cell_rec, size_t cap, size_t *n_cells);
 
+/* ScanMatch can run its whole Newton iteration as ONE persistent launch (csrc/ndt_align.hip: the workgroups stay resident,
+ * exchange their partial sums in-launch and each repeats the 6x6 solve) instead of one launch per derivative pass, when the
+ * call qualifies: single GPU, the trial loop of the line search dead as in every shipped configuration, at most one
+ * workgroup per CU, no trace; otherwise, and whenever the launch gives up (singular system -> SVD on the host, workgroups
+ * not all resident in time), the per-pass path runs.  Both give the same bits (tests/test_gpu_align_persistent.py).
+ * OFF by default: measured on MI355X it is no faster than the per-pass path alone (the in-launch exchange + the redundant
+ * solve cost what the launches did) and slower beside other streams; on = 1 or the environment variable LSA_PERSISTENT=1
+ * enables it.  The counters tell how many ScanMatch calls the persistent launch served and how many of its launches gave
+ * up and were redone per pass. */
+int lsa_ndt_set_persistent(lsa_ndt *ndt, int on);
+int lsa_ndt_align_counters(lsa_ndt *ndt, uint64_t *launches, uint64_t *fallbacks);
+
+/* diagnostics: with enable != 0 the next persistent ScanMatch calls record, per derivative pass, six 100 MHz clock values
+ * of workgroup 0 (pass body start, end, row published, every flag seen, rows reduced, Newton step done); out (optional)
+ * receives those of the last such call, 6 x 40 values, zero where no pass ran. */
+int lsa_ndt_align_stamps(lsa_ndt *ndt, int enable, uint64_t *out, size_t cap, size_t *n_out);
+
+/* Self-test of the scalar arithmetic the host driver and the device-side loop share (csrc/gn_math.h): n pseudo-random
+ * cases through both; mismatches[0..3] = bitwise differences in {sinf/cosf, sin/cos, Newton step, sqrt/division} (must be
+ * 0), mismatches[4] = how many cases were singular systems (taken by both sides alike). */
+int lsa_gn_math_selftest(lsa_context *ctx, size_t n, uint64_t seed, uint64_t mismatches[5]);
+
 /* Per-pass trace of the NEXT ScanMatch calls on this handle (rows as lsa_gn_solve_trace writes them); rows == NULL stops
  * it.  The buffers must stay valid while the trace is set. */
 int lsa_ndt_set_trace(lsa_ndt *ndt, double *rows, int cap_rows, int *n_rows);

@@ -17,6 +17,7 @@
 #include <cmath>
 #include <cstring>
 
+#include "gn_math.h"
 #include "lidar_slam_amd.h"
 
 namespace {
@@ -79,59 +80,15 @@ void svd6_solve(const double H[6][6], const double b[6], double x[6]) {
   }
 }
 
-// The Newton system is solved 4 times per scan on the critical path between two 9 us kernels, and the Jacobi SVD above
-// costs 2.5-5 us.  For a well-conditioned H (every scan that has planes in three directions) pinv(H) b == H^-1 b, so
-// Gaussian elimination with partial pivoting gives the same step to ~cond * eps (1e-11 relative here; the pose leaves
-// this function through an f32 matrix anyway) in ~0.2 us.  Anything else — a pivot ratio below 1e-10, a non-finite
-// value — returns false and the caller takes the SVD path, which alone implements Eigen's rank rule.
-bool lu6_solve(const double H[6][6], const double b[6], double x[6]) {
-  double A[6][7];
-  for (int i = 0; i < 6; i++) {
-    for (int j = 0; j < 6; j++) A[i][j] = H[i][j];
-    A[i][6] = b[i];
-  }
-  double pmax = 0.0, pmin = DBL_MAX;
-  for (int c = 0; c < 6; c++) {
-    int r = c;
-    double best = std::fabs(A[c][c]);
-    for (int i = c + 1; i < 6; i++)
-      if (std::fabs(A[i][c]) > best) { best = std::fabs(A[i][c]); r = i; }
-    if (!(best > 0.0) || !std::isfinite(best)) return false;
-    if (r != c)
-      for (int j = c; j < 7; j++) { double t = A[c][j]; A[c][j] = A[r][j]; A[r][j] = t; }
-    pmax = std::fmax(pmax, best);
-    pmin = std::fmin(pmin, best);
-    const double inv = 1.0 / A[c][c];
-    for (int i = c + 1; i < 6; i++) {
-      const double f = A[i][c] * inv;
-      if (f == 0.0) continue;
-      for (int j = c + 1; j < 7; j++) A[i][j] -= f * A[c][j];
-    }
-  }
-  if (!(pmin > 1e-10 * pmax)) return false;
-  for (int i = 5; i >= 0; i--) {
-    double v = A[i][6];
-    for (int j = i + 1; j < 6; j++) v -= A[i][j] * x[j];
-    x[i] = v / A[i][i];
-    if (!std::isfinite(x[i])) return false;
-  }
-  return true;
-}
+// The Newton system is solved 4 times per scan on the critical path between two passes, and the Jacobi SVD above costs
+// 2.5-5 us.  For a well-conditioned H (every scan that has planes in three directions) pinv(H) b == H^-1 b, so Gaussian
+// elimination with partial pivoting (gm::lu6_solve, shared with the device-side loop of ndt_align.hip) gives the same step
+// to ~cond * eps (1e-11 relative here; the pose leaves this function through an f32 matrix anyway) in ~0.2 us.  Anything
+// else — a pivot ratio below 1e-10, a non-finite value — makes it return false and the SVD path above is taken, which
+// alone implements Eigen's rank rule.
 
-// Eigen AngleAxis<float>::toRotationMatrix for a coordinate axis (Geometry/AngleAxis.h): the diagonal
-// entry on the axis is (1 - c) * 1 + c evaluated in f32, not the literal 1.
-void axis_rotation(float angle, int axis, float R[3][3]) {
-  float s = sinf(angle), c = cosf(angle);
-  float d = (1.0f - c) * 1.0f + c;
-  for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) R[i][j] = 0.0f;
-  int a = axis, b = (axis + 1) % 3, e = (axis + 2) % 3;
-  R[a][a] = d; R[b][b] = c; R[e][e] = c; R[b][e] = -s; R[e][b] = s;
-}
-
-void mul33(const float A[3][3], const float B[3][3], float C[3][3]) {
-  for (int i = 0; i < 3; i++)
-    for (int j = 0; j < 3; j++) C[i][j] = (A[i][0] * B[0][j] + A[i][1] * B[1][j]) + A[i][2] * B[2][j];
-}
+// libm fall-back of gm::pose_to_matrix for angles outside its range (|angle| >= 120 rad: never an Euler angle)
+void axis_rotation_libm(float angle, int axis, float R[3][3]) { gm::axis_rotation(sinf(angle), cosf(angle), axis, R); }
 
 // More-Thuente helpers (:69-75, :760-873, "Copied from ndt.hpp")
 inline double psi_mt(double a, double f_a, double f_0, double g_0, double mu) { return f_a - f_0 - mu * g_0 * a; }
@@ -280,13 +237,15 @@ struct Driver {
 }  // namespace
 
 extern "C" void lsa_pose_to_matrix(const double p[6], float T[16]) {
-  // (Translation3f(x) * AngleAxisf(roll, X) * AngleAxisf(pitch, Y) * AngleAxisf(yaw, Z)).matrix()  (:691-694)
+  // (Translation3f(x) * AngleAxisf(roll, X) * AngleAxisf(pitch, Y) * AngleAxisf(yaw, Z)).matrix()  (:691-694); the same
+  // arithmetic the device-side loop runs (gn_math.h: sinf / cosf restated from glibc, bit-identical to this image's libm)
+  if (gm::pose_to_matrix(p, T)) return;
   float Rx[3][3], Ry[3][3], Rz[3][3], Rxy[3][3], R[3][3];
-  axis_rotation((float)p[3], 0, Rx);
-  axis_rotation((float)p[4], 1, Ry);
-  axis_rotation((float)p[5], 2, Rz);
-  mul33(Rx, Ry, Rxy);
-  mul33(Rxy, Rz, R);
+  axis_rotation_libm((float)p[3], 0, Rx);
+  axis_rotation_libm((float)p[4], 1, Ry);
+  axis_rotation_libm((float)p[5], 2, Rz);
+  gm::mul33(Rx, Ry, Rxy);
+  gm::mul33(Rxy, Rz, R);
   memset(T, 0, 16 * sizeof(float));
   for (int r = 0; r < 3; r++)
     for (int c = 0; c < 3; c++) T[c * 4 + r] = R[r][c];
@@ -355,7 +314,7 @@ extern "C" int lsa_gn_solve_trace(lsa_pass_eval_fn eval, void *user, float res, 
   while (!converged) {
     double negg[6];
     for (int i = 0; i < 6; i++) negg[i] = -d.g[i];
-    if (!lu6_solve(d.H, negg, delta)) svd6_solve(d.H, negg, delta);
+    if (!gm::lu6_solve(d.H, negg, delta)) svd6_solve(d.H, negg, delta);
     double nrm2 = 0;
     for (int i = 0; i < 6; i++) nrm2 += delta[i] * delta[i];
     double nrm = std::sqrt(nrm2);

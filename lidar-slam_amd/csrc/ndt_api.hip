@@ -74,7 +74,19 @@ int scan_match_common(lsa_ndt *h, const float predict_pose[16], float result_pos
   lsa_ndt_gauss_constants(h->resolution, h->outlier_ratio, &h->d1, &h->d2);
   lsa_ndt_stats st;
   memset(&st, 0, sizeof(st));
-  int rc = lsa_gn_solve_trace(eval_trampoline, h, h->resolution, h->step_size, h->trans_eps, h->max_iter, h->outlier_ratio, h->mode, predict_pose, result_pose, &st,
+  int rc;
+  if (ndt_align_persistent_ok(h)) {  // the whole Newton iteration in one launch (ndt_align.hip)
+    bool done = false;
+    if ((rc = ndt_align_persistent(h, predict_pose, result_pose, &st, &done))) return rc;
+    if (done) {
+      memcpy(h->last_T, result_pose, sizeof(h->last_T));
+      h->has_result = true;
+      if (stats) *stats = st;
+      return LSA_OK;
+    }
+    memset(&st, 0, sizeof(st));
+  }
+  rc = lsa_gn_solve_trace(eval_trampoline, h, h->resolution, h->step_size, h->trans_eps, h->max_iter, h->outlier_ratio, h->mode, predict_pose, result_pose, &st,
                               h->trace_rows, h->trace_cap, h->trace_n);
   if (rc) return rc;
   memcpy(h->last_T, result_pose, sizeof(h->last_T));
@@ -119,6 +131,7 @@ extern "C" void lsa_ndt_destroy(lsa_ndt *h) {
   h->nn.release();
   h->vi.release(); h->d_target.release(); h->rec.release(); h->state.release(); h->vbits.release(); h->words.release(); h->d_small.release(); h->counts.release();
   h->dense.release();
+  h->align_rows.release(); h->align_flags.release(); h->h_result.release(); h->align_stamps.release();
   h->d_source_own.release(); h->h_stage.release(); h->partials.release(); h->d_out.release(); h->h_out.release(); h->h_partials.release();
   delete h;
 }
@@ -226,6 +239,19 @@ extern "C" int lsa_ndt_get_fitness_score(lsa_ndt *h, float *score) {
     return LSA_OK;
   }
   return ndt_fitness(h, score);
+}
+
+extern "C" int lsa_ndt_set_persistent(lsa_ndt *h, int on) {
+  if (!h) return LSA_ERR_INVALID;
+  h->no_persistent = !on;
+  return LSA_OK;
+}
+
+extern "C" int lsa_ndt_align_counters(lsa_ndt *h, uint64_t *launches, uint64_t *fallbacks) {
+  if (!h) return LSA_ERR_INVALID;
+  if (launches) *launches = h->align_launches;
+  if (fallbacks) *fallbacks = h->align_fallbacks;
+  return LSA_OK;
 }
 
 extern "C" int lsa_ndt_set_trace(lsa_ndt *h, double *rows, int cap_rows, int *n_rows) {

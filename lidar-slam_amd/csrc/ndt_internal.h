@@ -55,6 +55,17 @@ struct lsa_ndt {
   bool no_row_polling = getenv("LSA_NO_ROW_POLLING") != nullptr;  // diagnostics: wait for the stream per pass instead
   unsigned unsynced = 0;            // host-reduced passes enqueued since the stream was last waited for
 
+  // one-launch ScanMatch (ndt_align.hip)
+  DevBuf<double> align_rows;        // [2][grid][kOutDoubles]: the workgroups' rows, double-buffered by pass parity
+  DevBuf<unsigned> align_flags;     // [num_cus]: per-workgroup epoch flags
+  PinnedBuf<double> h_result;       // host-mapped result row
+  unsigned align_seq = 64;          // next launch's epoch base: a launch uses epochs base + 1 .. base + max_iter + 2
+  // opt-in (lsa_ndt_set_persistent / LSA_PERSISTENT=1): measured on MI355X it does not beat the per-pass path
+  bool no_persistent = getenv("LSA_PERSISTENT") == nullptr;
+  unsigned long long align_launches = 0, align_fallbacks = 0;
+  DevBuf<unsigned long long> align_stamps;  // diagnostics (lsa_ndt_align_stamps)
+  bool align_stamps_on = false;
+
   // multi-GPU
   lsa_allreduce_fn allreduce = nullptr;
   void *allreduce_user = nullptr;
@@ -73,5 +84,7 @@ int ndt_build_grid(lsa_ndt *h, const float4 *d_pts, size_t n);
 int ndt_count_valid(lsa_ndt *h);
 void ndt_fitness_invalidate(lsa_ndt *h);
 void ndt_fitness_release(lsa_ndt *h);
+bool ndt_align_persistent_ok(const lsa_ndt *h);
+int ndt_align_persistent(lsa_ndt *h, const float predict_pose[16], float result_pose[16], lsa_ndt_stats *stats, bool *done);
 
 #endif

@@ -1,0 +1,518 @@
+// ndt_pass_dev.h — internal, device only: the body of one NDT derivative pass, shared by the one-pass kernel
+// (ndt_derivatives.hip: k_ndt_pass) and the persistent whole-ScanMatch kernel (ndt_align.hip: k_ndt_align).
+// See ndt_derivatives.hip for what it replaces in the reference and for the design notes.
+#ifndef LSA_NDT_PASS_DEV_H_
+#define LSA_NDT_PASS_DEV_H_
+
+#include "ndt_internal.h"
+#include "ndt_pass.h"
+
+namespace {
+
+constexpr int kBlockD = 256;
+// Waves per SIMD requested from the register allocator = 256-lane workgroups resident per CU.  The pass is latency bound
+// (three dependent L2 round trips per tile), so occupancy is throughput: 2 -> 3 waves bought ~20 %.  The full pass
+// (28 f64 accumulators = 56 VGPRs live throughout) fits 3 waves (<= 168 VGPRs) without spilling, the gradient-only pass
+// of the line search fits 4 (<= 128).
+#ifndef LSA_PASS_WAVES
+#define LSA_PASS_WAVES 3
+#endif
+#ifndef LSA_PASS_WAVES_GRAD
+#define LSA_PASS_WAVES_GRAD 4
+#endif
+constexpr int pass_waves(int kind) { return kind == 1 ? LSA_PASS_WAVES_GRAD : LSA_PASS_WAVES; }
+
+template <int KIND>
+__device__ __forceinline__ void pair_update(const PassParams &P, const double *__restrict__ R, float tx, float ty, float tz,
+                                            const double pg[8], const double *ph /* LDS, read at the point of use */, double acc[28],
+                                            unsigned &accepted) {
+  // R: centroid(3), C = icov (xx,xy,xz,yy,yz,zz), w.
+  double d0 = (double)tx - R[0], d1 = (double)ty - R[1], d2 = (double)tz - R[2];  // x_trans - centroid (:434)
+  // the exact radius test of radiusSearch (VoxelGrid.cpp:470-472), on the squared f64 distance against the host-computed
+  // threshold.  The dense-table probe only pre-filters in f32 with a safety margin; the bitmap probe has already applied
+  // this very test, for which it is a no-op.
+  if (!(d0 * d0 + d1 * d1 + d2 * d2 <= P.r2max)) return;
+  accepted++;
+  double C00 = R[3], C01 = R[4], C02 = R[5], C11 = R[6], C12 = R[7], C22 = R[8];
+  double u0 = C00 * d0 + C01 * d1 + C02 * d2;
+  double u1 = C01 * d0 + C11 * d1 + C12 * d2;
+  double u2 = C02 * d0 + C12 * d1 + C22 * d2;
+  double q = d0 * u0 + d1 * u1 + d2 * u2;
+  double e = exp(-P.d2 * q / 2);  // :494
+  double f = P.d2 * e;
+  if (f > 1 || f < 0 || f != f) return;  // :499-501 / :884-886
+  if (KIND != 2) acc[0] += R[9] * (-P.d1 * e);  // static weight multiplies the score only (:440-441)
+  f *= P.d1;
+  // J columns 3..5: J3 = (0, pg0, pg1), J4 = (pg2, pg3, pg4), J5 = (pg5, pg6, pg7)   (:453-460)
+  double uJ3 = u1 * pg[0] + u2 * pg[1];
+  double uJ4 = u0 * pg[2] + u1 * pg[3] + u2 * pg[4];
+  double uJ5 = u0 * pg[5] + u1 * pg[6] + u2 * pg[7];
+  if (KIND != 2) {
+    acc[1] += f * u0; acc[2] += f * u1; acc[3] += f * u2;
+    acc[4] += f * uJ3; acc[5] += f * uJ4; acc[6] += f * uJ5;
+  }
+  if (KIND != 1) {
+    const double nd2 = -P.d2;
+    // H_ij += f * (-d2 (u.J_i)(u.J_j) + u.H_E(i,j) + J_j^T C J_i)   (:512-514).  Written column group by column group so
+    // that each C J_j (3 values) dies as soon as its column is done: the pair math is register-bound (28 f64
+    // accumulators stay live), and every register saved here buys occupancy.
+    // translation x translation: J_j^T C J_i = C_ij
+    acc[7] += f * (nd2 * u0 * u0 + C00);
+    acc[8] += f * (nd2 * u0 * u1 + C01);
+    acc[9] += f * (nd2 * u0 * u2 + C02);
+    acc[13] += f * (nd2 * u1 * u1 + C11);
+    acc[14] += f * (nd2 * u1 * u2 + C12);
+    acc[18] += f * (nd2 * u2 * u2 + C22);
+    // H_E blocks (:465-480): (3,3)=(0,ph0,ph1) (3,4)=(0,ph2,ph3) (3,5)=(0,ph4,ph5) (4,4)=(ph6..8) (4,5)=(ph9..11) (5,5)=(ph12..14)
+    {  // column 3: a = C J_3, J_3 = (0, pg0, pg1)
+      double ax = C01 * pg[0] + C02 * pg[1], ay = C11 * pg[0] + C12 * pg[1], az = C12 * pg[0] + C22 * pg[1];
+      acc[10] += f * (nd2 * u0 * uJ3 + ax);
+      acc[15] += f * (nd2 * u1 * uJ3 + ay);
+      acc[19] += f * (nd2 * u2 * uJ3 + az);
+      acc[22] += f * (nd2 * uJ3 * uJ3 + (u1 * ph[0] + u2 * ph[1]) + (pg[0] * ay + pg[1] * az));
+      acc[23] += f * (nd2 * uJ3 * uJ4 + (u1 * ph[2] + u2 * ph[3]) + (pg[2] * ax + pg[3] * ay + pg[4] * az));
+      acc[24] += f * (nd2 * uJ3 * uJ5 + (u1 * ph[4] + u2 * ph[5]) + (pg[5] * ax + pg[6] * ay + pg[7] * az));
+    }
+    {  // column 4: a = C J_4, J_4 = (pg2, pg3, pg4)
+      double ax = C00 * pg[2] + C01 * pg[3] + C02 * pg[4], ay = C01 * pg[2] + C11 * pg[3] + C12 * pg[4], az = C02 * pg[2] + C12 * pg[3] + C22 * pg[4];
+      acc[11] += f * (nd2 * u0 * uJ4 + ax);
+      acc[16] += f * (nd2 * u1 * uJ4 + ay);
+      acc[20] += f * (nd2 * u2 * uJ4 + az);
+      acc[25] += f * (nd2 * uJ4 * uJ4 + (u0 * ph[6] + u1 * ph[7] + u2 * ph[8]) + (pg[2] * ax + pg[3] * ay + pg[4] * az));
+      acc[26] += f * (nd2 * uJ4 * uJ5 + (u0 * ph[9] + u1 * ph[10] + u2 * ph[11]) + (pg[5] * ax + pg[6] * ay + pg[7] * az));
+    }
+    {  // column 5: a = C J_5, J_5 = (pg5, pg6, pg7)
+      double ax = C00 * pg[5] + C01 * pg[6] + C02 * pg[7], ay = C01 * pg[5] + C11 * pg[6] + C12 * pg[7], az = C02 * pg[5] + C12 * pg[6] + C22 * pg[7];
+      acc[12] += f * (nd2 * u0 * uJ5 + ax);
+      acc[17] += f * (nd2 * u1 * uJ5 + ay);
+      acc[21] += f * (nd2 * u2 * uJ5 + az);
+      acc[27] += f * (nd2 * uJ5 * uJ5 + (u0 * ph[12] + u1 * ph[13] + u2 * ph[14]) + (pg[5] * ax + pg[6] * ay + pg[7] * az));
+    }
+  }
+}
+
+// Each WAVE of a 256-lane workgroup walks its own tiles of 14 source points, in four phases per tile, without ever
+// waiting for the other three waves (the only workgroup barrier is the one before the final reduction):
+//   0. 4 lanes per point: one transforms it (f32, PCL order) and publishes the clipped 3x3x3 cell box, and each of the
+//      four computes its share of the 23 point-derivative dot products (8 Jacobian + 15 Hessian terms,
+//      computePointDerivatives) into LDS -- once per POINT, not once per pair as the reference does;
+//   A1. ROW probes: the <= 3 cells of one (y, z) row of a box are consecutive linear indices, i.e. adjacent bits of one
+//      (rarely two) 16-B {occ, valid, prefix} words.  14 points x 9 rows = 126 row probes (<= 2 per lane) read the word
+//      from L2, mask the valid bits and emit one CANDIDATE {point, record rank} per valid cell -- integer work only;
+//   A2. candidates (valid voxels inside the box, ~10 per point) load the 24-B centroid and take the radius test on the
+//      squared distance against a host-computed exact threshold (no f64 sqrt); survivors (Kbar ~ 2.5-5 per point) become
+//      PAIRS.  Both compactions place their output at offsets from wave-wide exclusive scans (no atomics), so the queue
+//      order -- and with it every f64 sum -- is reproducible run to run;
+//   B. the wave takes FULL rounds of 64 pairs off the queue (what is left joins the next tile's pairs): one (point,
+//      voxel) pair per lane per step, dense f64 pair math into 28 registers.
+// Tile size: 14 points = two probe rounds (16 points needed a third, three quarters empty) and 50 pairs per tile on
+// average at cfg5, which the carry-over packs into full rounds: 244 -> 216 us per pass against 16-point tiles drained
+// tile by tile.
+// Separating the cheap integer probe from the centroid test and that from the expensive pair math keeps the f64 pipes on
+// useful work (the reference computes a distance for all 27 cells of every point).  All hand-offs inside a tile go
+// through the wave's private LDS slice and need only wave-level ordering (LDS is in order per wave), so the 8 waves
+// resident on a CU drift apart and hide each other's L2 latency; a workgroup-wide formulation of the same phases (6
+// s_barrier per 64-point tile) left the VALUs idle half of the time.  A KITTI-sized pass (7-25 k points) spreads over
+// >= 470 waves.  The 69 angle-derivative constants are touched only in phase 0, which keeps them out of the pair loop's
+// scalar registers.
+constexpr int kWaves = kBlockD / 64;
+constexpr int kTilePts = 14;                                             // points per wave tile, 4 lanes per point in phase 0 (56 lanes)
+constexpr int kTileSlots = 16;                                           // LDS slots per buffer half (power of two)
+constexpr int kRowsPerPoint = 9;
+constexpr int kRowProbes = kTilePts * kRowsPerPoint;                     // 126
+constexpr int kRowRounds = (kRowProbes + 63) / 64;                       // 3
+constexpr int kQueueCap = kTilePts * 27;                                 // 378 candidates / pairs at most
+constexpr int kCandPerLane = 4;                                          // A2 candidates per lane per round
+constexpr int kPointTerms = 23;   // pg[8] + ph[15]
+constexpr int kTermStride = 24;
+constexpr int kRedStride = 29;    // 28 accumulators per lane, padded: conflict-free LDS transpose
+constexpr int kRedLanes = 128;    // the transpose runs in two rounds of 128 lanes to halve its LDS footprint
+
+struct TilePoint {
+  float tx, ty, tz;  // transformed point
+  int cell0;         // linear index of the box's low corner
+  int nxyz;          // box extent packed nx | ny << 8 | nz << 16 (0 = point contributes nothing)
+  float rx, ry, rz;  // transformed point relative to the low corner of the box's first cell (f32; dense-table pre-filter)
+};
+
+// per-wave LDS slice
+// The point data of a tile (TilePoint + its 23 terms) is double-buffered (nb = 2) in the passes that carry pairs over
+// from one tile to the next (see phase B): the pairs a tile leaves after its last FULL round of 64 join the next tile's
+// first round, whose phase 0 writes the other buffer.  The gradient-only pass of the line search (KIND 1) keeps one buffer:
+// its pair math is cheap and the 14 KB it saves per workgroup is what lets a fourth workgroup share the CU.
+constexpr int kLdsTp = 0;
+constexpr int kQueueSlots = kQueueCap + 64;                                              // a tile's pairs behind < 64 carried ones
+constexpr int lds_terms(int nb) { return nb * 512; }                                     // after nb x 16 * 32 B of TilePoint
+constexpr int lds_cand(int nb) { return lds_terms(nb) + nb * kTileSlots * kTermStride * 8; }  // + nb x 3072
+constexpr int lds_queue(int nb) { return lds_cand(nb) + kQueueCap * 4; }                 // + 1728
+constexpr int lds_slice(int nb) { return ((lds_queue(nb) + (kQueueSlots + 1) * 4 + 255) / 256) * 256; }  // 7424 / 11008 (queue + one dump slot)
+constexpr int lds_tiles(int nb) { return lds_slice(nb) * kWaves; }                       // 29696 / 44032
+constexpr int kLdsRed = kRedLanes * kRedStride * 8;                                      // 29696 (aliases the slices after the loops)
+constexpr int lds_red2(int nb) { return kLdsRed > lds_tiles(nb) ? kLdsRed : lds_tiles(nb); }
+constexpr int lds_const(int nb) { return lds_red2(nb) + (8 * 32 + 2 * kWaves) * 8; }     // + second-stage [8][32] + per-wave counters
+constexpr int lds_tl(int nb) { return lds_const(nb) + 72 * 8; }                          // + the 69 angle-derivative constants
+constexpr int lds_bytes(int nb) { return lds_tl(nb) + 16 * 4; }                          // + the 3x4 rigid transform
+constexpr int pass_bufs(int kind) { return kind == 1 ? 1 : 2; }
+static_assert(kTilePts <= kTileSlots && kTileSlots * (int)sizeof(TilePoint) <= 512, "tile points overflow their LDS slot");
+
+// wave-level ordering point for LDS hand-offs between lanes of ONE wave: LDS operations of a wave execute in order, so it
+// is enough to stop the compiler from moving accesses across it (this is what a workgroup barrier of a single-wave
+// workgroup is lowered to)
+__device__ __forceinline__ void wave_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// exclusive scan of one count per lane over the wave; returns this lane's offset, *total = wave sum
+__device__ __forceinline__ unsigned wave_excl_scan(unsigned cnt, int lane, unsigned *total) {
+  unsigned incl = cnt;
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    unsigned v = __shfl_up(incl, off, 64);
+    if (lane >= off) incl += v;
+  }
+  *total = __shfl(incl, 63, 64);
+  return incl - cnt;
+}
+
+// DENSE: the probe reads a dense per-cell table {centroid - cell corner (f32 x 3), record rank or -1} (16 B per cell,
+// built when the cell box is small enough, ndt_grid.hip) instead of the bitmap words: one 48-B row load answers "valid?",
+// "which record?" and "roughly how far?" for 3 cells, so the candidate stage (A2: a dependent centroid load from the
+// record table + a second compaction) disappears; the f32 distance is only a pre-filter with a safety margin, the exact
+// f64 test runs in the pair step on the record's centroid it loads anyway.  ~20 % fewer instructions per tile and one
+// L2 round trip less on the critical path.  The bitmap path stays for cell boxes too large for a dense table.
+template <int KIND, bool DENSE>
+__device__ __forceinline__ double ndt_pass_body(const float4 *__restrict__ src, size_t n, const PassParams &P, const float *Tl /* LDS: 3x4 row-major */,
+                                                const double *jh /* LDS: ja[8][3] then ha[15][3] */, const uint4 *__restrict__ words,
+                                                const float4 *__restrict__ dense, const double *__restrict__ rec, unsigned char *lds) {
+  constexpr int NB = pass_bufs(KIND);
+  constexpr int kLdsSlice = lds_slice(NB), kLdsTerms = lds_terms(NB), kLdsCand = lds_cand(NB), kLdsQueue = lds_queue(NB), kLdsRed2 = lds_red2(NB);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  unsigned char *slice = lds + wave * kLdsSlice;
+  TilePoint *tp = reinterpret_cast<TilePoint *>(slice + kLdsTp);
+  double *terms = reinterpret_cast<double *>(slice + kLdsTerms);
+  unsigned *cand = reinterpret_cast<unsigned *>(slice + kLdsCand);
+  unsigned *queue = reinterpret_cast<unsigned *>(slice + kLdsQueue);
+  double acc[28];
+#pragma unroll
+  for (int k = 0; k < 28; k++) acc[k] = 0.0;
+  unsigned long long npts = 0;  // wave total (meaningful in lane 0)
+  unsigned accepted = 0;        // (point, voxel) pairs this lane accepted
+  const int part4 = lane / kTilePts, ppl = lane - part4 * kTilePts;  // phase 0: 4 lanes per point (part4 == 4: the spare lanes 56..63)
+  const int dimx = P.dim[0], dimxy = P.dim[0] * P.dim[1];
+  const size_t ntiles = (n + kTilePts - 1) / kTilePts;
+  const size_t tile0 = (size_t)blockIdx.x * kWaves + wave, tstride = (size_t)gridDim.x * kWaves;
+  // jh = ja[8][3] followed by ha[15][3]: 23 constant 3-vectors.  Phase 0 indexes them per LANE (each of the 4 lanes of a
+  // point owns 6 of the 23 terms), which kernel arguments cannot do without turning into per-lane global loads: the
+  // caller has staged them (and the rigid transform) in LDS.
+  // software prefetch of the next tile's points (each of the 4 lanes of a point holds its own copy)
+  float4 s_next = make_float4(0.f, 0.f, 0.f, 0.f);
+  {
+    size_t i0 = tile0 * kTilePts + ppl;
+    if (i0 < n) s_next = src[i0];
+  }
+  unsigned carried = 0;  // pairs at the front of the queue left over by the previous tile (< 64, wave-uniform)
+  int pbase = 0;         // which half of tp / terms this tile uses: 0 or kTileSlots
+  for (size_t tile = tile0; tile < ntiles; tile += tstride, pbase ^= (NB == 2 ? kTileSlots : 0)) {
+    // ---- phase 0
+    {
+      size_t i = tile * kTilePts + ppl;
+      float4 s = s_next;
+      size_t inext = (tile + tstride) * kTilePts + ppl;
+      if (inext < n) s_next = src[inext];
+      if (part4 == 0) {
+        TilePoint t;
+        t.nxyz = 0; t.cell0 = 0; t.tx = t.ty = t.tz = 0.f; t.rx = t.ry = t.rz = 0.f;
+        if (i < n) {
+          // pcl::transformPointCloud: x' = m00*x + m01*y + m02*z + m03, f32, left to right, no FMA
+          float tx = lsa_fadd(lsa_fadd(lsa_fadd(lsa_fmul(Tl[0], s.x), lsa_fmul(Tl[1], s.y)), lsa_fmul(Tl[2], s.z)), Tl[3]);
+          float ty = lsa_fadd(lsa_fadd(lsa_fadd(lsa_fmul(Tl[4], s.x), lsa_fmul(Tl[5], s.y)), lsa_fmul(Tl[6], s.z)), Tl[7]);
+          float tz = lsa_fadd(lsa_fadd(lsa_fadd(lsa_fmul(Tl[8], s.x), lsa_fmul(Tl[9], s.y)), lsa_fmul(Tl[10], s.z)), Tl[11]);
+          t.tx = tx; t.ty = ty; t.tz = tz;
+          if (lsa_finite3(tx, ty, tz)) {
+            // radiusSearch cell box (VoxelGrid.cpp:438-455), relative to real_min, clipped to the occupied bounds
+            float r = P.res;
+            int hx, lx, hy, ly, hz, lz;
+            if (P.res_pow2) {
+              // a power-of-two leaf (the YAML default 1.0): x / r == x * (1 / r) exactly, so the six correctly rounded
+              // f32 divisions (~12 instructions each) collapse to multiplications without changing a single bit
+              float ir = P.inv_res;
+              hx = (int)floorf(lsa_fmul(lsa_fadd(tx, r), ir)) - P.min_b[0]; lx = (int)floorf(lsa_fmul(lsa_fsub(tx, r), ir)) - P.min_b[0];
+              hy = (int)floorf(lsa_fmul(lsa_fadd(ty, r), ir)) - P.min_b[1]; ly = (int)floorf(lsa_fmul(lsa_fsub(ty, r), ir)) - P.min_b[1];
+              hz = (int)floorf(lsa_fmul(lsa_fadd(tz, r), ir)) - P.min_b[2]; lz = (int)floorf(lsa_fmul(lsa_fsub(tz, r), ir)) - P.min_b[2];
+            } else {
+              hx = (int)floorf(lsa_fdiv(lsa_fadd(tx, r), r)) - P.min_b[0]; lx = (int)floorf(lsa_fdiv(lsa_fsub(tx, r), r)) - P.min_b[0];
+              hy = (int)floorf(lsa_fdiv(lsa_fadd(ty, r), r)) - P.min_b[1]; ly = (int)floorf(lsa_fdiv(lsa_fsub(ty, r), r)) - P.min_b[1];
+              hz = (int)floorf(lsa_fdiv(lsa_fadd(tz, r), r)) - P.min_b[2]; lz = (int)floorf(lsa_fdiv(lsa_fsub(tz, r), r)) - P.min_b[2];
+            }
+            hx = min(hx, P.dim[0] - 1); hy = min(hy, P.dim[1] - 1); hz = min(hz, P.dim[2] - 1);
+            lx = max(lx, 0); ly = max(ly, 0); lz = max(lz, 0);
+            // with radius == leaf the box is at most 3 cells wide per axis
+            int nx = min(hx - lx + 1, 3), ny = min(hy - ly + 1, 3), nz = min(hz - lz + 1, 3);
+            if (nx > 0 && ny > 0 && nz > 0) {
+              t.cell0 = lx + ly * dimx + lz * dimxy;
+              t.nxyz = nx | (ny << 8) | (nz << 16);
+              if (DENSE) {
+                t.rx = tx - (float)(lx + P.min_b[0]) * r; t.ry = ty - (float)(ly + P.min_b[1]) * r; t.rz = tz - (float)(lz + P.min_b[2]) * r;
+              }
+            }
+          }
+        }
+        tp[pbase + ppl] = t;
+      }
+      // computePointDerivatives (:448-482): dot products of the source point with the angle-derivative vectors;
+      // lane group g of a point owns terms 6g .. 6g+5 (KIND 1 needs only the 8 Jacobian terms)
+      double x = s.x, y = s.y, z = s.z;
+      const int k0 = part4 * 6, k1 = min(k0 + 6, (KIND == 1) ? 8 : kPointTerms);
+      for (int k = k0; k < k1; k++) terms[(pbase + ppl) * kTermStride + k] = x * jh[k * 3] + y * jh[k * 3 + 1] + z * jh[k * 3 + 2];
+      if (lane == 0) npts += min((size_t)kTilePts, n - tile * kTilePts);
+    }
+    wave_sync();
+    unsigned total = carried;  // the queue already holds the previous tile's left-over pairs
+    if constexpr (DENSE) {
+      // ---- phase A (dense table): row probes -> pairs, pre-filtered on the f32 distance
+      unsigned c_ent[kRowRounds * 3];
+      unsigned c_mask = 0;
+      int lane_v = lane;  // opaque copy: keeps ~30 registers of lane-only index arithmetic from being hoisted out of the tile loop
+      asm volatile("" : "+v"(lane_v));
+      int r_cell[kRowRounds], r_nx[kRowRounds], r_pl[kRowRounds];
+      float r_y[kRowRounds], r_z[kRowRounds];
+      float4 e0[kRowRounds], e1[kRowRounds], e2[kRowRounds];
+#pragma unroll
+      for (int j = 0; j < kRowRounds; j++) {
+        int q = lane_v + j * 64;
+        int pl = (q < kRowProbes) ? q / kRowsPerPoint : 0;
+        int o = q - pl * kRowsPerPoint;
+        int dz = o / 3, dy = o - dz * 3;
+        int nxyz = tp[pbase + pl].nxyz;
+        bool in_box = q < kRowProbes && dy < ((nxyz >> 8) & 0xff) && dz < (nxyz >> 16);
+        r_pl[j] = pl;
+        r_nx[j] = in_box ? (nxyz & 0xff) : 0;
+        r_cell[j] = in_box ? tp[pbase + pl].cell0 + dy * dimx + dz * dimxy : 0;
+        r_y[j] = tp[pbase + pl].ry - (float)dy * P.res;
+        r_z[j] = tp[pbase + pl].rz - (float)dz * P.res;
+      }
+      // all row loads first so the L2 round trips overlap (the table is padded by two cells past the last row)
+#pragma unroll
+      for (int j = 0; j < kRowRounds; j++) {
+        const float4 *row = dense + r_cell[j];
+        e0[j] = row[0]; e1[j] = row[1]; e2[j] = row[2];
+      }
+#pragma unroll
+      for (int j = 0; j < kRowRounds; j++) {
+        const float rx = tp[pbase + r_pl[j]].rx;
+        const float4 ev[3] = {e0[j], e1[j], e2[j]};
+#pragma unroll
+        for (int i = 0; i < 3; i++) {
+          float dx = (rx - (float)i * P.res) - ev[i].x, dy = r_y[j] - ev[i].y, dz = r_z[j] - ev[i].z;
+          float d2 = dx * dx + dy * dy + dz * dz;
+          int rank = __float_as_int(ev[i].w);  // -1: unoccupied, too few points or rejected eigenvalues (VoxelGrid.cpp:465)
+          bool ok = i < r_nx[j] && rank >= 0 && d2 <= P.r2f_pre;
+          c_ent[j * 3 + i] = ((unsigned)(pbase + r_pl[j])) | ((unsigned)rank << 6);  // point slot incl. its buffer half
+          if (ok) c_mask |= 1u << (j * 3 + i);
+        }
+      }
+      unsigned fresh;
+      unsigned pos = carried + wave_excl_scan(__popc(c_mask), lane, &fresh);
+      total += fresh;
+      // branch-free scatter: rejected entries go to a dump slot one past the queue
+#pragma unroll
+      for (int k = 0; k < kRowRounds * 3; k++) {
+        bool keep = (c_mask >> k) & 1u;
+        unsigned slot = keep ? pos + __popc(c_mask & ((1u << k) - 1u)) : (unsigned)kQueueSlots;
+        queue[slot] = c_ent[k];
+      }
+      wave_sync();
+    } else {
+    // ---- phase A1: row probes -> candidates (valid voxels inside the box)
+    unsigned c_ent[kRowRounds * 3];
+    unsigned c_mask = 0;
+    // The probe -> (point, row) mapping depends on the lane only, so the compiler would hoist ~30 registers of index
+    // arithmetic out of the tile loop and keep them live through the pair math, which is register-bound; an opaque copy
+    // of the lane id makes it recompute them per tile (a few dozen integer instructions) instead.
+    int lane_v = lane;
+    asm volatile("" : "+v"(lane_v));
+    {
+      int r_cell[kRowRounds], r_nx[kRowRounds], r_pl[kRowRounds];
+      uint4 w0[kRowRounds], w1[kRowRounds];
+#pragma unroll
+      for (int j = 0; j < kRowRounds; j++) {
+        int q = lane_v + j * 64;
+        int pl = (q < kRowProbes) ? q / kRowsPerPoint : 0;
+        int o = q - pl * kRowsPerPoint;
+        int dz = o / 3, dy = o - dz * 3;
+        int nxyz = tp[pbase + pl].nxyz;
+        bool in_box = q < kRowProbes && dy < ((nxyz >> 8) & 0xff) && dz < (nxyz >> 16);
+        r_pl[j] = pl;
+        r_nx[j] = in_box ? (nxyz & 0xff) : 0;
+        r_cell[j] = in_box ? tp[pbase + pl].cell0 + dy * dimx + dz * dimxy : 0;
+      }
+      // all word loads first so the L2 round trips overlap; the second word is needed only when the row straddles a
+      // 32-cell boundary (out-of-box probes read word 0 and are masked by nx == 0)
+#pragma unroll
+      for (int j = 0; j < kRowRounds; j++) {
+        int wi = r_cell[j] >> 5;
+        w0[j] = words[wi];
+        w1[j] = ((r_cell[j] & 31) + r_nx[j] > 32) ? words[wi + 1] : make_uint4(0u, 0u, 0u, 0u);
+      }
+#pragma unroll
+      for (int j = 0; j < kRowRounds; j++) {
+        // the row's bits as one 64-bit window over {word, next word}: prefix(next) = prefix(word) + popc(occ(word)), so
+        // rank(cell) = prefix(word) + popc(occ64 below the cell) holds on either side of the 32-cell boundary
+        const int sh = r_cell[j] & 31;
+        const unsigned long long occ = ((unsigned long long)w1[j].x << 32) | w0[j].x;
+        const unsigned long long val = (((unsigned long long)w1[j].y << 32) | w0[j].y) >> sh;
+#pragma unroll
+        for (int i = 0; i < 3; i++) {
+          // points_per_voxel >= min_points_per_voxel_ and accepted eigenvalues (VoxelGrid.cpp:465)
+          bool ok = i < r_nx[j] && ((val >> i) & 1ull);
+          unsigned rank = w0[j].z + (unsigned)__popcll(occ & ((1ull << (sh + i)) - 1ull));
+          c_ent[j * 3 + i] = ((unsigned)(pbase + r_pl[j])) | (rank << 6);
+          if (ok) c_mask |= 1u << (j * 3 + i);
+        }
+      }
+    }
+    unsigned total_c;
+    {
+      unsigned pos = wave_excl_scan(__popc(c_mask), lane, &total_c);
+#pragma unroll
+      for (int k = 0; k < kRowRounds * 3; k++)
+        if (c_mask & (1u << k)) cand[pos++] = c_ent[k];
+    }
+    wave_sync();
+    // ---- phase A2: candidates -> pairs (radius test on the centroid distance).  A lane owns a contiguous chunk of the
+    // candidate list, so one scan per round keeps the order; a round covers 64 x 4 candidates (a tile has ~160, the worst
+    // case 432 takes two rounds)
+    for (unsigned cbase = 0; cbase < total_c; cbase += 64 * kCandPerLane) {
+      const unsigned left = min(total_c - cbase, (unsigned)(64 * kCandPerLane));
+      const unsigned per = (left + 63) / 64;  // <= kCandPerLane
+      const unsigned c0 = cbase + lane * per, c_end = cbase + left;
+      unsigned p_ent[kCandPerLane];
+      unsigned p_mask = 0;
+      double pc[kCandPerLane][3];
+#pragma unroll
+      for (int k = 0; k < kCandPerLane; k++) {
+        unsigned ci = c0 + k;
+        bool live = (unsigned)k < per && ci < c_end;
+        unsigned e = live ? cand[ci] : 0u;
+        p_ent[k] = e;
+        if (live) p_mask |= 1u << k;
+        const double *R = rec + (size_t)(e >> 6) * kRecDoubles;
+        if (live) { pc[k][0] = R[0]; pc[k][1] = R[1]; pc[k][2] = R[2]; }
+        else { pc[k][0] = pc[k][1] = pc[k][2] = 0.0; }
+      }
+#pragma unroll
+      for (int k = 0; k < kCandPerLane; k++) {
+        const TilePoint &t = tp[p_ent[k] & 63u];
+        double cx = pc[k][0] - (double)t.tx, cy = pc[k][1] - (double)t.ty, cz = pc[k][2] - (double)t.tz;
+        double d2 = cx * cx + cy * cy + cz * cz;
+        if (!(d2 <= P.r2max)) p_mask &= ~(1u << k);  // sqrt(d2) < radius (VoxelGrid.cpp:470-472)
+      }
+      unsigned round_total;
+      unsigned pos = total + wave_excl_scan(__popc(p_mask), lane, &round_total);
+#pragma unroll
+      for (int k = 0; k < kCandPerLane; k++)
+        if (p_mask & (1u << k)) queue[pos++] = p_ent[k];
+      total += round_total;
+    }
+    wave_sync();
+    }
+    // ---- phase B: dense pair math, in FULL rounds of 64 pairs.  A tile leaves 57 pairs on average (cfg5), so one round
+    // per tile ran at 76 % lane use and every fifth tile paid a second, nearly empty one; instead the pairs beyond the last
+    // full round stay at the front of the queue and join the next tile's (their point data sits in the other buffer
+    // half, which that tile does not touch).  Pairs are never carried twice: the previous tile's are at the front and go
+    // out with the first round, and if even carried + fresh stays below 64 while something was carried, the round is run
+    // partly filled.
+    {
+      total = (unsigned)__builtin_amdgcn_readfirstlane((int)total);  // wave-uniform by construction: keep the round bookkeeping scalar
+      const unsigned full = total >> 6;
+      unsigned left = total & 63u;
+      // (single-buffered pass: nothing may be carried, every tile is drained)
+      const bool drain = NB == 1 ? left != 0 : (full == 0 && carried != 0);  // < 64 in all, part of it a tile old: run it now
+      const unsigned rounds = drain ? full + 1u : full;
+      for (unsigned r = 0; r < rounds; r++) {
+        const unsigned qi = r * 64 + lane;
+        if (qi < total) {
+          unsigned e = queue[qi];
+          const unsigned pl = e & 63u;
+          const double *R = rec + (size_t)(e >> 6) * kRecDoubles;
+          double pg[8];
+          const double *tm = terms + pl * kTermStride;
+#pragma unroll
+          for (int k = 0; k < 8; k++) pg[k] = tm[k];
+          // the 15 Hessian terms stay in LDS and are read where they are used: 30 fewer live registers in the pair math
+          pair_update<KIND>(P, R, tp[pl].tx, tp[pl].ty, tp[pl].tz, pg, tm + 8, acc, accepted);
+        }
+      }
+      if (drain) left = 0;
+      if (full != 0 && left != 0) {  // move the left-over pairs (all of THIS tile) to the front of the queue
+        unsigned e = lane < left ? queue[full * 64 + lane] : 0u;
+        wave_sync();
+        if (lane < left) queue[lane] = e;
+      }
+      carried = left;
+    }
+    wave_sync();  // the other half of tp / terms and the queue behind the carried pairs are rewritten by the next tile
+  }
+  // the last tile's left-over pairs
+  if (carried) {
+    if (lane < carried) {
+      unsigned e = queue[lane];
+      const unsigned pl = e & 63u;
+      const double *R = rec + (size_t)(e >> 6) * kRecDoubles;
+      double pg[8];
+      const double *tm = terms + pl * kTermStride;
+#pragma unroll
+      for (int k = 0; k < 8; k++) pg[k] = tm[k];
+      pair_update<KIND>(P, R, tp[pl].tx, tp[pl].ty, tp[pl].tz, pg, tm + 8, acc, accepted);
+    }
+  }
+  // block reduction through LDS in a fixed order (bitwise reproducible): transpose the 28 per-lane accumulators (two
+  // rounds of 128 lanes), 8 x 32 lanes add 32 rows each, then 32 lanes add the 8 partial rows
+  __syncthreads();  // the transposition area aliases the other waves' tile slices: every wave must have left its loop
+  double *red = reinterpret_cast<double *>(lds);
+  double *red2 = reinterpret_cast<double *>(lds + kLdsRed2);
+  double *wcnt = red2 + 8 * 32;  // [kWaves][2]: pairs, points per wave
+  {
+    unsigned wave_pairs = accepted;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) wave_pairs += __shfl_down(wave_pairs, off, 64);
+    if (lane == 0) { wcnt[wave * 2] = (double)wave_pairs; wcnt[wave * 2 + 1] = (double)npts; }
+  }
+#pragma unroll
+  for (int round = 0; round < kBlockD / kRedLanes; round++) {
+    if ((int)(threadIdx.x / kRedLanes) == round) {
+#pragma unroll
+      for (int k = 0; k < 28; k++) red[(threadIdx.x % kRedLanes) * kRedStride + k] = acc[k];
+    }
+    __syncthreads();
+    if (threadIdx.x < kRedLanes) {
+      int k = threadIdx.x & 31, part = threadIdx.x >> 5;  // 4 parts of 32 rows per round
+      double v = 0.0;
+      if (k < 28) {
+        const double *r = red + (size_t)(part * 32) * kRedStride + k;
+#pragma unroll 8
+        for (int c = 0; c < 32; c++) v += r[c * kRedStride];
+      }
+      red2[(round * (kRedLanes / 32) + part) * 32 + k] = v;
+    }
+    __syncthreads();
+  }
+  double v = 0.0;
+  if (threadIdx.x < kOutDoubles) {
+    if (threadIdx.x < 28) {
+#pragma unroll
+      for (int part = 0; part < 8; part++) v += red2[part * 32 + threadIdx.x];
+    } else if (threadIdx.x == 28) {
+      for (int w = 0; w < kWaves; w++) v += wcnt[w * 2];       // (point, voxel) pairs of this workgroup
+    } else if (threadIdx.x == 29) {
+      for (int w = 0; w < kWaves; w++) v += wcnt[w * 2 + 1];   // source points of this workgroup
+    }
+  }
+  return v;  // threads 0..31: column threadIdx.x of this workgroup's 32-double row
+}
+
+}  // namespace
+
+#endif

@@ -1,0 +1,149 @@
+"""GPU: ScanMatch as ONE persistent launch (csrc/ndt_align.hip) against the one-launch-per-pass path it replaces.
+
+Both paths run the same pass body on the same grid and the same scalar arithmetic (csrc/gn_math.h), so the bar is
+BIT-identical poses and identical statistics — on the nine bench scans (both NDT plugins' semantics), on the cfg1 pair, and
+on the edge cases that must leave the fast path (singular normal equations -> the SVD's rank rule on the host; a live line
+search; a source beyond one workgroup per CU).  The oracle tolerances on the same scans are test_gpu_bench_scans.py's.
+"""
+import ctypes as C
+import time
+
+import numpy as np
+import pytest
+
+from lidar_slam_amd import capi, cloud_filter, registration, synth
+from lidar_slam_amd import workloads as wl
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    c = capi.Context(0)
+    yield c
+    c.close()
+
+
+def test_gn_math_device_equals_host(ctx):
+    """The shared scalar arithmetic gives the same bits on gfx950 and on the host: sinf / cosf (glibc's algorithm), f64
+    sin / cos, the 6x6 solve + step clamp + pose -> matrix, sqrt and division."""
+    mm = (C.c_uint64 * 5)()
+    for seed in (1, 2, 3):
+        ctx.check(capi.lib().lsa_gn_math_selftest(ctx.h, 1 << 20, seed, mm))
+        assert list(mm[:4]) == [0, 0, 0, 0], list(mm)
+        assert mm[4] > 1000          # the singular branch was exercised (every 17th case), identically on both sides
+
+
+def _same_stats(a, b):
+    keys = ("iterations", "passes", "ls_iterations", "converged", "score", "trans_probability", "pairs_per_pass")
+    return all(a[k] == b[k] for k in keys) and np.array_equal(a["final_p"], b["final_p"])
+
+
+@pytest.fixture(scope="module")
+def cfg2(ctx):
+    import torch
+    poses, scans = wl.cfg2_dataset(workers=1)
+    map_filter = cloud_filter.VoxelFilterHip(ctx, 0.3, 0.3, 0.3)
+    frame_filter = cloud_filter.VoxelFilterHip(ctx, 0.5, 0.5, 0.5)
+    d_map_f = map_filter.filter_device(torch.from_numpy(wl.local_map(poses, scans)).cuda()).clone()
+    d_src = [frame_filter.filter_device(torch.from_numpy(np.ascontiguousarray(scans[k])).cuda()).clone() for k in wl.TEST_SCANS]
+    torch.cuda.synchronize()
+    map_filter.close(); frame_filter.close()
+    return dict(poses=poses, d_map_f=d_map_f, d_src=d_src, guesses=[wl.guess(poses, k) for k in wl.TEST_SCANS])
+
+
+@pytest.mark.parametrize("pcl", [False, True], ids=["ndtmanual", "pcl_semantics"])
+def test_persistent_equals_per_pass_on_the_bench_scans(ctx, cfg2, pcl):
+    n = registration.NDTRegistrationHip(ctx, pcl_mode=pcl, **wl.NDT_PARAMS)
+    n.SetInputTarget(cfg2["d_map_f"])
+    t_fast, t_slow = [], []
+    for rep in range(3):
+        for d_s, guess in zip(cfg2["d_src"], cfg2["guesses"]):
+            n.set_persistent(True)
+            c0 = n.align_counters()
+            t0 = time.perf_counter()
+            _, Ta = n.ScanMatch(d_s, guess)
+            t_fast.append(time.perf_counter() - t0)
+            sa = dict(n.last_stats)
+            c1 = n.align_counters()
+            n.set_persistent(False)
+            t0 = time.perf_counter()
+            _, Tb = n.ScanMatch(d_s, guess)
+            t_slow.append(time.perf_counter() - t0)
+            sb = dict(n.last_stats)
+            assert n.align_counters() == c1                   # the per-pass path did not touch the persistent launch
+            assert c1["launches"] + c1["fallbacks"] == c0["launches"] + c0["fallbacks"] + 1
+            assert np.array_equal(Ta, Tb), (Ta - Tb)
+            assert _same_stats(sa, sb), (sa, sb)
+    c = n.align_counters()
+    print("%s: persistent %.1f us / per-pass %.1f us per ScanMatch (median of %d), launches %d, fallbacks %d"
+          % ("pcl" if pcl else "manual", np.median(t_fast) * 1e6, np.median(t_slow) * 1e6, len(t_fast), c["launches"], c["fallbacks"]))
+    assert c["launches"] >= 0.8 * (c["launches"] + c["fallbacks"])   # the fast path is the one that runs
+    n.close()
+
+
+def test_persistent_edge_cases(ctx, oracle, scan_pair):
+    s0, s1, _, _ = scan_pair
+    tgt = synth.to_xyzi32(s0)
+    filt, _ = oracle.voxel_filter(synth.to_xyzi32(s1), 0.5)
+    src = synth.to_xyzi32(filt)
+    n = registration.NDTRegistrationHip(ctx)
+    n.SetInputTarget(tgt)
+
+    def both(source, guess):
+        n.set_persistent(True)
+        c0 = n.align_counters()
+        _, Ta = n.ScanMatch(source, guess)
+        sa = dict(n.last_stats)
+        c1 = n.align_counters()
+        n.set_persistent(False)
+        _, Tb = n.ScanMatch(source, guess)
+        sb = dict(n.last_stats)
+        assert np.array_equal(Ta, Tb) and _same_stats(sa, sb), (sa, sb)
+        return c1["launches"] - c0["launches"], c1["fallbacks"] - c0["fallbacks"], sa
+
+    eye = np.eye(4, dtype=np.float32)
+    # the ordinary case runs on the device
+    assert both(src, eye)[:2] == (1, 0)
+    # a guess in the flipped Euler chart (roll comes back as roll + pi): the f32 trig leaves the |x| < pi / 4 branch
+    g = synth.pose_matrix(0.4, -0.2, 0.05, -0.004, 0.003, 0.02).astype(np.float32)
+    assert both(src, g)[:2] == (1, 0)
+    # a source 1 km from the map: no pair, g = 0 and H = 0 -> singular system -> the launch hands over to the host driver
+    far = synth.to_xyzi32(s1[:500] + np.array([1000.0, 0, 0, 0], dtype=np.float32))
+    l, f, st = both(far, eye)
+    assert (l, f) == (0, 1) and st["passes"] == 1
+    # non-finite rows contribute nothing on either path
+    bad = src.copy()
+    bad[::97, 0] = np.nan
+    assert both(bad, eye)[:2] == (1, 0)
+    # an empty source never reaches the device loop
+    assert both(np.zeros((0, 8), dtype=np.float32), eye)[:2] == (0, 0)
+    n.close()
+    # max_iter 1 / trans_eps 0: the iteration-count exit; runs max_iter + 2 passes
+    m = registration.NDTRegistrationHip(ctx, 1.0, 0.1, 0.0, 3, 0.55)
+    m.SetInputTarget(tgt)
+    m.set_persistent(True)
+    _, Ta = m.ScanMatch(src, eye)
+    sa = dict(m.last_stats)
+    assert m.align_counters()["launches"] == 1 and sa["iterations"] == 5 and sa["passes"] == 6
+    m.set_persistent(False)
+    _, Tb = m.ScanMatch(src, eye)
+    assert np.array_equal(Ta, Tb) and _same_stats(sa, dict(m.last_stats))
+    m.close()
+    # a live line search (step_max == step_min) stays on the per-pass path
+    q = registration.NDTRegistrationHip(ctx, 1.0, 1.5, 3.0, 4, 0.55)
+    q.SetInputTarget(tgt)
+    q.ScanMatch(src, eye)
+    assert q.align_counters() == dict(launches=0, fallbacks=0) and q.last_stats["ls_iterations"] > 0
+    q.close()
+
+
+def test_persistent_path_limits(ctx, scan_pair):
+    """Beyond one workgroup per CU (here a raw 130 k-point source) ScanMatch takes the per-pass path by itself."""
+    import torch
+    s0, s1, _, _ = scan_pair
+    n = registration.NDTRegistrationHip(ctx)
+    n.SetInputTarget(torch.from_numpy(s0).cuda())
+    n.ScanMatch(torch.from_numpy(s1).cuda(), np.eye(4, dtype=np.float32))
+    assert n.align_counters() == dict(launches=0, fallbacks=0)
+    n.close()
