@@ -245,6 +245,7 @@ int lsa_rccl_comm_create(lsa_rccl_comm **out, lsa_context *ctx, const void *id12
 void lsa_rccl_comm_destroy(lsa_rccl_comm *comm);
 int lsa_ndt_set_allreduce_rccl(lsa_ndt *ndt, lsa_rccl_comm *comm);   /* comm == NULL clears it */
 int lsa_rccl_allreduce_f64(lsa_rccl_comm *comm, void *device_buf, size_t n_doubles);  /* in place, on the context's stream */
+int lsa_rccl_comm_count(lsa_rccl_comm *comm, int *count);                              /* ncclCommCount: ranks the communicator spans */
 
 /* ---- host-side Newton / More-Thuente driver with a caller-supplied pass evaluator ---------- */
 /* The same driver lsa_ndt_scan_match runs, exposed so the multi-process path can be exercised

@@ -131,6 +131,7 @@ def lib():
     L.lsa_rccl_comm_destroy.restype = None
     L.lsa_ndt_set_allreduce_rccl.argtypes = [vp, vp]
     L.lsa_rccl_allreduce_f64.argtypes = [vp, vp, sz]
+    L.lsa_rccl_comm_count.argtypes = [vp, C.POINTER(C.c_int)]
     L.lsa_icp_set_normal_leaf.argtypes = [vp, f]
     L.lsa_yaw_init_create.argtypes = [PVP, vp, C.c_double]
     L.lsa_yaw_init_destroy.argtypes = [vp]

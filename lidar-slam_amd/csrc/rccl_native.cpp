@@ -22,6 +22,7 @@ struct Api {
   NcclResult (*CommInitRank)(NcclComm *, int, NcclUniqueId, int) = nullptr;
   NcclResult (*CommDestroy)(NcclComm) = nullptr;
   NcclResult (*AllReduce)(const void *, void *, size_t, int, int, NcclComm, hipStream_t) = nullptr;
+  NcclResult (*CommCount)(const NcclComm, int *) = nullptr;
   const char *(*GetErrorString)(NcclResult) = nullptr;
   std::string err;
 };
@@ -43,6 +44,7 @@ Api &api() {
     a.CommDestroy = (decltype(a.CommDestroy))dlsym(a.lib, "ncclCommDestroy");
     a.AllReduce = (decltype(a.AllReduce))dlsym(a.lib, "ncclAllReduce");
     a.GetErrorString = (decltype(a.GetErrorString))dlsym(a.lib, "ncclGetErrorString");
+    a.CommCount = (decltype(a.CommCount))dlsym(a.lib, "ncclCommCount");
     if (!a.GetUniqueId || !a.CommInitRank || !a.CommDestroy || !a.AllReduce) a.err = "librccl lacks an expected symbol";
   });
   return a;
@@ -92,6 +94,16 @@ extern "C" void lsa_rccl_comm_destroy(lsa_rccl_comm *c) {
   Api &a = api();
   if (a.CommDestroy && c->comm) (void)a.CommDestroy(c->comm);
   delete c;
+}
+
+// ncclCommCount of the communicator: how many ranks the exchange step really spans (bench.py prints it on every N > 1 line)
+extern "C" int lsa_rccl_comm_count(lsa_rccl_comm *c, int *count) {
+  if (!c || !count) return LSA_ERR_INVALID;
+  Api &a = api();
+  if (!a.CommCount) { *count = c->world; return LSA_OK; }
+  NcclResult r = a.CommCount(c->comm, count);
+  if (r != 0) return lsa_fail(c->ctx, LSA_ERR_COLLECTIVE, "ncclCommCount: %s", nccl_err(a, r));
+  return LSA_OK;
 }
 
 // the lsa_allreduce_fn the library installs for lsa_ndt_set_allreduce_rccl

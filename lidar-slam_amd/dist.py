@@ -87,6 +87,14 @@ class NativeRccl:
         from . import capi
         self.ctx.check(capi.lib().lsa_ndt_set_allreduce_rccl(ndt.h, self.h))
 
+    def comm_count(self):
+        """ncclCommCount of the communicator."""
+        import ctypes as C
+        from . import capi
+        n = C.c_int(0)
+        self.ctx.check(capi.lib().lsa_rccl_comm_count(self.h, C.byref(n)))
+        return n.value
+
     def allreduce_(self, tensor):
         """In-place sum of a float64 CUDA tensor on the context's stream (self-test / other 32-double blocks)."""
         from . import capi

@@ -8,15 +8,22 @@ profiling scripts and the -m gpu parity tests run exactly the same clouds, local
   dense a second, KITTI-shaped bracket of cfg2: the same street with vegetation-like volumetric clutter and more
         facades.
 
-Nothing here touches the GPU or forks after it has been initialised: the generators are numpy; the optional worker pool
-uses the "spawn" start method.
+Nothing here touches the GPU or forks a process that holds a GPU context: the generators are numpy; the optional workers
+are plain child programs.
 """
 import os
 import time
 
 import numpy as np
 
-from . import synth
+if __name__ == "__main__":   # a dataset worker (see _dataset): import the sibling module without the package
+    import importlib.util as _ilu
+    import sys as _sys
+    _spec = _ilu.spec_from_file_location("lsa_synth_worker", os.path.join(os.path.dirname(os.path.abspath(__file__)), "synth.py"))
+    synth = _ilu.module_from_spec(_spec)
+    _spec.loader.exec_module(synth)
+else:
+    from . import synth
 
 NDT_PARAMS = dict(res=1.0, step_size=0.1, trans_eps=0.01, max_iter=30, outlier_ratio=0.55)   # config/mapping/front_end.yaml:24-29
 N_POSES = 30
@@ -27,8 +34,7 @@ DENSE_CACHE = "/tmp/lsa_bench_dense_v2.npz"
 DENSE_MAX_RANGE = 100.0
 
 
-def _gen_one(args):
-    kind, scene_seed, pose, seed = args
+def _gen_one(kind, scene_seed, pose, seed):
     if kind == "cfg2":
         return synth.gen_scan(synth.Scene(seed=scene_seed), pose, seed=seed)
     return synth.gen_scan(synth.DenseScene(seed=scene_seed), pose, seed=seed, max_range=DENSE_MAX_RANGE)
@@ -37,16 +43,25 @@ def _gen_one(args):
 def _dataset(kind, path, workers, leader=True):
     poses = synth.trajectory(N_POSES)
     if leader and not os.path.exists(path):
-        jobs = [(kind, 1, poses[i], 100 + i) for i in range(N_POSES)]
+        tmp = path + ".tmp%d" % os.getpid()
         if workers > 1:
-            import multiprocessing as mp
-            with mp.get_context("spawn").Pool(workers) as pool:   # spawn: safe even when the GPU is already initialised
-                scans = pool.map(_gen_one, jobs)
+            # worker PROCESSES started as plain child programs (this file run as a script over a slice of the poses): no fork
+            # of a process that may hold a GPU context, no pickling of functions from this hyphenated package
+            import subprocess
+            import sys
+            bounds = [(N_POSES * w) // workers for w in range(workers + 1)]
+            procs = [subprocess.Popen([sys.executable, os.path.abspath(__file__), kind, str(bounds[w]), str(bounds[w + 1]), tmp])
+                     for w in range(workers) if bounds[w + 1] > bounds[w]]
+            for pr in procs:
+                if pr.wait() != 0:
+                    raise RuntimeError("dataset worker failed (%s)" % kind)
+            scans = [np.load("%s.%d.npy" % (tmp, i)) for i in range(N_POSES)]
+            for i in range(N_POSES):
+                os.remove("%s.%d.npy" % (tmp, i))
         else:
-            scans = [_gen_one(j) for j in jobs]
-        tmp = path + ".tmp%d.npz" % os.getpid()
-        np.savez(tmp, **{"s%d" % i: s for i, s in enumerate(scans)})
-        os.replace(tmp, path)
+            scans = [_gen_one(kind, 1, poses[i], 100 + i) for i in range(N_POSES)]
+        np.savez(tmp + ".npz", **{"s%d" % i: s for i, s in enumerate(scans)})
+        os.replace(tmp + ".npz", path)
     t0 = time.time()
     while not os.path.exists(path):
         if time.time() - t0 > 600:
@@ -106,9 +121,45 @@ def cfg5_source(poses):
     return src, (np.linalg.inv(poses[0]) @ poses[8]).astype(np.float32)
 
 
+def wide_map(seed=3, half=160.0, n_source=2097152):
+    """A target that does NOT fit a 4 MiB per-XCD L2: an undulating surface over +-`half` m with 12
+    points per 1 m column, a second (canopy / roof) layer over a third of the area: >= 100 k valid 1 m voxels, a dense probe
+    table of ~320 x 320 x 16 cells (26 MB) and ~10 MB of records.  The source is `n_source` samples of the same surfaces
+    spread over the whole extent — in random order (every wave's 14 points land in 14 unrelated places: the adversarial
+    case for the table's cache residency) — and the guess a small offset."""
+    rng = np.random.RandomState(seed)
+
+    def height(x, y):
+        return 3.0 * np.sin(x / 37.0) * np.cos(y / 29.0) + 1.5 * np.sin((x + y) / 11.0)
+
+    def surface(n, zoff, noise, mask_frac=None):
+        x = rng.uniform(-half, half, n)
+        y = rng.uniform(-half, half, n)
+        if mask_frac is not None:   # keep the points whose 16 m tile is "covered" (a seeded third of the tiles)
+            tile = (np.floor(x / 16.0).astype(np.int64) * 73856093) ^ (np.floor(y / 16.0).astype(np.int64) * 19349663)
+            keep = (tile % 100) < int(mask_frac * 100)
+            x, y = x[keep], y[keep]
+        z = height(x, y) + zoff + rng.normal(0.0, noise, x.shape[0])
+        return np.stack([x, y, z, np.ones_like(x)], axis=1).astype(np.float32)
+
+    cols = int((2 * half) ** 2)
+    target = np.concatenate([surface(12 * cols, 0.0, 0.05), surface(24 * cols, 4.5, 0.35, mask_frac=0.33)], axis=0)
+    src = np.concatenate([surface(int(n_source * 0.8), 0.0, 0.05), surface(int(n_source * 0.2 / 0.33) + 4096, 4.5, 0.35, mask_frac=0.33)], axis=0)
+    src = np.ascontiguousarray(src[rng.permutation(src.shape[0])[:n_source]])
+    guess = synth.pose_matrix(0.06, -0.04, 0.02, 0.0005, -0.0004, 0.0008).astype(np.float32)
+    return np.ascontiguousarray(target), src, guess
+
+
 def pose_err(Ta, Tb):
     """(translation error in m, geodesic rotation angle in rad) between two 4x4 poses."""
     dt = float(np.linalg.norm(Ta[:3, 3].astype(np.float64) - Tb[:3, 3].astype(np.float64)))
     R = Ta[:3, :3].astype(np.float64).T @ Tb[:3, :3].astype(np.float64)
     v = 0.5 * np.array([R[2, 1] - R[1, 2], R[0, 2] - R[2, 0], R[1, 0] - R[0, 1]])
     return dt, float(np.arctan2(np.linalg.norm(v), (np.trace(R) - 1.0) / 2.0))
+
+
+if __name__ == "__main__":
+    _kind, _i0, _i1, _prefix = _sys.argv[1], int(_sys.argv[2]), int(_sys.argv[3]), _sys.argv[4]
+    _poses = synth.trajectory(N_POSES)
+    for _i in range(_i0, _i1):
+        np.save("%s.%d.npy" % (_prefix, _i), _gen_one(_kind, 1, _poses[_i], 100 + _i))
