@@ -33,21 +33,6 @@ int lsa_fail(lsa_context *ctx, int code, const char *fmt, ...) {
   return code;
 }
 
-void lsa_pack_xyzw(const void *pts, size_t n, size_t stride, size_t w_off, float *out4) {
-  const char *p = (const char *)pts;
-  if (w_off != SIZE_MAX) {
-    for (size_t i = 0; i < n; i++, p += stride) {
-      memcpy(out4 + 4 * i, p, 12);  // x, y, z: one 16-byte move pair for the optimiser instead of three scalar ones
-      memcpy(out4 + 4 * i + 3, p + w_off, 4);
-    }
-  } else {
-    for (size_t i = 0; i < n; i++, p += stride) {
-      memcpy(out4 + 4 * i, p, 12);
-      out4[4 * i + 3] = 1.0f;
-    }
-  }
-}
-
 // Host points -> device float4: packed into the pinned staging buffer and copied in a few chunks, each copy enqueued as
 // soon as its chunk is packed, so the PCIe transfer of chunk k runs under the packing of chunk k + 1 (a 131 k-point scan:
 // ~70 us of packing with ~40 us of copy behind it instead of after it).  The caller owns the ordering of h_stage reuse.
