@@ -52,6 +52,17 @@ struct DevParams {
   float mn[3], mx[3];           // bounding box of the finite points
 };
 
+// What the host already knows of the grid definition when a build REUSES the previous one (speculative builds of the frame
+// filter): handed to the kernels by value, so that none of them starts with a dependent (and, right after a kernel boundary,
+// cold: ~2 us) load of *dparams before it can touch the points.  valid == 0: read the definition from device memory.
+struct KnownParams {
+  int valid;
+  unsigned nsb;
+  unsigned long long W;
+  CellMap map;
+  FixScales fs;
+};
+
 struct VoxelIndex {
   DevBuf<uint32_t> bits, prefix;
   DevBuf<unsigned long long> scan_state;  // decoupled look-back states, one per 2048-word tile

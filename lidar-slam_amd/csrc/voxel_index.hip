@@ -204,11 +204,11 @@ __device__ __forceinline__ int lds_insert(int *keys, int cell) {
 }
 
 template <int TILE>
-__global__ __launch_bounds__(kBlock) void k_mark(const float4 *__restrict__ pts, size_t n, DevParams *__restrict__ dp, uint32_t *__restrict__ bits,
-                                                 int32_t *__restrict__ cell_idx) {
+__global__ __launch_bounds__(kBlock) void k_mark(const float4 *__restrict__ pts, size_t n, DevParams *__restrict__ dp, KnownParams kp,
+                                                 uint32_t *__restrict__ bits, int32_t *__restrict__ cell_idx) {
   constexpr int kTile = TILE, kHashCap = TILE / 2;
-  if (dp->status != VI_OK) return;
-  const CellMap m = dp->map;
+  if (!kp.valid && dp->status != VI_OK) return;
+  const CellMap m = kp.valid ? kp.map : dp->map;
   // the table is keyed by bitmap WORD (32 x-adjacent cells) and holds the OR of the tile's bits in it: the memory-side
   // atomics of the flush serialise on a shared word, and x-neighbours in one word are the common case (measured at 2 M
   // points / 0.3 m: 269 distinct cells but 107 distinct words per tile; one atomic per cell made the flush 42 of 56 us)
@@ -264,29 +264,69 @@ __global__ __launch_bounds__(kBlock) void k_mark(const float4 *__restrict__ pts,
 // is handed from tile to tile), so the device-scope atomics are RELAXED: an acquire / release pair would add an L2
 // invalidate / write-back per tile on this eight-L2 part.
 constexpr unsigned long long kFlagAgg = 1ull, kFlagPrefix = 2ull;
+constexpr unsigned kScanRedundantMax = 96;  // tiles (x 2048 words = 6.3 M cells): above this the look-back scan runs
 __device__ __forceinline__ unsigned long long scan_word(unsigned epoch, unsigned long long flag, unsigned value) {
   return ((unsigned long long)epoch << 34) | (flag << 32) | (unsigned long long)value;
 }
 
-__global__ __launch_bounds__(kBlock) void k_scan(const uint32_t *__restrict__ bits, DevParams *__restrict__ dp, unsigned long long *__restrict__ state,
-                                                 unsigned *__restrict__ ticket, unsigned epoch, uint32_t *__restrict__ prefix,
-                                                 int32_t *__restrict__ cell_of_rank) {
+__global__ __launch_bounds__(kBlock) void k_scan(const uint32_t *__restrict__ bits, DevParams *__restrict__ dp, KnownParams kp,
+                                                 unsigned long long *__restrict__ state, unsigned *__restrict__ ticket, unsigned epoch,
+                                                 uint32_t *__restrict__ prefix, int32_t *__restrict__ cell_of_rank) {
   __shared__ unsigned s_tile, s_excl;
-  __shared__ unsigned wt[kBlock / 64];
-  if (threadIdx.x == 0) {
-    unsigned t = atomicAdd(ticket, 1u);
-    if (t == gridDim.x - 1) *ticket = 0u;  // every ticket of this launch has been handed out: reset for the next one
-    s_tile = t;
+  __shared__ unsigned wt[kBlock / 64], wr[kBlock / 64];
+  // Small bitmaps (a lidar scan at 0.5 m: ~24 tiles) do not go through the look-back at all: the chain of tile-to-tile
+  // hand-offs through memory is serial (~0.5 us per hop across XCDs: k_scan took 12.8 us of the 31 us filter chain), while
+  // every workgroup can simply count the bits in FRONT of its tile itself — at most kScanRedundantMax x 8 KB of an
+  // L2-resident bitmap, no dependency on any other workgroup.  Which path runs is decided on the device (the tile count is
+  // only known there); the ticket counter is touched by the look-back path alone.
+  // the tile this workgroup will most likely own is loaded before anything is known of the grid definition (the grid
+  // covers the bitmap's capacity, so the address is valid whatever the definition says): its latency overlaps the
+  // definition's
+  const uint4 *spec_src = reinterpret_cast<const uint4 *>(bits + (size_t)blockIdx.x * kScanTile + (size_t)threadIdx.x * 8);
+  uint4 lo = spec_src[0], hi = spec_src[1];
+  const unsigned nsb = kp.valid ? kp.nsb : dp->nsb;
+  const bool redundant = nsb <= kScanRedundantMax;
+  if (!redundant) {
+    if (threadIdx.x == 0) {
+      unsigned t = atomicAdd(ticket, 1u);
+      if (t == gridDim.x - 1) *ticket = 0u;  // every ticket of this launch has been handed out: reset for the next one
+      s_tile = t;
+    }
+    __syncthreads();
   }
-  __syncthreads();
-  const unsigned tile = s_tile;
-  if (dp->status != VI_OK || tile >= dp->nsb) return;
-  const size_t W = dp->W;
-  // thread t owns 8 consecutive words (two 16-byte loads; the bitmap capacity is a multiple of the tile, and words past
-  // W are zero), so the in-block scan is one value per thread: wave shuffle scan + one barrier for the 4 wave totals
+  const unsigned tile = redundant ? blockIdx.x : s_tile;
+  if ((!kp.valid && dp->status != VI_OK) || tile >= nsb) return;
+  const size_t W = kp.valid ? (size_t)kp.W : (size_t)dp->W;
+  unsigned front = 0;  // redundant path: this thread's share of the popcount of words [0, tile * kScanTile)
+  if (redundant) {
+    // a predecessor tile is kScanTile / 4 = 512 uint4 = 2 per thread: both loads of up to eight tiles are issued before the
+    // first popcount (sixteen 16-byte loads in flight per lane), so the front count costs ~one L2 latency per eight tiles
+    const uint4 *all = reinterpret_cast<const uint4 *>(bits) + threadIdx.x;
+    unsigned t = 0;
+    for (; t + 8 <= tile; t += 8) {
+      uint4 v[16];
+#pragma unroll
+      for (int k = 0; k < 16; k++) v[k] = all[(size_t)(t * 2 + k) * kBlock];
+#pragma unroll
+      for (int k = 0; k < 16; k++) front += __popc(v[k].x) + __popc(v[k].y) + __popc(v[k].z) + __popc(v[k].w);
+    }
+    for (; t + 2 <= tile; t += 2) {
+      uint4 v[4];
+#pragma unroll
+      for (int k = 0; k < 4; k++) v[k] = all[(size_t)(t * 2 + k) * kBlock];
+#pragma unroll
+      for (int k = 0; k < 4; k++) front += __popc(v[k].x) + __popc(v[k].y) + __popc(v[k].z) + __popc(v[k].w);
+    }
+    for (; t < tile; t++) {
+      uint4 v0 = all[(size_t)(t * 2) * kBlock], v1 = all[(size_t)(t * 2 + 1) * kBlock];
+      front += __popc(v0.x) + __popc(v0.y) + __popc(v0.z) + __popc(v0.w) + __popc(v1.x) + __popc(v1.y) + __popc(v1.z) + __popc(v1.w);
+    }
+  }
   size_t base = (size_t)tile * kScanTile + (size_t)threadIdx.x * 8;
-  const uint4 *src = reinterpret_cast<const uint4 *>(bits + base);
-  uint4 lo = src[0], hi = src[1];
+  if (tile != blockIdx.x) {  // look-back path: tiles are handed out by ticket
+    const uint4 *src = reinterpret_cast<const uint4 *>(bits + base);
+    lo = src[0]; hi = src[1];
+  }
   uint32_t wv[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
   unsigned local = 0;
 #pragma unroll
@@ -302,11 +342,24 @@ __global__ __launch_bounds__(kBlock) void k_scan(const uint32_t *__restrict__ bi
     if (lane >= off) incl += v;
   }
   if (lane == 63) wt[wave] = incl;
+  if (redundant) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) front += __shfl_down(front, off, 64);
+    if (lane == 0) wr[wave] = front;
+  }
   __syncthreads();
   unsigned agg = 0;
 #pragma unroll
   for (int w = 0; w < kBlock / 64; w++) agg += wt[w];
-  if (wave == 0) {
+  if (redundant) {
+    if (threadIdx.x == 0) {
+      unsigned excl = 0;
+#pragma unroll
+      for (int w = 0; w < kBlock / 64; w++) excl += wr[w];
+      s_excl = excl;
+      if (tile == nsb - 1) dp->V = excl + agg;  // #occupied cells
+    }
+  } else if (wave == 0) {
     if (lane == 0) __hip_atomic_store(state + tile, scan_word(epoch, tile == 0 ? kFlagPrefix : kFlagAgg, agg), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     unsigned excl = 0;
     int j = (int)tile - 1;  // nearest predecessor not yet accounted for
@@ -333,7 +386,7 @@ __global__ __launch_bounds__(kBlock) void k_scan(const uint32_t *__restrict__ bi
     if (lane == 0) {
       if (tile != 0) __hip_atomic_store(state + tile, scan_word(epoch, kFlagPrefix, excl + agg), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       s_excl = excl;
-      if (tile == dp->nsb - 1) dp->V = excl + agg;  // #occupied cells
+      if (tile == nsb - 1) dp->V = excl + agg;  // #occupied cells
     }
   }
   __syncthreads();
@@ -343,16 +396,31 @@ __global__ __launch_bounds__(kBlock) void k_scan(const uint32_t *__restrict__ bi
 #pragma unroll
   for (int k = 0; k < 8; k++) {
     pf[k] = run;
-    uint32_t b = wv[k];
-    while (b) {
-      int bit = __ffs(b) - 1;
-      b &= b - 1;
-      cell_of_rank[run++] = (int32_t)((base + k) * 32 + bit);
-    }
+    run += __popc(wv[k]);
   }
   uint4 *dst = reinterpret_cast<uint4 *>(prefix + base);
   dst[0] = make_uint4(pf[0], pf[1], pf[2], pf[3]);
   dst[1] = make_uint4(pf[4], pf[5], pf[6], pf[7]);
+  // inverse map (rank -> cell).  A lane's 8 consecutive words are 256 x-adjacent cells, and occupied cells come in x-runs
+  // (the ground next to the sensor, a wall): written by the lane that scanned them, the densest lane set the kernel's
+  // duration (3.5 us for a tile whose other lanes had nothing to write).  The words and their ranks go through LDS and are
+  // dealt out again round-robin, so that a run of n dense words is written by n different lanes.
+  __shared__ uint32_t s_w[kScanTile], s_pf[kScanTile];
+#pragma unroll
+  for (int k = 0; k < 8; k++) { s_w[threadIdx.x * 8 + k] = wv[k]; s_pf[threadIdx.x * 8 + k] = pf[k]; }
+  __syncthreads();
+  const size_t tile_cell0 = (size_t)tile * kScanTile * 32;
+#pragma unroll 2
+  for (int k = 0; k < 8; k++) {
+    const int wi = k * kBlock + threadIdx.x;
+    uint32_t b = s_w[wi];
+    unsigned r = s_pf[wi];
+    while (b) {
+      int bit = __ffs(b) - 1;
+      b &= b - 1;
+      cell_of_rank[r++] = (int32_t)(tile_cell0 + (size_t)wi * 32 + bit);
+    }
+  }
 }
 
 template <int NS>
@@ -381,14 +449,14 @@ __device__ __forceinline__ unsigned cell_rank(const uint32_t *__restrict__ bits,
 // per-cell fixed-point sums: LDS pre-aggregation per tile, then one set of global atomics per distinct cell
 template <int NS, int TILE>
 __global__ __launch_bounds__(kBlock) void k_accum(const float4 *__restrict__ pts, const int32_t *__restrict__ cell_idx, size_t n,
-                                                  const DevParams *__restrict__ dp, const uint32_t *__restrict__ bits, const uint32_t *__restrict__ prefix,
-                                                  long long *__restrict__ acc, int32_t *__restrict__ cnt) {
+                                                  const DevParams *__restrict__ dp, KnownParams kp, const uint32_t *__restrict__ bits,
+                                                  const uint32_t *__restrict__ prefix, long long *__restrict__ acc, int32_t *__restrict__ cnt) {
   // table slots: TILE / 2, but TILE / 4 for the 10-sum rows (80 B each): 46 KB instead of 92 KB of LDS lets three
   // workgroups share a CU instead of one; a tile with more distinct cells than slots overflows to direct atomics
   constexpr int kTile = TILE, kHashCap = (NS > 4 && TILE >= 1024) ? TILE / 4 : TILE / 2;
-  if (dp->status != VI_OK) return;
-  const CellMap m = dp->map;
-  const FixScales fs = dp->fs;
+  if (!kp.valid && dp->status != VI_OK) return;
+  const CellMap m = kp.valid ? kp.map : dp->map;
+  const FixScales fs = kp.valid ? kp.fs : dp->fs;
   __shared__ int keys[kHashCap];
   __shared__ int counts[kHashCap];
   __shared__ unsigned long long sums[kHashCap][NS];
@@ -547,12 +615,20 @@ int vi_enqueue(lsa_context *ctx, VoxelIndex &vi, const float4 *d_pts, size_t n, 
     hipLaunchKernelGGL(k_bbox_final_params, dim3(1), dim3(kBlock), 0, ctx->stream, vi.scratch.p, (int)nb, req, vi.dparams.p);
   }
   const bool small = n < kSmallInput;
-  if (small) hipLaunchKernelGGL(k_mark<kTileSmall>, dim3(lsa_div_up(n, kTileSmall)), dim3(kBlock), 0, ctx->stream, d_pts, n, dp, vi.bits.p, vi.cell_idx.p);
-  else hipLaunchKernelGGL(k_mark<kTileBig>, dim3(lsa_div_up(n, kTileBig)), dim3(kBlock), 0, ctx->stream, d_pts, n, dp, vi.bits.p, vi.cell_idx.p);
-  hipLaunchKernelGGL(k_scan, dim3(nsb_cap), dim3(kBlock), 0, ctx->stream, vi.bits.p, vi.dparams.p, vi.scan_state.p, vi.tickets.p + 1, vi.scan_epoch,
+  KnownParams kp;
+  memset(&kp, 0, sizeof(kp));
+  if (spec) {  // the definition the device holds is the one vi_wait() read back after the previous build
+    kp.valid = 1;
+    kp.map = vi.map; kp.fs = vi.fs;
+    kp.W = (unsigned long long)vi.W;
+    kp.nsb = (unsigned)((vi.W + kScanTile - 1) / kScanTile);
+  }
+  if (small) hipLaunchKernelGGL(k_mark<kTileSmall>, dim3(lsa_div_up(n, kTileSmall)), dim3(kBlock), 0, ctx->stream, d_pts, n, dp, kp, vi.bits.p, vi.cell_idx.p);
+  else hipLaunchKernelGGL(k_mark<kTileBig>, dim3(lsa_div_up(n, kTileBig)), dim3(kBlock), 0, ctx->stream, d_pts, n, dp, kp, vi.bits.p, vi.cell_idx.p);
+  hipLaunchKernelGGL(k_scan, dim3(nsb_cap), dim3(kBlock), 0, ctx->stream, vi.bits.p, vi.dparams.p, kp, vi.scan_state.p, vi.tickets.p + 1, vi.scan_epoch,
                      vi.prefix.p, vi.cell_of_rank.p);
   unsigned g = lsa_div_up(n, small ? kTileSmall : kTileBig);
-#define LSA_LAUNCH_ACCUM(NS_, TILE_) hipLaunchKernelGGL((k_accum<NS_, TILE_>), dim3(g), dim3(kBlock), 0, ctx->stream, d_pts, vi.cell_idx.p, n, dp, vi.bits.p, vi.prefix.p, vi.acc.p, vi.cnt.p)
+#define LSA_LAUNCH_ACCUM(NS_, TILE_) hipLaunchKernelGGL((k_accum<NS_, TILE_>), dim3(g), dim3(kBlock), 0, ctx->stream, d_pts, vi.cell_idx.p, n, dp, kp, vi.bits.p, vi.prefix.p, vi.acc.p, vi.cnt.p)
   if (ns == 4) { if (small) LSA_LAUNCH_ACCUM(4, kTileSmall); else LSA_LAUNCH_ACCUM(4, kTileBig); }
   else { if (small) LSA_LAUNCH_ACCUM(10, kTileSmall); else LSA_LAUNCH_ACCUM(10, kTileBig); }
 #undef LSA_LAUNCH_ACCUM
