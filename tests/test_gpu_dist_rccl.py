@@ -66,3 +66,78 @@ def test_scan_match_through_rccl_world_1(tmp_path):
     script.write_text("ROOT = %r\n" % ROOT + CHILD)
     p = subprocess.run([sys.executable, str(script)], env=env, capture_output=True, text=True, timeout=600)
     assert p.returncode == 0 and "RCCL_PATH_OK" in p.stdout, (p.stdout[-2000:], p.stderr[-3000:])
+
+
+CHILD2 = r'''
+import os, sys
+import numpy as np
+sys.path.insert(0, os.path.join(ROOT, "tests")); sys.path.insert(0, ROOT)
+import conftest
+import ctypes as C
+import torch
+import torch.distributed as dist
+from lidar_slam_amd import capi, cloud_filter, registration, synth, dist as lsa_dist
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+torch.cuda.set_device(0)                       # both ranks on the ONE GPU of the test box (RCCL refuses that: gloo staged)
+dist.init_process_group("gloo", rank=rank, world_size=world)
+s = torch.cuda.Stream(); torch.cuda.set_stream(s)
+ctx = capi.Context(0, s.cuda_stream)
+fs = torch.cuda.Stream()
+ctx_f = capi.Context(0, fs.cuda_stream)
+scene = synth.Scene(seed=1)
+T = [synth.pose_matrix(), synth.pose_matrix(1.0, 0.05, 0.01, 0.002, -0.003, 0.02), synth.pose_matrix(2.0, 0.11, 0.0, 0.001, -0.002, 0.04)]
+scans = [synth.gen_scan(scene, T[i], seed=10 + i, beams=32, az_steps=1024) for i in range(3)]
+d_t = torch.from_numpy(scans[0]).cuda()
+d_scans = [torch.from_numpy(np.ascontiguousarray(scans[i])).cuda() for i in (1, 2)]
+torch.cuda.synchronize()
+ff = cloud_filter.VoxelFilterHip(ctx_f, 0.5, 0.5, 0.5)
+ndt = registration.NDTRegistrationHip(ctx)
+ndt.SetInputTarget(d_t)
+L = capi.lib()
+L.lsa_pipeline_scan_match.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t), C.POINTER(C.c_float),
+                                      C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_float), C.POINTER(capi.NdtStats), C.POINTER(C.c_size_t)]
+cap = max(x.shape[0] for x in d_scans)
+buf = [torch.empty((cap, 4), dtype=torch.float32, device="cuda") for _ in range(2)]
+pred = np.stack([capi.colmajor(np.eye(4, dtype=np.float32)), capi.colmajor(T[1].astype(np.float32))]).astype(np.float32)
+ptrs = (C.c_void_p * 2)(*[x.data_ptr() for x in d_scans]); nn = (C.c_size_t * 2)(*[x.shape[0] for x in d_scans])
+
+def run(r, w):
+    out = np.zeros((2, 16), dtype=np.float32); st = (capi.NdtStats * 2)(); nf = (C.c_size_t * 2)()
+    rc = L.lsa_pipeline_scan_match(ff.h, ndt.h, 2, ptrs, nn, capi.fptr(pred), buf[0].data_ptr(), buf[1].data_ptr(), r, w, capi.fptr(out), st, nf)
+    ctx.check(rc)
+    return out, [st[i].as_dict() for i in range(2)], [int(nf[i]) for i in range(2)]
+
+whole, st_w, nf_w = run(0, 1)                  # every rank: the unsharded reference, no collective
+ndt.set_allreduce(lsa_dist.make_gloo_staged_allreduce())
+shard, st_s, nf_s = run(rank, world)           # this rank's shard of every filtered scan, one all-reduce per pass
+ndt.set_allreduce(None)
+assert nf_s == nf_w
+for i in range(2):
+    assert st_s[i]["iterations"] == st_w[i]["iterations"] and st_s[i]["passes"] == st_w[i]["passes"], (st_s[i], st_w[i])
+    assert abs(st_s[i]["pairs_per_pass"] - st_w[i]["pairs_per_pass"]) < 1e-9 * st_w[i]["pairs_per_pass"]   # the all-reduce summed every shard
+    assert np.max(np.abs(shard[i] - whole[i])) <= 1e-6, (shard[i] - whole[i])   # the reduction order differs, nothing else
+# every rank took the identical solve: compare the poses across the ranks bit for bit
+t = torch.from_numpy(shard.copy())
+gathered = [torch.zeros_like(t) for _ in range(world)]
+dist.all_gather(gathered, t)
+assert all(torch.equal(g, gathered[0]) for g in gathered)
+ndt.close(); ff.close(); ctx_f.close(); ctx.close()
+dist.barrier(); dist.destroy_process_group()
+print("PIPELINE_SHARDED_OK rank %d" % rank)
+'''
+
+
+@pytest.mark.gpu
+def test_pipeline_scan_match_sharded_two_ranks_one_gpu(tmp_path):
+    """lsa_pipeline_scan_match(rank, world) with world = 2: two processes on the one GPU of the box, the 32-double block summed over
+    gloo (staged through the host) once per pass — the rehearsal gpurun_out/b2.json ran by hand in round 1, as a test: same
+    counts as the unsharded run, poses within reduction-order rounding of it and bit-identical ACROSS the ranks."""
+    script = tmp_path / "child2.py"
+    script.write_text("ROOT = %r\n" % ROOT + CHILD2)
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29541", RANK=str(r), WORLD_SIZE="2", HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs.append(subprocess.Popen([sys.executable, str(script)], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+    outs = [p.communicate(timeout=600) for p in procs]
+    for r, (p, (so, se)) in enumerate(zip(procs, outs)):
+        assert p.returncode == 0 and ("PIPELINE_SHARDED_OK rank %d" % r) in so, (so[-2000:], se[-3000:])
