@@ -190,6 +190,15 @@ int lsa_ndt_grid_info(lsa_ndt *ndt, int64_t info[9]);
  * rec: centroid(3) icov sym (xx,xy,xz,yy,yz,zz) weight(1) -> 10 doubles per cell. cap in cells. */
 int lsa_ndt_grid_dump(lsa_ndt *ndt, int32_t *cell_ints, double *cell_rec, size_t cap, size_t *n_cells);
 
+/* Armed passes (default ON; 0 or the environment variable LSA_NO_ARMED disables them): with the trial loop of the line search
+ * dead (every shipped configuration) each Newton iteration is exactly one full derivative pass, so ScanMatch enqueues the
+ * kernel of the NEXT pass right behind the current one; it waits on the device for its parameters, which the host posts into
+ * a mailbox in device memory once the current pass's sums have produced them (csrc/ndt_derivatives.hip).  Launch and dispatch
+ * latency leave the critical path; results are bit-identical.  The counters: passes served that way, armed kernels cancelled
+ * (one per ScanMatch, at convergence). */
+int lsa_ndt_set_armed(lsa_ndt *ndt, int on);
+int lsa_ndt_armed_counters(lsa_ndt *ndt, uint64_t *passes, uint64_t *cancels);
+
 /* ScanMatch can run its whole Newton iteration as ONE persistent launch (csrc/ndt_align.hip: the workgroups stay resident,
  * exchange their partial sums in-launch and each repeats the 6x6 solve) instead of one launch per derivative pass, when the
  * call qualifies: single GPU, the trial loop of the line search dead as in every shipped configuration, at most one

@@ -156,6 +156,8 @@ def lib():
     L.lsa_gn_solve_mode.argtypes = [PASS_EVAL_FN, vp, f, f, f, i, f, i, PF, PF, C.POINTER(NdtStats)]
     L.lsa_gn_solve_trace.argtypes = [PASS_EVAL_FN, vp, f, f, f, i, f, i, PF, PF, C.POINTER(NdtStats), PD, i, C.POINTER(C.c_int)]
     L.lsa_ndt_set_trace.argtypes = [vp, PD, i, C.POINTER(C.c_int)]
+    L.lsa_ndt_set_armed.argtypes = [vp, i]
+    L.lsa_ndt_armed_counters.argtypes = [vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
     L.lsa_ndt_set_persistent.argtypes = [vp, i]
     L.lsa_ndt_align_counters.argtypes = [vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
     L.lsa_ndt_align_stamps.argtypes = [vp, i, C.POINTER(C.c_uint64), sz, PSZ]

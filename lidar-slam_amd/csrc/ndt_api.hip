@@ -19,12 +19,71 @@ int upload_points(lsa_ndt *h, const void *pts, size_t n, size_t stride, size_t w
   return lsa_upload_xyzw(ctx, pts, n, stride, w_off, h->h_stage.p, dst.p);
 }
 
+// the mailbox of the armed passes: fine-grained device memory the host writes through the (large) PCIe BAR; pinned host
+// memory where the device has no large BAR (the pollers then read over the link)
+int mail_ensure(lsa_ndt *h) {
+  if (h->mail || h->mail_tried) return LSA_OK;
+  h->mail_tried = true;
+  lsa_context *ctx = h->ctx;
+  hipDeviceProp_t prop;
+  void *m = nullptr;
+  if (hipGetDeviceProperties(&prop, ctx->device) == hipSuccess && prop.isLargeBar &&
+      hipExtMallocWithFlags(&m, 4096, hipDeviceMallocFinegrained) == hipSuccess) {
+    h->mail = m; h->mail_is_device = true;
+  } else if (hipHostMalloc(&m, 4096, hipHostMallocMapped | hipHostMallocCoherent) == hipSuccess) {
+    h->mail = m; h->mail_is_device = false;
+  } else {
+    (void)hipGetLastError();
+    return LSA_OK;  // no mailbox: the passes are launched the ordinary way
+  }
+  LSA_HIP(ctx, hipMemsetAsync(h->mail, 0, 4096, ctx->stream));
+  LSA_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return LSA_OK;
+}
+
+void armed_cancel(lsa_ndt *h) {
+  if (!h->armed_outstanding) return;
+  ndt_mail_post(reinterpret_cast<PassMail *>(h->mail), nullptr, h->armed_seq, true);
+  h->armed_outstanding = false;
+  h->armed_seq++;
+  h->armed_cancels++;
+}
+
 // one pass, synchronous: kernel(s) -> [all-reduce] -> D2H of 32 doubles
 int run_pass(lsa_ndt *h, const float T[16], const double p[6], int kind, double out32[32]) {
   lsa_context *ctx = h->ctx;
   PassParams P;
   ndt_make_pass_params(h, T, p, &P);
   int rc;
+  if (h->armed_scope && kind == 0 && h->mail && ndt_pass_host_reduce(h, 0)) {
+    // armed: this pass's kernel is already waiting on the device (or is launched now, for the first pass of a ScanMatch);
+    // post its parameters, enqueue the kernel of the NEXT pass behind it, then take the rows as they arrive
+    const unsigned long long seq = h->armed_seq;
+    if (!h->armed_outstanding && (rc = ndt_launch_armed(h, P, seq))) return rc;
+    ndt_mail_post(reinterpret_cast<PassMail *>(h->mail), &P, seq, false);
+    h->armed_seq = seq + 1;
+    h->armed_outstanding = false;
+    if ((rc = ndt_launch_armed(h, P, seq + 1))) return rc;
+    h->armed_outstanding = true;
+    h->armed_passes++;
+    const unsigned g = ndt_pass_grid(h, h->n_source, 0);
+    bool ok = !h->no_row_polling && ndt_reduce_partials_host(h->h_partials.p, g, ndt_armed_row_key(seq), 20.0, out32);
+    if (!ok) {
+      // rows missing (the host thread was held up for longer than the kernel's 20 ms patience, or polling is switched
+      // off): let everything enqueued drain, look again, and if the pass really did not run do it the ordinary way — and
+      // stay unarmed for the rest of this ScanMatch
+      armed_cancel(h);
+      LSA_HIP(ctx, hipStreamSynchronize(ctx->stream));
+      h->unsynced = 0;
+      if (ndt_reduce_partials_host(h->h_partials.p, g, ndt_armed_row_key(seq), 0.0, out32)) return LSA_OK;
+      h->armed_scope = false;
+      return run_pass(h, T, p, kind, out32);
+    } else if ((h->unsynced += 2) >= 256) {
+      // (not a wait for the armed kernel: it is parked until its mail comes, so only every so often, between ScanMatches)
+      h->unsynced = 256;
+    }
+    return LSA_OK;
+  }
   if (ndt_pass_host_reduce(h, kind)) {
     unsigned g = 0;
     unsigned long long key = 0;
@@ -86,8 +145,19 @@ int scan_match_common(lsa_ndt *h, const float predict_pose[16], float result_pos
     }
     memset(&st, 0, sizeof(st));
   }
+  // armed passes: only where every pass of the ScanMatch is a full (kind 0) pass, i.e. the trial loop is dead, on one GPU
+  h->armed_scope = !h->no_armed && !h->allreduce && h->n_source > 0 && (double)h->step_size > (double)h->trans_eps / 2;
+  if (h->armed_scope && (rc = mail_ensure(h))) { h->armed_scope = false; return rc; }
   rc = lsa_gn_solve_trace(eval_trampoline, h, h->resolution, h->step_size, h->trans_eps, h->max_iter, h->outlier_ratio, h->mode, predict_pose, result_pose, &st,
                               h->trace_rows, h->trace_cap, h->trace_n);
+  if (h->armed_scope) {
+    armed_cancel(h);  // the kernel enqueued for a pass that never came leaves at once
+    h->armed_scope = false;
+    if (h->unsynced >= 256) {  // let the runtime retire its commands now and then (nothing is parked on the device any more)
+      (void)hipStreamSynchronize(ctx->stream);
+      h->unsynced = 0;
+    }
+  }
   if (rc) return rc;
   memcpy(h->last_T, result_pose, sizeof(h->last_T));
   h->has_result = true;
@@ -131,6 +201,7 @@ extern "C" void lsa_ndt_destroy(lsa_ndt *h) {
   h->nn.release();
   h->vi.release(); h->d_target.release(); h->rec.release(); h->state.release(); h->vbits.release(); h->words.release(); h->d_small.release(); h->counts.release();
   h->dense.release();
+  if (h->mail) { if (h->mail_is_device) (void)hipFree(h->mail); else (void)hipHostFree(h->mail); }
   h->align_rows.release(); h->align_flags.release(); h->h_result.release(); h->align_stamps.release();
   h->d_source_own.release(); h->h_stage.release(); h->partials.release(); h->d_out.release(); h->h_out.release(); h->h_partials.release();
   delete h;
@@ -239,6 +310,19 @@ extern "C" int lsa_ndt_get_fitness_score(lsa_ndt *h, float *score) {
     return LSA_OK;
   }
   return ndt_fitness(h, score);
+}
+
+extern "C" int lsa_ndt_set_armed(lsa_ndt *h, int on) {
+  if (!h) return LSA_ERR_INVALID;
+  h->no_armed = !on;
+  return LSA_OK;
+}
+
+extern "C" int lsa_ndt_armed_counters(lsa_ndt *h, uint64_t *passes, uint64_t *cancels) {
+  if (!h) return LSA_ERR_INVALID;
+  if (passes) *passes = h->armed_passes;
+  if (cancels) *cancels = h->armed_cancels;
+  return LSA_OK;
 }
 
 extern "C" int lsa_ndt_set_persistent(lsa_ndt *h, int on) {

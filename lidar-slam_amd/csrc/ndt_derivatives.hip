@@ -18,6 +18,7 @@
 //   latency bound at KITTI size and VALU-issue bound at 2 M points, not HBM bound.
 #include <chrono>
 #include <cstring>
+#include <immintrin.h>
 #include "gn_math.h"
 #include "ndt_pass_dev.h"
 
@@ -38,6 +39,117 @@ __global__ __launch_bounds__(kBlockD, pass_waves(KIND)) void k_ndt_pass(const fl
   // one 256-byte row per workgroup, written once (check-worded when it goes straight to the host)
   if (threadIdx.x < kOutDoubles) lsa_store_row32(partials + (size_t)blockIdx.x * kOutDoubles, (int)threadIdx.x, v, key);
 }
+
+}  // namespace
+
+constexpr unsigned kHostReduceMaxBlocks = 1024;
+
+// ---- armed pass: the NEXT pass's kernel is launched before its parameters exist -------------------------------------
+// A pass kernel at KITTI size is ~5 us of work behind ~3 us of host launch call and ~4.5 us until its first wave runs, and
+// the host can only launch it once the previous pass's sums have produced the next transform.  With the line search dead
+// (one full pass per Newton iteration, see ndt_align.hip) the kind of the next kernel is known in advance, so it is
+// enqueued right behind the current one and its workgroups wait — resident, for the ~3 us the host needs to take the
+// rows, solve and post — for the dynamic part of the parameters (rigid transform + the 69 angle-derivative constants,
+// 600 B) in a MAILBOX in fine-grained device memory that the host writes through the PCIe BAR (measured: host store ->
+// visible to a polling wave -> echo in host memory 1.95 us round trip).  The pollers read device memory, not the link.
+// The mail carries the pass's sequence number and a check word over the payload (the host's write-combined stores may
+// land in any order; a torn read is simply repeated); a CANCEL mail (converged: the armed kernel is not needed) or a
+// 20 ms timeout makes the kernel exit without writing its row.  Same body, same grid, same rows: the results are the bits
+// of the unarmed path.
+struct PassMail {
+  unsigned long long words[76];   // [0..5] the 12 floats of T, [6..74] jh (ja then ha), [75] unused
+  unsigned long long check;       // key(seq) ^ XOR_c rotl(word_c, c % 31 + 1)
+  unsigned long long seq;         // sequence number of the pass these parameters are for; | kMailCancel: that pass is cancelled
+};
+constexpr unsigned long long kMailCancel = 1ull << 63;
+__host__ __device__ inline unsigned long long mail_key(unsigned long long seq) { return (seq + 1) * 0x9E3779B97F4A7C15ull; }
+
+namespace {
+template <bool DENSE>
+__global__ __launch_bounds__(kBlockD, pass_waves(0)) void k_ndt_pass_armed(const float4 *__restrict__ src, size_t n, PassParams P, const uint4 *__restrict__ words,
+                                                                         const float4 *__restrict__ dense, const double *__restrict__ rec,
+                                                                         double *__restrict__ partials, const PassMail *mail, unsigned long long seq) {
+  constexpr int NB = 2;
+  __shared__ __align__(16) unsigned char lds[lds_bytes(NB)];
+  __shared__ int s_go;
+  double *jh = reinterpret_cast<double *>(lds + lds_const(NB));
+  float *Tl = reinterpret_cast<float *>(lds + lds_tl(NB));
+  const int tid = (int)threadIdx.x, lane = tid & 63;
+  if (tid < 64) {  // wave 0: wait for this pass's mail, take the payload, verify it
+    const unsigned long long *mw = reinterpret_cast<const unsigned long long *>(mail);
+    const unsigned long long t0 = wall_clock64();
+    int go = 0;
+    for (;;) {
+      const unsigned long long sq = __hip_atomic_load(&mail->seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      if ((sq & ~kMailCancel) > seq || sq == (seq | kMailCancel)) break;  // cancelled, or the host has already moved on to a later pass
+      if (sq == seq) {
+        unsigned long long w0 = __hip_atomic_load(mw + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        unsigned long long w1 = lane < 12 ? __hip_atomic_load(mw + 64 + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) : 0ull;
+        const unsigned long long chk = __hip_atomic_load(&mail->check, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        unsigned long long x = lsa_row_mix(w0, lane % 31) ^ (lane < 12 ? lsa_row_mix(w1, (64 + lane) % 31) : 0ull);
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) x ^= __shfl_xor(x, off, 64);
+        if ((x ^ mail_key(seq)) == chk) {
+          unsigned long long *dstw = reinterpret_cast<unsigned long long *>(lds + lds_const(NB));   // jh[0..68] then, behind 72 doubles, Tl
+          if (lane >= 6) dstw[lane - 6] = w0;                                       // jh[0..57]
+          else reinterpret_cast<unsigned long long *>(Tl)[lane] = w0;               // T: 6 words = 12 floats
+          if (lane < 11) dstw[58 + lane] = w1;                                      // jh[58..68]
+          go = 1;
+          break;
+        }
+      }
+      if (wall_clock64() - t0 > 2000000ull) break;  // 20 ms: nobody posted — leave (the host notices the missing rows)
+      __builtin_amdgcn_s_sleep(1);
+    }
+    if (lane == 0) s_go = go;
+  }
+  __syncthreads();
+  if (!s_go) return;
+  const double v = ndt_pass_body<0, DENSE>(src, n, P, Tl, jh, words, dense, rec, lds);
+  if (tid < kOutDoubles) lsa_store_row32(partials + (size_t)blockIdx.x * kOutDoubles, tid, v, mail_key(seq) | 1ull);
+}
+}  // namespace
+
+// host: post the dynamic parameters of pass `seq` (or its cancellation) into the mailbox
+void ndt_mail_post(PassMail *mail, const PassParams *P, unsigned long long seq, bool cancel) {
+  if (cancel) {
+    __atomic_store_n(&mail->seq, seq | kMailCancel, __ATOMIC_RELEASE);
+    _mm_sfence();
+    return;
+  }
+  unsigned long long w[76];
+  memset(w, 0, sizeof(w));
+  memcpy(&w[0], P->T, 12 * sizeof(float));
+  memcpy(&w[6], &P->ja[0][0], 24 * sizeof(double));
+  memcpy(&w[30], &P->ha[0][0], 45 * sizeof(double));
+  unsigned long long x = 0;
+  for (int c = 0; c < 76; c++) x ^= lsa_row_mix(w[c], c % 31);
+  for (int c = 0; c < 76; c++) mail->words[c] = w[c];
+  mail->check = x ^ mail_key(seq);
+  _mm_sfence();   // payload before the sequence number (the BAR mapping may be write-combining)
+  __atomic_store_n(&mail->seq, seq, __ATOMIC_RELEASE);
+  _mm_sfence();
+}
+
+int ndt_launch_armed(lsa_ndt *h, const PassParams &P, unsigned long long seq) {
+  lsa_context *ctx = h->ctx;
+  unsigned g = ndt_pass_grid(h, h->n_source, 0);
+  int rc;
+  if ((rc = h->h_partials.reserve(ctx, (size_t)kHostReduceMaxBlocks * kOutDoubles))) return rc;
+  const PassMail *mail = reinterpret_cast<const PassMail *>(h->mail);
+  if (h->use_dense)
+    hipLaunchKernelGGL((k_ndt_pass_armed<true>), dim3(g), dim3(kBlockD), 0, ctx->stream, h->d_source, h->n_source, P, h->words.p, h->dense.p, h->rec.p,
+                       h->h_partials.p, mail, seq);
+  else
+    hipLaunchKernelGGL((k_ndt_pass_armed<false>), dim3(g), dim3(kBlockD), 0, ctx->stream, h->d_source, h->n_source, P, h->words.p, h->dense.p, h->rec.p,
+                       h->h_partials.p, mail, seq);
+  LSA_HIP(ctx, hipGetLastError());
+  return LSA_OK;
+}
+
+unsigned long long ndt_armed_row_key(unsigned long long seq) { return mail_key(seq) | 1ull; }
+
+namespace {
 
 // second stage: out[c] = sum_b partials[b][c], fixed order -> deterministic. 1024 threads = 32 columns x 32 row lanes.
 __global__ __launch_bounds__(1024) void k_reduce_partials(const double *__restrict__ partials, int nb, double *__restrict__ out) {
@@ -162,8 +274,6 @@ int ndt_enqueue_pass(lsa_ndt *h, const PassParams &P, int kind, bool reduce) {
 // second stage runs on the host as the rows arrive, which removes a kernel launch, a copy and the stream wait from every
 // pass (cfg2: ~10 us of ~25; cfg4, 768 rows: 44 -> 35 us per pass).  The summation order is the one k_reduce_partials
 // uses, so both paths give the same bits.  1024 rows covers every grid ndt_pass_grid() produces (<= 256 CUs x 4).
-constexpr unsigned kHostReduceMaxBlocks = 1024;
-
 bool ndt_pass_host_reduce(const lsa_ndt *h, int kind) { return !h->allreduce && ndt_pass_grid(h, h->n_source, kind) <= kHostReduceMaxBlocks; }
 
 int ndt_enqueue_pass_host(lsa_ndt *h, const PassParams &P, int kind, unsigned *grid_out, unsigned long long *key_out) {

@@ -66,6 +66,15 @@ struct lsa_ndt {
   DevBuf<unsigned long long> align_stamps;  // diagnostics (lsa_ndt_align_stamps)
   bool align_stamps_on = false;
 
+  // armed passes (ndt_derivatives.hip): the next pass's kernel waits on the device for its parameters
+  void *mail = nullptr;             // PassMail in fine-grained device memory, written by the host through the BAR
+  bool mail_tried = false, mail_is_device = false;
+  bool no_armed = getenv("LSA_NO_ARMED") != nullptr;   // lsa_ndt_set_armed
+  bool armed_scope = false;         // inside a ScanMatch whose passes are all of kind 0 (line search dead, single GPU)
+  bool armed_outstanding = false;   // a kernel for pass `armed_seq` is enqueued and waiting for its mail
+  unsigned long long armed_seq = 1;
+  unsigned long long armed_passes = 0, armed_cancels = 0;
+
   // multi-GPU
   lsa_allreduce_fn allreduce = nullptr;
   void *allreduce_user = nullptr;

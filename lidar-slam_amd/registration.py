@@ -128,6 +128,15 @@ class NDTRegistrationHip(RegistrationInterface):
         self.ctx.check(capi.lib().lsa_ndt_derivatives_timed(self.h, capi.fptr(Tc), capi.dptr(p), kind, repeat, capi.dptr(out), C.byref(ms)))
         return unpack_out32(out), ms.value
 
+    def set_armed(self, on):
+        """Armed passes (default on): the next pass's kernel is enqueued ahead and waits on the device for its parameters."""
+        self.ctx.check(capi.lib().lsa_ndt_set_armed(self.h, 1 if on else 0))
+
+    def armed_counters(self):
+        a, b = C.c_uint64(0), C.c_uint64(0)
+        self.ctx.check(capi.lib().lsa_ndt_armed_counters(self.h, C.byref(a), C.byref(b)))
+        return dict(passes=a.value, cancels=b.value)
+
     def set_persistent(self, on):
         """ScanMatch as ONE persistent launch (default) or one launch per derivative pass (lsa_ndt_set_persistent)."""
         self.ctx.check(capi.lib().lsa_ndt_set_persistent(self.h, 1 if on else 0))

@@ -147,3 +147,47 @@ def test_persistent_path_limits(ctx, scan_pair):
     n.ScanMatch(torch.from_numpy(s1).cuda(), np.eye(4, dtype=np.float32))
     assert n.align_counters() == dict(launches=0, fallbacks=0)
     n.close()
+
+
+def test_armed_passes_equal_ordinary_launches(ctx, cfg2):
+    """Armed passes (the next pass's kernel enqueued ahead, parameters posted into a device mailbox) against the ordinary
+    launch per pass: bit-identical poses and statistics on the bench scans, one cancelled kernel per ScanMatch, and the
+    single-pass entry point (lsa_ndt_derivatives) never leaves a kernel parked."""
+    n = registration.NDTRegistrationHip(ctx, **wl.NDT_PARAMS)
+    n.SetInputTarget(cfg2["d_map_f"])
+    t_on, t_off = [], []
+    for rep in range(3):
+        for d_s, guess in zip(cfg2["d_src"], cfg2["guesses"]):
+            n.set_armed(True)
+            c0 = n.armed_counters()
+            t0 = time.perf_counter()
+            _, Ta = n.ScanMatch(d_s, guess)
+            t_on.append(time.perf_counter() - t0)
+            sa = dict(n.last_stats)
+            c1 = n.armed_counters()
+            assert c1["passes"] - c0["passes"] == sa["passes"] and c1["cancels"] - c0["cancels"] == 1
+            n.set_armed(False)
+            t0 = time.perf_counter()
+            _, Tb = n.ScanMatch(d_s, guess)
+            t_off.append(time.perf_counter() - t0)
+            sb = dict(n.last_stats)
+            assert n.armed_counters() == c1
+            assert np.array_equal(Ta, Tb) and _same_stats(sa, sb), (sa, sb)
+    print("armed %.1f us / ordinary %.1f us per ScanMatch (median of %d)" % (np.median(t_on) * 1e6, np.median(t_off) * 1e6, len(t_on)))
+    # a single derivative pass through the API is never armed, and works right after an armed ScanMatch
+    n.set_armed(True)
+    n.ScanMatch(cfg2["d_src"][0], cfg2["guesses"][0])
+    c = n.armed_counters()
+    p = np.array(n.last_stats["final_p"])
+    n.set_source(cfg2["d_src"][0])
+    a = n.derivatives(cfg2["guesses"][0], p, 0)
+    b = n.derivatives(cfg2["guesses"][0], p, 0)
+    assert a[0] == b[0] and n.armed_counters() == c
+    # changing the source size between armed ScanMatches (another grid) is fine
+    for d_s, guess in zip(cfg2["d_src"][:3], cfg2["guesses"][:3]):
+        _, T1 = n.ScanMatch(d_s[: d_s.shape[0] // 2], guess)
+        n.set_armed(False)
+        _, T2 = n.ScanMatch(d_s[: d_s.shape[0] // 2], guess)
+        n.set_armed(True)
+        assert np.array_equal(T1, T2)
+    n.close()
