@@ -147,7 +147,7 @@ extern "C" int lsa_box_filter_create(lsa_box_filter **out, lsa_context *ctx, con
 
 extern "C" void lsa_box_filter_destroy(lsa_box_filter *f) {
   if (!f) return;
-  (void)hipSetDevice(f->ctx->device);
+  (void)lsa_enter(f->ctx);
   (void)hipStreamSynchronize(f->ctx->stream);
   f->d_in.release(); f->d_out.release(); f->block_cnt.release(); f->d_total.release(); f->h_total.release(); f->h_stage.release();
   delete f;
@@ -176,7 +176,7 @@ extern "C" int lsa_box_filter_get_edge(lsa_box_filter *f, float edge[6]) {
 extern "C" int lsa_box_filter_apply_device(lsa_box_filter *f, const float *d_in_xyzw, size_t n, float *d_out_xyzw, size_t *n_out) {
   if (!f || !n_out || (n && (!d_in_xyzw || !d_out_xyzw))) return f ? lsa_fail(f->ctx, LSA_ERR_INVALID, "lsa_box_filter_apply_device: null argument") : LSA_ERR_INVALID;
   if (n && d_in_xyzw == d_out_xyzw) return lsa_fail(f->ctx, LSA_ERR_INVALID, "lsa_box_filter_apply_device: in-place not supported on device buffers");
-  LSA_HIP(f->ctx, hipSetDevice(f->ctx->device));
+  LSA_HIP(f->ctx, lsa_enter(f->ctx));
   return box_device(f, (const float4 *)d_in_xyzw, n, (float4 *)d_out_xyzw, n_out);
 }
 
@@ -187,7 +187,7 @@ extern "C" int lsa_box_filter_apply(lsa_box_filter *f, const void *in_pts, size_
   *n_out = 0;
   if (n == 0) return LSA_OK;
   if (in_stride < 12 || out_stride < 12) return lsa_fail(ctx, LSA_ERR_INVALID, "lsa_box_filter_apply: stride < 12");
-  LSA_HIP(ctx, hipSetDevice(ctx->device));
+  LSA_HIP(ctx, lsa_enter(ctx));
   int rc;
   // the staging buffer may still be feeding an earlier async copy, and growing a buffer frees the old one: wait first
   LSA_HIP(ctx, hipStreamSynchronize(ctx->stream));

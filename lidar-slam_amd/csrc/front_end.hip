@@ -266,7 +266,7 @@ extern "C" int lsa_front_end_create(lsa_front_end **out, lsa_context *ctx, const
 
 extern "C" void lsa_front_end_destroy(lsa_front_end *fe) {
   if (!fe) return;
-  (void)hipSetDevice(fe->ctx->device);
+  (void)lsa_enter(fe->ctx);
   (void)hipStreamSynchronize(fe->ctx->stream);
   for (KeyFrame *f : fe->frames) { f->pts.release(); delete f; }
   for (KeyFrame *f : fe->pool) { f->pts.release(); delete f; }
@@ -285,7 +285,7 @@ extern "C" int lsa_front_end_set_init_pose(lsa_front_end *fe, const float pose[1
 
 extern "C" int lsa_front_end_update_device(lsa_front_end *fe, const float *d_xyzw, size_t n, float pose_out[16], lsa_front_end_stats *stats) {
   if (!fe || !pose_out || (n && !d_xyzw)) return fe ? lsa_fail(fe->ctx, LSA_ERR_INVALID, "lsa_front_end_update_device: null argument") : LSA_ERR_INVALID;
-  LSA_HIP(fe->ctx, hipSetDevice(fe->ctx->device));
+  LSA_HIP(fe->ctx, lsa_enter(fe->ctx));
   return fe_update_device(fe, (const float4 *)d_xyzw, n, pose_out, stats);
 }
 
@@ -293,7 +293,7 @@ extern "C" int lsa_front_end_update(lsa_front_end *fe, const void *cloud, size_t
                                     lsa_front_end_stats *stats) {
   if (!fe || !pose_out || (n && (!cloud || stride < 12))) return fe ? lsa_fail(fe->ctx, LSA_ERR_INVALID, "lsa_front_end_update: bad argument") : LSA_ERR_INVALID;
   lsa_context *ctx = fe->ctx;
-  LSA_HIP(ctx, hipSetDevice(ctx->device));
+  LSA_HIP(ctx, lsa_enter(ctx));
   int rc;
   LSA_HIP(ctx, hipStreamSynchronize(ctx->stream));  // before the reserves: they may free a buffer an earlier copy still reads
   if ((rc = fe->h_stage.reserve(ctx, (n ? n : 1) * 4))) return rc;

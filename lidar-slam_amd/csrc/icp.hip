@@ -386,7 +386,7 @@ struct lsa_icp {
 namespace {
 int icp_check(lsa_icp *h) {
   if (!h) return LSA_ERR_INVALID;
-  hipError_t e = hipSetDevice(h->ctx->device);
+  hipError_t e = lsa_enter(h->ctx);
   if (e != hipSuccess) return lsa_fail(h->ctx, LSA_ERR_NO_DEVICE, "hipSetDevice(%d): %s", h->ctx->device, hipGetErrorString(e));
   return LSA_OK;
 }
@@ -725,7 +725,7 @@ extern "C" int lsa_icp_get_stats(lsa_icp *h, lsa_icp_stats *st) {
 
 extern "C" void lsa_icp_destroy(lsa_icp *h) {
   if (!h) return;
-  (void)hipSetDevice(h->ctx->device);
+  (void)lsa_enter(h->ctx);
   (void)hipStreamSynchronize(h->ctx->stream);
   h->grid.release(); h->vi_n.release(); h->cell_normals.release(); h->slot_normals.release(); h->d_target.release(); h->d_source_own.release(); h->d_work.release();
   h->partials.release(); h->d_out.release(); h->h_out.release(); h->h_partials.release(); h->h_stage.release(); h->prev.release();

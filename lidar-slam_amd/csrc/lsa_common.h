@@ -19,7 +19,20 @@ struct lsa_context {
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   int num_cus = 256;
   std::string err;
+  // A handle may leave a kernel PARKED on this context's stream between two calls (an armed NDT pass waiting for the next
+  // ScanMatch's parameters, ndt_api.hip).  Everything else that is about to use the stream releases it first.
+  void (*unpark)(void *) = nullptr;
+  void *unpark_arg = nullptr;
 };
+
+inline void lsa_ctx_unpark(lsa_context *ctx, const void *except = nullptr) {
+  if (ctx->unpark && ctx->unpark_arg != except) ctx->unpark(ctx->unpark_arg);
+}
+// entry of every public call that touches the stream: release a parked kernel, select the device
+inline hipError_t lsa_enter(lsa_context *ctx) {
+  lsa_ctx_unpark(ctx);
+  return hipSetDevice(ctx->device);
+}
 
 void lsa_set_global_error(const char *fmt, ...);
 int lsa_fail(lsa_context *ctx, int code, const char *fmt, ...);

@@ -113,7 +113,7 @@ extern "C" int lsa_context_create(lsa_context **out, int device, void *hip_strea
 
 extern "C" void lsa_context_destroy(lsa_context *ctx) {
   if (!ctx) return;
-  (void)hipSetDevice(ctx->device);
+  (void)lsa_enter(ctx);
   (void)hipStreamSynchronize(ctx->stream);
   if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
   if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
@@ -125,7 +125,7 @@ extern "C" void *lsa_context_stream(lsa_context *ctx) { return ctx ? (void *)ctx
 
 extern "C" int lsa_context_synchronize(lsa_context *ctx) {
   if (!ctx) return LSA_ERR_INVALID;
-  LSA_HIP(ctx, hipSetDevice(ctx->device));
+  LSA_HIP(ctx, lsa_enter(ctx));
   LSA_HIP(ctx, hipStreamSynchronize(ctx->stream));
   return LSA_OK;
 }

@@ -264,7 +264,7 @@ __global__ __launch_bounds__(kBlockD, 1) void k_ndt_align(const float4 *__restri
   __syncthreads();
   for (unsigned pass = 0;; pass++) {
     ALIGN_STAMP(0);
-    const double v = ndt_pass_body<0, DENSE>(src, n, P, Tl, jh, words, dense, rec, lds);
+    const double v = ndt_pass_body<0, DENSE>(src, n, P, Tl, jh, words, dense, rec, lds, gridDim.x);
     ALIGN_STAMP(1);
     // ---- publish this workgroup's row, then wait for everybody's
     const unsigned epoch = A.epoch0 + pass + 1u;
@@ -491,7 +491,7 @@ __global__ __launch_bounds__(64) void k_gn_selftest(uint64_t seed, size_t n, Sel
 
 extern "C" int lsa_gn_math_selftest(lsa_context *ctx, size_t n, uint64_t seed, uint64_t mismatches[5]) {
   if (!ctx || !mismatches || n == 0 || n > (1u << 20)) return ctx ? lsa_fail(ctx, LSA_ERR_INVALID, "lsa_gn_math_selftest: bad argument") : LSA_ERR_INVALID;
-  LSA_HIP(ctx, hipSetDevice(ctx->device));
+  LSA_HIP(ctx, lsa_enter(ctx));
   SelfOut *d = nullptr;
   LSA_HIP(ctx, hipMalloc((void **)&d, n * sizeof(SelfOut)));
   hipLaunchKernelGGL(k_gn_selftest, dim3((unsigned)n), dim3(64), 0, ctx->stream, seed, n, d);

@@ -42,11 +42,22 @@ int mail_ensure(lsa_ndt *h) {
 }
 
 void armed_cancel(lsa_ndt *h) {
+  if (h->ctx->unpark_arg == h) { h->ctx->unpark = nullptr; h->ctx->unpark_arg = nullptr; }
   if (!h->armed_outstanding) return;
-  ndt_mail_post(reinterpret_cast<PassMail *>(h->mail), nullptr, h->armed_seq, true);
+  ndt_mail_post(reinterpret_cast<PassMail *>(h->mail), nullptr, h->armed_seq, true, nullptr, 0, 0);
   h->armed_outstanding = false;
   h->armed_seq++;
   h->armed_cancels++;
+}
+void armed_cancel_cb(void *user) { armed_cancel((lsa_ndt *)user); }
+
+constexpr double kArmedPatienceUs = 300.0;   // how long an armed kernel waits for its mail before it leaves by itself
+
+// launch grid of an armed kernel for a pass that needs g workgroups: a quarter more, so that the kernel left parked at the
+// end of a ScanMatch also fits the next scan's (slightly different) source size
+unsigned armed_headroom(const lsa_ndt *h, unsigned g) {
+  unsigned cap = (unsigned)h->ctx->num_cus * 3u, want = g + g / 4 + 2;
+  return want < cap ? want : (g < cap ? cap : g);
 }
 
 // one pass, synchronous: kernel(s) -> [all-reduce] -> D2H of 32 doubles
@@ -56,32 +67,40 @@ int run_pass(lsa_ndt *h, const float T[16], const double p[6], int kind, double 
   ndt_make_pass_params(h, T, p, &P);
   int rc;
   if (h->armed_scope && kind == 0 && h->mail && ndt_pass_host_reduce(h, 0)) {
-    // armed: this pass's kernel is already waiting on the device (or is launched now, for the first pass of a ScanMatch);
-    // post its parameters, enqueue the kernel of the NEXT pass behind it, then take the rows as they arrive
-    const unsigned long long seq = h->armed_seq;
-    if (!h->armed_outstanding && (rc = ndt_launch_armed(h, P, seq))) return rc;
-    ndt_mail_post(reinterpret_cast<PassMail *>(h->mail), &P, seq, false);
+    // armed: this pass's kernel is already waiting on the device — enqueued behind the previous pass, or left parked by
+    // the previous ScanMatch — or is launched now; post its parameters, enqueue the kernel of the NEXT pass behind it, then
+    // take the rows as they arrive
+    const unsigned g = ndt_pass_grid(h, h->n_source, 0);
+    volatile unsigned long long *gave_up = h->h_gave_up.p ? reinterpret_cast<volatile unsigned long long *>(h->h_gave_up.p) : nullptr;
+    if (h->armed_outstanding && (h->armed_grid < g || h->armed_gen != h->target_gen || (gave_up && *gave_up == h->armed_seq)))
+      armed_cancel(h);   // parked for another table / too small a grid, or it has already left: not usable
+    unsigned long long seq = h->armed_seq;
+    if (!h->armed_outstanding) {
+      if ((rc = ndt_launch_armed(h, P, seq, armed_headroom(h, g), kArmedPatienceUs))) return rc;
+      gave_up = reinterpret_cast<volatile unsigned long long *>(h->h_gave_up.p);
+    }
+    ndt_mail_post(reinterpret_cast<PassMail *>(h->mail), &P, seq, false, h->d_source, h->n_source, g);
     h->armed_seq = seq + 1;
     h->armed_outstanding = false;
-    if ((rc = ndt_launch_armed(h, P, seq + 1))) return rc;
+    if ((rc = ndt_launch_armed(h, P, seq + 1, armed_headroom(h, g), kArmedPatienceUs))) return rc;
     h->armed_outstanding = true;
+    h->armed_grid = armed_headroom(h, g);
+    h->armed_gen = h->target_gen;
     h->armed_passes++;
-    const unsigned g = ndt_pass_grid(h, h->n_source, 0);
-    bool ok = !h->no_row_polling && ndt_reduce_partials_host(h->h_partials.p, g, ndt_armed_row_key(seq), 20.0, out32);
+    bool ok = !h->no_row_polling && ndt_reduce_partials_host(h->h_partials.p, g, ndt_armed_row_key(seq), 20.0, out32, gave_up, seq);
     if (!ok) {
-      // rows missing (the host thread was held up for longer than the kernel's 20 ms patience, or polling is switched
-      // off): let everything enqueued drain, look again, and if the pass really did not run do it the ordinary way — and
-      // stay unarmed for the rest of this ScanMatch
+      // rows missing — the kernel's patience ran out before the mail came (this thread was held up), or polling is switched
+      // off: let everything enqueued drain, look again, and if the pass really did not run do it the ordinary way, unarmed
+      // for the rest of this ScanMatch
       armed_cancel(h);
       LSA_HIP(ctx, hipStreamSynchronize(ctx->stream));
       h->unsynced = 0;
       if (ndt_reduce_partials_host(h->h_partials.p, g, ndt_armed_row_key(seq), 0.0, out32)) return LSA_OK;
       h->armed_scope = false;
+      h->armed_fallbacks++;
       return run_pass(h, T, p, kind, out32);
-    } else if ((h->unsynced += 2) >= 256) {
-      // (not a wait for the armed kernel: it is parked until its mail comes, so only every so often, between ScanMatches)
-      h->unsynced = 256;
     }
+    h->unsynced += 2;
     return LSA_OK;
   }
   if (ndt_pass_host_reduce(h, kind)) {
@@ -122,6 +141,15 @@ int eval_trampoline(void *user, const float T[16], const double p[6], int kind, 
 
 int check(lsa_ndt *h) {
   if (!h) return LSA_ERR_INVALID;
+  hipError_t e = lsa_enter(h->ctx);
+  if (e != hipSuccess) return lsa_fail(h->ctx, LSA_ERR_NO_DEVICE, "hipSetDevice(%d): %s", h->ctx->device, hipGetErrorString(e));
+  return LSA_OK;
+}
+
+// entry of the ScanMatch calls: like check(), but a kernel this very handle left parked stays (the call is what it waits for)
+int check_keep(lsa_ndt *h) {
+  if (!h) return LSA_ERR_INVALID;
+  lsa_ctx_unpark(h->ctx, h);
   hipError_t e = hipSetDevice(h->ctx->device);
   if (e != hipSuccess) return lsa_fail(h->ctx, LSA_ERR_NO_DEVICE, "hipSetDevice(%d): %s", h->ctx->device, hipGetErrorString(e));
   return LSA_OK;
@@ -151,11 +179,21 @@ int scan_match_common(lsa_ndt *h, const float predict_pose[16], float result_pos
   rc = lsa_gn_solve_trace(eval_trampoline, h, h->resolution, h->step_size, h->trans_eps, h->max_iter, h->outlier_ratio, h->mode, predict_pose, result_pose, &st,
                               h->trace_rows, h->trace_cap, h->trace_n);
   if (h->armed_scope) {
-    armed_cancel(h);  // the kernel enqueued for a pass that never came leaves at once
     h->armed_scope = false;
-    if (h->unsynced >= 256) {  // let the runtime retire its commands now and then (nothing is parked on the device any more)
-      (void)hipStreamSynchronize(ctx->stream);
-      h->unsynced = 0;
+    // The kernel enqueued for the pass that never came: cancelled — or, when scans follow each other on this handle and
+    // nothing else uses the stream in between (lsa_pipeline_scan_match), left PARKED for the first pass of the next
+    // ScanMatch (it reads source pointer, size and grid from its mail), whose launch + dispatch latency it then saves.  It
+    // leaves by itself after kArmedPatienceUs; any other call on this context releases it first (lsa_enter).
+    if (rc || !h->armed_carry || h->unsynced >= 256) {
+      armed_cancel(h);
+      if (h->unsynced >= 256) {  // let the runtime retire its commands now and then (nothing is parked any more)
+        (void)hipStreamSynchronize(ctx->stream);
+        h->unsynced = 0;
+      }
+    } else if (h->armed_outstanding) {
+      lsa_ctx_unpark(ctx, h);
+      ctx->unpark = armed_cancel_cb;
+      ctx->unpark_arg = h;
     }
   }
   if (rc) return rc;
@@ -181,28 +219,32 @@ extern "C" int lsa_ndt_create(lsa_ndt **out, lsa_context *ctx, float res, float 
 extern "C" int lsa_ndt_set_mode(lsa_ndt *h, int mode) {
   if (!h) return LSA_ERR_INVALID;
   if (mode != LSA_NDT_MODE_MANUAL && mode != LSA_NDT_MODE_PCL) return lsa_fail(h->ctx, LSA_ERR_INVALID, "lsa_ndt_set_mode: unknown mode %d", mode);
-  if (mode != h->mode) { h->has_target = false; h->has_result = false; }  // the voxel table depends on the mode
+  lsa_ctx_unpark(h->ctx);
+  if (mode != h->mode) { h->has_target = false; h->has_result = false; h->target_gen++; }  // the voxel table depends on the mode
   h->mode = mode;
   return LSA_OK;
 }
 
 extern "C" int lsa_ndt_set_dense_limit(lsa_ndt *h, long long max_cells) {
   if (!h) return LSA_ERR_INVALID;
+  lsa_ctx_unpark(h->ctx);
   h->dense_max_cells = max_cells < 0 ? 0 : max_cells;
   h->has_target = false;  // the probe structure is chosen when the table is built
+  h->target_gen++;
   return LSA_OK;
 }
 
 extern "C" void lsa_ndt_destroy(lsa_ndt *h) {
   if (!h) return;
-  (void)hipSetDevice(h->ctx->device);
+  (void)lsa_enter(h->ctx);
+  armed_cancel(h);
   (void)hipStreamSynchronize(h->ctx->stream);
   ndt_fitness_release(h);
   h->nn.release();
   h->vi.release(); h->d_target.release(); h->rec.release(); h->state.release(); h->vbits.release(); h->words.release(); h->d_small.release(); h->counts.release();
   h->dense.release();
   if (h->mail) { if (h->mail_is_device) (void)hipFree(h->mail); else (void)hipHostFree(h->mail); }
-  h->align_rows.release(); h->align_flags.release(); h->h_result.release(); h->align_stamps.release();
+  h->align_rows.release(); h->align_flags.release(); h->h_result.release(); h->align_stamps.release(); h->h_gave_up.release();
   h->d_source_own.release(); h->h_stage.release(); h->partials.release(); h->d_out.release(); h->h_out.release(); h->h_partials.release();
   delete h;
 }
@@ -212,6 +254,7 @@ extern "C" int lsa_ndt_set_input_target_device(lsa_ndt *h, const float *d_xyzw, 
   if (rc) return rc;
   if (n == 0) return LSA_OK;  // setInputTarget ignores an empty cloud (NormalDistributionsTransform.cpp:94)
   if (!d_xyzw) return lsa_fail(h->ctx, LSA_ERR_INVALID, "set_input_target: null points");
+  h->target_gen++;
   return ndt_build_grid(h, (const float4 *)d_xyzw, n);
 }
 
@@ -221,6 +264,7 @@ extern "C" int lsa_ndt_set_input_target(lsa_ndt *h, const void *pts, size_t n, s
   if (n == 0) return LSA_OK;
   if (!pts || stride < 12) return lsa_fail(h->ctx, LSA_ERR_INVALID, "set_input_target: bad points / stride");
   if ((rc = upload_points(h, pts, n, stride, w_off, h->d_target))) return rc;
+  h->target_gen++;
   return ndt_build_grid(h, h->d_target.p, n);
 }
 
@@ -283,8 +327,11 @@ extern "C" int lsa_ndt_derivatives_timed(lsa_ndt *h, const float T[16], const do
 
 extern "C" int lsa_ndt_scan_match_device(lsa_ndt *h, const float *d_src_xyzw, size_t n, const float predict_pose[16], float result_pose[16],
                                          lsa_ndt_stats *stats) {
-  int rc = lsa_ndt_set_source_device(h, d_src_xyzw, n);
+  int rc = check_keep(h);  // a kernel this handle left parked for exactly this call stays
   if (rc) return rc;
+  if (n && !d_src_xyzw) return lsa_fail(h->ctx, LSA_ERR_INVALID, "ScanMatch: null points");
+  h->d_source = (const float4 *)d_src_xyzw;
+  h->n_source = n;
   if (!predict_pose || !result_pose) return lsa_fail(h->ctx, LSA_ERR_INVALID, "ScanMatch: null pose");
   return scan_match_common(h, predict_pose, result_pose, stats);
 }
@@ -314,6 +361,7 @@ extern "C" int lsa_ndt_get_fitness_score(lsa_ndt *h, float *score) {
 
 extern "C" int lsa_ndt_set_armed(lsa_ndt *h, int on) {
   if (!h) return LSA_ERR_INVALID;
+  lsa_ctx_unpark(h->ctx);
   h->no_armed = !on;
   return LSA_OK;
 }
@@ -322,6 +370,13 @@ extern "C" int lsa_ndt_armed_counters(lsa_ndt *h, uint64_t *passes, uint64_t *ca
   if (!h) return LSA_ERR_INVALID;
   if (passes) *passes = h->armed_passes;
   if (cancels) *cancels = h->armed_cancels;
+  return LSA_OK;
+}
+
+extern "C" int lsa_ndt_set_armed_carry(lsa_ndt *h, int on) {
+  if (!h) return LSA_ERR_INVALID;
+  lsa_ctx_unpark(h->ctx);
+  h->armed_carry = on != 0;
   return LSA_OK;
 }
 

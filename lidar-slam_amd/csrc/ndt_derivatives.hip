@@ -35,7 +35,7 @@ __global__ __launch_bounds__(kBlockD, pass_waves(KIND)) void k_ndt_pass(const fl
   if (threadIdx.x < 69) jh[threadIdx.x] = (&P.ja[0][0])[threadIdx.x];
   else if (threadIdx.x < 69 + 12) Tl[threadIdx.x - 69] = P.T[threadIdx.x - 69];
   __syncthreads();
-  const double v = ndt_pass_body<KIND, DENSE>(src, n, P, Tl, jh, words, dense, rec, lds);
+  const double v = ndt_pass_body<KIND, DENSE>(src, n, P, Tl, jh, words, dense, rec, lds, gridDim.x);
   // one 256-byte row per workgroup, written once (check-worded when it goes straight to the host)
   if (threadIdx.x < kOutDoubles) lsa_store_row32(partials + (size_t)blockIdx.x * kOutDoubles, (int)threadIdx.x, v, key);
 }
@@ -57,7 +57,7 @@ constexpr unsigned kHostReduceMaxBlocks = 1024;
 // 20 ms timeout makes the kernel exit without writing its row.  Same body, same grid, same rows: the results are the bits
 // of the unarmed path.
 struct PassMail {
-  unsigned long long words[76];   // [0..5] the 12 floats of T, [6..74] jh (ja then ha), [75] unused
+  unsigned long long words[80];   // [0..5] the 12 floats of T, [6..74] jh (ja then ha), [75] virtual grid, [76] source pointer, [77] #points
   unsigned long long check;       // key(seq) ^ XOR_c rotl(word_c, c % 31 + 1)
   unsigned long long seq;         // sequence number of the pass these parameters are for; | kMailCancel: that pass is cancelled
 };
@@ -66,12 +66,14 @@ __host__ __device__ inline unsigned long long mail_key(unsigned long long seq) {
 
 namespace {
 template <bool DENSE>
-__global__ __launch_bounds__(kBlockD, pass_waves(0)) void k_ndt_pass_armed(const float4 *__restrict__ src, size_t n, PassParams P, const uint4 *__restrict__ words,
-                                                                         const float4 *__restrict__ dense, const double *__restrict__ rec,
-                                                                         double *__restrict__ partials, const PassMail *mail, unsigned long long seq) {
+__global__ __launch_bounds__(kBlockD, pass_waves(0)) void k_ndt_pass_armed(PassParams P, const uint4 *__restrict__ words, const float4 *__restrict__ dense,
+                                                                         const double *__restrict__ rec, double *__restrict__ partials, const PassMail *mail,
+                                                                         unsigned long long seq, unsigned long long patience_ticks,
+                                                                         unsigned long long *gave_up /* host-mapped */) {
   constexpr int NB = 2;
   __shared__ __align__(16) unsigned char lds[lds_bytes(NB)];
   __shared__ int s_go;
+  __shared__ unsigned long long s_dyn[3];   // virtual grid, source pointer, #points
   double *jh = reinterpret_cast<double *>(lds + lds_const(NB));
   float *Tl = reinterpret_cast<float *>(lds + lds_tl(NB));
   const int tid = (int)threadIdx.x, lane = tid & 63;
@@ -84,65 +86,81 @@ __global__ __launch_bounds__(kBlockD, pass_waves(0)) void k_ndt_pass_armed(const
       if ((sq & ~kMailCancel) > seq || sq == (seq | kMailCancel)) break;  // cancelled, or the host has already moved on to a later pass
       if (sq == seq) {
         unsigned long long w0 = __hip_atomic_load(mw + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-        unsigned long long w1 = lane < 12 ? __hip_atomic_load(mw + 64 + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) : 0ull;
+        unsigned long long w1 = lane < 16 ? __hip_atomic_load(mw + 64 + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) : 0ull;
         const unsigned long long chk = __hip_atomic_load(&mail->check, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-        unsigned long long x = lsa_row_mix(w0, lane % 31) ^ (lane < 12 ? lsa_row_mix(w1, (64 + lane) % 31) : 0ull);
+        unsigned long long x = lsa_row_mix(w0, lane % 31) ^ (lane < 16 ? lsa_row_mix(w1, (64 + lane) % 31) : 0ull);
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) x ^= __shfl_xor(x, off, 64);
         if ((x ^ mail_key(seq)) == chk) {
-          unsigned long long *dstw = reinterpret_cast<unsigned long long *>(lds + lds_const(NB));   // jh[0..68] then, behind 72 doubles, Tl
+          unsigned long long *dstw = reinterpret_cast<unsigned long long *>(lds + lds_const(NB));   // jh[0..68]
           if (lane >= 6) dstw[lane - 6] = w0;                                       // jh[0..57]
           else reinterpret_cast<unsigned long long *>(Tl)[lane] = w0;               // T: 6 words = 12 floats
           if (lane < 11) dstw[58 + lane] = w1;                                      // jh[58..68]
+          else if (lane < 14) s_dyn[lane - 11] = w1;                                // words 75, 76, 77
           go = 1;
           break;
         }
       }
-      if (wall_clock64() - t0 > 2000000ull) break;  // 20 ms: nobody posted — leave (the host notices the missing rows)
+      if (wall_clock64() - t0 > patience_ticks) {  // nobody posted in time: leave, and tell the host so that it does not wait for rows
+        if (blockIdx.x == 0 && lane == 0) __hip_atomic_store(gave_up, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        break;
+      }
       __builtin_amdgcn_s_sleep(1);
     }
     if (lane == 0) s_go = go;
   }
   __syncthreads();
   if (!s_go) return;
-  const double v = ndt_pass_body<0, DENSE>(src, n, P, Tl, jh, words, dense, rec, lds);
+  const unsigned vgrid = (unsigned)s_dyn[0];
+  if (blockIdx.x >= vgrid) return;   // launched with head-room for a larger source than this pass has
+  const float4 *src = reinterpret_cast<const float4 *>(s_dyn[1]);
+  const size_t n = (size_t)s_dyn[2];
+  const double v = ndt_pass_body<0, DENSE>(src, n, P, Tl, jh, words, dense, rec, lds, vgrid);
   if (tid < kOutDoubles) lsa_store_row32(partials + (size_t)blockIdx.x * kOutDoubles, tid, v, mail_key(seq) | 1ull);
 }
 }  // namespace
 
 // host: post the dynamic parameters of pass `seq` (or its cancellation) into the mailbox
-void ndt_mail_post(PassMail *mail, const PassParams *P, unsigned long long seq, bool cancel) {
+void ndt_mail_post(PassMail *mail, const PassParams *P, unsigned long long seq, bool cancel, const void *d_src, size_t n, unsigned vgrid) {
   if (cancel) {
     __atomic_store_n(&mail->seq, seq | kMailCancel, __ATOMIC_RELEASE);
     _mm_sfence();
     return;
   }
-  unsigned long long w[76];
+  unsigned long long w[80];
   memset(w, 0, sizeof(w));
   memcpy(&w[0], P->T, 12 * sizeof(float));
   memcpy(&w[6], &P->ja[0][0], 24 * sizeof(double));
   memcpy(&w[30], &P->ha[0][0], 45 * sizeof(double));
+  w[75] = vgrid;
+  w[76] = (unsigned long long)(uintptr_t)d_src;
+  w[77] = (unsigned long long)n;
   unsigned long long x = 0;
-  for (int c = 0; c < 76; c++) x ^= lsa_row_mix(w[c], c % 31);
-  for (int c = 0; c < 76; c++) mail->words[c] = w[c];
+  for (int c = 0; c < 80; c++) x ^= lsa_row_mix(w[c], c % 31);
+  for (int c = 0; c < 80; c++) mail->words[c] = w[c];
   mail->check = x ^ mail_key(seq);
   _mm_sfence();   // payload before the sequence number (the BAR mapping may be write-combining)
   __atomic_store_n(&mail->seq, seq, __ATOMIC_RELEASE);
   _mm_sfence();
 }
 
-int ndt_launch_armed(lsa_ndt *h, const PassParams &P, unsigned long long seq) {
+// enqueue the kernel of pass `seq` with `grid` workgroups (>= the grid the pass will turn out to need: the mail names the
+// number that share the tiles, the others leave); it waits at most patience_us for its mail
+int ndt_launch_armed(lsa_ndt *h, const PassParams &P, unsigned long long seq, unsigned grid, double patience_us) {
   lsa_context *ctx = h->ctx;
-  unsigned g = ndt_pass_grid(h, h->n_source, 0);
   int rc;
   if ((rc = h->h_partials.reserve(ctx, (size_t)kHostReduceMaxBlocks * kOutDoubles))) return rc;
+  if (!h->h_gave_up.p) {
+    if ((rc = h->h_gave_up.reserve(ctx, 8))) return rc;
+    memset(h->h_gave_up.p, 0, 8 * sizeof(double));
+  }
   const PassMail *mail = reinterpret_cast<const PassMail *>(h->mail);
+  const unsigned long long ticks = (unsigned long long)(patience_us * 100.0);
+  unsigned long long *gu = reinterpret_cast<unsigned long long *>(h->h_gave_up.p);
   if (h->use_dense)
-    hipLaunchKernelGGL((k_ndt_pass_armed<true>), dim3(g), dim3(kBlockD), 0, ctx->stream, h->d_source, h->n_source, P, h->words.p, h->dense.p, h->rec.p,
-                       h->h_partials.p, mail, seq);
+    hipLaunchKernelGGL((k_ndt_pass_armed<true>), dim3(grid), dim3(kBlockD), 0, ctx->stream, P, h->words.p, h->dense.p, h->rec.p, h->h_partials.p, mail, seq, ticks, gu);
   else
-    hipLaunchKernelGGL((k_ndt_pass_armed<false>), dim3(g), dim3(kBlockD), 0, ctx->stream, h->d_source, h->n_source, P, h->words.p, h->dense.p, h->rec.p,
-                       h->h_partials.p, mail, seq);
+    hipLaunchKernelGGL((k_ndt_pass_armed<false>), dim3(grid), dim3(kBlockD), 0, ctx->stream, P, h->words.p, h->dense.p, h->rec.p, h->h_partials.p, mail, seq, ticks, gu);
   LSA_HIP(ctx, hipGetLastError());
   return LSA_OK;
 }
@@ -301,7 +319,8 @@ int ndt_enqueue_pass_host(lsa_ndt *h, const PassParams &P, int kind, unsigned *g
 // return false (the caller then waits for the stream the ordinary way and calls again).
 // One check-worded row out of host-mapped memory, taken as it ARRIVES: accepted once its check word matches (the kernel
 // may still be running, nothing waits for the stream).  false: the row did not show up within limit_ms.
-bool ndt_fetch_row_host(const double *row, unsigned long long key, double limit_ms, unsigned long long out32[32]) {
+bool ndt_fetch_row_host(const double *row, unsigned long long key, double limit_ms, unsigned long long out32[32], const volatile unsigned long long *abort_word,
+                        unsigned long long abort_value) {
   const volatile unsigned long long *wr = reinterpret_cast<const volatile unsigned long long *>(row);
   std::chrono::steady_clock::time_point t0;
   bool timing = false;
@@ -316,6 +335,7 @@ bool ndt_fetch_row_host(const double *row, unsigned long long key, double limit_
       return true;
     }
     if ((++spins & 63u) == 0u) {
+      if (abort_word && *abort_word == abort_value) return false;   // the producer has said that it will not deliver
       if (!timing) { t0 = std::chrono::steady_clock::now(); timing = true; }
       else if (std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count() > limit_ms) return false;
     }
@@ -323,7 +343,8 @@ bool ndt_fetch_row_host(const double *row, unsigned long long key, double limit_
   }
 }
 
-bool ndt_reduce_partials_host(const double *partials, unsigned nb, unsigned long long key, double limit_ms, double out32[32]) {
+bool ndt_reduce_partials_host(const double *partials, unsigned nb, unsigned long long key, double limit_ms, double out32[32],
+                              const volatile unsigned long long *abort_word, unsigned long long abort_value) {
   double sm[32][32];
   for (int rl = 0; rl < 32; rl++)
     for (int col = 0; col < 32; col++) sm[rl][col] = 0.0;
@@ -332,7 +353,7 @@ bool ndt_reduce_partials_host(const double *partials, unsigned nb, unsigned long
     double v[32];
     if (key) {
       unsigned long long w[32];
-      if (!ndt_fetch_row_host(row, key, limit_ms, w)) return false;  // the limit applies per row: a stalled kernel stalls at its first missing one
+      if (!ndt_fetch_row_host(row, key, limit_ms, w, abort_word, abort_value)) return false;  // the limit applies per row: a stalled kernel stalls at its first missing one
       memcpy(v, w, sizeof(v));
     } else {
       memcpy(v, row, sizeof(v));

@@ -73,7 +73,11 @@ struct lsa_ndt {
   bool armed_scope = false;         // inside a ScanMatch whose passes are all of kind 0 (line search dead, single GPU)
   bool armed_outstanding = false;   // a kernel for pass `armed_seq` is enqueued and waiting for its mail
   unsigned long long armed_seq = 1;
-  unsigned long long armed_passes = 0, armed_cancels = 0;
+  unsigned armed_grid = 0;          // launch grid of the outstanding kernel
+  unsigned long long armed_gen = 0, target_gen = 0;   // the voxel table it was launched for / the current one
+  bool armed_carry = getenv("LSA_NO_CARRY") == nullptr;   // leave the last armed kernel parked for the next ScanMatch
+  PinnedBuf<double> h_gave_up;      // [0]: sequence number of the last armed kernel that left because no mail came
+  unsigned long long armed_passes = 0, armed_cancels = 0, armed_fallbacks = 0;
 
   // multi-GPU
   lsa_allreduce_fn allreduce = nullptr;

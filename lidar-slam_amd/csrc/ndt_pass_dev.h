@@ -185,7 +185,8 @@ __device__ __forceinline__ unsigned wave_excl_scan(unsigned cnt, int lane, unsig
 template <int KIND, bool DENSE>
 __device__ __forceinline__ double ndt_pass_body(const float4 *__restrict__ src, size_t n, const PassParams &P, const float *Tl /* LDS: 3x4 row-major */,
                                                 const double *jh /* LDS: ja[8][3] then ha[15][3] */, const uint4 *__restrict__ words,
-                                                const float4 *__restrict__ dense, const double *__restrict__ rec, unsigned char *lds) {
+                                                const float4 *__restrict__ dense, const double *__restrict__ rec, unsigned char *lds,
+                                                unsigned vgrid /* workgroups sharing the tiles: gridDim.x, or fewer for an armed launch */) {
   constexpr int NB = pass_bufs(KIND);
   constexpr int kLdsSlice = lds_slice(NB), kLdsTerms = lds_terms(NB), kLdsCand = lds_cand(NB), kLdsQueue = lds_queue(NB), kLdsRed2 = lds_red2(NB);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -202,7 +203,7 @@ __device__ __forceinline__ double ndt_pass_body(const float4 *__restrict__ src, 
   const int part4 = lane / kTilePts, ppl = lane - part4 * kTilePts;  // phase 0: 4 lanes per point (part4 == 4: the spare lanes 56..63)
   const int dimx = P.dim[0], dimxy = P.dim[0] * P.dim[1];
   const size_t ntiles = (n + kTilePts - 1) / kTilePts;
-  const size_t tile0 = (size_t)blockIdx.x * kWaves + wave, tstride = (size_t)gridDim.x * kWaves;
+  const size_t tile0 = (size_t)blockIdx.x * kWaves + wave, tstride = (size_t)vgrid * kWaves;
   // jh = ja[8][3] followed by ha[15][3]: 23 constant 3-vectors.  Phase 0 indexes them per LANE (each of the 4 lanes of a
   // point owns 6 of the 23 terms), which kernel arguments cannot do without turning into per-lane global loads: the
   // caller has staged them (and the rigid transform) in LDS.

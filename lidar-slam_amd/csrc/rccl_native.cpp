@@ -75,7 +75,7 @@ extern "C" int lsa_rccl_comm_create(lsa_rccl_comm **out, lsa_context *ctx, const
   *out = nullptr;
   Api &a = api();
   if (!a.err.empty()) return lsa_fail(ctx, LSA_ERR_COLLECTIVE, "%s", a.err.c_str());
-  LSA_HIP(ctx, hipSetDevice(ctx->device));
+  LSA_HIP(ctx, lsa_enter(ctx));
   NcclUniqueId id;
   memcpy(id.internal, id128, sizeof(id.internal));
   NcclComm comm = nullptr;
@@ -89,7 +89,7 @@ extern "C" int lsa_rccl_comm_create(lsa_rccl_comm **out, lsa_context *ctx, const
 
 extern "C" void lsa_rccl_comm_destroy(lsa_rccl_comm *c) {
   if (!c) return;
-  (void)hipSetDevice(c->ctx->device);
+  (void)lsa_enter(c->ctx);
   (void)hipStreamSynchronize(c->ctx->stream);
   Api &a = api();
   if (a.CommDestroy && c->comm) (void)a.CommDestroy(c->comm);
@@ -125,6 +125,6 @@ extern "C" int lsa_ndt_set_allreduce_rccl(lsa_ndt *ndt, lsa_rccl_comm *comm) {
 // call the NDT passes make, exposed for self-tests and for reducing other per-rank blocks (ICP's 32 doubles)
 extern "C" int lsa_rccl_allreduce_f64(lsa_rccl_comm *c, void *d_buf, size_t n) {
   if (!c || !d_buf) return LSA_ERR_INVALID;
-  LSA_HIP(c->ctx, hipSetDevice(c->ctx->device));
+  LSA_HIP(c->ctx, lsa_enter(c->ctx));
   return rccl_allreduce_cb(c, d_buf, n, (void *)c->ctx->stream) == 0 ? LSA_OK : LSA_ERR_COLLECTIVE;
 }

@@ -172,6 +172,7 @@ void filter_post_job(lsa_voxel_filter *f, int kind) {
 extern "C" int lsa_voxel_filter_apply_device_async(lsa_voxel_filter *f, const float *d_in_xyzw, size_t n, float *d_out_xyzw) {
   if (!f || (n && (!d_in_xyzw || !d_out_xyzw))) return f ? lsa_fail(f->ctx, LSA_ERR_INVALID, "lsa_voxel_filter_apply_device_async: null argument") : LSA_ERR_INVALID;
   if (f->pending) return lsa_fail(f->ctx, LSA_ERR_INVALID, "lsa_voxel_filter_apply_device_async: a filter is already in flight on this handle");
+  lsa_ctx_unpark(f->ctx);  // the helper thread enqueues on this context's stream
   f->p_in = (const float4 *)d_in_xyzw; f->p_out = (float4 *)d_out_xyzw; f->p_n = n;
   f->pending = true;
   if (n == 0) return LSA_OK;
@@ -185,7 +186,7 @@ extern "C" int lsa_voxel_filter_wait(lsa_voxel_filter *f, size_t *n_out) {
   f->pending = false;
   *n_out = 0;
   if (f->p_n == 0) return LSA_OK;
-  LSA_HIP(f->ctx, hipSetDevice(f->ctx->device));
+  LSA_HIP(f->ctx, lsa_enter(f->ctx));
   while (f->job_state.load(std::memory_order_acquire) != 2) {}  // the helper is still issuing the launches (<= ~30 us)
   f->job_state.store(0, std::memory_order_release);
   if (f->job_rc) return f->job_rc;
@@ -223,7 +224,7 @@ extern "C" void lsa_voxel_filter_destroy(lsa_voxel_filter *f) {
     f->cv.notify_one();
     f->worker.join();
   }
-  (void)hipSetDevice(f->ctx->device);
+  (void)lsa_enter(f->ctx);
   (void)hipStreamSynchronize(f->ctx->stream);
   if (f->stream2) { (void)hipStreamSynchronize(f->stream2); (void)hipStreamDestroy(f->stream2); (void)hipEventDestroy(f->ev2); }
   f->vi.release(); f->d_in.release(); f->d_out.release(); f->h_stage.release();
@@ -232,7 +233,7 @@ extern "C" void lsa_voxel_filter_destroy(lsa_voxel_filter *f) {
 
 extern "C" int lsa_voxel_filter_apply_device(lsa_voxel_filter *f, const float *d_in_xyzw, size_t n, float *d_out_xyzw, size_t *n_out) {
   if (!f || !n_out || (n && (!d_in_xyzw || !d_out_xyzw))) return f ? lsa_fail(f->ctx, LSA_ERR_INVALID, "lsa_voxel_filter_apply_device: null argument") : LSA_ERR_INVALID;
-  LSA_HIP(f->ctx, hipSetDevice(f->ctx->device));
+  LSA_HIP(f->ctx, lsa_enter(f->ctx));
   // filter_device returns once the output is complete (it waits on the pipeline's completion event); the bitmap
   // clean-up kernel queued behind that event keeps running and is ordered before anything enqueued later
   return filter_device(f, (const float4 *)d_in_xyzw, n, (float4 *)d_out_xyzw, n_out);
@@ -245,7 +246,7 @@ extern "C" int lsa_voxel_filter_apply(lsa_voxel_filter *f, const void *in_pts, s
   *n_out = 0;
   if (n == 0) return LSA_OK;
   if (in_stride < 12 || out_stride < 12) return lsa_fail(ctx, LSA_ERR_INVALID, "lsa_voxel_filter_apply: stride < 12");
-  LSA_HIP(ctx, hipSetDevice(ctx->device));
+  LSA_HIP(ctx, lsa_enter(ctx));
   int rc;
   // the staging buffer may still be feeding an earlier async copy, and growing a buffer frees the old one: wait first
   LSA_HIP(ctx, hipStreamSynchronize(ctx->stream));

@@ -351,7 +351,7 @@ int yaw_score(lsa_yaw_init *h, const float4 *d_scan, size_t n, double *yaw, doub
 
 int yaw_check(lsa_yaw_init *h) {
   if (!h) return LSA_ERR_INVALID;
-  hipError_t e = hipSetDevice(h->ctx->device);
+  hipError_t e = lsa_enter(h->ctx);
   if (e != hipSuccess) return lsa_fail(h->ctx, LSA_ERR_NO_DEVICE, "hipSetDevice(%d): %s", h->ctx->device, hipGetErrorString(e));
   return LSA_OK;
 }
@@ -368,7 +368,7 @@ extern "C" int lsa_yaw_init_create(lsa_yaw_init **out, lsa_context *ctx, double 
 
 extern "C" void lsa_yaw_init_destroy(lsa_yaw_init *h) {
   if (!h) return;
-  (void)hipSetDevice(h->ctx->device);
+  (void)lsa_enter(h->ctx);
   (void)hipStreamSynchronize(h->ctx->stream);
   h->d_pts.release(); h->d_rot.release(); h->scratch.release(); h->ordered_z.release(); h->mu.release(); h->sigma.release();
   h->cell_of.release(); h->cnt.release(); h->count.release(); h->start.release(); h->fill.release(); h->slots.release();

@@ -132,6 +132,10 @@ class NDTRegistrationHip(RegistrationInterface):
         """Armed passes (default on): the next pass's kernel is enqueued ahead and waits on the device for its parameters."""
         self.ctx.check(capi.lib().lsa_ndt_set_armed(self.h, 1 if on else 0))
 
+    def set_armed_carry(self, on):
+        """Leave the last armed kernel parked for the next ScanMatch (default) or cancel it at every ScanMatch end."""
+        self.ctx.check(capi.lib().lsa_ndt_set_armed_carry(self.h, 1 if on else 0))
+
     def armed_counters(self):
         a, b = C.c_uint64(0), C.c_uint64(0)
         self.ctx.check(capi.lib().lsa_ndt_armed_counters(self.h, C.byref(a), C.byref(b)))

@@ -165,13 +165,13 @@ def test_armed_passes_equal_ordinary_launches(ctx, cfg2):
             t_on.append(time.perf_counter() - t0)
             sa = dict(n.last_stats)
             c1 = n.armed_counters()
-            assert c1["passes"] - c0["passes"] == sa["passes"] and c1["cancels"] - c0["cancels"] == 1
+            assert c1["passes"] - c0["passes"] == sa["passes"] and c1["cancels"] - c0["cancels"] <= 1
             n.set_armed(False)
             t0 = time.perf_counter()
             _, Tb = n.ScanMatch(d_s, guess)
             t_off.append(time.perf_counter() - t0)
             sb = dict(n.last_stats)
-            assert n.armed_counters() == c1
+            assert n.armed_counters()["passes"] == c1["passes"]     # (switching off releases the kernel the call left parked)
             assert np.array_equal(Ta, Tb) and _same_stats(sa, sb), (sa, sb)
     print("armed %.1f us / ordinary %.1f us per ScanMatch (median of %d)" % (np.median(t_on) * 1e6, np.median(t_off) * 1e6, len(t_on)))
     # a single derivative pass through the API is never armed, and works right after an armed ScanMatch
@@ -182,7 +182,7 @@ def test_armed_passes_equal_ordinary_launches(ctx, cfg2):
     n.set_source(cfg2["d_src"][0])
     a = n.derivatives(cfg2["guesses"][0], p, 0)
     b = n.derivatives(cfg2["guesses"][0], p, 0)
-    assert a[0] == b[0] and n.armed_counters() == c
+    assert a[0] == b[0] and n.armed_counters()["passes"] == c["passes"]
     # changing the source size between armed ScanMatches (another grid) is fine
     for d_s, guess in zip(cfg2["d_src"][:3], cfg2["guesses"][:3]):
         _, T1 = n.ScanMatch(d_s[: d_s.shape[0] // 2], guess)
@@ -190,4 +190,60 @@ def test_armed_passes_equal_ordinary_launches(ctx, cfg2):
         _, T2 = n.ScanMatch(d_s[: d_s.shape[0] // 2], guess)
         n.set_armed(True)
         assert np.array_equal(T1, T2)
+    n.close()
+
+
+def test_armed_kernel_carried_between_scan_matches(ctx, cfg2):
+    """By default the armed kernel of the pass that never came stays parked for the next ScanMatch on the handle (it takes
+    source, size and grid from its mail): same bits as with a cancel at every ScanMatch end, through sources of different
+    sizes, a SetInputTarget in between, other calls on the same context, and an idle gap longer than its patience."""
+    import torch
+    n = registration.NDTRegistrationHip(ctx, **wl.NDT_PARAMS)
+    n.SetInputTarget(cfg2["d_map_f"])
+    ref = []
+    n.set_armed_carry(False)
+    for d_s, guess in zip(cfg2["d_src"], cfg2["guesses"]):
+        _, T = n.ScanMatch(d_s, guess)
+        ref.append((T, dict(n.last_stats)))
+    n.set_armed_carry(True)
+    c0 = n.armed_counters()
+    for rep in range(2):
+        for (T0, s0), d_s, guess in zip(ref, cfg2["d_src"], cfg2["guesses"]):
+            _, T = n.ScanMatch(d_s, guess)
+            assert np.array_equal(T, T0) and _same_stats(dict(n.last_stats), s0)
+    c1 = n.armed_counters()
+    assert c1["cancels"] - c0["cancels"] <= 3          # 18 ScanMatches back to back: the parked kernel is used, not cancelled
+    # a smaller and a much larger source (the parked grid does not fit the latter: cancelled and relaunched)
+    for frac in (0.5, 1.0):
+        d_s = cfg2["d_src"][0][: int(cfg2["d_src"][0].shape[0] * frac)]
+        n.set_armed_carry(False)
+        _, Ta = n.ScanMatch(d_s, cfg2["guesses"][0])
+        n.set_armed_carry(True)
+        _, Tb = n.ScanMatch(d_s, cfg2["guesses"][0])
+        _, Tc = n.ScanMatch(d_s, cfg2["guesses"][0])
+        assert np.array_equal(Ta, Tb) and np.array_equal(Ta, Tc)
+    # other work on the same context in between releases the parked kernel instead of queueing behind it
+    f = cloud_filter.VoxelFilterHip(ctx, 0.5, 0.5, 0.5)
+    for _ in range(3):
+        f.filter_device(cfg2["d_src"][1])      # (first calls size the filter's buffers)
+    n.ScanMatch(cfg2["d_src"][1], cfg2["guesses"][1])
+    t0 = time.perf_counter()
+    f.filter_device(cfg2["d_src"][1])
+    dt = time.perf_counter() - t0
+    assert dt < 250e-6                         # released at once, not after the kernel's 300 us patience
+    _, T = n.ScanMatch(cfg2["d_src"][1], cfg2["guesses"][1])
+    assert np.array_equal(T, ref[1][0])
+    f.close()
+    # SetInputTarget between two ScanMatches (every key-frame): the parked kernel belongs to the old table
+    n.ScanMatch(cfg2["d_src"][2], cfg2["guesses"][2])
+    n.SetInputTarget(cfg2["d_map_f"])
+    _, T = n.ScanMatch(cfg2["d_src"][2], cfg2["guesses"][2])
+    assert np.array_equal(T, ref[2][0])
+    # an idle gap longer than the kernel's patience: it has left by itself, the next ScanMatch notices and relaunches
+    n.ScanMatch(cfg2["d_src"][3], cfg2["guesses"][3])
+    time.sleep(0.01)
+    _, T = n.ScanMatch(cfg2["d_src"][3], cfg2["guesses"][3])
+    assert np.array_equal(T, ref[3][0]) and _same_stats(dict(n.last_stats), ref[3][1])
+    torch.cuda.synchronize()
+    print("filter right after a ScanMatch that left a kernel parked: %.0f us" % (dt * 1e6))
     n.close()
