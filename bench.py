@@ -349,12 +349,14 @@ def main():
         alg_bytes = M * (16.0 + 4.0 * 27.0 + 48.0 * kbar)
         achieved = alg_bytes / (ms * 1e-3) / 1e9
         traffic = None
-        tpath = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
-        if os.path.exists(tpath):
-            try:
-                traffic = json.load(open(tpath)).get("k_ndt_pass_kind0_bytes_per_launch")
-            except Exception:
-                traffic = None
+        for tname in ("r02_pmc_traffic.json", "r01_pmc_traffic.json"):   # PMC passes of this command, see profiles/README.md
+            tpath = os.path.join(ROOT, "profiles", tname)
+            if os.path.exists(tpath):
+                try:
+                    traffic = json.load(open(tpath)).get("k_ndt_pass_kind0_bytes_per_launch")
+                    break
+                except Exception:
+                    traffic = None
         roofline = {"bound": "hbm", "kernel": "k_ndt_pass<0>", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic, "us_per_launch": round(ms * 1e3, 3),
                     "alg_bytes_per_launch": int(alg_bytes), "source_points": M, "kbar": round(kbar, 3),

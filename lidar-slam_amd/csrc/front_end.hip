@@ -258,6 +258,9 @@ extern "C" int lsa_front_end_create(lsa_front_end **out, lsa_context *ctx, const
   if (cfg->use_frame_filter) rc = lsa_voxel_filter_create(&fe->frame_filter, ctx, cfg->frame_leaf[0], cfg->frame_leaf[1], cfg->frame_leaf[2]);
   if (!rc && cfg->use_map_filter) rc = lsa_voxel_filter_create(&fe->map_filter, ctx, cfg->map_leaf[0], cfg->map_leaf[1], cfg->map_leaf[2]);
   if (!rc) rc = lsa_ndt_create(&fe->ndt, ctx, cfg->ndt_res, cfg->ndt_step_size, cfg->ndt_trans_eps, cfg->ndt_max_iter, cfg->ndt_outlier_ratio);
+  // every Update puts the frame filter (and, on key-frames, the local-map work) on this context's stream between two
+  // ScanMatches: an armed kernel parked across them would only have to be released again
+  if (!rc) rc = lsa_ndt_set_armed_carry(fe->ndt, 0);
   if (rc) { lsa_front_end_destroy(fe); return rc; }
   identity16(fe->init_pose); identity16(fe->last_pose); identity16(fe->predict_pose); identity16(fe->step_pose); identity16(fe->last_kf_pose);
   *out = fe;
