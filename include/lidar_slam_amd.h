@@ -199,8 +199,10 @@ int lsa_ndt_grid_dump(lsa_ndt *ndt, int32_t *cell_ints, double *cell_rec, size_t
 int lsa_ndt_set_armed(lsa_ndt *ndt, int on);
 /* At the end of a ScanMatch the armed kernel of the pass that never came is, by default, not cancelled but left PARKED for the
  * first pass of the next ScanMatch on the same handle (its mail also carries the source pointer, the point count and the
- * grid), which then starts without launch or dispatch latency.  It leaves by itself after 0.3 ms; any other call on the same
- * context releases it first.  on = 0 (or the environment variable LSA_NO_CARRY) cancels at every ScanMatch end instead. */
+ * grid), which then starts without launch or dispatch latency.  It leaves by itself after 0.3 ms; any other call of this library
+ * on the same context releases it first.  Work the APPLICATION enqueues itself on a stream it handed to lsa_context_create
+ * would queue behind the parked kernel for up to those 0.3 ms: such callers switch the carry off, or call
+ * lsa_context_synchronize first.  on = 0 (or the environment variable LSA_NO_CARRY) cancels at every ScanMatch end instead. */
 int lsa_ndt_set_armed_carry(lsa_ndt *ndt, int on);
 int lsa_ndt_armed_counters(lsa_ndt *ndt, uint64_t *passes, uint64_t *cancels);
 
