@@ -111,10 +111,15 @@ __global__ __launch_bounds__(kBlockD, pass_waves(0)) void k_ndt_pass_armed(PassP
   }
   __syncthreads();
   if (!s_go) return;
-  const unsigned vgrid = (unsigned)s_dyn[0];
+  // workgroup-uniform values out of LDS: into scalar registers (the pass body has no vector register to spare)
+  auto uniform64 = [](unsigned long long v) {
+    unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)v), hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(v >> 32));
+    return ((unsigned long long)hi << 32) | lo;
+  };
+  const unsigned vgrid = (unsigned)uniform64(s_dyn[0]);
   if (blockIdx.x >= vgrid) return;   // launched with head-room for a larger source than this pass has
-  const float4 *src = reinterpret_cast<const float4 *>(s_dyn[1]);
-  const size_t n = (size_t)s_dyn[2];
+  const float4 *src = reinterpret_cast<const float4 *>(uniform64(s_dyn[1]));
+  const size_t n = (size_t)uniform64(s_dyn[2]);
   const double v = ndt_pass_body<0, DENSE>(src, n, P, Tl, jh, words, dense, rec, lds, vgrid);
   if (tid < kOutDoubles) lsa_store_row32(partials + (size_t)blockIdx.x * kOutDoubles, tid, v, mail_key(seq) | 1ull);
 }

@@ -213,6 +213,19 @@ __device__ __forceinline__ double ndt_pass_body(const float4 *__restrict__ src, 
     size_t i0 = tile0 * kTilePts + ppl;
     if (i0 < n) s_next = src[i0];
   }
+  unsigned probe_lut = 0;  // dense path: {point slot : 6, -, dy : 2, dz : 2, -, live : 1} per probe round of this lane
+  if (DENSE) {
+#pragma unroll
+    for (int j = 0; j < kRowRounds; j++) {
+      const int q = lane + j * 64;
+      if (q < kRowProbes) {  // (the last round has a few idle lanes: all-zero entry, live bit clear)
+        const int pl = q / kRowsPerPoint;
+        const int o = q - pl * kRowsPerPoint;
+        const int dz = o / 3, dy = o - dz * 3;
+        probe_lut |= ((unsigned)pl | ((unsigned)dy << 8) | ((unsigned)dz << 10) | 0x8000u) << (16 * j);
+      }
+    }
+  }
   unsigned carried = 0;  // pairs at the front of the queue left over by the previous tile (< 64, wave-uniform)
   int pbase = 0;         // which half of tp / terms this tile uses: 0 or kTileSlots
   for (size_t tile = tile0; tile < ntiles; tile += tstride, pbase ^= (NB == 2 ? kTileSlots : 0)) {
@@ -275,22 +288,24 @@ __device__ __forceinline__ double ndt_pass_body(const float4 *__restrict__ src, 
       // ---- phase A (dense table): row probes -> pairs, pre-filtered on the f32 distance
       unsigned c_ent[kRowRounds * 3];
       unsigned c_mask = 0;
-      int lane_v = lane;  // opaque copy: keeps ~30 registers of lane-only index arithmetic from being hoisted out of the tile loop
-      asm volatile("" : "+v"(lane_v));
+      // which (point, dy, dz) a lane probes in each round depends on the lane only: packed once per kernel into ONE register
+      // (probe_lut: 8 bits per field, 16 bits per round) instead of ~12 integer instructions per round and tile — and instead
+      // of the ~30 registers the compiler would keep live through the pair math if it hoisted the unpacked values
+      unsigned lut_v = probe_lut;  // opaque copy: the unpacked fields must not be hoisted out of the tile loop (registers)
+      asm volatile("" : "+v"(lut_v));
       int r_cell[kRowRounds], r_nx[kRowRounds], r_pl[kRowRounds];
       float r_y[kRowRounds], r_z[kRowRounds];
       float4 e0[kRowRounds], e1[kRowRounds], e2[kRowRounds];
 #pragma unroll
       for (int j = 0; j < kRowRounds; j++) {
-        int q = lane_v + j * 64;
-        int pl = (q < kRowProbes) ? q / kRowsPerPoint : 0;
-        int o = q - pl * kRowsPerPoint;
-        int dz = o / 3, dy = o - dz * 3;
+        const unsigned lut = lut_v >> (16 * j);
+        const int pl = lut & 0x3f, dy = (lut >> 8) & 3, dz = (lut >> 10) & 3;
+        const bool live = (lut >> 15) & 1;
         int nxyz = tp[pbase + pl].nxyz;
-        bool in_box = q < kRowProbes && dy < ((nxyz >> 8) & 0xff) && dz < (nxyz >> 16);
+        bool in_box = live && dy < ((nxyz >> 8) & 0xff) && dz < (nxyz >> 16);
         r_pl[j] = pl;
         r_nx[j] = in_box ? (nxyz & 0xff) : 0;
-        r_cell[j] = in_box ? tp[pbase + pl].cell0 + dy * dimx + dz * dimxy : 0;
+        r_cell[j] = in_box ? tp[pbase + pl].cell0 + __mul24(dy, dimx) + ((dz & 1) ? dimxy : 0) + ((dz & 2) ? 2 * dimxy : 0) : 0;
         r_y[j] = tp[pbase + pl].ry - (float)dy * P.res;
         r_z[j] = tp[pbase + pl].rz - (float)dz * P.res;
       }
@@ -399,7 +414,7 @@ __device__ __forceinline__ double ndt_pass_body(const float4 *__restrict__ src, 
         unsigned e = live ? cand[ci] : 0u;
         p_ent[k] = e;
         if (live) p_mask |= 1u << k;
-        const double *R = rec + (size_t)(e >> 6) * kRecDoubles;
+        const double *R = reinterpret_cast<const double *>(reinterpret_cast<const char *>(rec) + (e >> 6) * (unsigned)(kRecDoubles * sizeof(double)));
         if (live) { pc[k][0] = R[0]; pc[k][1] = R[1]; pc[k][2] = R[2]; }
         else { pc[k][0] = pc[k][1] = pc[k][2] = 0.0; }
       }
@@ -437,7 +452,7 @@ __device__ __forceinline__ double ndt_pass_body(const float4 *__restrict__ src, 
         if (qi < total) {
           unsigned e = queue[qi];
           const unsigned pl = e & 63u;
-          const double *R = rec + (size_t)(e >> 6) * kRecDoubles;
+          const double *R = reinterpret_cast<const double *>(reinterpret_cast<const char *>(rec) + (e >> 6) * (unsigned)(kRecDoubles * sizeof(double)));
           double pg[8];
           const double *tm = terms + pl * kTermStride;
 #pragma unroll
@@ -461,7 +476,7 @@ __device__ __forceinline__ double ndt_pass_body(const float4 *__restrict__ src, 
     if (lane < carried) {
       unsigned e = queue[lane];
       const unsigned pl = e & 63u;
-      const double *R = rec + (size_t)(e >> 6) * kRecDoubles;
+      const double *R = reinterpret_cast<const double *>(reinterpret_cast<const char *>(rec) + (e >> 6) * (unsigned)(kRecDoubles * sizeof(double)));
       double pg[8];
       const double *tm = terms + pl * kTermStride;
 #pragma unroll
