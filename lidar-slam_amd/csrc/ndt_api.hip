@@ -3,6 +3,7 @@
 #include "ndt_internal.h"
 #include "ndt_pass.h"
 
+#include <chrono>
 #include <vector>
 
 int ndt_fitness(lsa_ndt *h, float *score);  // ndt_fitness.hip
