@@ -670,6 +670,9 @@ def main():
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         sys.path.insert(0, os.path.join(ROOT, "oracle"))
         import oracle_py
+        if _under_profiler() and not os.path.exists(os.path.join(ROOT, "oracle", "liblsa_oracle_fast.so")):
+            raise SystemExit("bench.py under a profiler: build the oracle first (python -c 'import __graft_entry__ as g; g.build()') "
+                             "or pass --no-cpu-baseline; it is not built from a process whose GPU is already initialised")
         oracle_py.build(ref=False)
         o = oracle_py.Oracle(fast=True)
         ondt = oracle_py.OracleNDT(fast=True, **NDT_PARAMS)

@@ -80,6 +80,8 @@ class FrontEndHip:
         out = np.zeros(16, dtype=np.float32)
         st = FrontEndStats()
         if hasattr(cloud, "data_ptr"):
+            from .registration import check_points_tensor
+            check_points_tensor(cloud, "FrontEnd.Update")
             self._keep = cloud
             rc = capi.lib().lsa_front_end_update_device(self.h, cloud.data_ptr(), cloud.shape[0], capi.fptr(out), C.byref(st))
         else:

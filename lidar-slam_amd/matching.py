@@ -23,6 +23,8 @@ class YawInitHip:
     def SetLocalMap(self, local_map, origin):  # noqa: N802  (ResetLocalMap + SetInitPose -> generateGauss2DMapCells)
         og = np.ascontiguousarray(origin, dtype=np.float32)
         if hasattr(local_map, "data_ptr"):
+            from .registration import check_points_tensor
+            check_points_tensor(local_map, "SetLocalMap")
             self._keep = local_map
             self.ctx.check(capi.lib().lsa_yaw_init_set_local_map_device(self.h, local_map.data_ptr(), local_map.shape[0], capi.fptr(og)))
         else:
@@ -35,6 +37,8 @@ class YawInitHip:
         yaw = C.c_double(0)
         probs = np.zeros(270)
         if hasattr(scan, "data_ptr"):
+            from .registration import check_points_tensor
+            check_points_tensor(scan, "GetInitialYawAngle")
             rc = capi.lib().lsa_yaw_init_get_initial_yaw_device(self.h, scan.data_ptr(), scan.shape[0], C.byref(yaw), capi.dptr(probs))
         else:
             pts = np.ascontiguousarray(scan, dtype=np.float32)

@@ -48,6 +48,7 @@ class NDTRegistrationHip(RegistrationInterface):
     # ---- RegistrationInterface -------------------------------------------------------------
     def SetInputTarget(self, input_target):  # noqa: N802
         if _is_tensor(input_target):
+            check_points_tensor(input_target, "SetInputTarget")
             self._keep = input_target
             self.ctx.check(capi.lib().lsa_ndt_set_input_target_device(self.h, input_target.data_ptr(), input_target.shape[0]))
         else:
@@ -78,6 +79,7 @@ class NDTRegistrationHip(RegistrationInterface):
 
     def _scan_match(self, input_source, guess, out, st):
         if _is_tensor(input_source):
+            check_points_tensor(input_source, "ScanMatch")
             self._src_keep = input_source
             rc = capi.lib().lsa_ndt_scan_match_device(self.h, input_source.data_ptr(), input_source.shape[0], capi.fptr(guess), capi.fptr(out), C.byref(st))
         else:
@@ -106,6 +108,7 @@ class NDTRegistrationHip(RegistrationInterface):
 
     def set_source(self, src):
         if _is_tensor(src):
+            check_points_tensor(src, "set_source")
             self._src_keep = src
             self.ctx.check(capi.lib().lsa_ndt_set_source_device(self.h, src.data_ptr(), src.shape[0]))
         else:
@@ -207,6 +210,7 @@ class ICPRegistrationHip(RegistrationInterface):
 
     def SetInputTarget(self, input_target):  # noqa: N802
         if _is_tensor(input_target):
+            check_points_tensor(input_target, "SetInputTarget")
             self._keep = input_target
             self.ctx.check(capi.lib().lsa_icp_set_input_target_device(self.h, input_target.data_ptr(), input_target.shape[0]))
         else:
@@ -218,6 +222,7 @@ class ICPRegistrationHip(RegistrationInterface):
         guess = capi.colmajor(predict_pose)
         out = np.zeros(16, dtype=np.float32)
         if _is_tensor(input_source):
+            check_points_tensor(input_source, "ScanMatch")
             self._src_keep = input_source
             rc = capi.lib().lsa_icp_scan_match_device(self.h, input_source.data_ptr(), input_source.shape[0], capi.fptr(guess), capi.fptr(out))
         else:
@@ -294,3 +299,11 @@ def gn_solve(eval_fn, res, step_size, trans_eps, max_iter, outlier_ratio, predic
 
 def _is_tensor(x):
     return hasattr(x, "data_ptr") and hasattr(x, "is_cuda")
+
+
+def check_points_tensor(t, what):
+    """Device clouds are packed float4 {x, y, z, intensity}: anything else would be read with the wrong stride."""
+    import torch
+    if not (t.is_cuda and t.dtype == torch.float32 and t.dim() == 2 and t.shape[1] == 4 and t.is_contiguous()):
+        raise ValueError("%s: expected a contiguous CUDA float32 tensor of shape (n, 4), got %s %s on %s (contiguous=%s)"
+                         % (what, t.dtype, tuple(t.shape), t.device, t.is_contiguous()))

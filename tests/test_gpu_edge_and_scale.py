@@ -196,3 +196,37 @@ def test_filter_properties_at_2m_points(ctx, big):
     lin = (ijk[:, 0] - mn[0]) + (ijk[:, 1] - mn[1]) * d[0] + (ijk[:, 2] - mn[2]) * d[0] * d[1]
     assert bool((lin[1:] > lin[:-1]).all())
     f.close()
+
+
+def test_point_row_layouts_and_intensity_offset(ctx, scan_pair):
+    """(n, 3) xyz rows carry no intensity (static weight 1), (n, 4) rows are packed x, y, z, w, wider rows follow PointXYZI;
+    an intensity offset that does not fit the row is refused instead of reading the next point."""
+    import ctypes as C
+    import torch
+    s0, s1, _, _ = scan_pair
+    xyz3 = np.ascontiguousarray(s0[:20000, :3])
+    xyz4 = np.ascontiguousarray(s0[:20000])                  # w == 1
+    xyz8 = synth.to_xyzi32(xyz4)
+    n = registration.NDTRegistrationHip(ctx)
+    recs = []
+    for arr in (xyz3, xyz4, xyz8):
+        n.SetInputTarget(arr)
+        recs.append(n.grid_dump()[1])
+    assert np.array_equal(recs[0], recs[1]) and np.array_equal(recs[0], recs[2])
+    # exactly-sized (n, 3) rows with a PointXYZI-style offset: invalid, not an out-of-bounds read
+    rc = capi.lib().lsa_ndt_set_input_target(n.h, xyz3.ctypes.data, xyz3.shape[0], 12, 12)
+    assert rc == capi.LSA_ERR_INVALID
+    f = cloud_filter.VoxelFilterHip(ctx, 0.5, 0.5, 0.5)
+    out = np.zeros((xyz3.shape[0], 8), dtype=np.float32)
+    n_out = C.c_size_t(0)
+    rc = capi.lib().lsa_voxel_filter_apply(f.h, xyz3.ctypes.data, xyz3.shape[0], 12, 16, out.ctypes.data, xyz3.shape[0], 32, 16, C.byref(n_out))
+    assert rc == capi.LSA_ERR_INVALID
+    _, a = f.Filter(xyz3)
+    _, b = f.Filter(xyz8)
+    assert np.array_equal(a, b)
+    # device clouds must be contiguous float32 (n, 4)
+    with pytest.raises(ValueError):
+        n.SetInputTarget(torch.from_numpy(xyz3).cuda())
+    with pytest.raises(ValueError):
+        n.ScanMatch(torch.from_numpy(xyz4).cuda().double(), np.eye(4, dtype=np.float32))
+    f.close(); n.close()
