@@ -38,6 +38,7 @@ struct lsa_voxel_filter {
   int job_kind = 1;
   const void *u_pts = nullptr;
   size_t u_n = 0, u_stride = 0, u_w_off = 0, u_off = 0;
+  unsigned long long n_miss = 0, n_calls = 0, n_cap = 0;
   hipStream_t stream2 = nullptr;   // second copy queue of the host path (two SDMA queues move 2 MB in ~50 us, one in ~73)
   hipEvent_t ev2 = nullptr;
 };
@@ -83,6 +84,7 @@ int filter_device(lsa_voxel_filter *f, const float4 *d_in, size_t n, float4 *d_o
   // trip; the host then waits ONCE for the 200-byte parameter block that carries the voxel count and the status.
   VoxelIndex &vi = f->vi;
   int rc, status = VI_OK;
+  f->n_calls++;
   for (int attempt = 0; attempt < 3; attempt++) {
     if ((rc = vi_enqueue(ctx, vi, d_in, n, /*mode PCL*/ 0, f->leaf, 4, /*allow_spec*/ true))) return rc;
     hipLaunchKernelGGL(k_filter_finalize, dim3(lsa_div_up(n, kBlock)), dim3(kBlock), 0, ctx->stream, vi.acc.p, vi.cnt.p, vi.cell_of_rank.p, vi.dparams.p,
@@ -91,8 +93,9 @@ int filter_device(lsa_voxel_filter *f, const float4 *d_in, size_t n, float4 *d_o
     if ((rc = vi_mark_done(ctx, vi))) return rc;
     if ((rc = vi_wait(ctx, vi, &status))) return rc;
     vi.clean = (status == VI_OK || status == VI_SPEC_MISS);  // the finalize kernel zeroed what this build touched
-    if (status == VI_SPEC_MISS) continue;  // a point fell outside the reused cell box: rebuild from the bounding box
+    if (status == VI_SPEC_MISS) { f->n_miss++; continue; }  // a point fell outside the reused cell box: rebuild from the bounding box
     if (status != VI_CAPACITY) break;
+    f->n_cap++;
     if ((rc = vi_grow(ctx, vi))) return rc;  // first call / bigger extent than ever seen: size the bitmap and redo
   }
   if (status == VI_RANGE) return lsa_fail(ctx, LSA_ERR_RANGE, "voxel filter: leaf size too small for the input dataset, integer indices would overflow");
@@ -216,6 +219,7 @@ extern "C" int lsa_voxel_filter_create(lsa_voxel_filter **out, lsa_context *ctx,
 
 extern "C" void lsa_voxel_filter_destroy(lsa_voxel_filter *f) {
   if (!f) return;
+  if (getenv("LSA_DBG_FILTER")) fprintf(stderr, "voxel filter: %llu sync calls, %llu speculative misses, %llu capacity growths, W_cap %zu, last W %zu dims %d %d %d\n", f->n_calls, f->n_miss, f->n_cap, f->vi.W_cap, f->vi.W, f->vi.map.dim[0], f->vi.map.dim[1], f->vi.map.dim[2]);
   if (f->worker_started) {
     {
       std::lock_guard<std::mutex> lk(f->mu);
