@@ -22,6 +22,7 @@ void ndt_make_pass_params(const lsa_ndt *h, const float T[16], const double p[6]
 unsigned ndt_pass_grid(const lsa_ndt *h, size_t n, int kind);
 int ndt_enqueue_pass(lsa_ndt *h, const PassParams &P, int kind, bool reduce = true);
 bool ndt_pass_host_reduce(const lsa_ndt *h, int kind);
+int ndt_publish_out(lsa_ndt *h, unsigned long long *key_out);
 int ndt_enqueue_pass_host(lsa_ndt *h, const PassParams &P, int kind, unsigned *grid_out, unsigned long long *key_out);
 struct PassMail;
 void ndt_mail_post(PassMail *mail, const PassParams *P, unsigned long long seq, bool cancel, const void *d_src, size_t n, unsigned vgrid);
