@@ -290,6 +290,7 @@ def main():
     # the headline run, in the mode the policy chose (the exchange step is brought up first only if that mode needs it)
     elapsed = run_timed(shard_policy, args.steps, args.warmup, args.ramp_seconds)
     collect()
+    armed_after_headline = ndt.armed_counters()   # passes served by a kernel enqueued ahead / cancelled kernels / passes redone
     # N > 1: also time the mode the policy did NOT choose (a quarter of the steps) so the line shows both
     alt = None
     if dist_mode and world > 1:
@@ -753,6 +754,7 @@ def main():
                 "passes": float(np.mean([s["passes"] for s in st_list])),
                 "converged": int(min(s["converged"] for s in st_list)),
                 "set_target_ms": round(set_target_ms, 3),
+                "armed_passes": armed_after_headline,
                 "parallelism": "1 GPU" if world == 1 else (
                     "every scan's source sharded x%d, one 256-B RCCL all-reduce per pass (strong scaling)" % world if shard_policy else
                     "%d independent scan streams, one per GPU, no data-path collective (weak scaling): %d source points per scan "

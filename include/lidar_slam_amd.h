@@ -195,7 +195,8 @@ int lsa_ndt_grid_dump(lsa_ndt *ndt, int32_t *cell_ints, double *cell_rec, size_t
  * kernel of the NEXT pass right behind the current one; it waits on the device for its parameters, which the host posts into
  * a mailbox in device memory once the current pass's sums have produced them (csrc/ndt_derivatives.hip).  Launch and dispatch
  * latency leave the critical path; results are bit-identical.  The counters: passes served that way, armed kernels cancelled
- * (one per ScanMatch, at convergence). */
+ * (at most one per ScanMatch, at convergence), and passes that had to be redone the ordinary way because the armed kernel had
+ * left before its mail came (the calling thread was held up for longer than the kernel's 0.3 ms patience).  Any may be NULL. */
 int lsa_ndt_set_armed(lsa_ndt *ndt, int on);
 /* At the end of a ScanMatch the armed kernel of the pass that never came is, by default, not cancelled but left PARKED for the
  * first pass of the next ScanMatch on the same handle (its mail also carries the source pointer, the point count and the
@@ -204,7 +205,7 @@ int lsa_ndt_set_armed(lsa_ndt *ndt, int on);
  * would queue behind the parked kernel for up to those 0.3 ms: such callers switch the carry off, or call
  * lsa_context_synchronize first.  on = 0 (or the environment variable LSA_NO_CARRY) cancels at every ScanMatch end instead. */
 int lsa_ndt_set_armed_carry(lsa_ndt *ndt, int on);
-int lsa_ndt_armed_counters(lsa_ndt *ndt, uint64_t *passes, uint64_t *cancels);
+int lsa_ndt_armed_counters(lsa_ndt *ndt, uint64_t *passes, uint64_t *cancels, uint64_t *fallbacks);
 
 /* ScanMatch can run its whole Newton iteration as ONE persistent launch (csrc/ndt_align.hip: the workgroups stay resident,
  * exchange their partial sums in-launch and each repeats the 6x6 solve) instead of one launch per derivative pass, when the

@@ -158,7 +158,7 @@ def lib():
     L.lsa_ndt_set_trace.argtypes = [vp, PD, i, C.POINTER(C.c_int)]
     L.lsa_ndt_set_armed.argtypes = [vp, i]
     L.lsa_ndt_set_armed_carry.argtypes = [vp, i]
-    L.lsa_ndt_armed_counters.argtypes = [vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
+    L.lsa_ndt_armed_counters.argtypes = [vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
     L.lsa_ndt_set_persistent.argtypes = [vp, i]
     L.lsa_ndt_align_counters.argtypes = [vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
     L.lsa_ndt_align_stamps.argtypes = [vp, i, C.POINTER(C.c_uint64), sz, PSZ]

@@ -196,9 +196,9 @@ int scan_match_common(lsa_ndt *h, const float predict_pose[16], float result_pos
     // nothing else uses the stream in between (lsa_pipeline_scan_match), left PARKED for the first pass of the next
     // ScanMatch (it reads source pointer, size and grid from its mail), whose launch + dispatch latency it then saves.  It
     // leaves by itself after kArmedPatienceUs; any other call on this context releases it first (lsa_enter).
-    if (rc || !h->armed_carry || h->unsynced >= 256) {
+    if (rc || !h->armed_carry || h->unsynced >= 1024) {
       armed_cancel(h);
-      if (h->unsynced >= 256) {  // let the runtime retire its commands now and then (nothing is parked any more)
+      if (h->unsynced >= 1024) {  // let the runtime retire its commands now and then (nothing is parked any more)
         (void)hipStreamSynchronize(ctx->stream);
         h->unsynced = 0;
       }
@@ -378,10 +378,11 @@ extern "C" int lsa_ndt_set_armed(lsa_ndt *h, int on) {
   return LSA_OK;
 }
 
-extern "C" int lsa_ndt_armed_counters(lsa_ndt *h, uint64_t *passes, uint64_t *cancels) {
+extern "C" int lsa_ndt_armed_counters(lsa_ndt *h, uint64_t *passes, uint64_t *cancels, uint64_t *fallbacks) {
   if (!h) return LSA_ERR_INVALID;
   if (passes) *passes = h->armed_passes;
   if (cancels) *cancels = h->armed_cancels;
+  if (fallbacks) *fallbacks = h->armed_fallbacks;
   return LSA_OK;
 }
 

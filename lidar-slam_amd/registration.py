@@ -140,9 +140,9 @@ class NDTRegistrationHip(RegistrationInterface):
         self.ctx.check(capi.lib().lsa_ndt_set_armed_carry(self.h, 1 if on else 0))
 
     def armed_counters(self):
-        a, b = C.c_uint64(0), C.c_uint64(0)
-        self.ctx.check(capi.lib().lsa_ndt_armed_counters(self.h, C.byref(a), C.byref(b)))
-        return dict(passes=a.value, cancels=b.value)
+        a, b, c = C.c_uint64(0), C.c_uint64(0), C.c_uint64(0)
+        self.ctx.check(capi.lib().lsa_ndt_armed_counters(self.h, C.byref(a), C.byref(b), C.byref(c)))
+        return dict(passes=a.value, cancels=b.value, fallbacks=c.value)
 
     def set_persistent(self, on):
         """ScanMatch as ONE persistent launch (default) or one launch per derivative pass (lsa_ndt_set_persistent)."""
