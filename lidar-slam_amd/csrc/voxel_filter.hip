@@ -219,7 +219,7 @@ extern "C" int lsa_voxel_filter_create(lsa_voxel_filter **out, lsa_context *ctx,
 
 extern "C" void lsa_voxel_filter_destroy(lsa_voxel_filter *f) {
   if (!f) return;
-  if (getenv("LSA_DBG_FILTER")) fprintf(stderr, "voxel filter: %llu sync calls, %llu speculative misses, %llu capacity growths, W_cap %zu, last W %zu dims %d %d %d\n", f->n_calls, f->n_miss, f->n_cap, f->vi.W_cap, f->vi.W, f->vi.map.dim[0], f->vi.map.dim[1], f->vi.map.dim[2]);
+  if (getenv("LSA_FILTER_STATS")) fprintf(stderr, "voxel filter: %llu sync calls, %llu speculative misses, %llu capacity growths, W_cap %zu, last W %zu dims %d %d %d\n", f->n_calls, f->n_miss, f->n_cap, f->vi.W_cap, f->vi.W, f->vi.map.dim[0], f->vi.map.dim[1], f->vi.map.dim[2]);
   if (f->worker_started) {
     {
       std::lock_guard<std::mutex> lk(f->mu);
