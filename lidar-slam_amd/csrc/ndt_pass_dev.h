@@ -25,14 +25,16 @@ constexpr int pass_waves(int kind) { return kind == 1 ? LSA_PASS_WAVES_GRAD : LS
 template <int KIND>
 __device__ __forceinline__ void pair_update(const PassParams &P, const double *__restrict__ R, float tx, float ty, float tz,
                                             const double pg[8], const double *ph /* LDS, read at the point of use */, double acc[28],
-                                            unsigned &accepted) {
+                                            bool live, unsigned &accepted /* wave-uniform */) {
   // R: centroid(3), C = icov (xx,xy,xz,yy,yz,zz), w.
   double d0 = (double)tx - R[0], d1 = (double)ty - R[1], d2 = (double)tz - R[2];  // x_trans - centroid (:434)
   // the exact radius test of radiusSearch (VoxelGrid.cpp:470-472), on the squared f64 distance against the host-computed
   // threshold.  The dense-table probe only pre-filters in f32 with a safety margin; the bitmap probe has already applied
   // this very test, for which it is a no-op.
-  if (!(d0 * d0 + d1 * d1 + d2 * d2 <= P.r2max)) return;
-  accepted++;
+  // (`live`: the lane holds a pair at all — the callers run every lane so that the count below is one scalar per wave)
+  const bool in = live && (d0 * d0 + d1 * d1 + d2 * d2 <= P.r2max);
+  accepted += (unsigned)__popcll(__ballot(in));
+  if (!in) return;
   double C00 = R[3], C01 = R[4], C02 = R[5], C11 = R[6], C12 = R[7], C22 = R[8];
   double u0 = C00 * d0 + C01 * d1 + C02 * d2;
   double u1 = C01 * d0 + C11 * d1 + C12 * d2;
@@ -189,7 +191,9 @@ __device__ __forceinline__ double ndt_pass_body(const float4 *__restrict__ src, 
                                                 unsigned vgrid /* workgroups sharing the tiles: gridDim.x, or fewer for an armed launch */) {
   constexpr int NB = pass_bufs(KIND);
   constexpr int kLdsSlice = lds_slice(NB), kLdsTerms = lds_terms(NB), kLdsCand = lds_cand(NB), kLdsQueue = lds_queue(NB), kLdsRed2 = lds_red2(NB);
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  // (the wave index is uniform across the wave: as a scalar, everything derived from it — the LDS slice, the tile walk — stays
+  // out of the vector registers)
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   unsigned char *slice = lds + wave * kLdsSlice;
   TilePoint *tp = reinterpret_cast<TilePoint *>(slice + kLdsTp);
   double *terms = reinterpret_cast<double *>(slice + kLdsTerms);
@@ -198,9 +202,10 @@ __device__ __forceinline__ double ndt_pass_body(const float4 *__restrict__ src, 
   double acc[28];
 #pragma unroll
   for (int k = 0; k < 28; k++) acc[k] = 0.0;
-  unsigned long long npts = 0;  // wave total (meaningful in lane 0)
-  unsigned accepted = 0;        // (point, voxel) pairs this lane accepted
-  const int part4 = lane / kTilePts, ppl = lane - part4 * kTilePts;  // phase 0: 4 lanes per point (part4 == 4: the spare lanes 56..63)
+  unsigned accepted = 0;        // (point, voxel) pairs this WAVE accepted (wave-uniform: a scalar register)
+  // phase 0: the 4 lanes of a QUAD share a point (quad 14 and 15 = lanes 56..63 are spare: they work on tile slots 14 / 15,
+  // which exist in LDS and which nothing reads)
+  const int part4 = lane & 3, ppl = lane >> 2;
   const int dimx = P.dim[0], dimxy = P.dim[0] * P.dim[1];
   const size_t ntiles = (n + kTilePts - 1) / kTilePts;
   const size_t tile0 = (size_t)blockIdx.x * kWaves + wave, tstride = (size_t)vgrid * kWaves;
@@ -211,7 +216,7 @@ __device__ __forceinline__ double ndt_pass_body(const float4 *__restrict__ src, 
   float4 s_next = make_float4(0.f, 0.f, 0.f, 0.f);
   {
     size_t i0 = tile0 * kTilePts + ppl;
-    if (i0 < n) s_next = src[i0];
+    if (ppl < kTilePts && i0 < n) s_next = src[i0];
   }
   unsigned probe_lut = 0;  // dense path: {point slot : 6, -, dy : 2, dz : 2, -, live : 1} per probe round of this lane
   if (DENSE) {
@@ -234,60 +239,62 @@ __device__ __forceinline__ double ndt_pass_body(const float4 *__restrict__ src, 
       size_t i = tile * kTilePts + ppl;
       float4 s = s_next;
       size_t inext = (tile + tstride) * kTilePts + ppl;
-      if (inext < n) s_next = src[inext];
-      if (part4 == 0) {
-        TilePoint t;
-        t.nxyz = 0; t.cell0 = 0; t.tx = t.ty = t.tz = 0.f; t.rx = t.ry = t.rz = 0.f;
-        if (i < n) {
-          // pcl::transformPointCloud: x' = m00*x + m01*y + m02*z + m03, f32, left to right, no FMA
-          float tx = lsa_fadd(lsa_fadd(lsa_fadd(lsa_fmul(Tl[0], s.x), lsa_fmul(Tl[1], s.y)), lsa_fmul(Tl[2], s.z)), Tl[3]);
-          float ty = lsa_fadd(lsa_fadd(lsa_fadd(lsa_fmul(Tl[4], s.x), lsa_fmul(Tl[5], s.y)), lsa_fmul(Tl[6], s.z)), Tl[7]);
-          float tz = lsa_fadd(lsa_fadd(lsa_fadd(lsa_fmul(Tl[8], s.x), lsa_fmul(Tl[9], s.y)), lsa_fmul(Tl[10], s.z)), Tl[11]);
-          t.tx = tx; t.ty = ty; t.tz = tz;
-          if (lsa_finite3(tx, ty, tz)) {
-            // radiusSearch cell box (VoxelGrid.cpp:438-455), relative to real_min, clipped to the occupied bounds
-            float r = P.res;
-            int hx, lx, hy, ly, hz, lz;
-            if (P.res_pow2) {
-              // a power-of-two leaf (the YAML default 1.0): x / r == x * (1 / r) exactly, so the six correctly rounded
-              // f32 divisions (~12 instructions each) collapse to multiplications without changing a single bit
-              float ir = P.inv_res;
-              hx = (int)floorf(lsa_fmul(lsa_fadd(tx, r), ir)) - P.min_b[0]; lx = (int)floorf(lsa_fmul(lsa_fsub(tx, r), ir)) - P.min_b[0];
-              hy = (int)floorf(lsa_fmul(lsa_fadd(ty, r), ir)) - P.min_b[1]; ly = (int)floorf(lsa_fmul(lsa_fsub(ty, r), ir)) - P.min_b[1];
-              hz = (int)floorf(lsa_fmul(lsa_fadd(tz, r), ir)) - P.min_b[2]; lz = (int)floorf(lsa_fmul(lsa_fsub(tz, r), ir)) - P.min_b[2];
-            } else {
-              hx = (int)floorf(lsa_fdiv(lsa_fadd(tx, r), r)) - P.min_b[0]; lx = (int)floorf(lsa_fdiv(lsa_fsub(tx, r), r)) - P.min_b[0];
-              hy = (int)floorf(lsa_fdiv(lsa_fadd(ty, r), r)) - P.min_b[1]; ly = (int)floorf(lsa_fdiv(lsa_fsub(ty, r), r)) - P.min_b[1];
-              hz = (int)floorf(lsa_fdiv(lsa_fadd(tz, r), r)) - P.min_b[2]; lz = (int)floorf(lsa_fdiv(lsa_fsub(tz, r), r)) - P.min_b[2];
-            }
-            hx = min(hx, P.dim[0] - 1); hy = min(hy, P.dim[1] - 1); hz = min(hz, P.dim[2] - 1);
-            lx = max(lx, 0); ly = max(ly, 0); lz = max(lz, 0);
-            // with radius == leaf the box is at most 3 cells wide per axis
-            int nx = min(hx - lx + 1, 3), ny = min(hy - ly + 1, 3), nz = min(hz - lz + 1, 3);
-            if (nx > 0 && ny > 0 && nz > 0) {
-              t.cell0 = lx + ly * dimx + lz * dimxy;
-              t.nxyz = nx | (ny << 8) | (nz << 16);
-              if (DENSE) {
-                t.rx = tx - (float)(lx + P.min_b[0]) * r; t.ry = ty - (float)(ly + P.min_b[1]) * r; t.rz = tz - (float)(lz + P.min_b[2]) * r;
-              }
-            }
-          }
+      if (ppl < kTilePts && inext < n) s_next = src[inext];
+      {
+        // One AXIS per lane: lane group g < 3 of a point transforms coordinate g (f32, PCL order) and clips that axis of the
+        // radiusSearch cell box (VoxelGrid.cpp:438-455, relative to real_min, clipped to the occupied bounds); the three
+        // axes are independent until the very end, where the quad's first lane gathers the box from its neighbours (DPP
+        // quad broadcasts, no LDS).  (The whole transform + box ran in 14 of the wave's 64 lanes before: ~100 issue slots
+        // per tile, now ~45.)
+        int a = part4 < 3 ? part4 : 0;
+        asm volatile("" : "+v"(a));  // lane-constant: do not hoist its selects out of the tile loop (registers)
+        const int mb = a == 0 ? P.min_b[0] : (a == 1 ? P.min_b[1] : P.min_b[2]);
+        const int dmax = (a == 0 ? P.dim[0] : (a == 1 ? P.dim[1] : P.dim[2])) - 1;
+        const int stride = a == 0 ? 1 : (a == 1 ? dimx : dimxy);
+        const float *Ta = Tl + 4 * a;
+        // pcl::transformPointCloud: x' = m00*x + m01*y + m02*z + m03, f32, left to right, no FMA
+        const float t = lsa_fadd(lsa_fadd(lsa_fadd(lsa_fmul(Ta[0], s.x), lsa_fmul(Ta[1], s.y)), lsa_fmul(Ta[2], s.z)), Ta[3]);
+        const float r = P.res;
+        int h, l;
+        if (P.res_pow2) {
+          // a power-of-two leaf (the YAML default 1.0): x / r == x * (1 / r) exactly, so the correctly rounded f32
+          // divisions (~12 instructions each) collapse to multiplications without changing a single bit
+          const float ir = P.inv_res;
+          h = (int)floorf(lsa_fmul(lsa_fadd(t, r), ir)) - mb; l = (int)floorf(lsa_fmul(lsa_fsub(t, r), ir)) - mb;
+        } else {
+          h = (int)floorf(lsa_fdiv(lsa_fadd(t, r), r)) - mb; l = (int)floorf(lsa_fdiv(lsa_fsub(t, r), r)) - mb;
         }
-        tp[pbase + ppl] = t;
+        h = min(h, dmax);
+        l = max(l, 0);
+        const int na = min(h - l + 1, 3);  // with radius == leaf the box is at most 3 cells wide per axis
+        const bool ok = ppl < kTilePts && i < n && part4 < 3 && (__float_as_uint(t) & 0x7f800000u) != 0x7f800000u && na > 0;
+        unsigned w = ok ? (((unsigned)na << (8 * a)) | (1u << (24 + a))) : 0u;  // extent of this axis + "axis fine" bit
+        int lin = ok ? l * stride : 0;
+        const float rr = t - (float)(l + mb) * r;  // relative to the low corner of the box's first cell (dense pre-filter)
+        // quad_perm broadcasts of lane 1 (0x55) and lane 2 (0xaa) of each quad
+        w += (unsigned)__builtin_amdgcn_mov_dpp((int)w, 0x55, 0xf, 0xf, true) + (unsigned)__builtin_amdgcn_mov_dpp((int)w, 0xaa, 0xf, 0xf, true);
+        lin += __builtin_amdgcn_mov_dpp(lin, 0x55, 0xf, 0xf, true) + __builtin_amdgcn_mov_dpp(lin, 0xaa, 0xf, 0xf, true);
+        float *tpw = reinterpret_cast<float *>(tp + pbase + ppl);
+        if (part4 < 3) {
+          tpw[a] = t;        // TilePoint::tx / ty / tz
+          tpw[5 + a] = rr;   // TilePoint::rx / ry / rz (read only behind a valid box)
+        }
+        if (part4 == 0) {
+          const bool valid = (w >> 24) == 7u;  // all three coordinates finite, box not empty on any axis
+          tp[pbase + ppl].cell0 = valid ? lin : 0;
+          tp[pbase + ppl].nxyz = valid ? (int)(w & 0xffffffu) : 0;
+        }
       }
       // computePointDerivatives (:448-482): dot products of the source point with the angle-derivative vectors;
       // lane group g of a point owns terms 6g .. 6g+5 (KIND 1 needs only the 8 Jacobian terms)
       double x = s.x, y = s.y, z = s.z;
       const int k0 = part4 * 6, k1 = min(k0 + 6, (KIND == 1) ? 8 : kPointTerms);
       for (int k = k0; k < k1; k++) terms[(pbase + ppl) * kTermStride + k] = x * jh[k * 3] + y * jh[k * 3 + 1] + z * jh[k * 3 + 2];
-      if (lane == 0) npts += min((size_t)kTilePts, n - tile * kTilePts);
     }
     wave_sync();
     unsigned total = carried;  // the queue already holds the previous tile's left-over pairs
     if constexpr (DENSE) {
       // ---- phase A (dense table): row probes -> pairs, pre-filtered on the f32 distance
-      unsigned c_ent[kRowRounds * 3];
-      unsigned c_mask = 0;
       // which (point, dy, dz) a lane probes in each round depends on the lane only: packed once per kernel into ONE register
       // (probe_lut: 8 bits per field, 16 bits per round) instead of ~12 integer instructions per round and tile — and instead
       // of the ~30 registers the compiler would keep live through the pair math if it hoisted the unpacked values
@@ -315,6 +322,9 @@ __device__ __forceinline__ double ndt_pass_body(const float4 *__restrict__ src, 
         const float4 *row = dense + r_cell[j];
         e0[j] = row[0]; e1[j] = row[1]; e2[j] = row[2];
       }
+      // The survivors go to the queue in (round, cell, lane) order: one wave ballot per (round, cell) gives every keeping
+      // lane its slot (count of keeping lanes below it) and the wave the running total as a SCALAR — no cross-lane scan,
+      // no stores for rejected entries.  The order is a function of the data only, so every f64 sum stays reproducible.
 #pragma unroll
       for (int j = 0; j < kRowRounds; j++) {
         const float rx = tp[pbase + r_pl[j]].rx;
@@ -325,19 +335,11 @@ __device__ __forceinline__ double ndt_pass_body(const float4 *__restrict__ src, 
           float d2 = dx * dx + dy * dy + dz * dz;
           int rank = __float_as_int(ev[i].w);  // -1: unoccupied, too few points or rejected eigenvalues (VoxelGrid.cpp:465)
           bool ok = i < r_nx[j] && rank >= 0 && d2 <= P.r2f_pre;
-          c_ent[j * 3 + i] = ((unsigned)(pbase + r_pl[j])) | ((unsigned)rank << 6);  // point slot incl. its buffer half
-          if (ok) c_mask |= 1u << (j * 3 + i);
+          const unsigned long long m = __ballot(ok);
+          const unsigned below = __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
+          if (ok) queue[total + below] = ((unsigned)(pbase + r_pl[j])) | ((unsigned)rank << 6);  // point slot incl. its buffer half
+          total += (unsigned)__popcll(m);
         }
-      }
-      unsigned fresh;
-      unsigned pos = carried + wave_excl_scan(__popc(c_mask), lane, &fresh);
-      total += fresh;
-      // branch-free scatter: rejected entries go to a dump slot one past the queue
-#pragma unroll
-      for (int k = 0; k < kRowRounds * 3; k++) {
-        bool keep = (c_mask >> k) & 1u;
-        unsigned slot = keep ? pos + __popc(c_mask & ((1u << k) - 1u)) : (unsigned)kQueueSlots;
-        queue[slot] = c_ent[k];
       }
       wave_sync();
     } else {
@@ -449,17 +451,16 @@ __device__ __forceinline__ double ndt_pass_body(const float4 *__restrict__ src, 
       const unsigned rounds = drain ? full + 1u : full;
       for (unsigned r = 0; r < rounds; r++) {
         const unsigned qi = r * 64 + lane;
-        if (qi < total) {
-          unsigned e = queue[qi];
-          const unsigned pl = e & 63u;
-          const double *R = reinterpret_cast<const double *>(reinterpret_cast<const char *>(rec) + (e >> 6) * (unsigned)(kRecDoubles * sizeof(double)));
-          double pg[8];
-          const double *tm = terms + pl * kTermStride;
+        const bool live = qi < total;          // (only the last round of a drained tile has idle lanes: they read entry 0)
+        const unsigned e = live ? queue[qi] : 0u;
+        const unsigned pl = e & 63u;
+        const double *R = reinterpret_cast<const double *>(reinterpret_cast<const char *>(rec) + (e >> 6) * (unsigned)(kRecDoubles * sizeof(double)));
+        double pg[8];
+        const double *tm = terms + pl * kTermStride;
 #pragma unroll
-          for (int k = 0; k < 8; k++) pg[k] = tm[k];
-          // the 15 Hessian terms stay in LDS and are read where they are used: 30 fewer live registers in the pair math
-          pair_update<KIND>(P, R, tp[pl].tx, tp[pl].ty, tp[pl].tz, pg, tm + 8, acc, accepted);
-        }
+        for (int k = 0; k < 8; k++) pg[k] = tm[k];
+        // the 15 Hessian terms stay in LDS and are read where they are used: 30 fewer live registers in the pair math
+        pair_update<KIND>(P, R, tp[pl].tx, tp[pl].ty, tp[pl].tz, pg, tm + 8, acc, live, accepted);
       }
       if (drain) left = 0;
       if (full != 0 && left != 0) {  // move the left-over pairs (all of THIS tile) to the front of the queue
@@ -473,16 +474,15 @@ __device__ __forceinline__ double ndt_pass_body(const float4 *__restrict__ src, 
   }
   // the last tile's left-over pairs
   if (carried) {
-    if (lane < carried) {
-      unsigned e = queue[lane];
-      const unsigned pl = e & 63u;
-      const double *R = reinterpret_cast<const double *>(reinterpret_cast<const char *>(rec) + (e >> 6) * (unsigned)(kRecDoubles * sizeof(double)));
-      double pg[8];
-      const double *tm = terms + pl * kTermStride;
+    const bool live = (unsigned)lane < carried;
+    const unsigned e = live ? queue[lane] : 0u;
+    const unsigned pl = e & 63u;
+    const double *R = reinterpret_cast<const double *>(reinterpret_cast<const char *>(rec) + (e >> 6) * (unsigned)(kRecDoubles * sizeof(double)));
+    double pg[8];
+    const double *tm = terms + pl * kTermStride;
 #pragma unroll
-      for (int k = 0; k < 8; k++) pg[k] = tm[k];
-      pair_update<KIND>(P, R, tp[pl].tx, tp[pl].ty, tp[pl].tz, pg, tm + 8, acc, accepted);
-    }
+    for (int k = 0; k < 8; k++) pg[k] = tm[k];
+    pair_update<KIND>(P, R, tp[pl].tx, tp[pl].ty, tp[pl].tz, pg, tm + 8, acc, live, accepted);
   }
   // block reduction through LDS in a fixed order (bitwise reproducible): transpose the 28 per-lane accumulators (two
   // rounds of 128 lanes), 8 x 32 lanes add 32 rows each, then 32 lanes add the 8 partial rows
@@ -491,9 +491,14 @@ __device__ __forceinline__ double ndt_pass_body(const float4 *__restrict__ src, 
   double *red2 = reinterpret_cast<double *>(lds + kLdsRed2);
   double *wcnt = red2 + 8 * 32;  // [kWaves][2]: pairs, points per wave
   {
-    unsigned wave_pairs = accepted;
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) wave_pairs += __shfl_down(wave_pairs, off, 64);
+    const unsigned wave_pairs = accepted;
+    // source points this wave walked: its tiles are tile0, tile0 + tstride, ...; all full but possibly the cloud's last one
+    unsigned long long npts = 0;
+    if (tile0 < ntiles) {
+      const size_t last = ntiles - 1 - tile0;
+      npts = (unsigned long long)(last / tstride + 1) * kTilePts;
+      if (last % tstride == 0) npts -= (unsigned long long)(ntiles * kTilePts - n);
+    }
     if (lane == 0) { wcnt[wave * 2] = (double)wave_pairs; wcnt[wave * 2 + 1] = (double)npts; }
   }
 #pragma unroll
