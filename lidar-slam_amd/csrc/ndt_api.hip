@@ -80,7 +80,10 @@ int run_pass(lsa_ndt *h, const float T[16], const double p[6], int kind, double 
       if ((rc = ndt_launch_armed(h, P, seq, armed_headroom(h, g), kArmedPatienceUs))) return rc;
       gave_up = reinterpret_cast<volatile unsigned long long *>(h->h_gave_up.p);
     }
-    ndt_mail_post(reinterpret_cast<PassMail *>(h->mail), &P, seq, false, h->d_source, h->n_source, g);
+    // (after the first armed pass of this ScanMatch the kernels hold their first tiles from the kept copy)
+    static const bool no_keep = getenv("LSA_NO_KEEP") != nullptr;   // A/B switch for measurements (scratch: ab_match.py)
+    const bool kept = !no_keep && h->keep_match == h->match_id && h->keep_n == h->n_source;
+    ndt_mail_post(reinterpret_cast<PassMail *>(h->mail), &P, seq, false, h->d_source, h->n_source, g, kept);
     h->armed_seq = seq + 1;
     h->armed_outstanding = false;
     if ((rc = ndt_launch_armed(h, P, seq + 1, armed_headroom(h, g), kArmedPatienceUs))) return rc;
@@ -102,6 +105,7 @@ int run_pass(lsa_ndt *h, const float T[16], const double p[6], int kind, double 
       return run_pass(h, T, p, kind, out32);
     }
     h->unsynced += 2;
+    if (!kept) { h->keep_match = h->match_id; h->keep_n = h->n_source; }   // that pass kept its first tiles
     return LSA_OK;
   }
   if (ndt_pass_host_reduce(h, kind)) {
@@ -186,6 +190,7 @@ int scan_match_common(lsa_ndt *h, const float predict_pose[16], float result_pos
     memset(&st, 0, sizeof(st));
   }
   // armed passes: only where every pass of the ScanMatch is a full (kind 0) pass, i.e. the trial loop is dead, on one GPU
+  h->match_id++;
   h->armed_scope = !h->no_armed && !h->allreduce && h->n_source > 0 && (double)h->step_size > (double)h->trans_eps / 2;
   if (h->armed_scope && (rc = mail_ensure(h))) { h->armed_scope = false; return rc; }
   rc = lsa_gn_solve_trace(eval_trampoline, h, h->resolution, h->step_size, h->trans_eps, h->max_iter, h->outlier_ratio, h->mode, predict_pose, result_pose, &st,

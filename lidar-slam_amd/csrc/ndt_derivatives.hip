@@ -57,7 +57,8 @@ constexpr unsigned kHostReduceMaxBlocks = 1024;
 // 20 ms timeout makes the kernel exit without writing its row.  Same body, same grid, same rows: the results are the bits
 // of the unarmed path.
 struct PassMail {
-  unsigned long long words[80];   // [0..5] the 12 floats of T, [6..74] jh (ja then ha), [75] virtual grid, [76] source pointer, [77] #points
+  unsigned long long words[80];   // [0..5] the 12 floats of T, [6..74] jh (ja then ha), [75] virtual grid, [76] source pointer, [77] #points,
+                                  // [78] 1: the kept copy of the first tiles (see k_ndt_pass_armed) is this pass's source
   unsigned long long check;       // key(seq) ^ XOR_c rotl(word_c, c % 31 + 1)
   unsigned long long seq;         // sequence number of the pass these parameters are for; | kMailCancel: that pass is cancelled
 };
@@ -69,14 +70,25 @@ template <bool DENSE>
 __global__ __launch_bounds__(kBlockD, pass_waves(0)) void k_ndt_pass_armed(PassParams P, const uint4 *__restrict__ words, const float4 *__restrict__ dense,
                                                                          const double *__restrict__ rec, double *__restrict__ partials, const PassMail *mail,
                                                                          unsigned long long seq, unsigned long long patience_ticks,
-                                                                         unsigned long long *gave_up /* host-mapped */) {
+                                                                         unsigned long long *gave_up /* host-mapped */, float4 *__restrict__ keep,
+                                                                         unsigned keep_cap) {
   constexpr int NB = 2;
   __shared__ __align__(16) unsigned char lds[lds_bytes(NB)];
   __shared__ int s_go;
-  __shared__ unsigned long long s_dyn[3];   // virtual grid, source pointer, #points
+  __shared__ unsigned long long s_dyn[4];   // virtual grid, source pointer, #points, "source = the kept copy"
   double *jh = reinterpret_cast<double *>(lds + lds_const(NB));
   float *Tl = reinterpret_cast<float *>(lds + lds_tl(NB));
   const int tid = (int)threadIdx.x, lane = tid & 63;
+  // Every pass of a ScanMatch reads the same source cloud and a wave's first tile is a function of its position in the grid
+  // only, so each pass KEEPS its first tiles' points in memory the handle owns and the next one loads them from there right
+  // now, before it knows anything else: that takes the source load (a cold-cache miss at the head of the dependency chain)
+  // off the path between the mail's arrival and the rows.  The mail says whether the copy is this pass's source (not for
+  // the first pass of a ScanMatch: the caller's cloud is only ever read once the mail names it).
+  float4 s_pre = make_float4(0.f, 0.f, 0.f, 0.f);
+  {
+    const size_t i0 = ((size_t)blockIdx.x * kWaves + (size_t)(tid >> 6)) * kTilePts + (size_t)(lane >> 2);
+    if ((lane >> 2) < kTilePts && i0 < keep_cap) s_pre = keep[i0];
+  }
   if (tid < 64) {  // wave 0: wait for this pass's mail, take the payload, verify it
     const unsigned long long *mw = reinterpret_cast<const unsigned long long *>(mail);
     const unsigned long long t0 = wall_clock64();
@@ -96,7 +108,7 @@ __global__ __launch_bounds__(kBlockD, pass_waves(0)) void k_ndt_pass_armed(PassP
           if (lane >= 6) dstw[lane - 6] = w0;                                       // jh[0..57]
           else reinterpret_cast<unsigned long long *>(Tl)[lane] = w0;               // T: 6 words = 12 floats
           if (lane < 11) dstw[58 + lane] = w1;                                      // jh[58..68]
-          else if (lane < 14) s_dyn[lane - 11] = w1;                                // words 75, 76, 77
+          else if (lane < 15) s_dyn[lane - 11] = w1;                                // words 75, 76, 77, 78
           go = 1;
           break;
         }
@@ -120,13 +132,14 @@ __global__ __launch_bounds__(kBlockD, pass_waves(0)) void k_ndt_pass_armed(PassP
   if (blockIdx.x >= vgrid) return;   // launched with head-room for a larger source than this pass has
   const float4 *src = reinterpret_cast<const float4 *>(uniform64(s_dyn[1]));
   const size_t n = (size_t)uniform64(s_dyn[2]);
-  const double v = ndt_pass_body<0, DENSE>(src, n, P, Tl, jh, words, dense, rec, lds, vgrid);
+  const bool kept = __builtin_amdgcn_readfirstlane((int)(unsigned)s_dyn[3]) != 0 && n <= (size_t)keep_cap;
+  const double v = ndt_pass_body<0, DENSE>(src, n, P, Tl, jh, words, dense, rec, lds, vgrid, kept, s_pre, (!kept && n <= (size_t)keep_cap) ? keep : nullptr);
   if (tid < kOutDoubles) lsa_store_row32(partials + (size_t)blockIdx.x * kOutDoubles, tid, v, mail_key(seq) | 1ull);
 }
 }  // namespace
 
 // host: post the dynamic parameters of pass `seq` (or its cancellation) into the mailbox
-void ndt_mail_post(PassMail *mail, const PassParams *P, unsigned long long seq, bool cancel, const void *d_src, size_t n, unsigned vgrid) {
+void ndt_mail_post(PassMail *mail, const PassParams *P, unsigned long long seq, bool cancel, const void *d_src, size_t n, unsigned vgrid, bool kept) {
   if (cancel) {
     __atomic_store_n(&mail->seq, seq | kMailCancel, __ATOMIC_RELEASE);
     _mm_sfence();
@@ -140,6 +153,7 @@ void ndt_mail_post(PassMail *mail, const PassParams *P, unsigned long long seq, 
   w[75] = vgrid;
   w[76] = (unsigned long long)(uintptr_t)d_src;
   w[77] = (unsigned long long)n;
+  w[78] = kept ? 1ull : 0ull;
   unsigned long long x = 0;
   for (int c = 0; c < 80; c++) x ^= lsa_row_mix(w[c], c % 31);
   for (int c = 0; c < 80; c++) mail->words[c] = w[c];
@@ -159,13 +173,15 @@ int ndt_launch_armed(lsa_ndt *h, const PassParams &P, unsigned long long seq, un
     if ((rc = h->h_gave_up.reserve(ctx, 8))) return rc;
     memset(h->h_gave_up.p, 0, 8 * sizeof(double));
   }
+  // first-tile points kept from pass to pass (k_ndt_pass_armed): sized once for the largest armed grid, never moved
+  if (!h->src_keep.p && (rc = h->src_keep.reserve(ctx, (size_t)kHostReduceMaxBlocks * kWaves * kTilePts))) return rc;
   const PassMail *mail = reinterpret_cast<const PassMail *>(h->mail);
   const unsigned long long ticks = (unsigned long long)(patience_us * 100.0);
   unsigned long long *gu = reinterpret_cast<unsigned long long *>(h->h_gave_up.p);
   if (h->use_dense)
-    hipLaunchKernelGGL((k_ndt_pass_armed<true>), dim3(grid), dim3(kBlockD), 0, ctx->stream, P, h->words.p, h->dense.p, h->rec.p, h->h_partials.p, mail, seq, ticks, gu);
+    hipLaunchKernelGGL((k_ndt_pass_armed<true>), dim3(grid), dim3(kBlockD), 0, ctx->stream, P, h->words.p, h->dense.p, h->rec.p, h->h_partials.p, mail, seq, ticks, gu, h->src_keep.p, (unsigned)h->src_keep.cap);
   else
-    hipLaunchKernelGGL((k_ndt_pass_armed<false>), dim3(grid), dim3(kBlockD), 0, ctx->stream, P, h->words.p, h->dense.p, h->rec.p, h->h_partials.p, mail, seq, ticks, gu);
+    hipLaunchKernelGGL((k_ndt_pass_armed<false>), dim3(grid), dim3(kBlockD), 0, ctx->stream, P, h->words.p, h->dense.p, h->rec.p, h->h_partials.p, mail, seq, ticks, gu, h->src_keep.p, (unsigned)h->src_keep.cap);
   LSA_HIP(ctx, hipGetLastError());
   return LSA_OK;
 }

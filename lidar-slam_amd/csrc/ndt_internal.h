@@ -76,6 +76,9 @@ struct lsa_ndt {
   unsigned armed_grid = 0;          // launch grid of the outstanding kernel
   unsigned long long armed_gen = 0, target_gen = 0;   // the voxel table it was launched for / the current one
   bool armed_carry = getenv("LSA_NO_CARRY") == nullptr;   // leave the last armed kernel parked for the next ScanMatch
+  DevBuf<float4> src_keep;          // first-tile source points kept by the last armed pass (see k_ndt_pass_armed)
+  unsigned long long match_id = 0, keep_match = ~0ull;   // ScanMatch counter; the ScanMatch whose source src_keep holds
+  size_t keep_n = 0;
   PinnedBuf<double> h_gave_up;      // [0]: sequence number of the last armed kernel that left because no mail came
   unsigned long long armed_passes = 0, armed_cancels = 0, armed_fallbacks = 0;
 

@@ -25,7 +25,7 @@ bool ndt_pass_host_reduce(const lsa_ndt *h, int kind);
 int ndt_publish_out(lsa_ndt *h, unsigned long long *key_out);
 int ndt_enqueue_pass_host(lsa_ndt *h, const PassParams &P, int kind, unsigned *grid_out, unsigned long long *key_out);
 struct PassMail;
-void ndt_mail_post(PassMail *mail, const PassParams *P, unsigned long long seq, bool cancel, const void *d_src, size_t n, unsigned vgrid);
+void ndt_mail_post(PassMail *mail, const PassParams *P, unsigned long long seq, bool cancel, const void *d_src, size_t n, unsigned vgrid, bool kept = false);
 int ndt_launch_armed(lsa_ndt *h, const PassParams &P, unsigned long long seq, unsigned grid, double patience_us);
 unsigned long long ndt_armed_row_key(unsigned long long seq);
 bool ndt_fetch_row_host(const double *row, unsigned long long key, double limit_ms, unsigned long long out32[32],

@@ -188,7 +188,9 @@ template <int KIND, bool DENSE>
 __device__ __forceinline__ double ndt_pass_body(const float4 *__restrict__ src, size_t n, const PassParams &P, const float *Tl /* LDS: 3x4 row-major */,
                                                 const double *jh /* LDS: ja[8][3] then ha[15][3] */, const uint4 *__restrict__ words,
                                                 const float4 *__restrict__ dense, const double *__restrict__ rec, unsigned char *lds,
-                                                unsigned vgrid /* workgroups sharing the tiles: gridDim.x, or fewer for an armed launch */) {
+                                                unsigned vgrid /* workgroups sharing the tiles: gridDim.x, or fewer for an armed launch */,
+                                                bool have_first = false /* wave-uniform */, float4 s_first = make_float4(0.f, 0.f, 0.f, 0.f),
+                                                float4 *__restrict__ keep = nullptr) {
   constexpr int NB = pass_bufs(KIND);
   constexpr int kLdsSlice = lds_slice(NB), kLdsTerms = lds_terms(NB), kLdsCand = lds_cand(NB), kLdsQueue = lds_queue(NB), kLdsRed2 = lds_red2(NB);
   // (the wave index is uniform across the wave: as a scalar, everything derived from it — the LDS slice, the tile walk — stays
@@ -214,7 +216,11 @@ __device__ __forceinline__ double ndt_pass_body(const float4 *__restrict__ src, 
   // caller has staged them (and the rigid transform) in LDS.
   // software prefetch of the next tile's points (each of the 4 lanes of a point holds its own copy)
   float4 s_next = make_float4(0.f, 0.f, 0.f, 0.f);
-  {
+  // (an armed launch may already hold its first tile's points: it took them from the copy the previous pass of the same
+  // ScanMatch kept, before the parameters of this pass had even arrived)
+  if (have_first) {
+    s_next = s_first;
+  } else {
     size_t i0 = tile0 * kTilePts + ppl;
     if (ppl < kTilePts && i0 < n) s_next = src[i0];
   }
@@ -240,6 +246,7 @@ __device__ __forceinline__ double ndt_pass_body(const float4 *__restrict__ src, 
       float4 s = s_next;
       size_t inext = (tile + tstride) * kTilePts + ppl;
       if (ppl < kTilePts && inext < n) s_next = src[inext];
+      if (keep != nullptr && tile == tile0 && part4 == 3 && ppl < kTilePts && i < n) keep[i] = s;  // for the next pass's early start
       {
         // One AXIS per lane: lane group g < 3 of a point transforms coordinate g (f32, PCL order) and clips that axis of the
         // radiusSearch cell box (VoxelGrid.cpp:438-455, relative to real_min, clipped to the occupied bounds); the three
