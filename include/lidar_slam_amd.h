@@ -190,6 +190,12 @@ int lsa_ndt_grid_info(lsa_ndt *ndt, int64_t info[9]);
  * rec: centroid(3) icov sym (xx,xy,xz,yy,yz,zz) weight(1) -> 10 doubles per cell. cap in cells. */
 int lsa_ndt_grid_dump(lsa_ndt *ndt, int32_t *cell_ints, double *cell_rec, size_t cap, size_t *n_cells);
 
+/* diagnostics of the armed passes: sums over the armed passes since the last reset — out[0] passes, out[1] us spent posting
+ * the mail, out[2] us from the mail posted to all rows taken, out[3] us from all rows taken to the next mail's post begun
+ * (within one ScanMatch: row sums, Newton step, parameters), out[4] us the kernels waited on the device for their mail
+ * (mean over workgroups, summed over passes), out[5] us from the mail taken to the row stored (same).  reset != 0 clears. */
+int lsa_ndt_armed_timing(lsa_ndt *ndt, double out[6], int reset);
+
 /* Armed passes (default ON; 0 or the environment variable LSA_NO_ARMED disables them): with the trial loop of the line search
  * dead (every shipped configuration) each Newton iteration is exactly one full derivative pass, so ScanMatch enqueues the
  * kernel of the NEXT pass right behind the current one; it waits on the device for its parameters, which the host posts into

@@ -161,6 +161,7 @@ def lib():
     L.lsa_ndt_armed_counters.argtypes = [vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
     L.lsa_ndt_set_persistent.argtypes = [vp, i]
     L.lsa_ndt_align_counters.argtypes = [vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
+    L.lsa_ndt_armed_timing.argtypes = [vp, C.POINTER(C.c_double), i]
     L.lsa_ndt_align_stamps.argtypes = [vp, i, C.POINTER(C.c_uint64), sz, PSZ]
     L.lsa_gn_math_selftest.argtypes = [vp, sz, C.c_uint64, C.POINTER(C.c_uint64)]
     _lib = L

@@ -83,7 +83,9 @@ int run_pass(lsa_ndt *h, const float T[16], const double p[6], int kind, double 
     // (after the first armed pass of this ScanMatch the kernels hold their first tiles from the kept copy)
     static const bool no_keep = getenv("LSA_NO_KEEP") != nullptr;   // A/B switch for measurements (scratch: ab_match.py)
     const bool kept = !no_keep && h->keep_match == h->match_id && h->keep_n == h->n_source;
+    const auto at0 = std::chrono::steady_clock::now();
     ndt_mail_post(reinterpret_cast<PassMail *>(h->mail), &P, seq, false, h->d_source, h->n_source, g, kept);
+    const auto at1 = std::chrono::steady_clock::now();
     h->armed_seq = seq + 1;
     h->armed_outstanding = false;
     if ((rc = ndt_launch_armed(h, P, seq + 1, armed_headroom(h, g), kArmedPatienceUs))) return rc;
@@ -103,6 +105,17 @@ int run_pass(lsa_ndt *h, const float T[16], const double p[6], int kind, double 
       h->armed_scope = false;
       h->armed_fallbacks++;
       return run_pass(h, T, p, kind, out32);
+    }
+    {  // diagnostics (lsa_ndt_armed_timing)
+      const auto at2 = std::chrono::steady_clock::now();
+      h->at_passes += 1;
+      h->at_post_us += std::chrono::duration<double, std::micro>(at1 - at0).count();
+      h->at_post_to_rows_us += std::chrono::duration<double, std::micro>(at2 - at1).count();
+      if (h->at_have_last) h->at_rows_to_post_us += std::chrono::duration<double, std::micro>(at0 - h->at_last_rows).count();
+      h->at_last_rows = at2; h->at_have_last = true;
+      const unsigned long long st = (unsigned long long)out32[30];   // sum over the workgroups of (wait << 20) + body
+      h->at_dev_wait_ticks += (double)(st >> 20) / (double)g;
+      h->at_dev_body_ticks += (double)(st & 0xfffffull) / (double)g;
     }
     h->unsynced += 2;
     if (!kept) { h->keep_match = h->match_id; h->keep_n = h->n_source; }   // that pass kept its first tiles
@@ -191,6 +204,7 @@ int scan_match_common(lsa_ndt *h, const float predict_pose[16], float result_pos
   }
   // armed passes: only where every pass of the ScanMatch is a full (kind 0) pass, i.e. the trial loop is dead, on one GPU
   h->match_id++;
+  h->at_have_last = false;
   h->armed_scope = !h->no_armed && !h->allreduce && h->n_source > 0 && (double)h->step_size > (double)h->trans_eps / 2;
   if (h->armed_scope && (rc = mail_ensure(h))) { h->armed_scope = false; return rc; }
   rc = lsa_gn_solve_trace(eval_trampoline, h, h->resolution, h->step_size, h->trans_eps, h->max_iter, h->outlier_ratio, h->mode, predict_pose, result_pose, &st,
@@ -388,6 +402,16 @@ extern "C" int lsa_ndt_armed_counters(lsa_ndt *h, uint64_t *passes, uint64_t *ca
   if (passes) *passes = h->armed_passes;
   if (cancels) *cancels = h->armed_cancels;
   if (fallbacks) *fallbacks = h->armed_fallbacks;
+  return LSA_OK;
+}
+
+extern "C" int lsa_ndt_armed_timing(lsa_ndt *h, double out[6], int reset) {
+  if (!h) return LSA_ERR_INVALID;
+  if (out) {
+    out[0] = h->at_passes; out[1] = h->at_post_us; out[2] = h->at_post_to_rows_us; out[3] = h->at_rows_to_post_us;
+    out[4] = h->at_dev_wait_ticks * 0.01; out[5] = h->at_dev_body_ticks * 0.01;
+  }
+  if (reset) { h->at_passes = h->at_post_us = h->at_post_to_rows_us = h->at_rows_to_post_us = h->at_dev_wait_ticks = h->at_dev_body_ticks = 0; h->at_have_last = false; }
   return LSA_OK;
 }
 

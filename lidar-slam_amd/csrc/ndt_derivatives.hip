@@ -79,6 +79,7 @@ __global__ __launch_bounds__(kBlockD, pass_waves(0)) void k_ndt_pass_armed(PassP
   double *jh = reinterpret_cast<double *>(lds + lds_const(NB));
   float *Tl = reinterpret_cast<float *>(lds + lds_tl(NB));
   const int tid = (int)threadIdx.x, lane = tid & 63;
+  unsigned long long t_mail = 0, t_start = 0;   // (wave 0) 100 MHz clock: kernel start, mail taken — diagnostics in row column 30
   // Every pass of a ScanMatch reads the same source cloud and a wave's first tile is a function of its position in the grid
   // only, so each pass KEEPS its first tiles' points in memory the handle owns and the next one loads them from there right
   // now, before it knows anything else: that takes the source load (a cold-cache miss at the head of the dependency chain)
@@ -92,14 +93,18 @@ __global__ __launch_bounds__(kBlockD, pass_waves(0)) void k_ndt_pass_armed(PassP
   if (tid < 64) {  // wave 0: wait for this pass's mail, take the payload, verify it
     const unsigned long long *mw = reinterpret_cast<const unsigned long long *>(mail);
     const unsigned long long t0 = wall_clock64();
+    t_start = t0;
     int go = 0;
     for (;;) {
+      // ONE round trip per look: sequence number, payload and check word are fetched together and the payload is taken if it
+      // is whole (the check word is keyed with the sequence number, so words of two different posts cannot pass) — not
+      // "see the number, then fetch the payload", which put a second uncached read between the mail's arrival and the pass
       const unsigned long long sq = __hip_atomic_load(&mail->seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      const unsigned long long w0 = __hip_atomic_load(mw + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      const unsigned long long w1 = lane < 16 ? __hip_atomic_load(mw + 64 + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) : 0ull;
+      const unsigned long long chk = __hip_atomic_load(&mail->check, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
       if ((sq & ~kMailCancel) > seq || sq == (seq | kMailCancel)) break;  // cancelled, or the host has already moved on to a later pass
       if (sq == seq) {
-        unsigned long long w0 = __hip_atomic_load(mw + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-        unsigned long long w1 = lane < 16 ? __hip_atomic_load(mw + 64 + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) : 0ull;
-        const unsigned long long chk = __hip_atomic_load(&mail->check, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         unsigned long long x = lsa_row_mix(w0, lane % 31) ^ (lane < 16 ? lsa_row_mix(w1, (64 + lane) % 31) : 0ull);
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) x ^= __shfl_xor(x, off, 64);
@@ -110,6 +115,7 @@ __global__ __launch_bounds__(kBlockD, pass_waves(0)) void k_ndt_pass_armed(PassP
           if (lane < 11) dstw[58 + lane] = w1;                                      // jh[58..68]
           else if (lane < 15) s_dyn[lane - 11] = w1;                                // words 75, 76, 77, 78
           go = 1;
+          t_mail = wall_clock64();
           break;
         }
       }
@@ -134,7 +140,9 @@ __global__ __launch_bounds__(kBlockD, pass_waves(0)) void k_ndt_pass_armed(PassP
   const size_t n = (size_t)uniform64(s_dyn[2]);
   const bool kept = __builtin_amdgcn_readfirstlane((int)(unsigned)s_dyn[3]) != 0 && n <= (size_t)keep_cap;
   const double v = ndt_pass_body<0, DENSE>(src, n, P, Tl, jh, words, dense, rec, lds, vgrid, kept, s_pre, (!kept && n <= (size_t)keep_cap) ? keep : nullptr);
-  if (tid < kOutDoubles) lsa_store_row32(partials + (size_t)blockIdx.x * kOutDoubles, tid, v, mail_key(seq) | 1ull);
+  // column 30 (unused by the sums' consumers): ticks this workgroup waited for its mail x 2^20 + ticks from the mail to here
+  const double stamp = (double)(((t_mail - t_start) << 20) + ((wall_clock64() - t_mail) & 0xfffffull));
+  if (tid < kOutDoubles) lsa_store_row32(partials + (size_t)blockIdx.x * kOutDoubles, tid, tid == 30 ? stamp : v, mail_key(seq) | 1ull);
 }
 }  // namespace
 

@@ -2,6 +2,7 @@
 #ifndef LSA_NDT_INTERNAL_H_
 #define LSA_NDT_INTERNAL_H_
 
+#include <chrono>
 #include <cstdlib>
 #include "nn_grid.h"
 #include "voxel_index_dev.h"
@@ -76,6 +77,10 @@ struct lsa_ndt {
   unsigned armed_grid = 0;          // launch grid of the outstanding kernel
   unsigned long long armed_gen = 0, target_gen = 0;   // the voxel table it was launched for / the current one
   bool armed_carry = getenv("LSA_NO_CARRY") == nullptr;   // leave the last armed kernel parked for the next ScanMatch
+  // diagnostics of the armed passes (lsa_ndt_armed_timing): sums over passes
+  double at_passes = 0, at_post_to_rows_us = 0, at_rows_to_post_us = 0, at_dev_wait_ticks = 0, at_dev_body_ticks = 0, at_post_us = 0;
+  std::chrono::steady_clock::time_point at_last_rows;
+  bool at_have_last = false;
   DevBuf<float4> src_keep;          // first-tile source points kept by the last armed pass (see k_ndt_pass_armed)
   unsigned long long match_id = 0, keep_match = ~0ull;   // ScanMatch counter; the ScanMatch whose source src_keep holds
   size_t keep_n = 0;

@@ -144,6 +144,14 @@ class NDTRegistrationHip(RegistrationInterface):
         self.ctx.check(capi.lib().lsa_ndt_armed_counters(self.h, C.byref(a), C.byref(b), C.byref(c)))
         return dict(passes=a.value, cancels=b.value, fallbacks=c.value)
 
+    def armed_timing(self, reset=False):
+        """Per-pass means of the armed passes' timeline (lsa_ndt_armed_timing), microseconds."""
+        out = (C.c_double * 6)()
+        self.ctx.check(capi.lib().lsa_ndt_armed_timing(self.h, out, 1 if reset else 0))
+        n = max(out[0], 1.0)
+        return dict(passes=int(out[0]), post_us=out[1] / n, post_to_rows_us=out[2] / n, rows_to_post_us=out[3] / n,
+                    dev_wait_us=out[4] / n, dev_body_us=out[5] / n)
+
     def set_persistent(self, on):
         """ScanMatch as ONE persistent launch (default) or one launch per derivative pass (lsa_ndt_set_persistent)."""
         self.ctx.check(capi.lib().lsa_ndt_set_persistent(self.h, 1 if on else 0))
