@@ -250,6 +250,7 @@ __global__ __launch_bounds__(kBlockD, 1) void k_ndt_align(const float4 *__restri
   int *sti = reinterpret_cast<int *>(st + kStInts);
   const int tid = (int)threadIdx.x, lane = tid & 63;
   const unsigned G = gridDim.x;
+  const PassScalars Q = pass_scalars(P);
   if (tid < 69) jh[tid] = (&P.ja[0][0])[tid];
   else if (tid < 69 + 12) Tl[tid - 69] = P.T[tid - 69];
   if (tid == 128) {
@@ -264,7 +265,7 @@ __global__ __launch_bounds__(kBlockD, 1) void k_ndt_align(const float4 *__restri
   __syncthreads();
   for (unsigned pass = 0;; pass++) {
     ALIGN_STAMP(0);
-    const double v = ndt_pass_body<0, DENSE>(src, n, P, Tl, jh, words, dense, rec, lds, gridDim.x);
+    const double v = ndt_pass_body<0, DENSE>(src, n, Q, Tl, jh, words, dense, rec, lds, gridDim.x);
     ALIGN_STAMP(1);
     // ---- publish this workgroup's row, then wait for everybody's
     const unsigned epoch = A.epoch0 + pass + 1u;

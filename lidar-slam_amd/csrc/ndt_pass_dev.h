@@ -22,8 +22,35 @@ constexpr int kBlockD = 256;
 #endif
 constexpr int pass_waves(int kind) { return kind == 1 ? LSA_PASS_WAVES_GRAD : LSA_PASS_WAVES; }
 
+// The scalar part of PassParams a pass works with.  A kernel's arguments are fetched by scalar loads at the point of first use,
+// and right after a launch the scalar cache is cold: each such fetch is a trip to memory.  The pass kernels therefore copy
+// these values into registers up front — the armed kernel BEFORE it starts waiting for its mail (pass_scalars_pin), so that
+// nothing between the mail's arrival and the rows waits for a kernel argument (measured: 0.8 us in front of the transform).
+struct PassScalars {
+  double d1, d2, r2max;
+  float res, inv_res, r2f_pre;
+  int res_pow2;
+  int min_b0, min_b1, min_b2;
+  int dim0, dim1, dim2;
+};
+__device__ __forceinline__ PassScalars pass_scalars(const PassParams &P) {
+  PassScalars q;
+  q.d1 = P.d1; q.d2 = P.d2; q.r2max = P.r2max;
+  q.res = P.res; q.inv_res = P.inv_res; q.r2f_pre = P.r2f_pre; q.res_pow2 = P.res_pow2;
+  q.min_b0 = P.min_b[0]; q.min_b1 = P.min_b[1]; q.min_b2 = P.min_b[2];
+  q.dim0 = P.dim[0]; q.dim1 = P.dim[1]; q.dim2 = P.dim[2];
+  return q;
+}
+// forces every value into a scalar register HERE (and keeps the compiler from fetching it again later)
+template <bool DENSE>
+__device__ __forceinline__ void pass_scalars_pin(PassScalars &q) {
+  if (!DENSE) return;   // (the bitmap-probe variant is short of scalar registers: pinned values would spill)
+  asm volatile("" : "+s"(q.d1), "+s"(q.d2), "+s"(q.r2max), "+s"(q.res), "+s"(q.inv_res), "+s"(q.res_pow2), "+s"(q.r2f_pre));
+  asm volatile("" : "+s"(q.min_b0), "+s"(q.min_b1), "+s"(q.min_b2), "+s"(q.dim0), "+s"(q.dim1), "+s"(q.dim2));
+}
+
 template <int KIND>
-__device__ __forceinline__ void pair_update(const PassParams &P, const double *__restrict__ R, float tx, float ty, float tz,
+__device__ __forceinline__ void pair_update(const PassScalars P, const double *__restrict__ R, float tx, float ty, float tz,
                                             const double pg[8], const double *ph /* LDS, read at the point of use */, double acc[28],
                                             bool live, unsigned &accepted /* wave-uniform */) {
   // R: centroid(3), C = icov (xx,xy,xz,yy,yz,zz), w.
@@ -185,7 +212,7 @@ __device__ __forceinline__ unsigned wave_excl_scan(unsigned cnt, int lane, unsig
 // f64 test runs in the pair step on the record's centroid it loads anyway.  ~20 % fewer instructions per tile and one
 // L2 round trip less on the critical path.  The bitmap path stays for cell boxes too large for a dense table.
 template <int KIND, bool DENSE>
-__device__ __forceinline__ double ndt_pass_body(const float4 *__restrict__ src, size_t n, const PassParams &P, const float *Tl /* LDS: 3x4 row-major */,
+__device__ __forceinline__ double ndt_pass_body(const float4 *__restrict__ src, size_t n, const PassScalars P, const float *Tl /* LDS: 3x4 row-major */,
                                                 const double *jh /* LDS: ja[8][3] then ha[15][3] */, const uint4 *__restrict__ words,
                                                 const float4 *__restrict__ dense, const double *__restrict__ rec, unsigned char *lds,
                                                 unsigned vgrid /* workgroups sharing the tiles: gridDim.x, or fewer for an armed launch */,
@@ -208,7 +235,7 @@ __device__ __forceinline__ double ndt_pass_body(const float4 *__restrict__ src, 
   // phase 0: the 4 lanes of a QUAD share a point (quad 14 and 15 = lanes 56..63 are spare: they work on tile slots 14 / 15,
   // which exist in LDS and which nothing reads)
   const int part4 = lane & 3, ppl = lane >> 2;
-  const int dimx = P.dim[0], dimxy = P.dim[0] * P.dim[1];
+  const int dimx = P.dim0, dimxy = P.dim0 * P.dim1;
   const size_t ntiles = (n + kTilePts - 1) / kTilePts;
   const size_t tile0 = (size_t)blockIdx.x * kWaves + wave, tstride = (size_t)vgrid * kWaves;
   // jh = ja[8][3] followed by ha[15][3]: 23 constant 3-vectors.  Phase 0 indexes them per LANE (each of the 4 lanes of a
@@ -255,8 +282,8 @@ __device__ __forceinline__ double ndt_pass_body(const float4 *__restrict__ src, 
         // per tile, now ~45.)
         int a = part4 < 3 ? part4 : 0;
         asm volatile("" : "+v"(a));  // lane-constant: do not hoist its selects out of the tile loop (registers)
-        const int mb = a == 0 ? P.min_b[0] : (a == 1 ? P.min_b[1] : P.min_b[2]);
-        const int dmax = (a == 0 ? P.dim[0] : (a == 1 ? P.dim[1] : P.dim[2])) - 1;
+        const int mb = a == 0 ? P.min_b0 : (a == 1 ? P.min_b1 : P.min_b2);
+        const int dmax = (a == 0 ? P.dim0 : (a == 1 ? P.dim1 : P.dim2)) - 1;
         const int stride = a == 0 ? 1 : (a == 1 ? dimx : dimxy);
         const float *Ta = Tl + 4 * a;
         // pcl::transformPointCloud: x' = m00*x + m01*y + m02*z + m03, f32, left to right, no FMA
