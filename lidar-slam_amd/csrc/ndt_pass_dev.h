@@ -322,8 +322,18 @@ __device__ __forceinline__ double ndt_pass_body(const float4 *__restrict__ src, 
       // computePointDerivatives (:448-482): dot products of the source point with the angle-derivative vectors;
       // lane group g of a point owns terms 6g .. 6g+5 (KIND 1 needs only the 8 Jacobian terms)
       double x = s.x, y = s.y, z = s.z;
-      const int k0 = part4 * 6, k1 = min(k0 + 6, (KIND == 1) ? 8 : kPointTerms);
-      for (int k = k0; k < k1; k++) terms[(pbase + ppl) * kTermStride + k] = x * jh[k * 3] + y * jh[k * 3 + 1] + z * jh[k * 3 + 2];
+      // (a fixed trip count: the six terms' 18 constants are fetched from LDS together instead of term by term)
+      const int k0 = part4 * 6;
+      constexpr int kLast = (KIND == 1) ? 8 : kPointTerms;
+      double tv[6];
+#pragma unroll
+      for (int u = 0; u < 6; u++) {
+        const int k = min(k0 + u, kLast - 1);
+        tv[u] = x * jh[k * 3] + y * jh[k * 3 + 1] + z * jh[k * 3 + 2];
+      }
+#pragma unroll
+      for (int u = 0; u < 6; u++)
+        if (k0 + u < kLast) terms[(pbase + ppl) * kTermStride + k0 + u] = tv[u];
     }
     wave_sync();
     unsigned total = carried;  // the queue already holds the previous tile's left-over pairs
