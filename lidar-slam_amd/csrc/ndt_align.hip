@@ -265,7 +265,9 @@ __global__ __launch_bounds__(kBlockD, 1) void k_ndt_align(const float4 *__restri
   __syncthreads();
   for (unsigned pass = 0;; pass++) {
     ALIGN_STAMP(0);
-    const double v = ndt_pass_body<0, DENSE>(src, n, Q, Tl, jh, words, dense, rec, lds, gridDim.x);
+    PassPre pre;
+    pass_pre_init<DENSE>(pre);
+    const double v = ndt_pass_body<0, DENSE>(src, n, Q, Tl, jh, words, dense, rec, lds, gridDim.x, pre);
     ALIGN_STAMP(1);
     // ---- publish this workgroup's row, then wait for everybody's
     const unsigned epoch = A.epoch0 + pass + 1u;

@@ -36,7 +36,9 @@ __global__ __launch_bounds__(kBlockD, pass_waves(KIND)) void k_ndt_pass(const fl
   else if (threadIdx.x < 69 + 12) Tl[threadIdx.x - 69] = P.T[threadIdx.x - 69];
   __syncthreads();
   const PassScalars Q = pass_scalars(P);
-  const double v = ndt_pass_body<KIND, DENSE>(src, n, Q, Tl, jh, words, dense, rec, lds, gridDim.x);
+  PassPre pre;
+  pass_pre_init<DENSE>(pre);
+  const double v = ndt_pass_body<KIND, DENSE>(src, n, Q, Tl, jh, words, dense, rec, lds, gridDim.x, pre);
   // one 256-byte row per workgroup, written once (check-worded when it goes straight to the host)
   if (threadIdx.x < kOutDoubles) lsa_store_row32(partials + (size_t)blockIdx.x * kOutDoubles, (int)threadIdx.x, v, key);
 }
@@ -82,6 +84,9 @@ __global__ __launch_bounds__(kBlockD, pass_waves(0)) void k_ndt_pass_armed(PassP
   const int tid = (int)threadIdx.x, lane = tid & 63;
   PassScalars Q = pass_scalars(P);   // every kernel argument the pass needs, fetched now, while there is nothing else to do
   pass_scalars_pin<DENSE>(Q);
+  PassPre pre;   // zeroed accumulators + probe index fields: also ready before the wait
+  pass_pre_init<DENSE>(pre);
+  pass_pre_pin(pre);
   unsigned long long t_mail = 0, t_start = 0;   // (wave 0) 100 MHz clock: kernel start, mail taken — diagnostics in row column 30
   // Every pass of a ScanMatch reads the same source cloud and a wave's first tile is a function of its position in the grid
   // only, so each pass KEEPS its first tiles' points in memory the handle owns and the next one loads them from there right
@@ -142,7 +147,7 @@ __global__ __launch_bounds__(kBlockD, pass_waves(0)) void k_ndt_pass_armed(PassP
   const float4 *src = reinterpret_cast<const float4 *>(uniform64(s_dyn[1]));
   const size_t n = (size_t)uniform64(s_dyn[2]);
   const bool kept = __builtin_amdgcn_readfirstlane((int)(unsigned)s_dyn[3]) != 0 && n <= (size_t)keep_cap;
-  const double v = ndt_pass_body<0, DENSE>(src, n, Q, Tl, jh, words, dense, rec, lds, vgrid, kept, s_pre, (!kept && n <= (size_t)keep_cap) ? keep : nullptr);
+  const double v = ndt_pass_body<0, DENSE>(src, n, Q, Tl, jh, words, dense, rec, lds, vgrid, pre, kept, s_pre, (!kept && n <= (size_t)keep_cap) ? keep : nullptr);
   // column 30 (unused by the sums' consumers): ticks this workgroup waited for its mail x 2^20 + ticks from the mail to here
   const double stamp = (double)(((t_mail - t_start) << 20) + ((wall_clock64() - t_mail) & 0xfffffull));
   if (tid < kOutDoubles) lsa_store_row32(partials + (size_t)blockIdx.x * kOutDoubles, tid, tid == 30 ? stamp : v, mail_key(seq) | 1ull);

@@ -205,6 +205,40 @@ __device__ __forceinline__ unsigned wave_excl_scan(unsigned cnt, int lane, unsig
   return incl - cnt;
 }
 
+// What a pass can prepare before it knows its transform: the zeroed accumulators and, for the dense probe, which (point, dy, dz)
+// a lane probes in each round — {point slot : 6, -, dy : 2, dz : 2, -, live : 1}, 16 bits per round, a function of the lane
+// only.  The armed kernel builds it BEFORE it starts waiting for its mail (pass_pre_pin keeps the compiler from sinking the
+// work behind the wait): ~90 register moves and a few integer divisions less between the mail and the rows.
+struct PassPre {
+  double acc[28];
+  unsigned probe_lut;
+};
+template <bool DENSE>
+__device__ __forceinline__ void pass_pre_init(PassPre &pre) {
+#pragma unroll
+  for (int k = 0; k < 28; k++) pre.acc[k] = 0.0;
+  const int lane = threadIdx.x & 63;
+  unsigned probe_lut = 0;
+  if (DENSE) {
+#pragma unroll
+    for (int j = 0; j < kRowRounds; j++) {
+      const int q = lane + j * 64;
+      if (q < kRowProbes) {  // (the last round has a few idle lanes: all-zero entry, live bit clear)
+        const int pl = q / kRowsPerPoint;
+        const int o = q - pl * kRowsPerPoint;
+        const int dz = o / 3, dy = o - dz * 3;
+        probe_lut |= ((unsigned)pl | ((unsigned)dy << 8) | ((unsigned)dz << 10) | 0x8000u) << (16 * j);
+      }
+    }
+  }
+  pre.probe_lut = probe_lut;
+}
+__device__ __forceinline__ void pass_pre_pin(PassPre &pre) {
+#pragma unroll
+  for (int k = 0; k < 28; k++) asm volatile("" : "+v"(pre.acc[k]));
+  asm volatile("" : "+v"(pre.probe_lut));
+}
+
 // DENSE: the probe reads a dense per-cell table {centroid - cell corner (f32 x 3), record rank or -1} (16 B per cell,
 // built when the cell box is small enough, ndt_grid.hip) instead of the bitmap words: one 48-B row load answers "valid?",
 // "which record?" and "roughly how far?" for 3 cells, so the candidate stage (A2: a dependent centroid load from the
@@ -216,8 +250,8 @@ __device__ __forceinline__ double ndt_pass_body(const float4 *__restrict__ src, 
                                                 const double *jh /* LDS: ja[8][3] then ha[15][3] */, const uint4 *__restrict__ words,
                                                 const float4 *__restrict__ dense, const double *__restrict__ rec, unsigned char *lds,
                                                 unsigned vgrid /* workgroups sharing the tiles: gridDim.x, or fewer for an armed launch */,
-                                                bool have_first = false /* wave-uniform */, float4 s_first = make_float4(0.f, 0.f, 0.f, 0.f),
-                                                float4 *__restrict__ keep = nullptr) {
+                                                PassPre &pre, bool have_first = false /* wave-uniform */,
+                                                float4 s_first = make_float4(0.f, 0.f, 0.f, 0.f), float4 *__restrict__ keep = nullptr) {
   constexpr int NB = pass_bufs(KIND);
   constexpr int kLdsSlice = lds_slice(NB), kLdsTerms = lds_terms(NB), kLdsCand = lds_cand(NB), kLdsQueue = lds_queue(NB), kLdsRed2 = lds_red2(NB);
   // (the wave index is uniform across the wave: as a scalar, everything derived from it — the LDS slice, the tile walk — stays
@@ -228,9 +262,7 @@ __device__ __forceinline__ double ndt_pass_body(const float4 *__restrict__ src, 
   double *terms = reinterpret_cast<double *>(slice + kLdsTerms);
   unsigned *cand = reinterpret_cast<unsigned *>(slice + kLdsCand);
   unsigned *queue = reinterpret_cast<unsigned *>(slice + kLdsQueue);
-  double acc[28];
-#pragma unroll
-  for (int k = 0; k < 28; k++) acc[k] = 0.0;
+  double (&acc)[28] = pre.acc;
   unsigned accepted = 0;        // (point, voxel) pairs this WAVE accepted (wave-uniform: a scalar register)
   // phase 0: the 4 lanes of a QUAD share a point (quad 14 and 15 = lanes 56..63 are spare: they work on tile slots 14 / 15,
   // which exist in LDS and which nothing reads)
@@ -251,19 +283,7 @@ __device__ __forceinline__ double ndt_pass_body(const float4 *__restrict__ src, 
     size_t i0 = tile0 * kTilePts + ppl;
     if (ppl < kTilePts && i0 < n) s_next = src[i0];
   }
-  unsigned probe_lut = 0;  // dense path: {point slot : 6, -, dy : 2, dz : 2, -, live : 1} per probe round of this lane
-  if (DENSE) {
-#pragma unroll
-    for (int j = 0; j < kRowRounds; j++) {
-      const int q = lane + j * 64;
-      if (q < kRowProbes) {  // (the last round has a few idle lanes: all-zero entry, live bit clear)
-        const int pl = q / kRowsPerPoint;
-        const int o = q - pl * kRowsPerPoint;
-        const int dz = o / 3, dy = o - dz * 3;
-        probe_lut |= ((unsigned)pl | ((unsigned)dy << 8) | ((unsigned)dz << 10) | 0x8000u) << (16 * j);
-      }
-    }
-  }
+  const unsigned probe_lut = pre.probe_lut;
   unsigned carried = 0;  // pairs at the front of the queue left over by the previous tile (< 64, wave-uniform)
   int pbase = 0;         // which half of tp / terms this tile uses: 0 or kTileSlots
   for (size_t tile = tile0; tile < ntiles; tile += tstride, pbase ^= (NB == 2 ? kTileSlots : 0)) {
