@@ -275,7 +275,7 @@ extern "C" void lsa_ndt_destroy(lsa_ndt *h) {
   h->vi.release(); h->d_target.release(); h->rec.release(); h->state.release(); h->vbits.release(); h->words.release(); h->d_small.release(); h->counts.release();
   h->dense.release();
   if (h->mail) { if (h->mail_is_device) (void)hipFree(h->mail); else (void)hipHostFree(h->mail); }
-  h->align_rows.release(); h->align_flags.release(); h->h_result.release(); h->align_stamps.release(); h->h_gave_up.release();
+  h->align_rows.release(); h->align_flags.release(); h->h_result.release(); h->align_stamps.release(); h->h_gave_up.release(); h->src_keep.release();
   h->d_source_own.release(); h->h_stage.release(); h->partials.release(); h->d_out.release(); h->h_out.release(); h->h_partials.release();
   delete h;
 }

@@ -246,4 +246,26 @@ def test_armed_kernel_carried_between_scan_matches(ctx, cfg2):
     assert np.array_equal(T, ref[3][0]) and _same_stats(dict(n.last_stats), ref[3][1])
     torch.cuda.synchronize()
     print("filter right after a ScanMatch that left a kernel parked: %.0f us" % (dt * 1e6))
+    # the armed passes keep their first tiles' source points for the NEXT pass of the same ScanMatch only: a caller that
+    # refills the SAME device buffer with another scan of the same size (a double buffer) must get that scan's result
+    # (compare: a second handle with the armed passes off)
+    m = min(cfg2["d_src"][0].shape[0], cfg2["d_src"][1].shape[0])
+    buf = cfg2["d_src"][0][:m].clone()
+    plain = registration.NDTRegistrationHip(ctx, **wl.NDT_PARAMS)
+    plain.SetInputTarget(cfg2["d_map_f"])
+    plain.set_armed(False)
+    for k in (0, 1, 0, 1):
+        buf.copy_(cfg2["d_src"][k][:m])
+        torch.cuda.synchronize()
+        _, Ta = n.ScanMatch(buf, cfg2["guesses"][k])
+        _, Tb = plain.ScanMatch(cfg2["d_src"][k][:m].contiguous(), cfg2["guesses"][k])
+        assert np.array_equal(Ta, Tb)
+    # the timeline diagnostics of the armed passes: per-pass means, positive and of a plausible size
+    n.armed_timing(reset=True)
+    for d_s, guess in zip(cfg2["d_src"][:3], cfg2["guesses"][:3]):
+        n.ScanMatch(d_s, guess)
+    tl = n.armed_timing()
+    assert tl["passes"] >= 3 and 0.0 < tl["dev_body_us"] < 100.0 and 0.0 <= tl["dev_wait_us"] < 400.0 and 0.0 < tl["post_to_rows_us"] < 1000.0, tl
+    print("armed pass timeline (us per pass):", {k: round(v, 2) for k, v in tl.items()})
+    plain.close()
     n.close()
