@@ -192,6 +192,7 @@ int scan_match_common(lsa_ndt *h, const float predict_pose[16], float result_pos
   memset(&st, 0, sizeof(st));
   int rc;
   if (ndt_align_persistent_ok(h)) {  // the whole Newton iteration in one launch (ndt_align.hip)
+    armed_cancel(h);   // (a kernel an earlier per-pass ScanMatch left parked would hold the stream for its whole patience)
     bool done = false;
     if ((rc = ndt_align_persistent(h, predict_pose, result_pose, &st, &done))) return rc;
     if (done) {
