@@ -195,9 +195,25 @@ def main():
             # C-ABI, no Python per pass; the 128-byte unique id travels over the gloo group).  LSA_BENCH_NATIVE_RCCL=0 takes
             # torch.distributed's "nccl" backend on a process group of its own instead: measured in the world-of-one
             # rehearsal 154 us per sharded cfg2 step against 99 us.
-            if os.environ.get("LSA_BENCH_NATIVE_RCCL", "1") != "0":
-                exchange["native"] = lsa_dist.NativeRccl(ctx, rank, world)
-            else:
+            # Bring-up is agreed on by ALL ranks (a min over the gloo group): if the library's own communicator fails anywhere
+            # (librccl not loadable, ncclCommInitRank error), every rank falls back to torch.distributed's "nccl" group together
+            # instead of one rank raising while the others wait in a collective; the line says which backend carried the sums.
+            want_native = os.environ.get("LSA_BENCH_NATIVE_RCCL", "1") != "0"
+            ok = 1
+            if want_native:
+                try:
+                    exchange["native"] = lsa_dist.NativeRccl(ctx, rank, world)
+                except Exception as e:  # noqa: BLE001
+                    ok = 0
+                    print("[bench] native RCCL bring-up failed on rank %d: %s" % (rank, e), file=sys.stderr, flush=True)
+                flag = torch.tensor([ok], dtype=torch.int32)
+                dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+                if int(flag.item()) == 0:
+                    if exchange["native"] is not None:
+                        exchange["native"].close()
+                        exchange["native"] = None
+                    exchange["fallback"] = "library RCCL communicator failed on at least one rank"
+            if exchange["native"] is None:
                 exchange["cb"] = lsa_dist.make_rccl_allreduce(group=dist.new_group(backend="nccl"))
         exchange["ready"] = True
 
@@ -495,6 +511,8 @@ def main():
             exchange_info = {"backend": "gloo staged through the host (one-GPU rehearsal: RCCL refuses two ranks on one device)", "comm_ranks": world}
         else:
             exchange_info = {"backend": "torch.distributed nccl (= RCCL) process group", "comm_ranks": dist.get_world_size()}
+            if exchange.get("fallback"):
+                exchange_info["note"] = exchange["fallback"]
 
         def sharded(src_np, guess, label):
             """BASELINE.json configs[3] / [4]: the source sharded over the ranks against the replicated 2 M-point target, one
