@@ -105,14 +105,17 @@ __global__ __launch_bounds__(kBlock) void k_icp_pass(const float4 *__restrict__ 
   }
   __shared__ double sm[kBlock / 64][kOut];
   int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-#pragma unroll
-  for (int k = 0; k < 27; k++) {
-    double v = lsa_wave_sum(acc[k]);
-    if (lane == 0) sm[wave][1 + k] = v;
-  }
   {
-    double vc = lsa_wave_sum((double)ncorr), vn = lsa_wave_sum((double)npts);
-    if (lane == 0) { sm[wave][0] = 0.0; sm[wave][28] = vc; sm[wave][29] = vn; sm[wave][30] = 0.0; sm[wave][31] = 0.0; }
+    double red[29];
+#pragma unroll
+    for (int k = 0; k < 27; k++) red[k] = acc[k];
+    red[27] = (double)ncorr; red[28] = (double)npts;
+    lsa_wave_sum_n<29>(red);   // all 29 sums step by step together (see lsa_wave_sum_n)
+    if (lane == 0) {
+#pragma unroll
+      for (int k = 0; k < 27; k++) sm[wave][1 + k] = red[k];
+      sm[wave][0] = 0.0; sm[wave][28] = red[27]; sm[wave][29] = red[28]; sm[wave][30] = 0.0; sm[wave][31] = 0.0;
+    }
   }
   __syncthreads();
   if (threadIdx.x < kOut) {
@@ -215,14 +218,17 @@ __global__ __launch_bounds__(kBlock) void k_plane_pass(const float4 *__restrict_
   }
   __shared__ double sm[kBlock / 64][kOut];
   int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-#pragma unroll
-  for (int k = 0; k < 27; k++) {
-    double v = lsa_wave_sum(acc[k]);
-    if (lane == 0) sm[wave][1 + k] = v;
-  }
   {
-    double vc = lsa_wave_sum((double)ncorr), vn = lsa_wave_sum((double)npts);
-    if (lane == 0) { sm[wave][0] = 0.0; sm[wave][28] = vc; sm[wave][29] = vn; sm[wave][30] = 0.0; sm[wave][31] = 0.0; }
+    double red[29];
+#pragma unroll
+    for (int k = 0; k < 27; k++) red[k] = acc[k];
+    red[27] = (double)ncorr; red[28] = (double)npts;
+    lsa_wave_sum_n<29>(red);   // all 29 sums step by step together (see lsa_wave_sum_n)
+    if (lane == 0) {
+#pragma unroll
+      for (int k = 0; k < 27; k++) sm[wave][1 + k] = red[k];
+      sm[wave][0] = 0.0; sm[wave][28] = red[27]; sm[wave][29] = red[28]; sm[wave][30] = 0.0; sm[wave][31] = 0.0;
+    }
   }
   __syncthreads();
   if (threadIdx.x < kOut) {
@@ -271,14 +277,17 @@ __global__ __launch_bounds__(kBlock) void k_pcl_pass(const float4 *__restrict__ 
   int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   if (threadIdx.x < kOut) for (int w = 0; w < kBlock / 64; w++) sm[w][threadIdx.x] = 0.0;
   __syncthreads();
-#pragma unroll
-  for (int k = 0; k < 16; k++) {
-    double v = lsa_wave_sum(acc[k]);
-    if (lane == 0) sm[wave][k] = v;
-  }
   {
-    double vc = lsa_wave_sum((double)ncorr), vn = lsa_wave_sum((double)npts);
-    if (lane == 0) { sm[wave][28] = vc; sm[wave][29] = vn; }
+    double red[18];
+#pragma unroll
+    for (int k = 0; k < 16; k++) red[k] = acc[k];
+    red[16] = (double)ncorr; red[17] = (double)npts;
+    lsa_wave_sum_n<18>(red);   // (see lsa_wave_sum_n)
+    if (lane == 0) {
+#pragma unroll
+      for (int k = 0; k < 16; k++) sm[wave][k] = red[k];
+      sm[wave][28] = red[16]; sm[wave][29] = red[17];
+    }
   }
   __syncthreads();
   if (threadIdx.x < kOut) {

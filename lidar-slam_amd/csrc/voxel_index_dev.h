@@ -91,6 +91,22 @@ __device__ __forceinline__ void lsa_store_row32(double *__restrict__ row, int co
   __hip_atomic_store(reinterpret_cast<unsigned long long *>(row) + col, w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
+// N wave sums at once, STEP-major: the N exchanges of one step are issued together and waited for once.  Calling lsa_wave_sum
+// per value serialises N x 6 cross-lane exchanges (each a ~100-cycle LDS-crossbar round trip the compiler does not overlap:
+// 27 sums = 162 dependent waits, ~9 us at the tail of an ICP pass); the association order per value is the same, so lane 0
+// ends up with the same bits.
+template <int N>
+__device__ __forceinline__ void lsa_wave_sum_n(double (&v)[N]) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    double t[N];
+#pragma unroll
+    for (int k = 0; k < N; k++) t[k] = __shfl_down(v[k], off, 64);
+#pragma unroll
+    for (int k = 0; k < N; k++) v[k] += t[k];
+  }
+}
+
 __device__ __forceinline__ double lsa_wave_sum(double v) {
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
