@@ -204,14 +204,33 @@ int lsa_ndt_armed_timing(lsa_ndt *ndt, double out[6], int reset);
  * (at most one per ScanMatch, at convergence), and passes that had to be redone the ordinary way because the armed kernel had
  * left before its mail came (the calling thread was held up for longer than the kernel's 0.3 ms patience).  Any may be NULL. */
 int lsa_ndt_set_armed(lsa_ndt *ndt, int on);
-/* At the end of a ScanMatch the armed kernel of the pass that never came is, by default, not cancelled but left PARKED for the
- * first pass of the next ScanMatch on the same handle (its mail also carries the source pointer, the point count and the
- * grid), which then starts without launch or dispatch latency.  It leaves by itself after 0.3 ms; any other call of this library
- * on the same context releases it first.  Work the APPLICATION enqueues itself on a stream it handed to lsa_context_create
- * would queue behind the parked kernel for up to those 0.3 ms: such callers switch the carry off, or call
- * lsa_context_synchronize first.  on = 0 (or the environment variable LSA_NO_CARRY) cancels at every ScanMatch end instead. */
+/* At the end of a ScanMatch the armed kernel of the pass that never came is cancelled — no entry point of this library
+ * returns with a kernel spinning on the caller's stream.  A caller whose next ScanMatch on the same handle follows at once
+ * and who enqueues nothing of its own on the stream in between may OPT IN (on = 1, or the environment variable LSA_CARRY=1)
+ * to leaving it PARKED for the first pass of the next ScanMatch (its mail also carries the source pointer, the point count
+ * and the grid), which then starts without launch or dispatch latency (~8 us per ScanMatch).  A parked kernel leaves by itself
+ * after its patience (0.3 ms) and any other call of this library on the same context releases it first; work the APPLICATION
+ * enqueues itself on the stream, or a hipStreamSynchronize of its own, would wait out that patience.
+ * lsa_pipeline_scan_match, which knows that scans follow back to back, carries between its scans by itself and cancels
+ * behind its last one. */
 int lsa_ndt_set_armed_carry(lsa_ndt *ndt, int on);
 int lsa_ndt_armed_counters(lsa_ndt *ndt, uint64_t *passes, uint64_t *cancels, uint64_t *fallbacks);
+/* Everything the armed path (and the row hand-over of the ordinary passes) can do other than the plain case, counted:
+ * nothing about a slow or lost pass is silent. */
+typedef struct {
+  uint64_t passes;        /* passes served by a kernel enqueued ahead */
+  uint64_t cancels;       /* armed kernels released by a cancel mail (ScanMatch end, another call on the context, ...) */
+  uint64_t fallbacks;     /* passes redone the ordinary way: the armed kernel (or part of it) had left before its mail came */
+  uint64_t late;          /* armed passes whose rows missed the polling limit (2 ms) but were complete once the stream had drained */
+  uint64_t rows_late;     /* the same for ordinary passes (limit 20 ms) */
+  uint64_t gave_up_seen;  /* times the host, waiting for rows, saw a workgroup report that it had left */
+  uint64_t expired;       /* parked kernels found to have left before the next ScanMatch came (cancelled and relaunched) */
+  double rows_wait_max_us;/* longest time from a pass's parameters being posted / its kernel launched to its last row taken */
+  int32_t parked;         /* 1 while this handle has a kernel parked on its context's stream */
+} lsa_ndt_armed_stats_t;
+int lsa_ndt_armed_stats(lsa_ndt *ndt, lsa_ndt_armed_stats_t *out, int reset);
+/* diagnostics / tests: how long an armed kernel waits for its mail before it leaves by itself (default 300 us; [1, 1e5]) */
+int lsa_ndt_set_armed_patience(lsa_ndt *ndt, double patience_us);
 
 /* ScanMatch can run its whole Newton iteration as ONE persistent launch (csrc/ndt_align.hip: the workgroups stay resident,
  * exchange their partial sums in-launch and each repeats the 6x6 solve) instead of one launch per derivative pass, when the

@@ -34,6 +34,16 @@ class IcpStats(C.Structure):
     _fields_ = [("iterations", C.c_int32), ("converged", C.c_int32), ("correspondences", C.c_double), ("mse", C.c_double)]
 
 
+class NdtArmedStats(C.Structure):
+    """lsa_ndt_armed_stats_t"""
+    _fields_ = [("passes", C.c_uint64), ("cancels", C.c_uint64), ("fallbacks", C.c_uint64), ("late", C.c_uint64), ("rows_late", C.c_uint64),
+                ("gave_up_seen", C.c_uint64), ("expired", C.c_uint64), ("rows_wait_max_us", C.c_double), ("parked", C.c_int32)]
+
+    def as_dict(self):
+        return dict(passes=self.passes, cancels=self.cancels, fallbacks=self.fallbacks, late=self.late, rows_late=self.rows_late,
+                    gave_up_seen=self.gave_up_seen, expired=self.expired, rows_wait_max_us=round(self.rows_wait_max_us, 2), parked=self.parked)
+
+
 class NdtStats(C.Structure):
     _fields_ = [
         ("iterations", C.c_int32),
@@ -159,6 +169,9 @@ def lib():
     L.lsa_ndt_set_armed.argtypes = [vp, i]
     L.lsa_ndt_set_armed_carry.argtypes = [vp, i]
     L.lsa_ndt_armed_counters.argtypes = [vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
+    L.lsa_pipeline_scan_match.argtypes = [vp, vp, sz, PVP, PSZ, PF, vp, vp, i, i, PF, C.POINTER(NdtStats), PSZ]
+    L.lsa_ndt_armed_stats.argtypes = [vp, C.POINTER(NdtArmedStats), i]
+    L.lsa_ndt_set_armed_patience.argtypes = [vp, C.c_double]
     L.lsa_ndt_set_persistent.argtypes = [vp, i]
     L.lsa_ndt_align_counters.argtypes = [vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
     L.lsa_ndt_armed_timing.argtypes = [vp, C.POINTER(C.c_double), i]

@@ -708,6 +708,7 @@ extern "C" int lsa_icp_create(lsa_icp **out, lsa_context *ctx, float max_corresp
   if (!(max_correspond_dis > 0) || max_iter < 0) return lsa_fail(ctx, LSA_ERR_INVALID, "lsa_icp_create: bad parameters");
   lsa_icp *h = new lsa_icp();
   h->ctx = ctx; h->max_corr = max_correspond_dis; h->max_iter = max_iter; h->mode = mode;
+  h->pass_seq = lsa_seq_base();   // row check words from a range of this handle's own (lsa_common.h)
   *out = h;
   return LSA_OK;
 }

@@ -34,6 +34,11 @@ inline hipError_t lsa_enter(lsa_context *ctx) {
   return hipSetDevice(ctx->device);
 }
 
+// Base of a handle's pass / mail sequence numbers: distinct for every handle of the process, so that the check words
+// derived from them (rows handed to the host as they arrive, the armed passes' mail) can never match what another handle
+// — destroyed, its pinned memory recycled — left behind.  Bit 63 stays clear (the mail's cancel flag); 2^36 numbers per handle.
+unsigned long long lsa_seq_base();
+
 void lsa_set_global_error(const char *fmt, ...);
 int lsa_fail(lsa_context *ctx, int code, const char *fmt, ...);
 
@@ -76,6 +81,10 @@ struct PinnedBuf {
     size_t want = n + n / 4;
     hipError_t e = hipHostMalloc((void **)&p, want * sizeof(T), hipHostMallocMapped | hipHostMallocCoherent);
     if (e != hipSuccess) return lsa_fail(ctx, LSA_ERR_HIP, "hipHostMalloc(%zu B) failed: %s", want * sizeof(T), hipGetErrorString(e));
+    // The runtime recycles pinned memory WITH its contents.  Several of these buffers receive check-worded rows that the
+    // host accepts by key the moment they look whole: a block inherited from a destroyed handle must not offer it that
+    // handle's rows (see lsa_seq_base: the keys are per-handle too).
+    memset(p, 0, want * sizeof(T));
     cap = want;
     return LSA_OK;
   }

@@ -1,6 +1,7 @@
 // lsa_context.hip — context lifecycle, error text, host-side packing helpers.
 #include "lsa_common.h"
 
+#include <atomic>
 #include <mutex>
 
 #include <cstdlib>
@@ -48,6 +49,11 @@ int lsa_upload_xyzw(lsa_context *ctx, const void *pts, size_t n, size_t stride, 
     LSA_HIP(ctx, hipMemcpyAsync(d_dst + off, h_stage + 4 * off, m * sizeof(float4), hipMemcpyHostToDevice, ctx->stream));
   }
   return LSA_OK;
+}
+
+unsigned long long lsa_seq_base() {
+  static std::atomic<unsigned long long> next{1};
+  return (next.fetch_add(1, std::memory_order_relaxed) & 0x3ffffffull) << 36;
 }
 
 extern "C" int lsa_version(void) { return LSA_VERSION_MAJOR * 100 + LSA_VERSION_MINOR; }

@@ -20,7 +20,7 @@
 //      no release fence (the in-launch "last block reduces" variant with an agent release cost 10-25 us).
 //
 // Rows are double-buffered by pass parity (a workgroup can be at most one pass ahead of the slowest one, because it needs
-// that one's row to go on); flags carry epoch0 + pass + 1 with epoch0 advancing by 64 per launch, compared as a signed
+// that one's row to go on); flags carry epoch0 + pass + 1 with epoch0 advancing by max_iter + 8 per launch, compared as a signed
 // difference, so nothing has to be zeroed between launches.  Every wait is bounded (wall clock): a launch whose workgroups
 // are not all resident gives up with a status word and the host falls back to the per-pass path — as it does when the
 // 6x6 system needs the SVD's rank rule, when the line search is live (step_max <= step_min), with an all-reduce
@@ -528,6 +528,7 @@ extern "C" int lsa_ndt_align_stamps(lsa_ndt *h, int enable, uint64_t *out, size_
   h->align_stamps_on = enable != 0;
   if (n_out) *n_out = 0;
   if (!out || !h->align_stamps.p) return LSA_OK;
+  LSA_HIP(ctx, lsa_enter(ctx));   // (the copy below goes onto the stream: release anything parked on it first)
   size_t n = (size_t)kStampsPerPass * kStampPasses;
   if (n > cap) n = cap;
   LSA_HIP(ctx, hipMemcpyAsync(out, h->align_stamps.p, n * sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));

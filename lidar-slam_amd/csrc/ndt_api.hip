@@ -52,7 +52,11 @@ void armed_cancel(lsa_ndt *h) {
 }
 void armed_cancel_cb(void *user) { armed_cancel((lsa_ndt *)user); }
 
-constexpr double kArmedPatienceUs = 300.0;   // how long an armed kernel waits for its mail before it leaves by itself
+// A pass whose mail has been posted delivers its rows within microseconds (tens under heavy contention).  Beyond this limit
+// the host stops polling, waits for the stream the ordinary way and looks again; both outcomes are COUNTED
+// (lsa_ndt_armed_stats), nothing about a slow pass is silent.
+constexpr double kArmedRowLimitMs = 2.0;
+constexpr double kRowLimitMs = 20.0;   // ordinary (unarmed) passes: up to 190 us of kernel at 2 M points, more beside other streams
 
 // launch grid of an armed kernel for a pass that needs g workgroups: a quarter more, so that the kernel left parked at the
 // end of a ScanMatch also fits the next scan's (slightly different) source size
@@ -73,11 +77,13 @@ int run_pass(lsa_ndt *h, const float T[16], const double p[6], int kind, double 
     // take the rows as they arrive
     const unsigned g = ndt_pass_grid(h, h->n_source, 0);
     volatile unsigned long long *gave_up = h->h_gave_up.p ? reinterpret_cast<volatile unsigned long long *>(h->h_gave_up.p) : nullptr;
-    if (h->armed_outstanding && (h->armed_grid < g || h->armed_gen != h->target_gen || (gave_up && *gave_up == h->armed_seq)))
+    if (h->armed_outstanding && (h->armed_grid < g || h->armed_gen != h->target_gen || (gave_up && *gave_up == h->armed_seq))) {
+      if (gave_up && *gave_up == h->armed_seq) h->armed_expired++;
       armed_cancel(h);   // parked for another table / too small a grid, or it has already left: not usable
+    }
     unsigned long long seq = h->armed_seq;
     if (!h->armed_outstanding) {
-      if ((rc = ndt_launch_armed(h, P, seq, armed_headroom(h, g), kArmedPatienceUs))) return rc;
+      if ((rc = ndt_launch_armed(h, P, seq, armed_headroom(h, g), h->armed_patience_us))) return rc;
       gave_up = reinterpret_cast<volatile unsigned long long *>(h->h_gave_up.p);
     }
     // (after the first armed pass of this ScanMatch the kernels hold their first tiles from the kept copy)
@@ -88,20 +94,32 @@ int run_pass(lsa_ndt *h, const float T[16], const double p[6], int kind, double 
     const auto at1 = std::chrono::steady_clock::now();
     h->armed_seq = seq + 1;
     h->armed_outstanding = false;
-    if ((rc = ndt_launch_armed(h, P, seq + 1, armed_headroom(h, g), kArmedPatienceUs))) return rc;
+    if ((rc = ndt_launch_armed(h, P, seq + 1, armed_headroom(h, g), h->armed_patience_us))) return rc;
     h->armed_outstanding = true;
     h->armed_grid = armed_headroom(h, g);
     h->armed_gen = h->target_gen;
     h->armed_passes++;
-    bool ok = !h->no_row_polling && ndt_reduce_partials_host(h->h_partials.p, g, ndt_armed_row_key(seq), 20.0, out32, gave_up, seq);
+    bool ok = !h->no_row_polling && ndt_reduce_partials_host(h->h_partials.p, g, ndt_armed_row_key(seq), kArmedRowLimitMs, out32, gave_up, seq);
+    {
+      const double w = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - at1).count();
+      if (w > h->rows_wait_max_us) h->rows_wait_max_us = w;
+    }
     if (!ok) {
-      // rows missing — the kernel's patience ran out before the mail came (this thread was held up), or polling is switched
-      // off: let everything enqueued drain, look again, and if the pass really did not run do it the ordinary way, unarmed
-      // for the rest of this ScanMatch
+      // rows missing.  Either a workgroup of the kernel ran out of patience before the mail came (this thread was held up;
+      // EVERY workgroup that leaves says so in *gave_up, so the wait above ends at once instead of at its limit), or the rows
+      // are slow (limit), or polling is switched off: let everything enqueued drain, look again, and if the pass really did
+      // not run (completely) do it the ordinary way, unarmed for the rest of this ScanMatch.  Each outcome is counted.
+      const bool left = gave_up && *gave_up == seq;
+      if (left) h->armed_gave_up_seen++;
       armed_cancel(h);
       LSA_HIP(ctx, hipStreamSynchronize(ctx->stream));
       h->unsynced = 0;
-      if (ndt_reduce_partials_host(h->h_partials.p, g, ndt_armed_row_key(seq), 0.0, out32)) return LSA_OK;
+      if (ndt_reduce_partials_host(h->h_partials.p, g, ndt_armed_row_key(seq), 0.0, out32)) {
+        // complete after all: the rows were slow (counted as late), or only a workgroup of the launch's head-room — one that
+        // has no row to deliver — ran out of patience while the others took the mail (counted above)
+        if (!h->no_row_polling && !left) h->armed_late++;
+        return LSA_OK;
+      }
       h->armed_scope = false;
       h->armed_fallbacks++;
       return run_pass(h, T, p, kind, out32);
@@ -128,12 +146,18 @@ int run_pass(lsa_ndt *h, const float T[16], const double p[6], int kind, double 
     // The rows are consumed as they arrive in host memory (check word per row): the host does not wait for the stream
     // per pass (measured: 17 us in hipStreamSynchronize around a 9 us kernel), only every so often so that the runtime
     // can retire its commands.  A row that does not arrive in 20 ms falls back to the ordinary wait.
-    bool ok = !h->no_row_polling && ndt_reduce_partials_host(h->h_partials.p, g, key, 20.0, out32);
+    const auto rt0 = std::chrono::steady_clock::now();
+    bool ok = !h->no_row_polling && ndt_reduce_partials_host(h->h_partials.p, g, key, kRowLimitMs, out32);
+    {
+      const double w = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - rt0).count();
+      if (w > h->rows_wait_max_us) h->rows_wait_max_us = w;
+    }
     if (!ok) {
       LSA_HIP(ctx, hipStreamSynchronize(ctx->stream));
       h->unsynced = 0;
       if (!ndt_reduce_partials_host(h->h_partials.p, g, key, 0.0, out32))
         return lsa_fail(ctx, LSA_ERR_HIP, "NDT pass: workgroup rows incomplete after the kernel finished");
+      if (!h->no_row_polling) h->rows_late++;
     } else if (++h->unsynced >= 256) {
       LSA_HIP(ctx, hipStreamSynchronize(ctx->stream));
       h->unsynced = 0;
@@ -151,11 +175,12 @@ int run_pass(lsa_ndt *h, const float T[16], const double p[6], int kind, double 
   unsigned long long key = 0;
   if ((rc = ndt_publish_out(h, &key))) return rc;
   unsigned long long w[32];
-  bool ok = !h->no_row_polling && ndt_fetch_row_host(h->h_out.p, key, 20.0, w);
+  bool ok = !h->no_row_polling && ndt_fetch_row_host(h->h_out.p, key, kRowLimitMs, w);
   if (!ok) {
     LSA_HIP(ctx, hipStreamSynchronize(ctx->stream));
     h->unsynced = 0;
     if (!ndt_fetch_row_host(h->h_out.p, key, 0.0, w)) return lsa_fail(ctx, LSA_ERR_HIP, "NDT pass: reduced row incomplete after the stream drained");
+    if (!h->no_row_polling) h->rows_late++;
   } else if (++h->unsynced >= 256) {
     LSA_HIP(ctx, hipStreamSynchronize(ctx->stream));
     h->unsynced = 0;
@@ -207,7 +232,11 @@ int scan_match_common(lsa_ndt *h, const float predict_pose[16], float result_pos
   h->match_id++;
   h->at_have_last = false;
   h->armed_scope = !h->no_armed && !h->allreduce && h->n_source > 0 && (double)h->step_size > (double)h->trans_eps / 2;
-  if (h->armed_scope && (rc = mail_ensure(h))) { h->armed_scope = false; return rc; }
+  if (h->armed_scope && (rc = mail_ensure(h))) { h->armed_scope = false; armed_cancel(h); return rc; }
+  if (h->armed_scope && !h->mail) h->armed_scope = false;
+  // a kernel this handle left parked (check_keep kept it for this call) that the call will NOT feed — an all-reduce was
+  // installed meanwhile, the source is empty, there is no mailbox — would hold the ordinary passes back for its whole patience
+  if (!h->armed_scope) armed_cancel(h);
   rc = lsa_gn_solve_trace(eval_trampoline, h, h->resolution, h->step_size, h->trans_eps, h->max_iter, h->outlier_ratio, h->mode, predict_pose, result_pose, &st,
                               h->trace_rows, h->trace_cap, h->trace_n);
   if (h->armed_scope) {
@@ -215,7 +244,9 @@ int scan_match_common(lsa_ndt *h, const float predict_pose[16], float result_pos
     // The kernel enqueued for the pass that never came: cancelled — or, when scans follow each other on this handle and
     // nothing else uses the stream in between (lsa_pipeline_scan_match), left PARKED for the first pass of the next
     // ScanMatch (it reads source pointer, size and grid from its mail), whose launch + dispatch latency it then saves.  It
-    // leaves by itself after kArmedPatienceUs; any other call on this context releases it first (lsa_enter).
+    // leaves by itself after armed_patience_us; any other call on this context releases it first (lsa_enter).  The carry is
+    // OPT-IN (lsa_ndt_set_armed_carry) except between the scans of lsa_pipeline_scan_match, which switches it on itself and
+    // cancels behind its last scan: no entry point returns with a kernel spinning on the caller's stream unless asked to.
     if (rc || !h->armed_carry || h->unsynced >= 1024) {
       armed_cancel(h);
       if (h->unsynced >= 1024) {  // let the runtime retire its commands now and then (nothing is parked any more)
@@ -244,6 +275,10 @@ extern "C" int lsa_ndt_create(lsa_ndt **out, lsa_context *ctx, float res, float 
   h->ctx = ctx;
   h->resolution = res; h->step_size = step_size; h->trans_eps = trans_eps; h->max_iter = max_iter; h->outlier_ratio = outlier_ratio;
   lsa_ndt_gauss_constants(res, outlier_ratio, &h->d1, &h->d2);
+  // sequence numbers (row check words, mail) from a range of this handle's own: a row another handle left in recycled pinned
+  // memory can never carry this handle's key
+  h->pass_seq = lsa_seq_base();
+  h->armed_seq = h->pass_seq + 1;
   *out = h;
   return LSA_OK;
 }
@@ -406,6 +441,61 @@ extern "C" int lsa_ndt_armed_counters(lsa_ndt *h, uint64_t *passes, uint64_t *ca
   return LSA_OK;
 }
 
+extern "C" int lsa_ndt_armed_stats(lsa_ndt *h, lsa_ndt_armed_stats_t *out, int reset) {
+  if (!h) return LSA_ERR_INVALID;
+  if (out) {
+    out->passes = h->armed_passes; out->cancels = h->armed_cancels; out->fallbacks = h->armed_fallbacks;
+    out->late = h->armed_late; out->rows_late = h->rows_late; out->gave_up_seen = h->armed_gave_up_seen;
+    out->expired = h->armed_expired;
+    out->rows_wait_max_us = h->rows_wait_max_us;
+    out->parked = (h->armed_outstanding && h->ctx->unpark_arg == h) ? 1 : 0;
+  }
+  if (reset) { h->armed_passes = h->armed_cancels = h->armed_fallbacks = h->armed_late = h->rows_late = h->armed_gave_up_seen = h->armed_expired = 0; h->rows_wait_max_us = 0; }
+  return LSA_OK;
+}
+
+extern "C" int lsa_ndt_set_armed_patience(lsa_ndt *h, double patience_us) {
+  if (!h) return LSA_ERR_INVALID;
+  if (!(patience_us >= 1.0) || patience_us > 1e5) return lsa_fail(h->ctx, LSA_ERR_INVALID, "lsa_ndt_set_armed_patience: %g us is outside [1, 1e5]", patience_us);
+  lsa_ctx_unpark(h->ctx);
+  h->armed_patience_us = patience_us;
+  return LSA_OK;
+}
+
+// internal (pipeline.cpp): the carry between the scans of a batch, without releasing what is parked; returns the previous setting
+bool ndt_carry_scope(lsa_ndt *h, bool on) {
+  const bool prev = h->armed_carry;
+  h->armed_carry = on;
+  return prev;
+}
+// internal (pipeline.cpp): a batch is about to call ScanMatch on this handle as soon as its first filter is done — enqueue
+// the armed kernel of the first pass NOW (it takes source, size and grid from its mail), so that its launch and dispatch
+// latency pass while the filter runs.  Sized for the previous ScanMatch's source (a grid that turns out too small is
+// cancelled and relaunched by run_pass like any parked kernel that does not fit).  Nothing happens where the armed passes
+// would not be used.
+void ndt_prearm(lsa_ndt *h) {
+  lsa_context *ctx = h->ctx;
+  if (h->no_armed || h->allreduce || !h->has_target || h->armed_outstanding || h->n_source == 0 || !((double)h->step_size > (double)h->trans_eps / 2)) return;
+  if (ndt_align_persistent_ok(h) || hipSetDevice(ctx->device) != hipSuccess) return;
+  if (mail_ensure(h) != LSA_OK || !h->mail) return;
+  lsa_ctx_unpark(ctx, h);
+  lsa_ndt_gauss_constants(h->resolution, h->outlier_ratio, &h->d1, &h->d2);
+  const float T[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
+  const double p[6] = {0, 0, 0, 0, 0, 0};
+  PassParams P;
+  ndt_make_pass_params(h, T, p, &P);   // (only the static part is used: the transform and the angle tables come by mail)
+  const unsigned grid = armed_headroom(h, ndt_pass_grid(h, h->n_source, 0));
+  if (ndt_launch_armed(h, P, h->armed_seq, grid, h->armed_patience_us) != LSA_OK) return;
+  h->armed_outstanding = true;
+  h->armed_grid = grid;
+  h->armed_gen = h->target_gen;
+  ctx->unpark = armed_cancel_cb;
+  ctx->unpark_arg = h;
+}
+
+// internal: release a kernel this handle has left parked (the batch is over and nobody is known to follow)
+void ndt_release_parked(lsa_ndt *h) { armed_cancel(h); }
+
 extern "C" int lsa_ndt_armed_timing(lsa_ndt *h, double out[6], int reset) {
   if (!h) return LSA_ERR_INVALID;
   if (out) {
@@ -446,6 +536,7 @@ extern "C" int lsa_ndt_set_trace(lsa_ndt *h, double *rows, int cap_rows, int *n_
 
 extern "C" int lsa_ndt_set_allreduce(lsa_ndt *h, lsa_allreduce_fn fn, void *user) {
   if (!h) return LSA_ERR_INVALID;
+  lsa_ctx_unpark(h->ctx);   // sharded passes are not armed: a parked kernel would only be in their way
   h->allreduce = fn;
   h->allreduce_user = user;
   return LSA_OK;

@@ -56,8 +56,8 @@ constexpr unsigned kHostReduceMaxBlocks = 1024;
 // 600 B) in a MAILBOX in fine-grained device memory that the host writes through the PCIe BAR (measured: host store ->
 // visible to a polling wave -> echo in host memory 1.95 us round trip).  The pollers read device memory, not the link.
 // The mail carries the pass's sequence number and a check word over the payload (the host's write-combined stores may
-// land in any order; a torn read is simply repeated); a CANCEL mail (converged: the armed kernel is not needed) or a
-// 20 ms timeout makes the kernel exit without writing its row.  Same body, same grid, same rows: the results are the bits
+// land in any order; a torn read is simply repeated); a CANCEL mail (converged: the armed kernel is not needed) or the end of
+// its patience (0.3 ms by default, lsa_ndt_set_armed_patience) makes the kernel exit without writing its row.  Same body, same grid, same rows: the results are the bits
 // of the unarmed path.
 struct PassMail {
   unsigned long long words[80];   // [0..5] the 12 floats of T, [6..74] jh (ja then ha), [75] virtual grid, [76] source pointer, [77] #points,
@@ -127,8 +127,11 @@ __global__ __launch_bounds__(kBlockD, pass_waves(0)) void k_ndt_pass_armed(PassP
           break;
         }
       }
-      if (wall_clock64() - t0 > patience_ticks) {  // nobody posted in time: leave, and tell the host so that it does not wait for rows
-        if (blockIdx.x == 0 && lane == 0) __hip_atomic_store(gave_up, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      if (wall_clock64() - t0 > patience_ticks) {
+        // nobody posted in time: leave, and tell the host so that it does not wait for rows.  EVERY workgroup that leaves says
+        // so (they all store the same number): the patience clocks are per workgroup, so a mail that lands inside their skew is
+        // taken by some workgroups and not by others — the host must learn of one missing row at once, whichever it is
+        if (lane == 0) __hip_atomic_store(gave_up, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         break;
       }
       __builtin_amdgcn_s_sleep(1);
@@ -359,9 +362,12 @@ int ndt_enqueue_pass_host(lsa_ndt *h, const PassParams &P, int kind, unsigned *g
   const uint4 *words = h->words.p;
   const double *rec = h->rec.p;
   double *dst = h->h_partials.p;  // pinned + mapped: the same pointer is valid on the device
-  // a fresh non-zero key per pass (odd multiplier: a bijection of the counter, so consecutive keys share no pattern)
-  unsigned long long key = (++h->pass_seq) * 0x9E3779B97F4A7C15ull;
-  if (!key) key = (++h->pass_seq) * 0x9E3779B97F4A7C15ull;
+  // a fresh non-zero key per pass (odd multiplier: a bijection of the counter, so consecutive keys share no pattern).
+  // EVEN: the armed passes write their rows into the same host buffer under ODD keys (ndt_armed_row_key) drawn from a counter
+  // of their own, and a row one kind left behind must never pass for the other's (found by the short-patience stress test:
+  // passes redone the ordinary way between armed ones took stale armed rows whose key happened to coincide)
+  unsigned long long key = ((++h->pass_seq) * 0x9E3779B97F4A7C15ull) & ~1ull;
+  if (!key) key = ((++h->pass_seq) * 0x9E3779B97F4A7C15ull) & ~1ull;
   launch_pass(h, P, kind, g, words, rec, dst, key);
   LSA_HIP(ctx, hipGetLastError());
   *grid_out = g;

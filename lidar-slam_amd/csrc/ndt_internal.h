@@ -76,7 +76,11 @@ struct lsa_ndt {
   unsigned long long armed_seq = 1;
   unsigned armed_grid = 0;          // launch grid of the outstanding kernel
   unsigned long long armed_gen = 0, target_gen = 0;   // the voxel table it was launched for / the current one
-  bool armed_carry = getenv("LSA_NO_CARRY") == nullptr;   // leave the last armed kernel parked for the next ScanMatch
+  // leave the last armed kernel parked for the next ScanMatch: OPT-IN for the plain ScanMatch calls (lsa_ndt_set_armed_carry /
+  // LSA_CARRY=1; a parked kernel spins on the caller's stream for up to its patience), switched on by the library itself
+  // between the scans of a batch (lsa_pipeline_scan_match), where the next ScanMatch is known to follow at once
+  bool armed_carry = getenv("LSA_CARRY") != nullptr;
+  double armed_patience_us = 300.0;   // how long an armed kernel waits for its mail before it leaves by itself
   // diagnostics of the armed passes (lsa_ndt_armed_timing): sums over passes
   double at_passes = 0, at_post_to_rows_us = 0, at_rows_to_post_us = 0, at_dev_wait_ticks = 0, at_dev_body_ticks = 0, at_post_us = 0;
   std::chrono::steady_clock::time_point at_last_rows;
@@ -86,6 +90,10 @@ struct lsa_ndt {
   size_t keep_n = 0;
   PinnedBuf<double> h_gave_up;      // [0]: sequence number of the last armed kernel that left because no mail came
   unsigned long long armed_passes = 0, armed_cancels = 0, armed_fallbacks = 0;
+  // what used to be silent: rows that missed their polling limit but were there once the stream had drained (armed /
+  // ordinary host-reduced passes), armed kernels seen to have given up, and the longest time any pass's rows took
+  unsigned long long armed_late = 0, rows_late = 0, armed_gave_up_seen = 0, armed_expired = 0;
+  double rows_wait_max_us = 0;
 
   // multi-GPU
   lsa_allreduce_fn allreduce = nullptr;
@@ -102,6 +110,8 @@ struct lsa_ndt {
 };
 
 int ndt_build_grid(lsa_ndt *h, const float4 *d_pts, size_t n);
+bool ndt_carry_scope(lsa_ndt *h, bool on);   // ndt_api.hip: carry between the scans of a batch; returns the previous setting
+void ndt_release_parked(lsa_ndt *h);
 int ndt_count_valid(lsa_ndt *h);
 void ndt_fitness_invalidate(lsa_ndt *h);
 void ndt_fitness_release(lsa_ndt *h);

@@ -5,6 +5,13 @@
 // stage.  Results are exactly those of the sequential calls: every scan is filtered once and registered once.
 #include "lsa_common.h"
 
+bool ndt_carry_scope(lsa_ndt *h, bool on);   // ndt_api.hip
+void ndt_release_parked(lsa_ndt *h);
+void ndt_prearm(lsa_ndt *h);
+void lsa_voxel_filter_retire_begin(lsa_voxel_filter *f);
+void lsa_voxel_filter_retire_end(lsa_voxel_filter *f);
+int lsa_voxel_filter_apply_device_async_here(lsa_voxel_filter *f, const float *d_in_xyzw, size_t n, float *d_out_xyzw);   // voxel_filter.hip
+
 extern "C" int lsa_pipeline_scan_match(lsa_voxel_filter *frame_filter, lsa_ndt *ndt, size_t count, const float *const *d_scans_xyzw,
                                        const size_t *n_points, const float *predict_poses, float *d_filtered_a, float *d_filtered_b, int rank,
                                        int world, float *result_poses, lsa_ndt_stats *stats, size_t *n_filtered) {
@@ -13,16 +20,30 @@ extern "C" int lsa_pipeline_scan_match(lsa_voxel_filter *frame_filter, lsa_ndt *
   if (world < 1 || rank < 0 || rank >= world) return LSA_ERR_INVALID;
   if (count == 0) return LSA_OK;
   float *buf[2] = {d_filtered_a, d_filtered_b};
-  int rc = lsa_voxel_filter_apply_device_async(frame_filter, d_scans_xyzw[0], n_points[0], buf[0]);
+  int rc = lsa_voxel_filter_apply_device_async_here(frame_filter, d_scans_xyzw[0], n_points[0], buf[0]);
   if (rc) return rc;
+  // Between the scans of the batch the next ScanMatch is known to follow at once and nothing else uses the NDT's stream, so
+  // the armed kernel of the pass that never came stays parked for the next scan's first pass; behind the LAST scan it is
+  // cancelled (unless the caller opted into the carry himself): the batch returns with nothing spinning on the stream.
+  ndt_prearm(ndt);   // the first pass's kernel, enqueued while the first filter runs
+  const bool carry_user = ndt_carry_scope(ndt, true);
+  struct Restore {
+    lsa_ndt *h; bool prev;
+    ~Restore() { (void)ndt_carry_scope(h, prev); if (!prev) ndt_release_parked(h); }
+  } restore{ndt, carry_user};
   for (size_t k = 0; k < count; k++) {
     size_t m = 0;
     if ((rc = lsa_voxel_filter_wait(frame_filter, &m))) return rc;
     if (k + 1 < count && (rc = lsa_voxel_filter_apply_device_async(frame_filter, d_scans_xyzw[k + 1], n_points[k + 1], buf[(k + 1) & 1]))) return rc;
     // multi-GPU: this rank's contiguous shard of the filtered source; the all-reduce callback installed on
     // the NDT handle sums the per-rank normal equations
+    if (k + 1 == count) {
+      (void)ndt_carry_scope(ndt, carry_user);
+      lsa_voxel_filter_retire_begin(frame_filter);   // nothing more to filter: the helper thread retires the filter's stream meanwhile
+    }
     size_t lo = (m * (size_t)rank) / (size_t)world, hi = (m * (size_t)(rank + 1)) / (size_t)world;
     rc = lsa_ndt_scan_match_device(ndt, buf[k & 1] + 4 * lo, hi - lo, predict_poses + 16 * k, result_poses + 16 * k, stats ? stats + k : nullptr);
+    if (k + 1 == count) lsa_voxel_filter_retire_end(frame_filter);
     if (rc) {  // leave no filter in flight behind an error
       if (k + 1 < count) { size_t dummy; (void)lsa_voxel_filter_wait(frame_filter, &dummy); }
       return rc;

@@ -33,7 +33,9 @@ struct lsa_voxel_filter {
   std::condition_variable cv;
   std::atomic<int> job_state{0};
   int job_rc = LSA_OK;
+  hipError_t job_hip = hipSuccess;   // kind 2: the helper's HIP status (the caller's thread turns it into the error text)
   bool worker_started = false;
+  bool retiring = false;   // job kind 3 in flight (lsa_voxel_filter_retire_begin / _end)
   // job kind 1: enqueue the filter of (p_in, p_n, p_out); kind 2: pack + upload the second half of a host cloud on stream2
   int job_kind = 1;
   const void *u_pts = nullptr;
@@ -134,7 +136,7 @@ void filter_worker(lsa_voxel_filter *f) {
       st = f->job_state.load(std::memory_order_acquire);
       if (st == 1 || st == -1) break;
       __builtin_ia32_pause();
-      if ((spin & 1023u) == 1023u && std::chrono::steady_clock::now() - spin_t0 > std::chrono::microseconds(40)) break;
+      if ((spin & 1023u) == 1023u && std::chrono::steady_clock::now() - spin_t0 > std::chrono::microseconds(100)) break;
     }
     if (st != 1 && st != -1) {
       std::unique_lock<std::mutex> lk(f->mu);
@@ -142,13 +144,32 @@ void filter_worker(lsa_voxel_filter *f) {
       st = f->job_state.load(std::memory_order_acquire);
     }
     if (st == -1) return;
+    if (f->job_kind == 0) {  // wake-up call only (the first filter of a batch is enqueued by the caller itself): back to spinning
+      f->job_state.store(0, std::memory_order_release);
+      continue;
+    }
+    if (f->job_kind == 3) {
+      // retire the stream's completed commands (the last filter of a batch has delivered; its stream would otherwise cost the
+      // caller's next wait on the device ~11 us of bookkeeping) while the caller's thread drives the last registration
+      f->job_hip = hipStreamSynchronize(f->ctx->stream);
+      f->job_rc = f->job_hip == hipSuccess ? LSA_OK : LSA_ERR_HIP;
+      f->job_state.store(2, std::memory_order_release);
+      continue;
+    }
     if (f->job_kind == 2) {
-      lsa_context c2 = *f->ctx;   // same device, the second copy queue
-      c2.stream = f->stream2;
-      f->job_rc = lsa_upload_xyzw(&c2, (const char *)f->u_pts + f->u_off * f->u_stride, f->u_n, f->u_stride, f->u_w_off, f->h_stage.p + 4 * f->u_off,
-                                  f->d_in.p + f->u_off);
-      if (f->job_rc) { std::lock_guard<std::mutex> lk(f->mu); f->ctx->err = c2.err; }
-      else if (hipEventRecord(f->ev2, f->stream2) != hipSuccess) f->job_rc = LSA_ERR_HIP;
+      // second half of a host cloud down the second copy queue.  The helper touches neither the context nor its error text
+      // (the caller's thread may be writing it): stride / offset were validated by the caller, a HIP failure comes back as
+      // a code in job_hip and the caller's thread reports it
+      constexpr size_t kChunk = 32768;
+      hipError_t e = hipSuccess;
+      for (size_t off = 0; off < f->u_n && e == hipSuccess; off += kChunk) {
+        const size_t m = f->u_n - off < kChunk ? f->u_n - off : kChunk, at = f->u_off + off;
+        lsa_pack_xyzw((const char *)f->u_pts + at * f->u_stride, m, f->u_stride, f->u_w_off, f->h_stage.p + 4 * at);
+        e = hipMemcpyAsync(f->d_in.p + at, f->h_stage.p + 4 * at, m * sizeof(float4), hipMemcpyHostToDevice, f->stream2);
+      }
+      if (e == hipSuccess) e = hipEventRecord(f->ev2, f->stream2);
+      f->job_hip = e;
+      f->job_rc = e == hipSuccess ? LSA_OK : LSA_ERR_HIP;
     } else {
       f->job_rc = filter_enqueue(f, f->p_in, f->p_n, f->p_out);
     }
@@ -163,6 +184,7 @@ void filter_post_job(lsa_voxel_filter *f, int kind) {
     f->worker = std::thread(filter_worker, f);
     f->worker_started = true;
   }
+  while (f->job_state.load(std::memory_order_acquire) == 1) __builtin_ia32_pause();   // (a wake-up call the helper has not taken yet)
   f->job_kind = kind;
   {
     std::lock_guard<std::mutex> lk(f->mu);
@@ -181,6 +203,37 @@ extern "C" int lsa_voxel_filter_apply_device_async(lsa_voxel_filter *f, const fl
   if (n == 0) return LSA_OK;
   filter_post_job(f, 1);
   return LSA_OK;
+}
+
+// internal (pipeline.cpp): the same call with the launches issued by the CALLER's thread — for the first scan of a batch,
+// where nothing is there to overlap with and the helper thread, asleep since the last batch, would take longer to wake up
+// (~50 us) than the ~20 us of launch calls cost; the helper is woken meanwhile so that it is spinning when the second scan's
+// filter is posted.  Completed by lsa_voxel_filter_wait like any other.
+int lsa_voxel_filter_apply_device_async_here(lsa_voxel_filter *f, const float *d_in_xyzw, size_t n, float *d_out_xyzw) {
+  if (!f || (n && (!d_in_xyzw || !d_out_xyzw))) return f ? lsa_fail(f->ctx, LSA_ERR_INVALID, "lsa_voxel_filter_apply_device_async: null argument") : LSA_ERR_INVALID;
+  if (f->pending) return lsa_fail(f->ctx, LSA_ERR_INVALID, "lsa_voxel_filter_apply_device_async: a filter is already in flight on this handle");
+  LSA_HIP(f->ctx, lsa_enter(f->ctx));
+  f->p_in = (const float4 *)d_in_xyzw; f->p_out = (float4 *)d_out_xyzw; f->p_n = n;
+  f->pending = true;
+  if (n == 0) return LSA_OK;
+  filter_post_job(f, 0);
+  f->job_rc = filter_enqueue(f, f->p_in, f->p_n, f->p_out);
+  while (f->job_state.load(std::memory_order_acquire) == 1) __builtin_ia32_pause();   // the wake-up call has been taken
+  f->job_state.store(2, std::memory_order_release);
+  return LSA_OK;
+}
+
+// internal (pipeline.cpp): see job kind 3.  _begin posts it to the helper thread, _end waits for it.
+void lsa_voxel_filter_retire_begin(lsa_voxel_filter *f) {
+  if (!f || f->pending || !f->worker_started) return;
+  filter_post_job(f, 3);
+  f->retiring = true;
+}
+void lsa_voxel_filter_retire_end(lsa_voxel_filter *f) {
+  if (!f || !f->retiring) return;
+  while (f->job_state.load(std::memory_order_acquire) != 2) __builtin_ia32_pause();
+  f->job_state.store(0, std::memory_order_release);
+  f->retiring = false;
 }
 
 extern "C" int lsa_voxel_filter_wait(lsa_voxel_filter *f, size_t *n_out) {
@@ -250,6 +303,9 @@ extern "C" int lsa_voxel_filter_apply(lsa_voxel_filter *f, const void *in_pts, s
   *n_out = 0;
   if (n == 0) return LSA_OK;
   if (in_stride < 12 || out_stride < 12) return lsa_fail(ctx, LSA_ERR_INVALID, "lsa_voxel_filter_apply: stride < 12");
+  // validated HERE, once, before any thread starts packing (lsa_upload_xyzw checks again for its other callers)
+  if (in_w_off != SIZE_MAX && in_w_off + 4 > in_stride)
+    return lsa_fail(ctx, LSA_ERR_INVALID, "point rows of %zu bytes cannot hold xyz + an intensity at offset %zu (pass SIZE_MAX for clouds without one)", in_stride, in_w_off);
   LSA_HIP(ctx, lsa_enter(ctx));
   int rc;
   // the staging buffer may still be feeding an earlier async copy, and growing a buffer frees the old one: wait first
@@ -272,8 +328,13 @@ extern "C" int lsa_voxel_filter_apply(lsa_voxel_filter *f, const void *in_pts, s
     rc = lsa_upload_xyzw(ctx, in_pts, half, in_stride, in_w_off, f->h_stage.p, f->d_in.p);
     while (f->job_state.load(std::memory_order_acquire) != 2) {}
     f->job_state.store(0, std::memory_order_release);
-    if (rc) return rc;
-    if (f->job_rc) return f->job_rc;
+    if (rc || f->job_rc) {
+      // leave no copy of either half in flight into d_in / out of h_stage behind an error
+      (void)hipStreamSynchronize(f->stream2);
+      (void)hipStreamSynchronize(ctx->stream);
+      if (rc) return rc;
+      return lsa_fail(ctx, LSA_ERR_HIP, "lsa_voxel_filter_apply: upload of the second half failed: %s", hipGetErrorString(f->job_hip));
+    }
     LSA_HIP(ctx, hipStreamWaitEvent(ctx->stream, f->ev2, 0));
   } else if ((rc = lsa_upload_xyzw(ctx, in_pts, n, in_stride, in_w_off, f->h_stage.p, f->d_in.p))) {
     return rc;

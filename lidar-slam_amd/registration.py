@@ -136,13 +136,24 @@ class NDTRegistrationHip(RegistrationInterface):
         self.ctx.check(capi.lib().lsa_ndt_set_armed(self.h, 1 if on else 0))
 
     def set_armed_carry(self, on):
-        """Leave the last armed kernel parked for the next ScanMatch (default) or cancel it at every ScanMatch end."""
+        """Opt in to leaving the last armed kernel parked for the next ScanMatch on this handle (default: cancelled at every
+        ScanMatch end; lsa_pipeline_scan_match carries between the scans of its batch by itself)."""
         self.ctx.check(capi.lib().lsa_ndt_set_armed_carry(self.h, 1 if on else 0))
 
     def armed_counters(self):
         a, b, c = C.c_uint64(0), C.c_uint64(0), C.c_uint64(0)
         self.ctx.check(capi.lib().lsa_ndt_armed_counters(self.h, C.byref(a), C.byref(b), C.byref(c)))
         return dict(passes=a.value, cancels=b.value, fallbacks=c.value)
+
+    def armed_stats(self, reset=False):
+        """Every non-plain outcome of the armed path / the row hand-over, counted (lsa_ndt_armed_stats)."""
+        st = capi.NdtArmedStats()
+        self.ctx.check(capi.lib().lsa_ndt_armed_stats(self.h, C.byref(st), 1 if reset else 0))
+        return st.as_dict()
+
+    def set_armed_patience(self, patience_us):
+        """diagnostics / tests: how long an armed kernel waits for its mail before it leaves by itself (default 300 us)"""
+        self.ctx.check(capi.lib().lsa_ndt_set_armed_patience(self.h, float(patience_us)))
 
     def armed_timing(self, reset=False):
         """Per-pass means of the armed passes' timeline (lsa_ndt_armed_timing), microseconds."""
@@ -153,7 +164,8 @@ class NDTRegistrationHip(RegistrationInterface):
                     dev_wait_us=out[4] / n, dev_body_us=out[5] / n)
 
     def set_persistent(self, on):
-        """ScanMatch as ONE persistent launch (default) or one launch per derivative pass (lsa_ndt_set_persistent)."""
+        """ScanMatch as ONE persistent launch (opt-in: measured no faster) instead of one launch per derivative
+        pass, the default (lsa_ndt_set_persistent)."""
         self.ctx.check(capi.lib().lsa_ndt_set_persistent(self.h, 1 if on else 0))
 
     def align_counters(self):
@@ -254,6 +266,28 @@ class ICPRegistrationHip(RegistrationInterface):
             self.close()
         except Exception:
             pass
+
+
+def pipeline_scan_match(frame_filter, ndt, d_scans, predict_poses, d_bufs, rank=0, world=1):
+    """lsa_pipeline_scan_match: the batch form of Filter (front_end.cpp:106-107) -> ScanMatch (:225) over device-resident
+    scans, the filter of scan k+1 (on the filter's own context) under the registration of scan k.  d_scans: CUDA (n, 4) f32
+    tensors; predict_poses: 4x4 arrays; d_bufs: two CUDA tensors of max(n) rows.  Returns (poses, stats dicts, filtered sizes)."""
+    count = len(d_scans)
+    for t in list(d_scans) + list(d_bufs):
+        check_points_tensor(t, "pipeline_scan_match")
+    ptrs = (C.c_void_p * count)(*[t.data_ptr() for t in d_scans])
+    nn = (C.c_size_t * count)(*[t.shape[0] for t in d_scans])
+    pred = np.ascontiguousarray(np.stack([capi.colmajor(g) for g in predict_poses]).astype(np.float32)) if count else np.zeros((0, 16), np.float32)
+    out = np.zeros((count, 16), dtype=np.float32)
+    st = (capi.NdtStats * max(count, 1))()
+    nf = (C.c_size_t * max(count, 1))()
+    rc = capi.lib().lsa_pipeline_scan_match(frame_filter.h, ndt.h, count, ptrs, nn, capi.fptr(pred), d_bufs[0].data_ptr(), d_bufs[1].data_ptr(),
+                                            rank, world, capi.fptr(out), st, nf)
+    if rc:
+        frame_filter.ctx.check(rc)
+        ndt.ctx.check(rc)
+        raise capi.LsaError(rc, "lsa_pipeline_scan_match failed")
+    return [capi.from_colmajor(out[i]) for i in range(count)], [st[i].as_dict() for i in range(count)], [int(nf[i]) for i in range(count)]
 
 
 def unpack_out32(out):

@@ -59,9 +59,16 @@ print("RCCL_PATH_OK", st_rccl["passes"])
 '''
 
 
+def _free_port():
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
+
+
 @pytest.mark.gpu
 def test_scan_match_through_rccl_world_1(tmp_path):
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29533", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()), HSA_ENABLE_IPC_MODE_LEGACY="0")
     script = tmp_path / "child.py"
     script.write_text("ROOT = %r\n" % ROOT + CHILD)
     p = subprocess.run([sys.executable, str(script)], env=env, capture_output=True, text=True, timeout=600)
@@ -135,8 +142,9 @@ def test_pipeline_scan_match_sharded_two_ranks_one_gpu(tmp_path):
     script = tmp_path / "child2.py"
     script.write_text("ROOT = %r\n" % ROOT + CHILD2)
     procs = []
+    port = str(_free_port())
     for r in range(2):
-        env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29541", RANK=str(r), WORLD_SIZE="2", HSA_ENABLE_IPC_MODE_LEGACY="0")
+        env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=port, RANK=str(r), WORLD_SIZE="2", HSA_ENABLE_IPC_MODE_LEGACY="0")
         procs.append(subprocess.Popen([sys.executable, str(script)], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
     outs = [p.communicate(timeout=600) for p in procs]
     for r, (p, (so, se)) in enumerate(zip(procs, outs)):
