@@ -425,6 +425,20 @@ int lsa_front_end_update(lsa_front_end *fe, const void *cloud, size_t n, size_t 
 int lsa_front_end_update_device(lsa_front_end *fe, const float *d_xyzw, size_t n, float pose_out[16], lsa_front_end_stats *stats);
 /* the NDT handle the front end owns (for GetFitnessScore / introspection); do not destroy it */
 lsa_ndt *lsa_front_end_registration(lsa_front_end *fe);
+/* Incremental local map (default ON; 0 or the environment variable LSA_FE_INCREMENTAL=0 selects the full rebuild).
+ * UpdateWithNewFrame (front_end.cpp:348-424) rebuilds filter output and voxel table from all <= 20 key-frames on every
+ * key-frame; with the incremental map the per-cell sums of both levels are persistent exact integers, a key-frame adds its own
+ * points, subtracts the evicted key-frame's and re-finalises only the cells either touched (csrc/local_map.hip).  Both paths
+ * produce the same voxel table bit for bit (tests/test_gpu_front_end.py), so switching is not observable in the poses. */
+int lsa_front_end_set_incremental(lsa_front_end *fe, int on);
+/* out[0] full target builds, [1] incremental updates, [2] rebuilds of the persistent tables, [3] re-fits of the dense window,
+ * [4] 1 while the NDT handle runs on the incremental map's table, [5] 1 if the incremental path switched itself off */
+int lsa_front_end_map_counters(lsa_front_end *fe, uint64_t out[6]);
+/* tests: rebuilds the target the full way on scratch handles and compares it with the incremental map, cell by cell and bit
+ * by bit.  out[0] occupied cells of the full table, [1] cells whose state or record differs in any bit (must be 0),
+ * [2] live cells / [3] valid voxels of the incremental map ([2] must equal [0]), [4] points of the full build's filtered map /
+ * [5] live cells of the incremental filter level (equal; both 0 while the map is unfiltered). */
+int lsa_front_end_map_verify(lsa_front_end *fe, uint64_t out[6]);
 
 #ifdef __cplusplus
 }

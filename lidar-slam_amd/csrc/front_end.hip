@@ -13,7 +13,8 @@
 // In the reference every key-frame re-uploads nothing (CPU) but re-transforms 20 x 120 k points and re-filters 2.4 M
 // points on one core (~100 ms); here the key-frame clouds stay on the device, so a key-frame costs one D2D copy, 20 small
 // transform kernels, one filter and one voxel-table build, with no host <-> device traffic at all.
-#include "voxel_index_dev.h"
+#include "local_map.h"
+#include "ndt_internal.h"
 
 #include <cmath>
 #include <deque>
@@ -123,7 +124,18 @@ struct lsa_front_end {
   size_t map_points = 0, target_points = 0;
   size_t slot_cap = 0;  // points per local-map slot
   long frames_seen = 0;
+  // incremental local map (local_map.hip): the persistent sums of the window, updated key-frame by key-frame; the NDT handle
+  // then runs on its records / dense table (an EXTERNAL table, ndt_internal.h) instead of a table rebuilt per key-frame
+  LocalMap lm;
+  bool incremental = getenv("LSA_FE_INCREMENTAL") ? atoi(getenv("LSA_FE_INCREMENTAL")) != 0 : true;
+  bool lm_off = false;       // fell back to the full build for good (window / table limits, coordinates out of range)
+  bool lm_adopted = false;   // the NDT handle currently runs on the local map's table
+  unsigned long long scale_n = 0;
+  unsigned long long n_full_builds = 0;
 };
+
+void lsa_voxel_filter_set_scale_floor(lsa_voxel_filter *f, unsigned long long n);   // voxel_filter.hip
+void ndt_set_scale_floor(lsa_ndt *h, unsigned long long n);                         // ndt_grid.hip
 
 namespace {
 // The local map buffer is `local_frame_num` slots of slot_cap points; a key-frame's transformed cloud lives in its slot
@@ -139,22 +151,17 @@ void fe_transform_into_slot(lsa_front_end *fe, KeyFrame *f) {
                      fe->d_map.p + (size_t)f->slot * fe->slot_cap);
 }
 
-int fe_rebuild_map(lsa_front_end *fe, KeyFrame *added) {
+// the FULL build of the target from the whole local-map buffer (every key-frame without the incremental map, and whenever
+// an entry point needs an ordinary table): 0.3 m filter once there are 10 key-frames (front_end.cpp:394-410), then the
+// voxel table
+int fe_full_target(lsa_front_end *fe) {
   lsa_context *ctx = fe->ctx;
-  size_t sum = 0, biggest = 0;
-  for (KeyFrame *f : fe->frames) { sum += f->n; biggest = std::max(biggest, f->n); }
-  int rc;
-  if (biggest > fe->slot_cap || !fe->d_map.p) {  // first frame, or a cloud larger than any before: lay the buffer out anew
-    fe->slot_cap = biggest + biggest / 8 + 1;
-    if ((rc = fe->d_map.reserve(ctx, fe->slot_cap * (size_t)fe->cfg.local_frame_num))) return rc;
-    int k = 0;
-    for (KeyFrame *f : fe->frames) { f->slot = k++; fe_transform_into_slot(fe, f); }
-  } else {
-    fe_transform_into_slot(fe, added);
-  }
+  size_t sum = 0;
+  for (KeyFrame *f : fe->frames) sum += f->n;
   const size_t total = fe->slot_cap * fe->frames.size();  // slots 0 .. size-1 are the occupied ones (see fe_add_key_frame)
-  LSA_HIP(ctx, hipGetLastError());
-  fe->map_points = sum;
+  fe->lm_adopted = false;
+  fe->n_full_builds++;
+  int rc;
   if ((int)fe->frames.size() < 10 || !fe->cfg.use_map_filter) {  // front_end.cpp:394-396: few key-frames -> unfiltered map
     fe->target_points = sum;
     return lsa_ndt_set_input_target_device(fe->ndt, (const float *)fe->d_map.p, total);
@@ -171,12 +178,106 @@ int fe_rebuild_map(lsa_front_end *fe, KeyFrame *added) {
   return lsa_ndt_set_input_target_device(fe->ndt, (const float *)fe->d_map_f.p, V);
 }
 
+int fe_materialize_cb(void *user) { return fe_full_target((lsa_front_end *)user); }
+
+int fe_lm_adopt(lsa_front_end *fe) {
+  fe->lm_adopted = true;
+  return ndt_adopt_external(fe->ndt, fe->lm.rec.p, fe->lm.dense.p, fe->lm.wmin, fe->lm.wdim, fe->target_points, fe_materialize_cb, fe);
+}
+
+// the persistent sums from scratch from the occupied slots; a map the tables / the window cannot hold switches the
+// incremental path off for good and builds the target the full way
+int fe_lm_rebuild(lsa_front_end *fe, bool filtered) {
+  const float4 *range = fe->d_map.p;
+  const size_t n = fe->slot_cap * fe->frames.size();
+  int rc = lm_rebuild(fe->lm, &range, &n, 1, filtered);
+  if (rc == LSA_ERR_CAPACITY || rc == LSA_ERR_RANGE) {
+    fe->lm_off = true;
+    return fe_full_target(fe);
+  }
+  if (rc) return rc;
+  if (filtered) fe->target_points = (size_t)(fe->lm.h_status.p->live_f > 0 ? fe->lm.h_status.p->live_f : 0);
+  return fe_lm_adopt(fe);
+}
+
+// Before a ScanMatch: what the last incremental update reported (its kernels have completed: the frame filter's wait on
+// the same stream came after them).  A valid voxel outside the dense window -> the window is re-fitted; tables filling up
+// -> rebuilt (larger).
+int fe_lm_settle(lsa_front_end *fe) {
+  if (!fe->lm.pending) return LSA_OK;
+  if (!fe->cfg.use_frame_filter) (void)hipStreamSynchronize(fe->ctx->stream);   // (nothing else ordered the host behind the update)
+  const int c = lm_check(fe->lm);
+  if (fe->lm.filtered && fe->lm_adopted) fe->target_points = (size_t)(fe->lm.h_status.p->live_f > 0 ? fe->lm.h_status.p->live_f : 0);
+  if (c == 2) return fe_lm_rebuild(fe, fe->lm.filtered);
+  if (c == 1) {
+    int rc = lm_refit_window(fe->lm);
+    if (rc == LSA_ERR_CAPACITY) { fe->lm_off = true; return fe_full_target(fe); }
+    if (rc) return rc;
+    return fe_lm_adopt(fe);
+  }
+  return LSA_OK;
+}
+
+// `added` is already in fe->frames; its cloud is still the caller's d_cloud (static weights reset to 1 on the way if reset_w)
+int fe_rebuild_map(lsa_front_end *fe, KeyFrame *added, bool evicted, const float4 *d_cloud, bool reset_w) {
+  lsa_context *ctx = fe->ctx;
+  size_t sum = 0, biggest = 0;
+  for (KeyFrame *f : fe->frames) { sum += f->n; biggest = std::max(biggest, f->n); }
+  int rc;
+  const bool relayout = biggest > fe->slot_cap || !fe->d_map.p;
+  const bool want_filtered = (int)fe->frames.size() >= 10 && fe->cfg.use_map_filter;
+  // the steady state of the incremental map: ONE launch takes the caller's cloud, keeps the key-frame's copy of it, writes its
+  // transformed points into the slot and swaps it for the evicted key-frame in the persistent sums
+  const bool steady = fe->incremental && !fe->lm_off && !relayout && fe->lm.valid && want_filtered == fe->lm.filtered;
+  if (!steady && added->n)
+    hipLaunchKernelGGL(k_copy_w, dim3(lsa_div_up(added->n, kBlock)), dim3(kBlock), 0, ctx->stream, d_cloud, added->n, added->pts.p, reset_w ? 1 : 0);
+  if (relayout) {  // first frame, or a cloud larger than any before: lay the buffer out anew
+    fe->slot_cap = biggest + biggest / 8 + 1;
+    if ((rc = fe->d_map.reserve(ctx, fe->slot_cap * (size_t)fe->cfg.local_frame_num))) return rc;
+    int k = 0;
+    for (KeyFrame *f : fe->frames) { f->slot = k++; fe_transform_into_slot(fe, f); }
+    // The fixed-point scales of every per-cell sum are a constant of the session from here on — sized for a full window of
+    // full slots, whatever the clouds at hand hold — so that a full build and the incremental map quantise alike
+    unsigned long long cap_pts = 2ull * fe->slot_cap * (unsigned long long)fe->cfg.local_frame_num, s = 1;
+    while (s < cap_pts) s <<= 1;
+    fe->scale_n = s;
+    if (fe->map_filter) lsa_voxel_filter_set_scale_floor(fe->map_filter, s);
+    ndt_set_scale_floor(fe->ndt, s);
+    fe->lm.valid = false;
+    if (fe->incremental && !fe->lm_off && (rc = lm_configure(fe->lm, ctx, fe->cfg.map_leaf, fe->cfg.ndt_res, /*pcl*/ 0, s))) return rc;
+  }
+  LSA_HIP(ctx, hipGetLastError());
+  fe->map_points = sum;
+  if (!fe->incremental || fe->lm_off) {
+    if (!relayout) fe_transform_into_slot(fe, added);
+    return fe_full_target(fe);
+  }
+  if (!steady) {
+    if (!relayout) fe_transform_into_slot(fe, added);
+    if (!want_filtered) fe->target_points = sum;
+    return fe_lm_rebuild(fe, want_filtered);
+  }
+  // the steady state: the evicted key-frame's points (still in the slot) leave the sums, the new key-frame's enter
+  float4 *slot = fe->d_map.p + (size_t)added->slot * fe->slot_cap;
+  float T[12];
+  for (int r = 0; r < 3; r++)
+    for (int c = 0; c < 4; c++) T[r * 4 + c] = added->pose[c * 4 + r];
+  if ((rc = lm_swap(fe->lm, slot, fe->slot_cap, evicted, d_cloud, added->n, T, added->pts.p, reset_w))) return rc;
+  if ((rc = lm_finish(fe->lm))) return rc;
+  if (!want_filtered) fe->target_points = sum;   // (filtered: the live-cell count arrives with the update's status)
+  if (!fe->lm_adopted) return fe_lm_adopt(fe);
+  ndt_touch_external(fe->ndt, fe->target_points);
+  return LSA_OK;
+}
+
 int fe_add_key_frame(lsa_front_end *fe, const float4 *d_cloud, size_t n, const float pose[16], bool reset_w) {
   lsa_context *ctx = fe->ctx;
   KeyFrame *kf;
+  bool evicted = false;
   if ((int)fe->frames.size() >= fe->cfg.local_frame_num && !fe->frames.empty()) {  // :364-372: slide the window
     kf = fe->frames.front();
     fe->frames.pop_front();
+    evicted = true;   // its transformed points are still in its slot of the map buffer
   } else if (!fe->pool.empty()) {  // (the evicted frame's object is reused and with it its slot of the map buffer)
     kf = fe->pool.back();
     fe->pool.pop_back();
@@ -189,13 +290,12 @@ int fe_add_key_frame(lsa_front_end *fe, const float4 *d_cloud, size_t n, const f
   if (rc) { fe->pool.push_back(kf); return rc; }
   kf->n = n;
   memcpy(kf->pose, pose, 16 * sizeof(float));
-  if (n) hipLaunchKernelGGL(k_copy_w, dim3(lsa_div_up(n, kBlock)), dim3(kBlock), 0, ctx->stream, d_cloud, n, kf->pts.p, reset_w ? 1 : 0);
   fe->frames.push_back(kf);
   while ((int)fe->frames.size() > fe->cfg.local_frame_num) {
     fe->pool.push_back(fe->frames.front());
     fe->frames.pop_front();
   }
-  return fe_rebuild_map(fe, kf);
+  return fe_rebuild_map(fe, kf, evicted, d_cloud, reset_w);
 }
 
 int fe_update_device(lsa_front_end *fe, const float4 *d_cloud, size_t n, float pose_out[16], lsa_front_end_stats *stats) {
@@ -224,6 +324,7 @@ int fe_update_device(lsa_front_end *fe, const float4 *d_cloud, size_t n, float p
     st.key_frame = 1;
   } else {
     float cur[16];
+    if (fe->incremental && !fe->lm_off && (rc = fe_lm_settle(fe))) return rc;
     if ((rc = lsa_ndt_scan_match_device(fe->ndt, (const float *)src, n_src, fe->predict_pose, cur, &st.ndt))) return rc;
     memcpy(pose_out, cur, sizeof(cur));
     float inv_last[16];
@@ -274,6 +375,7 @@ extern "C" void lsa_front_end_destroy(lsa_front_end *fe) {
   for (KeyFrame *f : fe->frames) { f->pts.release(); delete f; }
   for (KeyFrame *f : fe->pool) { f->pts.release(); delete f; }
   fe->d_in.release(); fe->d_filtered.release(); fe->d_map.release(); fe->d_map_f.release(); fe->h_stage.release();
+  fe->lm.release();
   lsa_voxel_filter_destroy(fe->frame_filter);
   lsa_voxel_filter_destroy(fe->map_filter);
   lsa_ndt_destroy(fe->ndt);
@@ -306,3 +408,63 @@ extern "C" int lsa_front_end_update(lsa_front_end *fe, const void *cloud, size_t
 }
 
 extern "C" lsa_ndt *lsa_front_end_registration(lsa_front_end *fe) { return fe ? fe->ndt : nullptr; }
+
+extern "C" int lsa_front_end_set_incremental(lsa_front_end *fe, int on) {
+  if (!fe) return LSA_ERR_INVALID;
+  LSA_HIP(fe->ctx, lsa_enter(fe->ctx));
+  const bool want = on != 0;
+  if (want == fe->incremental) return LSA_OK;
+  fe->incremental = want;
+  fe->lm.valid = false;
+  fe->lm_off = false;
+  // the target as the new setting builds it (same voxels either way: the two paths agree to the bit)
+  if (fe->frames.empty()) return LSA_OK;
+  if (!want) return fe->lm_adopted ? fe_full_target(fe) : LSA_OK;
+  int rc = lm_configure(fe->lm, fe->ctx, fe->cfg.map_leaf, fe->cfg.ndt_res, 0, fe->scale_n);
+  if (rc) return rc;
+  return fe_lm_rebuild(fe, (int)fe->frames.size() >= 10 && fe->cfg.use_map_filter);
+}
+
+// Verification for the tests: a FULL build of the target (filter + voxel table) on scratch handles from the very buffer the
+// incremental map was fed from, compared cell by cell, bit by bit, with the incremental map's level N.
+extern "C" int lsa_front_end_map_verify(lsa_front_end *fe, uint64_t out[6]) {
+  if (!fe || !out) return LSA_ERR_INVALID;
+  lsa_context *ctx = fe->ctx;
+  LSA_HIP(ctx, lsa_enter(ctx));
+  memset(out, 0, 6 * sizeof(uint64_t));
+  if (!fe->incremental || fe->lm_off || !fe->lm.valid) return lsa_fail(ctx, LSA_ERR_INVALID, "lsa_front_end_map_verify: no incremental map to verify");
+  int rc;
+  if ((rc = fe_lm_settle(fe))) return rc;
+  lsa_voxel_filter *sf = nullptr;
+  lsa_ndt *sn = nullptr;
+  if ((rc = lsa_ndt_create(&sn, ctx, fe->cfg.ndt_res, fe->cfg.ndt_step_size, fe->cfg.ndt_trans_eps, fe->cfg.ndt_max_iter, fe->cfg.ndt_outlier_ratio))) return rc;
+  ndt_set_scale_floor(sn, fe->scale_n);
+  const size_t total = fe->slot_cap * fe->frames.size();
+  DevBuf<float4> tmp;
+  if (fe->lm.filtered) {
+    rc = lsa_voxel_filter_create(&sf, ctx, fe->cfg.map_leaf[0], fe->cfg.map_leaf[1], fe->cfg.map_leaf[2]);
+    if (!rc) lsa_voxel_filter_set_scale_floor(sf, fe->scale_n);
+    size_t V = 0;
+    if (!rc) rc = tmp.reserve(ctx, total);
+    if (!rc) rc = lsa_voxel_filter_apply_device(sf, (const float *)fe->d_map.p, total, (float *)tmp.p, &V);
+    if (!rc) rc = lsa_ndt_set_input_target_device(sn, (const float *)tmp.p, V);
+    out[4] = V;
+    out[5] = (uint64_t)(fe->lm.h_status.p->live_f > 0 ? fe->lm.h_status.p->live_f : 0);
+  } else {
+    rc = lsa_ndt_set_input_target_device(sn, (const float *)fe->d_map.p, total);
+  }
+  unsigned long long res[4] = {0, 0, 0, 0};
+  if (!rc) rc = lm_verify(fe->lm, sn->vi.cell_of_rank.p, sn->rec.p, sn->state.p, sn->vi.nocc, sn->vi.map, res);
+  for (int k = 0; k < 4; k++) out[k] = res[k];
+  lsa_ndt_destroy(sn);
+  if (sf) lsa_voxel_filter_destroy(sf);
+  tmp.release();
+  return rc;
+}
+
+extern "C" int lsa_front_end_map_counters(lsa_front_end *fe, uint64_t out[6]) {
+  if (!fe || !out) return LSA_ERR_INVALID;
+  out[0] = fe->n_full_builds; out[1] = fe->lm.updates; out[2] = fe->lm.rebuilds; out[3] = fe->lm.refits;
+  out[4] = fe->lm_adopted ? 1 : 0; out[5] = fe->lm_off ? 1 : 0;
+  return LSA_OK;
+}

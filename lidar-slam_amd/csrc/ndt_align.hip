@@ -587,10 +587,10 @@ int ndt_align_persistent(lsa_ndt *h, const float predict_pose[16], float result_
   ndt_make_pass_params(h, T0, A.p0, &P);
   unsigned long long *rows = reinterpret_cast<unsigned long long *>(h->align_rows.p);
   if (h->use_dense)
-    hipLaunchKernelGGL((k_ndt_align<true>), dim3(G), dim3(kBlockD), 0, ctx->stream, h->d_source, h->n_source, P, A, h->words.p, h->dense.p, h->rec.p, rows,
+    hipLaunchKernelGGL((k_ndt_align<true>), dim3(G), dim3(kBlockD), 0, ctx->stream, h->d_source, h->n_source, P, A, h->words.p, ndt_dense(h), ndt_rec(h), rows,
                        h->align_flags.p, h->h_result.p);
   else
-    hipLaunchKernelGGL((k_ndt_align<false>), dim3(G), dim3(kBlockD), 0, ctx->stream, h->d_source, h->n_source, P, A, h->words.p, h->dense.p, h->rec.p, rows,
+    hipLaunchKernelGGL((k_ndt_align<false>), dim3(G), dim3(kBlockD), 0, ctx->stream, h->d_source, h->n_source, P, A, h->words.p, ndt_dense(h), ndt_rec(h), rows,
                        h->align_flags.p, h->h_result.p);
   LSA_HIP(ctx, hipGetLastError());
   unsigned long long w[32];

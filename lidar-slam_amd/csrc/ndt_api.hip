@@ -416,6 +416,7 @@ extern "C" int lsa_ndt_get_fitness_score(lsa_ndt *h, float *score) {
   if (rc) return rc;
   if (!score) return lsa_fail(h->ctx, LSA_ERR_INVALID, "GetFitnessScore: null output");
   if (!h->has_target || !h->has_result) return lsa_fail(h->ctx, LSA_ERR_NO_TARGET, "GetFitnessScore before SetInputTarget + ScanMatch");
+  if ((rc = ndt_materialize(h))) return rc;   // (an incremental local map's table: the octree / point search needs an ordinary one)
   if (h->mode == LSA_NDT_MODE_PCL) {  // pcl::Registration::getFitnessScore over the target POINTS (ndt_registration.cpp:63-66)
     if (!h->nn.built && (rc = nn_grid_build(h->ctx, h->nn, h->d_target_pts, h->n_target, h->resolution, "GetFitnessScore"))) return rc;
     double v = 0;
@@ -547,6 +548,7 @@ extern "C" int lsa_ndt_grid_info(lsa_ndt *h, int64_t info[9]) {
   if (rc) return rc;
   if (!info) return lsa_fail(h->ctx, LSA_ERR_INVALID, "grid_info: null output");
   if (!h->has_target) return lsa_fail(h->ctx, LSA_ERR_NO_TARGET, "grid_info before SetInputTarget");
+  if ((rc = ndt_materialize(h))) return rc;
   for (int a = 0; a < 3; a++) { info[a] = h->vi.map.dim[a]; info[3 + a] = h->vi.map.min_b[a]; }
   info[6] = (int64_t)h->vi.nocc;
   if ((rc = ndt_count_valid(h))) return rc;
@@ -561,6 +563,7 @@ extern "C" int lsa_ndt_grid_dump(lsa_ndt *h, int32_t *cell_ints, double *cell_re
   lsa_context *ctx = h->ctx;
   if (!n_cells) return lsa_fail(ctx, LSA_ERR_INVALID, "grid_dump: null output");
   if (!h->has_target) return lsa_fail(ctx, LSA_ERR_NO_TARGET, "grid_dump before SetInputTarget");
+  if ((rc = ndt_materialize(h))) return rc;
   size_t V = h->vi.nocc;
   *n_cells = V;
   if (!cell_ints && !cell_rec) return LSA_OK;

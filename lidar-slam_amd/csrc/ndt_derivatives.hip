@@ -198,9 +198,9 @@ int ndt_launch_armed(lsa_ndt *h, const PassParams &P, unsigned long long seq, un
   const unsigned long long ticks = (unsigned long long)(patience_us * 100.0);
   unsigned long long *gu = reinterpret_cast<unsigned long long *>(h->h_gave_up.p);
   if (h->use_dense)
-    hipLaunchKernelGGL((k_ndt_pass_armed<true>), dim3(grid), dim3(kBlockD), 0, ctx->stream, P, h->words.p, h->dense.p, h->rec.p, h->h_partials.p, mail, seq, ticks, gu, h->src_keep.p, (unsigned)h->src_keep.cap);
+    hipLaunchKernelGGL((k_ndt_pass_armed<true>), dim3(grid), dim3(kBlockD), 0, ctx->stream, P, h->words.p, ndt_dense(h), ndt_rec(h), h->h_partials.p, mail, seq, ticks, gu, h->src_keep.p, (unsigned)h->src_keep.cap);
   else
-    hipLaunchKernelGGL((k_ndt_pass_armed<false>), dim3(grid), dim3(kBlockD), 0, ctx->stream, P, h->words.p, h->dense.p, h->rec.p, h->h_partials.p, mail, seq, ticks, gu, h->src_keep.p, (unsigned)h->src_keep.cap);
+    hipLaunchKernelGGL((k_ndt_pass_armed<false>), dim3(grid), dim3(kBlockD), 0, ctx->stream, P, h->words.p, ndt_dense(h), ndt_rec(h), h->h_partials.p, mail, seq, ticks, gu, h->src_keep.p, (unsigned)h->src_keep.cap);
   LSA_HIP(ctx, hipGetLastError());
   return LSA_OK;
 }
@@ -273,6 +273,11 @@ void ndt_make_pass_params(const lsa_ndt *h, const float T[16], const double p[6]
       cmax = std::fmax(cmax, std::fabs((double)h->vi.map.min_b[a]) * r);
       cmax = std::fmax(cmax, std::fabs((double)(h->vi.map.min_b[a] + h->vi.map.dim[a])) * r);
     }
+    // The margin is a function of a coordinate BOUND, not of this target's box, wherever the box lies within +-4096 m: the
+    // pre-filter's survivors (false positives included) fill the pair queue, i.e. they decide which lane adds which pair, so
+    // two tables with the same voxels but different boxes (a full rebuild's bounding box, the incremental local map's
+    // window) only give the same BITS if they pre-filter alike.  (4 mm of slack on a 1 m radius: ~1 % more candidates.)
+    cmax = std::fmax(cmax, 4096.0);
     double margin = 16.0 * r * (cmax + 4.0 * r) * 1.1920929e-07 + 1e-6;
     P->r2f_pre = (float)(r * r + margin);
   }
@@ -302,7 +307,7 @@ namespace {
 template <bool DENSE>
 void launch_pass_t(lsa_ndt *h, const PassParams &P, int kind, unsigned g, const uint4 *words, const double *rec, double *dst, unsigned long long key) {
   hipStream_t st = h->ctx->stream;
-  const float4 *dense = h->dense.p;
+  const float4 *dense = ndt_dense(h);
   if (kind == 0) hipLaunchKernelGGL((k_ndt_pass<0, DENSE>), dim3(g), dim3(kBlockD), 0, st, h->d_source, h->n_source, P, words, dense, rec, dst, key);
   else if (kind == 1) hipLaunchKernelGGL((k_ndt_pass<1, DENSE>), dim3(g), dim3(kBlockD), 0, st, h->d_source, h->n_source, P, words, dense, rec, dst, key);
   else hipLaunchKernelGGL((k_ndt_pass<2, DENSE>), dim3(g), dim3(kBlockD), 0, st, h->d_source, h->n_source, P, words, dense, rec, dst, key);
@@ -341,7 +346,7 @@ int ndt_enqueue_pass(lsa_ndt *h, const PassParams &P, int kind, bool reduce) {
   if ((rc = h->partials.reserve(ctx, (size_t)g * kOutDoubles, 1.0))) return rc;
   if ((rc = h->d_out.reserve(ctx, kOutDoubles))) return rc;
   const uint4 *words = h->words.p;
-  const double *rec = h->rec.p;
+  const double *rec = ndt_rec(h);
   launch_pass(h, P, kind, g, words, rec, h->partials.p, 0ull);
   if (reduce) hipLaunchKernelGGL(k_reduce_partials, dim3(1), dim3(1024), 0, ctx->stream, h->partials.p, (int)g, h->d_out.p);
   LSA_HIP(ctx, hipGetLastError());
@@ -360,7 +365,7 @@ int ndt_enqueue_pass_host(lsa_ndt *h, const PassParams &P, int kind, unsigned *g
   int rc;
   if ((rc = h->h_partials.reserve(ctx, (size_t)kHostReduceMaxBlocks * kOutDoubles))) return rc;
   const uint4 *words = h->words.p;
-  const double *rec = h->rec.p;
+  const double *rec = ndt_rec(h);
   double *dst = h->h_partials.p;  // pinned + mapped: the same pointer is valid on the device
   // a fresh non-zero key per pass (odd multiplier: a bijection of the counter, so consecutive keys share no pattern).
   // EVEN: the armed passes write their rows into the same host buffer under ODD keys (ndt_armed_row_key) drawn from a counter

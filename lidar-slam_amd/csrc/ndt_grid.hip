@@ -9,106 +9,13 @@
 // here the lookup structure is 12 B per 32 cells plus 80 B per OCCUPIED cell, which stays in the 4 MiB per-XCD L2.
 #include <cstdlib>
 
-#include "eig3_dev.h"
+#include "ndt_cell_dev.h"
 #include "ndt_internal.h"
 
 namespace {
 constexpr int kBlock = 256;
 
-// ---- 3x3 symmetric eigen-solver exactly as the reference's hand-rolled one, including its two quirks
-// (reference: include/.../ndt_registration_manual/SymmetricEigenSolver.h:55-273; quirks :172-174 and :179-180).
-// They matter: with the mis-normalised first eigenvector the "eigenvectors" are an orthogonal but rotated frame,
-// and the regularised covariance V L' V^-1 (VoxelGrid.cpp:317) inherits that rotation.
-__device__ void cross3(const double u[3], const double v[3], double o[3]) {
-  o[0] = u[1] * v[2] - u[2] * v[1];
-  o[1] = u[2] * v[0] - u[0] * v[2];
-  o[2] = u[0] * v[1] - u[1] * v[0];
-}
-
-__device__ void eig3_reference(const double a_in[6] /*xx,xy,xz,yy,yz,zz*/, double evals[3], double V[3][3] /*columns*/) {
-  double a00 = a_in[0], a01 = a_in[1], a02 = a_in[2], a11 = a_in[3], a12 = a_in[4], a22 = a_in[5];
-  for (int i = 0; i < 3; i++) { evals[i] = 0; for (int j = 0; j < 3; j++) V[i][j] = 0; }
-  double max0 = fmax(fabs(a00), fabs(a01)), max1 = fmax(fabs(a02), fabs(a11)), max2 = fmax(fabs(a12), fabs(a22));
-  double maxAbs = fmax(fmax(max0, max1), max2);
-  if (maxAbs == 0.0) { V[0][0] = V[1][1] = V[2][2] = 1.0; return; }
-  double inv = 1.0 / maxAbs;
-  a00 *= inv; a01 *= inv; a02 *= inv; a11 *= inv; a12 *= inv; a22 *= inv;
-  double norm = a01 * a01 + a02 * a02 + a12 * a12;
-  if (norm > 0.0) {
-    double tr3 = (a00 + a11 + a22) / 3.0;
-    double b00 = a00 - tr3, b11 = a11 - tr3, b22 = a22 - tr3;
-    double denom = sqrt((b00 * b00 + b11 * b11 + b22 * b22 + norm * 2.0) / 6.0);
-    double c00 = b11 * b22 - a12 * a12, c01 = a01 * b22 - a12 * a02, c02 = a01 * a12 - b11 * a02;
-    double det = (b00 * c00 - a01 * c01 + a02 * c02) / (denom * denom * denom);
-    double halfDet = fmin(fmax(det * 0.5, -1.0), 1.0);
-    double angle = acos(halfDet) / 3.0;
-    double beta2 = cos(angle) * 2.0;
-    double beta0 = cos(angle + 3.14159265358979323846 * 2.0 / 3.0) * 2.0;
-    double beta1 = -(beta0 + beta2);
-    evals[0] = tr3 + denom * beta0; evals[1] = tr3 + denom * beta1; evals[2] = tr3 + denom * beta2;
-    int i0 = (halfDet >= 0.0) ? 2 : 0, i2 = (halfDet >= 0.0) ? 0 : 2, i1 = 1;
-    double w[3];
-    {  // computeEigenvector0
-      double e0 = evals[i0];
-      double r0[3] = {a00 - e0, a01, a02}, r1[3] = {a01, a11 - e0, a12}, r2[3] = {a02, a12, a22 - e0};
-      double x0[3], x1[3], x2[3];
-      cross3(r0, r1, x0); cross3(r0, r2, x1); cross3(r1, r2, x2);
-      double d0 = x0[0] * x0[0] + x0[1] * x0[1] * x0[2] * x0[2];  // sic: x^2 + y^2 * z^2
-      double d1 = x1[0] * x1[0] + x1[1] * x1[1] * x1[2] * x1[2];
-      double d2 = x2[0] * x2[0] + x2[1] * x2[1] * x2[2] * x2[2];
-      bool first = d0 > d1;
-      double dmax = first ? d0 : d1;
-      dmax = (d2 > dmax) ? d2 : dmax;  // sic: the row index never becomes 2
-      double s = sqrt(dmax);
-      for (int r = 0; r < 3; r++) w[r] = (first ? x0[r] : x1[r]) / s;
-    }
-    double u[3], v[3], e1v[3];
-    {  // computeOrthogonalComplement + computeEigenvector1
-      bool c = fabs(w[0]) > fabs(w[1]);
-      double il = c ? (1.0 / sqrt(w[0] * w[0] + w[2] * w[2])) : (1.0 / sqrt(w[1] * w[1] + w[2] * w[2]));
-      u[0] = c ? -w[2] * il : 0.0; u[1] = c ? 0.0 : w[2] * il; u[2] = c ? w[0] * il : -w[1] * il;
-      cross3(w, u, v);
-      double ev1 = evals[i1];
-      double au[3] = {(a00 - ev1) * u[0] + a01 * u[1] + a02 * u[2], a01 * u[0] + (a11 - ev1) * u[1] + a12 * u[2], a02 * u[0] + a12 * u[1] + (a22 - ev1) * u[2]};
-      double av[3] = {(a00 - ev1) * v[0] + a01 * v[1] + a02 * v[2], a01 * v[0] + (a11 - ev1) * v[1] + a12 * v[2], a02 * v[0] + a12 * v[1] + (a22 - ev1) * v[2]};
-      double m00 = u[0] * au[0] + u[1] * au[1] + u[2] * au[2];
-      double m01 = u[0] * av[0] + u[1] * av[1] + u[2] * av[2];
-      double m11 = v[0] * av[0] + v[1] * av[1] + v[2] * av[2];
-      double am00 = fabs(m00), am01 = fabs(m01), am11 = fabs(m11);
-      if (am00 > 0 || am01 > 0 || am11 > 0) {
-        double um = (am00 >= am11) ? m01 : m11, vm = (am00 >= am11) ? m00 : m01;
-        if (fabs(um) >= fabs(vm)) { vm /= um; um = 1.0 / sqrt(1.0 + vm * vm); vm *= um; }
-        else { um /= vm; vm = 1.0 / sqrt(1.0 + um * um); um *= vm; }
-        for (int r = 0; r < 3; r++) e1v[r] = u[r] * um - v[r] * vm;
-      } else {
-        for (int r = 0; r < 3; r++) e1v[r] = u[r];
-      }
-    }
-    double e2v[3];
-    cross3(w, e1v, e2v);
-    for (int r = 0; r < 3; r++) { V[r][i0] = w[r]; V[r][i1] = e1v[r]; V[r][i2] = e2v[r]; }
-  } else {
-    evals[0] = a00; evals[1] = a11; evals[2] = a22;
-    V[0][0] = V[1][1] = V[2][2] = 1.0;
-  }
-  evals[0] *= maxAbs; evals[1] *= maxAbs; evals[2] *= maxAbs;
-}
-
-// general 3x3 cofactor inverse (Eigen LU/InverseImpl.h:124-169, what Matrix3d::inverse() runs)
-__device__ void inv3(const double m[3][3], double o[3][3]) {
-  double c0 = m[1][1] * m[2][2] - m[1][2] * m[2][1];
-  double c1 = m[2][1] * m[0][2] - m[2][2] * m[0][1];  // cofactor<1,0>
-  double c2 = m[0][1] * m[1][2] - m[0][2] * m[1][1];  // cofactor<2,0>
-  double det = c0 * m[0][0] + (c1 * m[1][0] + c2 * m[2][0]);
-  double id = 1.0 / det;
-  o[0][0] = c0 * id; o[0][1] = c1 * id; o[0][2] = c2 * id;
-  o[1][0] = (m[1][2] * m[2][0] - m[1][0] * m[2][2]) * id;
-  o[1][1] = (m[2][2] * m[0][0] - m[2][0] * m[0][2]) * id;
-  o[1][2] = (m[0][2] * m[1][0] - m[0][0] * m[1][2]) * id;
-  o[2][0] = (m[1][0] * m[2][1] - m[1][1] * m[2][0]) * id;
-  o[2][1] = (m[2][0] * m[0][1] - m[2][1] * m[0][0]) * id;
-  o[2][2] = (m[0][0] * m[1][1] - m[0][1] * m[1][0]) * id;
-}
+// (the per-cell arithmetic — eigen-solver with the reference's quirks, eigenvalue floor, inverse — is ndt_cell_dev.h)
 
 // one thread per occupied cell (computeCentroidAndCovariance, VoxelGrid.cpp:273-323)
 __global__ __launch_bounds__(kBlock) void k_ndt_finalize(long long *__restrict__ acc, int32_t *__restrict__ cnt,
@@ -119,66 +26,13 @@ __global__ __launch_bounds__(kBlock) void k_ndt_finalize(long long *__restrict__
   if (r >= nocc) return;
   long long *a = acc + r * 10;
   int ni = cnt[r];
-  double n = (double)ni;
   int cell = cell_of_rank[r];
   double o[3];
   lsa_cell_origin(m, cell, o);
-  double md[3] = {((double)a[0] * fs.inv_s1) / n, ((double)a[1] * fs.inv_s1) / n, ((double)a[2] * fs.inv_s1) / n};
-  double *R = rec + r * kRecDoubles;
-  R[0] = o[0] + md[0]; R[1] = o[1] + md[1]; R[2] = o[2] + md[2];  // centroid (:286)
-  R[9] = pcl ? 1.0 : ((double)a[9] * fs.inv_sw) / n;                // mean static weight (:287); PCL has none
-  for (int k = 3; k < 9; k++) R[k] = 0.0;
-  int st = 0;  // 0: fewer than min_points_per_voxel_ (6) points, 1: valid, -1: rejected eigenvalues
-  if (ni >= 6) {
-    // reference: cov = ((I + sum p p^T) - 2 (sum p) mu^T) / n + mu mu^T, then *= (n - 1) / n (:257, :293-294)
-    //          = (C_pop + I / n) * (n - 1) / n with C_pop the population covariance, which is shift invariant and is
-    // evaluated here from the corner-relative sums (no 1e4 m^2 - 1e4 m^2 cancellation).
-    double f = (n - 1.0) / n, in = pcl ? 0.0 : 1.0 / n;  // PCL's VoxelGridCovariance accumulates from zero, not from I
-    double sxx = (double)a[3] * fs.inv_s2, sxy = (double)a[4] * fs.inv_s2, sxz = (double)a[5] * fs.inv_s2;
-    double syy = (double)a[6] * fs.inv_s2, syz = (double)a[7] * fs.inv_s2, szz = (double)a[8] * fs.inv_s2;
-    double c[6];
-    c[0] = (sxx / n - md[0] * md[0] + in) * f;
-    c[1] = (sxy / n - md[0] * md[1]) * f;
-    c[2] = (sxz / n - md[0] * md[2]) * f;
-    c[3] = (syy / n - md[1] * md[1] + in) * f;
-    c[4] = (syz / n - md[1] * md[2]) * f;
-    c[5] = (szz / n - md[2] * md[2] + in) * f;
-    double ev[3], V[3][3];
-    if (pcl) eig3_jacobi(c, ev, V);
-    else eig3_reference(c, ev, V);
-    // PCL mode: points of one azimuth column of a spinning lidar are exactly coplanar, so the smallest eigenvalue is 0
-    // up to rounding and the sign PCL tests is a coin flip of its summation order; here a value within rounding of zero
-    // counts as zero (the floor below then lifts it), only a clearly negative one rejects the leaf.
-    const double neg = pcl ? -1e-12 * fabs(ev[2]) : 0.0;
-    if (ev[0] < neg || ev[1] < neg || ev[2] <= 0) {  // :303-306
-      // PCL sets nr_points = -1 too, but the leaf's centroid is already in the kd-tree cloud and ndt.hpp never looks at
-      // nr_points: the leaf keeps contributing with its zero-initialised icov_ (score only)
-      st = pcl ? 1 : -1;
-    } else {
-      double cov[3][3] = {{c[0], c[1], c[2]}, {c[1], c[3], c[4]}, {c[2], c[4], c[5]}};
-      double mine = ev[2] * 0.01;
-      if (ev[0] < mine) {  // :310-318
-        ev[0] = mine;
-        if (ev[1] < mine) ev[1] = mine;
-        double VL[3][3], Vi[3][3];
-        for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) VL[i][j] = V[i][j] * ev[j];
-        inv3(V, Vi);
-        for (int i = 0; i < 3; i++)
-          for (int j = 0; j < 3; j++) cov[i][j] = VL[i][0] * Vi[0][j] + (VL[i][1] * Vi[1][j] + VL[i][2] * Vi[2][j]);
-      }
-      double ic[3][3];
-      inv3(cov, ic);  // :320
-      // the inverse is symmetric up to rounding (V has mutually orthogonal columns); store the symmetric part
-      R[3] = ic[0][0]; R[4] = 0.5 * (ic[0][1] + ic[1][0]); R[5] = 0.5 * (ic[0][2] + ic[2][0]);
-      R[6] = ic[1][1]; R[7] = 0.5 * (ic[1][2] + ic[2][1]); R[8] = ic[2][2];
-      st = 1;
-      if (pcl) {  // icov_.maxCoeff() == inf || icov_.minCoeff() == -inf: leaf dropped
-        bool inf = false;
-        for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) inf = inf || isinf(ic[i][j]);
-        if (inf) { st = -1; for (int k = 3; k < 9; k++) R[k] = 0.0; }
-      }
-    }
-  }
+  long long av[10];
+#pragma unroll
+  for (int k = 0; k < 10; k++) av[k] = a[k];
+  const int st = ndt_cell_record(av, ni, o, fs, pcl, rec + r * kRecDoubles);
   state[r] = st;
   if (st == 1) atomicOr(vbits + (cell >> 5), 1u << (cell & 31));
   // leave the index clean for the next SetInputTarget (no memset of the sums / counts then: 6.6 MB for a 66 k-point map);
@@ -208,10 +62,7 @@ __global__ __launch_bounds__(kBlock) void k_dense_fill(const double *__restrict_
   int cell = cell_of_rank[r];
   int ijk[3];
   lsa_cell_unravel(m, cell, ijk);
-  const double *R = rec + r * kRecDoubles;
-  // the corner exactly as the pass kernel forms it: (float)(absolute cell index) * res, in f32
-  float cx = (float)ijk[0] * m.leaf[0], cy = (float)ijk[1] * m.leaf[1], cz = (float)ijk[2] * m.leaf[2];
-  dense[cell] = make_float4((float)(R[0] - (double)cx), (float)(R[1] - (double)cy), (float)(R[2] - (double)cz), __int_as_float((int)r));
+  dense[cell] = ndt_dense_entry(rec + r * kRecDoubles, ijk, m.leaf, (int)r);
 }
 
 __global__ __launch_bounds__(kBlock) void k_count_valid(const int32_t *__restrict__ state, size_t nocc, unsigned *__restrict__ out) {
@@ -241,10 +92,53 @@ int ndt_count_valid(lsa_ndt *h) {
   return LSA_OK;
 }
 
+void ndt_set_scale_floor(lsa_ndt *h, unsigned long long n) { h->vi.scale_n_min = n; }
+
+int ndt_adopt_external(lsa_ndt *h, const double *rec, const float4 *dense, const int min_b[3], const int dim[3], size_t n_target,
+                       int (*materialize)(void *), void *user) {
+  h->rec_ext = rec; h->dense_ext = dense;
+  h->ext_materialize = materialize; h->ext_user = user;
+  CellMap &m = h->vi.map;
+  m.mode = 1;
+  m.ncells = 1;
+  for (int a = 0; a < 3; a++) {
+    m.leaf[a] = h->resolution; m.inv[a] = 1.0f / h->resolution;
+    m.min_b[a] = min_b[a]; m.dim[a] = dim[a];
+    m.ncells *= dim[a];
+  }
+  h->vi.nocc = 0;
+  h->use_dense = true;
+  h->d_target_pts = nullptr;
+  ndt_touch_external(h, n_target);
+  h->has_target = true;
+  return LSA_OK;
+}
+
+void ndt_touch_external(lsa_ndt *h, size_t n_target) {
+  h->target_gen++;            // an armed kernel parked for the previous contents is not reused
+  h->n_valid_known = false;
+  h->n_target = n_target;
+  ndt_fitness_invalidate(h);
+  h->nn.built = false;
+}
+
+int ndt_materialize(lsa_ndt *h) {
+  if (!h->rec_ext) return LSA_OK;
+  if (!h->ext_materialize) return lsa_fail(h->ctx, LSA_ERR_INVALID, "NDT handle with an external table and no owner to materialise it");
+  int (*fn)(void *) = h->ext_materialize;
+  void *user = h->ext_user;
+  const bool had_result = h->has_result;
+  int rc = fn(user);   // runs ndt_build_grid on this handle, which leaves the external mode
+  if (rc) return rc;
+  h->has_result = had_result;   // (the table is the same one, cell for cell: the last ScanMatch's pose still belongs to it)
+  return h->rec_ext ? lsa_fail(h->ctx, LSA_ERR_INVALID, "the owner of the external NDT table did not materialise it") : LSA_OK;
+}
+
 int ndt_build_grid(lsa_ndt *h, const float4 *d_pts, size_t n) {
   lsa_context *ctx = h->ctx;
   VoxelIndex &vi = h->vi;
   h->has_target = false;
+  h->rec_ext = nullptr; h->dense_ext = nullptr;   // an ordinary table from here on
   int rc, status = VI_OK;
   const float leaf[3] = {h->resolution, h->resolution, h->resolution};
   for (int attempt = 0; attempt < 2; attempt++) {

@@ -41,6 +41,15 @@ struct lsa_ndt {
   FitnessState *fitness = nullptr;       // lazily built leaf table for GetFitnessScore
   NNGrid nn;                             // PCL mode: lazily built point-level neighbour grid for GetFitnessScore
 
+  // EXTERNAL table (the front end's incremental local map, local_map.hip): records and dense probe table live in the
+  // owner's persistent structures and are updated in place key-frame by key-frame; vi.map holds the table's window.  The
+  // entry points that need more than the pass kernels do (grid_info / grid_dump / GetFitnessScore: ranks, counts, the
+  // octree's leaf layout) first ask the owner to materialise an ordinary table (ext_materialize), which leaves this mode.
+  const double *rec_ext = nullptr;
+  const float4 *dense_ext = nullptr;
+  int (*ext_materialize)(void *) = nullptr;
+  void *ext_user = nullptr;
+
   // source
   DevBuf<float4> d_source_own;
   const float4 *d_source = nullptr;
@@ -109,6 +118,13 @@ struct lsa_ndt {
   double pass_ms = 0;
 };
 
+inline const double *ndt_rec(const lsa_ndt *h) { return h->rec_ext ? h->rec_ext : h->rec.p; }
+inline const float4 *ndt_dense(const lsa_ndt *h) { return h->dense_ext ? h->dense_ext : h->dense.p; }
+// adopt / leave an external table (ndt_grid.hip); window = {min_b, dim} in cells of the handle's resolution
+int ndt_adopt_external(lsa_ndt *h, const double *rec, const float4 *dense, const int min_b[3], const int dim[3], size_t n_target,
+                       int (*materialize)(void *), void *user);
+void ndt_touch_external(lsa_ndt *h, size_t n_target);   // the owner changed the table's contents in place
+int ndt_materialize(lsa_ndt *h);                         // no-op unless the table is external
 int ndt_build_grid(lsa_ndt *h, const float4 *d_pts, size_t n);
 bool ndt_carry_scope(lsa_ndt *h, bool on);   // ndt_api.hip: carry between the scans of a batch; returns the previous setting
 void ndt_release_parked(lsa_ndt *h);

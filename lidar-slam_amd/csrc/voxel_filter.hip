@@ -61,16 +61,11 @@ __global__ __launch_bounds__(kBlock) void k_filter_finalize(long long *__restric
   const CellMap m = dp->map;
   const FixScales fs = dp->fs;
   long long *a = acc + r * 4;
-  double n = (double)cnt[r];
   double o[3];
   const int cell = cell_of_rank[r];
   lsa_cell_origin(m, cell, o);
-  float4 v;
-  v.x = (float)(o[0] + ((double)a[0] * fs.inv_s1) / n);
-  v.y = (float)(o[1] + ((double)a[1] * fs.inv_s1) / n);
-  v.z = (float)(o[2] + ((double)a[2] * fs.inv_s1) / n);
-  v.w = (float)(((double)a[3] * fs.inv_sw) / n);
-  out[r] = v;
+  const long long av[4] = {a[0], a[1], a[2], a[3]};
+  out[r] = vi_filter_mean(av, cnt[r], o, fs);
   // leave the index clean for the next scan (was a separate clean-up launch): this cell's sums, its count and its
   // bitmap word (cells sharing the word all store the same zero)
   a[0] = 0; a[1] = 0; a[2] = 0; a[3] = 0;
@@ -258,6 +253,11 @@ extern "C" int lsa_voxel_filter_wait(lsa_voxel_filter *f, size_t *n_out) {
   if (status == VI_RANGE) return lsa_fail(f->ctx, LSA_ERR_RANGE, "voxel filter: leaf size too small for the input dataset, integer indices would overflow");
   *n_out = (status == VI_OK) ? f->vi.nocc : 0;
   return LSA_OK;
+}
+
+// internal (front_end.hip): VoxelIndex::scale_n_min of this filter's index
+void lsa_voxel_filter_set_scale_floor(lsa_voxel_filter *f, unsigned long long n) {
+  if (f && f->vi.scale_n_min != n) { f->vi.scale_n_min = n; f->vi.spec_valid = false; }
 }
 
 extern "C" int lsa_voxel_filter_create(lsa_voxel_filter **out, lsa_context *ctx, float lx, float ly, float lz) {

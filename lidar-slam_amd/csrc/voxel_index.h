@@ -78,6 +78,10 @@ struct VoxelIndex {
   size_t acc_rows = 0;    // rows of acc / cnt known to be zero ("clean") on entry
   int acc_ns = 0;
   bool clean = false;     // bits[0..W_cap), acc, cnt are all zero
+  // floor of the point count the fixed-point scales are derived from: 0 = from the cloud at hand (default).  The front end
+  // sets it to the capacity of its local map so that the scales are a constant of the session, and the sums of a full
+  // rebuild are quantised exactly like the persistent sums of the incremental local map (local_map.hip)
+  unsigned long long scale_n_min = 0;
   // speculative reuse of the previous grid definition (VoxelFilter only, see vi_enqueue)
   bool spec_valid = false, last_allow_spec = false, last_was_spec = false;
   int spec_mode = 0;

@@ -49,12 +49,6 @@ __global__ __launch_bounds__(kBlock) void k_bbox_partial(const float4 *__restric
   }
 }
 
-__device__ int ceil_log2_dev(double v) {
-  if (!(v > 0)) return 0;
-  int e;
-  double f = frexp(v, &e);
-  return (f == 0.5) ? e - 1 : e;
-}
 
 // single block: final bbox reduction, then the grid definition by the requested rule set, on the device
 struct ReqParams {  // the request travels as a kernel argument: no H2D copy on the critical path
@@ -62,6 +56,7 @@ struct ReqParams {  // the request travels as a kernel argument: no H2D copy on 
   float leaf[3];
   unsigned long long W_cap;
   int expand;  // define the cell box with a margin so that the next scans can reuse it (vi_enqueue allow_spec)
+  unsigned long long scale_n_min;  // VoxelIndex::scale_n_min
 };
 
 __global__ __launch_bounds__(kBlock) void k_bbox_final_params(const float *__restrict__ partial, int nb, ReqParams req, DevParams *__restrict__ dp) {
@@ -176,22 +171,18 @@ __global__ __launch_bounds__(kBlock) void k_bbox_final_params(const float *__res
   }
   unsigned long long W = (unsigned long long)((m.ncells + 31) / 32);
   if (status == VI_OK && W > req.W_cap) status = VI_CAPACITY;
-  // fixed-point scales: |d| <= leaf (+ slop) < 2 * leaf, N <= n_finite summands, |intensity| < 1024 => no int64 overflow
+  // fixed-point scales (vi_make_scales); with `expand` they leave room for twice the points, so that later (speculative)
+  // builds can reuse them; a caller-set floor (scale_n_min) makes them a constant of the handle
   double leaf_max = fmax(fmax((double)m.leaf[0], (double)m.leaf[1]), (double)m.leaf[2]);
-  // with `expand` the scales leave room for twice the points, so that later (speculative) builds can reuse them
-  int bits_n = ceil_log2_dev((req.expand ? 2.0 : 1.0) * (double)nfin + 1.0), bits_d = ceil_log2_dev(2.0 * leaf_max);
-  int k1 = min(62 - bits_n - bits_d, 44), k2 = min(62 - bits_n - 2 * bits_d, 44), kw = min(62 - bits_n - 10, 40);
-  FixScales fs;
-  fs.s1 = ldexp(1.0, k1); fs.inv_s1 = ldexp(1.0, -k1);
-  fs.s2 = ldexp(1.0, k2); fs.inv_s2 = ldexp(1.0, -k2);
-  fs.sw = ldexp(1.0, kw); fs.inv_sw = ldexp(1.0, -kw);
+  unsigned long long n_cap = 0;
+  FixScales fs = vi_make_scales(fmax((req.expand ? 2.0 : 1.0) * (double)nfin, (double)req.scale_n_min), leaf_max, &n_cap);
   dp->map = m;
   dp->fs = fs;
   dp->W = W;
   dp->nsb = (unsigned)((W + kScanTile - 1) / kScanTile);
   dp->V = 0;
   dp->status = status;
-  dp->n_cap = (bits_n >= 62) ? ~0ull : ((1ull << bits_n) - 1ull);
+  dp->n_cap = n_cap;
   dp->spec_miss = 0;
   dp->expand = req.expand;
 }
@@ -454,19 +445,7 @@ template <int NS>
 __device__ __forceinline__ void point_terms(const CellMap &m, const FixScales &fs, int cell, const float4 &p, unsigned long long v[NS]) {
   double o[3];
   lsa_cell_origin(m, cell, o);
-  double dx = (double)p.x - o[0], dy = (double)p.y - o[1], dz = (double)p.z - o[2];
-  v[0] = (unsigned long long)__double2ll_rn(dx * fs.s1);
-  v[1] = (unsigned long long)__double2ll_rn(dy * fs.s1);
-  v[2] = (unsigned long long)__double2ll_rn(dz * fs.s1);
-  if (NS == 10) {
-    v[3] = (unsigned long long)__double2ll_rn(dx * dx * fs.s2);
-    v[4] = (unsigned long long)__double2ll_rn(dx * dy * fs.s2);
-    v[5] = (unsigned long long)__double2ll_rn(dx * dz * fs.s2);
-    v[6] = (unsigned long long)__double2ll_rn(dy * dy * fs.s2);
-    v[7] = (unsigned long long)__double2ll_rn(dy * dz * fs.s2);
-    v[8] = (unsigned long long)__double2ll_rn(dz * dz * fs.s2);
-  }
-  v[NS - 1] = (unsigned long long)__double2ll_rn((double)p.w * fs.sw);
+  vi_point_terms<NS>(o, fs, p, v);
 }
 
 __device__ __forceinline__ unsigned cell_rank(const uint32_t *__restrict__ bits, const uint32_t *__restrict__ prefix, int cell) {
@@ -624,6 +603,7 @@ int vi_enqueue(lsa_context *ctx, VoxelIndex &vi, const float4 *d_pts, size_t n, 
   req.mode = mode;
   for (int a = 0; a < 3; a++) req.leaf[a] = leaf[a];
   req.W_cap = vi.W_cap;
+  req.scale_n_min = vi.scale_n_min;
   // only for small inputs: there the two bounding-box launches are ~10 of ~50 us; on a 2 M-point map they are noise, the
   // extent moves with the vehicle, and a miss costs a whole second build
   req.expand = (allow_spec && mode == 0 && n < kSmallInput) ? 1 : 0;

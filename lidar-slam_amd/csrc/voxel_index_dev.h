@@ -33,6 +33,29 @@ __device__ __forceinline__ bool lsa_finite3(float x, float y, float z) {
   return isfinite(x) && isfinite(y) && isfinite(z);
 }
 
+__host__ __device__ inline int lsa_ceil_log2(double v) {
+  if (!(v > 0)) return 0;
+  int e;
+  double f = frexp(v, &e);
+  return (f == 0.5) ? e - 1 : e;
+}
+
+// Fixed-point scales of the per-cell sums for up to `n` summands of |d| <= leaf (+ slop) < 2 * leaf and |intensity| < 1024:
+// no int64 sum can overflow.  *n_cap: the largest point count the scales are safe for.  One function for the device-side
+// grid definition (voxel_index.hip) and the host (the incremental local map, whose persistent sums must be quantised
+// exactly as a full rebuild quantises them).
+__host__ __device__ inline FixScales vi_make_scales(double n, double leaf_max, unsigned long long *n_cap) {
+  int bits_n = lsa_ceil_log2(n + 1.0), bits_d = lsa_ceil_log2(2.0 * leaf_max);
+  int k1 = 62 - bits_n - bits_d, k2 = 62 - bits_n - 2 * bits_d, kw = 62 - bits_n - 10;
+  k1 = k1 < 44 ? k1 : 44; k2 = k2 < 44 ? k2 : 44; kw = kw < 40 ? kw : 40;
+  FixScales fs;
+  fs.s1 = ldexp(1.0, k1); fs.inv_s1 = ldexp(1.0, -k1);
+  fs.s2 = ldexp(1.0, k2); fs.inv_s2 = ldexp(1.0, -k2);
+  fs.sw = ldexp(1.0, kw); fs.inv_sw = ldexp(1.0, -kw);
+  if (n_cap) *n_cap = (bits_n >= 62) ? ~0ull : ((1ull << bits_n) - 1ull);
+  return fs;
+}
+
 // integer cell coordinates (relative to min_b) of a point.
 //  mode 0: PCL voxel_grid.hpp: ijk = (int)(floor(x * inverse_leaf) - (float)min_b)
 //  mode 1: reference VoxelGrid.cpp:218-222: floor(p.x / voxel_x_) - min_b   (f32 division, correctly rounded)
@@ -55,14 +78,53 @@ __device__ __forceinline__ int lsa_cell_linear(const CellMap &m, const int ijk[3
 
 // reference corner of a cell, the offset all fixed-point sums are taken against (any fixed value works;
 // the corner keeps |d| <= ~leaf so the sums stay far from int64 overflow)
+// (The three helpers below round every product and sum separately — contraction off — so that the full index build and the
+// incremental local map, which inline them into different kernels, cannot end up with differently fused arithmetic: their
+// per-cell results must agree to the bit.)
+__device__ __forceinline__ void lsa_abs_origin(const int ijk_abs[3], const float leaf[3], double o[3]) {
+#pragma clang fp contract(off)
+  o[0] = (double)ijk_abs[0] * (double)leaf[0];
+  o[1] = (double)ijk_abs[1] * (double)leaf[1];
+  o[2] = (double)ijk_abs[2] * (double)leaf[2];
+}
 __device__ __forceinline__ void lsa_cell_origin(const CellMap &m, int cell, double o[3]) {
   int k = cell / (m.dim[0] * m.dim[1]);
   int r = cell - k * (m.dim[0] * m.dim[1]);
   int j = r / m.dim[0];
   int i = r - j * m.dim[0];
-  o[0] = (double)(i + m.min_b[0]) * (double)m.leaf[0];
-  o[1] = (double)(j + m.min_b[1]) * (double)m.leaf[1];
-  o[2] = (double)(k + m.min_b[2]) * (double)m.leaf[2];
+  const int ijk[3] = {i + m.min_b[0], j + m.min_b[1], k + m.min_b[2]};
+  lsa_abs_origin(ijk, m.leaf, o);
+}
+
+// fixed-point terms of one point against its cell's low corner `o`: first moments (3), [second moments (6)], intensity
+template <int NS>
+__device__ __forceinline__ void vi_point_terms(const double o[3], const FixScales &fs, const float4 &p, unsigned long long v[NS]) {
+#pragma clang fp contract(off)
+  double dx = (double)p.x - o[0], dy = (double)p.y - o[1], dz = (double)p.z - o[2];
+  v[0] = (unsigned long long)__double2ll_rn(dx * fs.s1);
+  v[1] = (unsigned long long)__double2ll_rn(dy * fs.s1);
+  v[2] = (unsigned long long)__double2ll_rn(dz * fs.s1);
+  if (NS == 10) {
+    v[3] = (unsigned long long)__double2ll_rn(dx * dx * fs.s2);
+    v[4] = (unsigned long long)__double2ll_rn(dx * dy * fs.s2);
+    v[5] = (unsigned long long)__double2ll_rn(dx * dz * fs.s2);
+    v[6] = (unsigned long long)__double2ll_rn(dy * dy * fs.s2);
+    v[7] = (unsigned long long)__double2ll_rn(dy * dz * fs.s2);
+    v[8] = (unsigned long long)__double2ll_rn(dz * dz * fs.s2);
+  }
+  v[NS - 1] = (unsigned long long)__double2ll_rn((double)p.w * fs.sw);
+}
+
+// the VoxelFilter's output point of a cell: the f32 mean of x, y, z and the intensity from the cell's four sums
+__device__ __forceinline__ float4 vi_filter_mean(const long long a[4], int cnt, const double o[3], const FixScales &fs) {
+#pragma clang fp contract(off)
+  const double n = (double)cnt;
+  float4 v;
+  v.x = (float)(o[0] + ((double)a[0] * fs.inv_s1) / n);
+  v.y = (float)(o[1] + ((double)a[1] * fs.inv_s1) / n);
+  v.z = (float)(o[2] + ((double)a[2] * fs.inv_s1) / n);
+  v.w = (float)(((double)a[3] * fs.inv_sw) / n);
+  return v;
 }
 
 __device__ __forceinline__ void lsa_cell_unravel(const CellMap &m, int cell, int ijk_abs[3]) {

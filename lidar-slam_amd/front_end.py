@@ -63,6 +63,9 @@ class FrontEndHip:
         L.lsa_front_end_update_device.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.POINTER(C.c_float), C.POINTER(FrontEndStats)]
         L.lsa_front_end_registration.argtypes = [C.c_void_p]
         L.lsa_front_end_registration.restype = C.c_void_p
+        L.lsa_front_end_set_incremental.argtypes = [C.c_void_p, C.c_int]
+        L.lsa_front_end_map_counters.argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]
+        L.lsa_front_end_map_verify.argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]
         self.ctx = ctx
         self.cfg = config or default_config()
         h = C.c_void_p()
@@ -92,6 +95,21 @@ class FrontEndHip:
         self.last_stats = dict(key_frame=st.key_frame, local_map_frames=st.local_map_frames, filtered_points=st.filtered_points,
                                local_map_points=st.local_map_points, target_points=st.target_points, ndt=st.ndt.as_dict())
         return True, capi.from_colmajor(out)
+
+    def set_incremental(self, on):
+        """Incremental local map (default) or the full rebuild of filter output + voxel table on every key-frame."""
+        self.ctx.check(capi.lib().lsa_front_end_set_incremental(self.h, 1 if on else 0))
+
+    def map_counters(self):
+        out = (C.c_uint64 * 6)()
+        self.ctx.check(capi.lib().lsa_front_end_map_counters(self.h, out))
+        return dict(full_builds=out[0], updates=out[1], rebuilds=out[2], refits=out[3], adopted=out[4], switched_off=out[5])
+
+    def map_verify(self):
+        """Full build on scratch handles against the incremental map, bit by bit (lsa_front_end_map_verify)."""
+        out = (C.c_uint64 * 6)()
+        self.ctx.check(capi.lib().lsa_front_end_map_verify(self.h, out))
+        return dict(cells=out[0], mismatches=out[1], live_cells=out[2], valid_voxels=out[3], full_filtered_points=out[4], live_filter_cells=out[5])
 
     def close(self):
         if self.h and self.ctx.h:

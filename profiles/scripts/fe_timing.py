@@ -14,8 +14,9 @@ print("gen %.1f s, %d pts/scan" % (time.time() - t0, scans[0].shape[0]), flush=T
 ctx = capi.Context(0)
 d_scans = [torch.from_numpy(np.ascontiguousarray(s)).cuda() for s in scans]
 torch.cuda.synchronize()
-for rep in range(2):
+for rep in range(4):
     fe = front_end.FrontEndHip(ctx)
+    fe.set_incremental(rep >= 2)   # reps 0-1: full rebuild of filter output + voxel table per key-frame; reps 2-3: incremental local map
     fe.SetInitPose(poses[0].astype(np.float32))
     times, kf = [], []
     for i in range(N):
@@ -26,7 +27,11 @@ for rep in range(2):
         kf.append(fe.last_stats["key_frame"])
     err = np.linalg.norm(T[:3, 3] - poses[N - 1][:3, 3])
     times, kf = np.array(times), np.array(kf, dtype=bool)
-    print("rep %d: %d key-frames; per-scan median %.3f ms (no key-frame) / %.3f ms (key-frame), total %.1f ms for %d scans = %.0f scans/s; end drift %.3f m; map %d pts -> target %d" % (
-        rep, kf.sum(), np.median(times[~kf][2:]), np.median(times[kf][1:]), times[1:].sum(), N - 1, (N - 1) / times[1:].sum() * 1e3, err,
+    kfi = np.nonzero(kf)[0]
+    late = kfi[kfi >= 2 * 22]   # key-frames of the steady state: window full (20 key-frames), filtered map, evictions
+    print("   key-frame ms by phase: unfiltered (<10 kf) %.3f, filtered/filling %.3f, steady state (window slides) %.3f; counters %s" % (
+        np.median(times[kfi[1:9]]), np.median(times[kfi[10:20]]) if len(kfi) > 20 else -1, np.median(times[late]) if len(late) else -1, fe.map_counters()), flush=True)
+    print("rep %d (%s): %d key-frames; per-scan median %.3f ms (no key-frame) / %.3f ms (key-frame), total %.1f ms for %d scans = %.0f scans/s; end drift %.3f m; map %d pts -> target %d" % (
+        rep, "incremental" if rep >= 2 else "full rebuild", kf.sum(), np.median(times[~kf][2:]), np.median(times[kf][1:]), times[1:].sum(), N - 1, (N - 1) / times[1:].sum() * 1e3, err,
         fe.last_stats["local_map_points"], fe.last_stats["target_points"]), flush=True)
     fe.close()
