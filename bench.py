@@ -483,20 +483,21 @@ def main():
 
     # ---- a second, KITTI-residential-shaped workload through the same pipeline (workloads.dense_dataset: front gardens, hedges,
     # trees with volumetric crowns, second-row buildings; 100 m range): brackets the headline's bare street.  Extra key, rank 0.
-    progress("dense workload")
-    dense_key = None
-    if rank == 0 and world == 1 and not dist_mode:
-        poses_d, scans_d = wl.dense_dataset(workers)
-        d_map_d = map_filter.filter_device(torch.from_numpy(wl.local_map(poses_d, scans_d)).to(dev)).clone()
+    def second_workload(label, poses_d, scans_d, keyframes, tests, with_oracle=False, with_front_end=False):
+        """Another scene through the same Filter -> ScanMatch pipeline: local map of `keyframes` (filtered at 0.3 m), the `tests`
+        scans with the constant-velocity guess + prediction error of the headline."""
+        nt = len(tests)
+        d_map_d = map_filter.filter_device(torch.from_numpy(wl.local_map(poses_d, scans_d, keyframes)).to(dev)).clone()
         ndt_d = registration.NDTRegistrationHip(ctx, **NDT_PARAMS)
         ndt_d.SetInputTarget(d_map_d)
         gi_d = ndt_d.grid_info()
-        d_sc = [torch.from_numpy(np.ascontiguousarray(scans_d[k])).to(dev) for k in TEST_SCANS]
-        g_d = np.stack([capi.colmajor(wl.guess(poses_d, k)) for k in TEST_SCANS]).astype(np.float32)
+        d_sc = [torch.from_numpy(np.ascontiguousarray(scans_d[k])).to(dev) for k in tests]
+        g_list = [wl.guess(poses_d, k) for k in tests]
+        g_d = np.stack([capi.colmajor(g) for g in g_list]).astype(np.float32)
         buf_d = [torch.empty((max(x.shape[0] for x in d_sc), 4), dtype=torch.float32, device=dev) for _ in range(2)]
 
         def run_dense(count):
-            idx = [i % ns for i in range(count)]
+            idx = [i % nt for i in range(count)]
             ptrs = (C.c_void_p * count)(*[d_sc[k].data_ptr() for k in idx])
             nn = (C.c_size_t * count)(*[d_sc[k].shape[0] for k in idx])
             pred = np.ascontiguousarray(g_d[idx])
@@ -514,17 +515,87 @@ def main():
         idx, out_d, st_d, nf_d = run_dense(k_d)
         torch.cuda.synchronize()
         dt_d = time.perf_counter() - t0
-        last = range(k_d - ns, k_d)
-        e_d = np.array([pose_err(capi.from_colmajor(out_d[i]), wl.truth(poses_d, TEST_SCANS[idx[i]])) for i in last])
-        dense_key = {"workload": "dense: residential street (gardens, hedges, trees, second-row buildings; 100 m range) through the same Filter -> ScanMatch pipeline",
-                     "value": round(k_d / dt_d, 1), "unit": "scans/s", "ms_per_step": round(dt_d / k_d * 1e3, 4), "steps": k_d,
-                     "raw_points": int(np.mean([x.shape[0] for x in d_sc])), "source_points": int(np.mean([nf_d[i] for i in last])),
-                     "target_points": int(gi_d["n_target"]), "target_voxels_valid": int(gi_d["valid"]),
-                     "kbar": round(float(np.mean([st_d[i].pairs_per_pass / max(1, nf_d[i]) for i in last])), 3),
-                     "iterations": float(np.mean([st_d[i].iterations for i in last])), "passes": float(np.mean([st_d[i].passes for i in last])),
-                     "pose_rmse_vs_truth": {"t_m": float(np.sqrt(np.mean(e_d[:, 0] ** 2))), "r_rad": float(np.sqrt(np.mean(e_d[:, 1] ** 2)))}}
+        last = range(k_d - nt, k_d)
+        e_d = np.array([pose_err(capi.from_colmajor(out_d[i]), wl.truth(poses_d, tests[idx[i]])) for i in last])
+        key = {"workload": label, "value": round(k_d / dt_d, 1), "unit": "scans/s", "ms_per_step": round(dt_d / k_d * 1e3, 4), "steps": k_d,
+               "key_frames_in_local_map": len(keyframes),
+               "raw_points": int(np.mean([x.shape[0] for x in d_sc])), "source_points": int(np.mean([nf_d[i] for i in last])),
+               "target_points": int(gi_d["n_target"]), "target_voxels_occupied": int(gi_d["occupied"]), "target_voxels_valid": int(gi_d["valid"]),
+               "kbar": round(float(np.mean([st_d[i].pairs_per_pass / max(1, nf_d[i]) for i in last])), 3),
+               "iterations": float(np.mean([st_d[i].iterations for i in last])), "passes": float(np.mean([st_d[i].passes for i in last])),
+               "pose_rmse_vs_truth": {"t_m": float(np.sqrt(np.mean(e_d[:, 0] ** 2))), "r_rad": float(np.sqrt(np.mean(e_d[:, 1] ** 2)))}}
+        if with_oracle and not args.no_cpu_baseline:
+            # the same nine scans through the CPU oracle (the checker): NDTMANUAL on each side's own table, and the PCL-semantics
+            # mode with the oracle's table overwritten by the GPU's records (identical tables: states the iteration's parity on
+            # ALL nine scans, the ones its non-contractive iteration does not settle on included)
+            sys.path.insert(0, os.path.join(ROOT, "oracle"))
+            import oracle_py
+            if not (_under_profiler() and not os.path.exists(os.path.join(ROOT, "oracle", "liblsa_oracle_fast.so"))):
+                oracle_py.build(ref=False)
+                o_ = oracle_py.Oracle(fast=True)
+                map8 = synth.to_xyzi32(d_map_d.cpu().numpy())
+                on = oracle_py.OracleNDT(fast=True, **NDT_PARAMS)
+                on.set_input_target(map8)
+                ndt_p = registration.NDTRegistrationHip(ctx, pcl_mode=True, **NDT_PARAMS)
+                ndt_p.SetInputTarget(d_map_d)
+                gi_p, gr_p = ndt_p.grid_dump()
+                op = oracle_py.OracleNDT(fast=True, pcl_mode=True, **NDT_PARAMS)
+                op.set_input_target(map8)
+                op.override_cells(gi_p, gr_p)
+                e_n, e_p, capped = [], [], 0
+                res_last = {idx[i]: capi.from_colmajor(out_d[i]) for i in last}
+                for j, k in enumerate(tests):
+                    filt, _ = o_.voxel_filter(synth.to_xyzi32(scans_d[k]), 0.5)
+                    f8 = synth.to_xyzi32(filt)
+                    Tref, _st = on.scan_match(f8, g_list[j])
+                    e_n.append(pose_err(res_last[j], Tref))
+                    Tp_ref, st_p = op.scan_match(f8, g_list[j])
+                    _, Tp = ndt_p.ScanMatch(f8, g_list[j])
+                    capped += int(st_p["iterations"] > NDT_PARAMS["max_iter"])
+                    e_p.append(pose_err(Tp, Tp_ref))
+                e_n, e_p = np.array(e_n), np.array(e_p)
+                key["pose_rmse_vs_oracle"] = {"t_m": float(np.sqrt(np.mean(e_n[:, 0] ** 2))), "r_rad": float(np.sqrt(np.mean(e_n[:, 1] ** 2))), "scans": len(e_n)}
+                key["pose_rmse_pcl_mode_vs_oracle_identical_tables"] = {"t_m": float(np.sqrt(np.mean(e_p[:, 0] ** 2))), "r_rad": float(np.sqrt(np.mean(e_p[:, 1] ** 2))),
+                                                                        "scans": len(e_p), "scans_at_iteration_cap": capped}
+                ndt_p.close()
+        if with_front_end:
+            from lidar_slam_amd import front_end as lsa_fe
+            d_all = [torch.from_numpy(np.ascontiguousarray(sc)).to(dev) for sc in scans_d]
+            torch.cuda.synchronize()
+            for _rep in range(2):
+                fe = lsa_fe.FrontEndHip(ctx)
+                fe.SetInitPose(poses_d[0].astype(np.float32))
+                n_kf = 0
+                t0 = time.perf_counter()
+                for d_one in d_all:
+                    _, T_fe = fe.Update(d_one)
+                    n_kf += int(fe.last_stats["key_frame"])
+                torch.cuda.synchronize()
+                dt_fe = time.perf_counter() - t0
+                cnt_fe = fe.map_counters()
+                fe.close()
+            key["front_end_loop"] = {"scans": len(d_all), "key_frames": n_kf, "value": round(len(d_all) / dt_fe, 1), "unit": "scans/s",
+                                     "ms_per_scan": round(dt_fe / len(d_all) * 1e3, 4),
+                                     "end_drift_m": round(float(np.linalg.norm(T_fe[:3, 3] - poses_d[len(d_all) - 1][:3, 3])), 4), "local_map": cnt_fe}
+            del d_all
         ndt_d.close()
         del d_sc, d_map_d
+        return key
+
+    progress("dense workload")
+    dense_key = None
+    kitti_key = None
+    if rank == 0 and world == 1 and not dist_mode:
+        poses_d, scans_d = wl.dense_dataset(workers)
+        dense_key = second_workload("dense: residential street (gardens, hedges, trees, second-row buildings; 100 m range) through the same Filter -> ScanMatch pipeline",
+                                    poses_d, scans_d, MAP_KEYFRAMES, TEST_SCANS)
+        del poses_d, scans_d
+        progress("KITTI-shaped workload")
+        poses_k, scans_k = wl.kitti_dataset(workers)
+        kitti_key = second_workload("kitti_shaped: residential street on rolling terrain with vegetation and distant blocks, HDL-64E beam table, 120 m range, 50-pose drive; "
+                                    "local map = the reference's full window of 20 key-frames (front_end.yaml local_frame_num), filtered at 0.3 m",
+                                    poses_k, scans_k, wl.KITTI_MAP_KEYFRAMES, wl.KITTI_TEST_SCANS, with_oracle=True, with_front_end=True)
+        del poses_k, scans_k
 
     # ---- N > 1: the exchange step at the size it is meant for (BASELINE.json configs[3] / [4]): the 2,097,152-point source
     # sharded over the ranks against the replicated 2 M-point target, ONE all-reduce of the 32-double block per pass.
@@ -700,7 +771,16 @@ def main():
     if rank == 0 and world == 1 and not dist_mode:
         icp = registration.ICPRegistrationHip(ctx, 2.0, 30, mode=capi.ICP_MODE_PLANE)
         icp.SetInputTarget(d_map_f.contiguous())
-        t_icp, e_icp = [], []
+        t_icp, e_icp, e_icp_orc = [], [], []
+        icp_orc = None
+        if not args.no_cpu_baseline:   # the oracle's point-to-plane restatement on the same scans (the checker, not timed)
+            sys.path.insert(0, os.path.join(ROOT, "oracle"))
+            import oracle_py as icp_orc
+            if _under_profiler() and not os.path.exists(os.path.join(ROOT, "oracle", "liblsa_oracle.so")):
+                icp_orc = None
+            else:
+                icp_orc.build(ref=False)
+                map8 = synth.to_xyzi32(d_map_f.cpu().numpy())
         for k in range(len(d_scans)):
             f_k = frame_filter.filter_device(d_scans[k]).clone()
             torch.cuda.synchronize()
@@ -708,10 +788,16 @@ def main():
             _, T_icp = icp.ScanMatch(f_k, guesses[k])
             t_icp.append(time.perf_counter() - t0)
             e_icp.append(pose_err(T_icp, truths[k]))
+            if icp_orc is not None:
+                T_o, _ = icp_orc.icp_plane(map8, synth.to_xyzi32(f_k.cpu().numpy()), guesses[k], 2.0, 30, 1.0)
+                e_icp_orc.append(pose_err(T_icp, T_o))
         e_icp = np.array(e_icp)
         icp_plane = {"workload": "cfg3: point-to-plane ICP, 30 iterations, same scans / local map as the headline", "scans": len(t_icp),
                      "ms_per_scan_match": round(float(np.median(t_icp)) * 1e3, 4), "value": round(1.0 / float(np.median(t_icp)), 1), "unit": "scans/s",
                      "pose_rmse_vs_truth": {"t_m": float(np.sqrt(np.mean(e_icp[:, 0] ** 2))), "r_rad": float(np.sqrt(np.mean(e_icp[:, 1] ** 2)))}}
+        if e_icp_orc:
+            eo = np.array(e_icp_orc)
+            icp_plane["pose_rmse_vs_oracle"] = {"t_m": float(np.sqrt(np.mean(eo[:, 0] ** 2))), "r_rad": float(np.sqrt(np.mean(eo[:, 1] ** 2))), "scans": len(eo)}
         icp.close()
 
     # ---- CPU baseline: the oracle (single thread) on a bounded sample of the same scans; also the pose check
@@ -816,6 +902,7 @@ def main():
             "roofline_cfg5": roofline_cfg5,
             "wide_map": wide_probe,
             "dense_workload": dense_key,
+            "kitti_shaped": kitti_key,
             "cfg5_sharded": cfg5_sharded,
             "cfg4_sharded": cfg4_sharded,
             "exchange": exchange_info,

@@ -32,15 +32,25 @@ TEST_SCANS = list(range(21, 30))           # scans matched against that local ma
 CFG2_CACHE = "/tmp/lsa_bench_cfg2_v3.npz"
 DENSE_CACHE = "/tmp/lsa_bench_dense_v2.npz"
 DENSE_MAX_RANGE = 100.0
+# "kitti": the KITTI-residential-SHAPED workload: TerrainScene (rolling ground, vegetation belts, houses on
+# the terrain), the HDL-64E's real two-block beam table, 120 m range, a 50-pose drive, local map = the reference's full window
+# of local_frame_num = 20 key-frames (front_end.yaml:12) every 2 m, test scans 41..49
+KITTI_CACHE = "/tmp/lsa_bench_kitti_v4.npz"
+KITTI_POSES = 50
+KITTI_MAP_KEYFRAMES = list(range(0, 40, 2))
+KITTI_TEST_SCANS = list(range(41, 50))
+KITTI_MAX_RANGE = 120.0
 
 
 def _gen_one(kind, scene_seed, pose, seed):
     if kind == "cfg2":
         return synth.gen_scan(synth.Scene(seed=scene_seed), pose, seed=seed)
+    if kind == "kitti":
+        return synth.gen_scan(synth.TerrainScene(seed=scene_seed), pose, seed=seed, max_range=KITTI_MAX_RANGE, layout="hdl64e")
     return synth.gen_scan(synth.DenseScene(seed=scene_seed), pose, seed=seed, max_range=DENSE_MAX_RANGE)
 
 
-def _dataset(kind, path, workers, leader=True):
+def _dataset(kind, path, workers, leader=True, N_POSES=N_POSES):
     poses = synth.trajectory(N_POSES)
     if leader and not os.path.exists(path):
         tmp = path + ".tmp%d" % os.getpid()
@@ -50,7 +60,7 @@ def _dataset(kind, path, workers, leader=True):
             import subprocess
             import sys
             bounds = [(N_POSES * w) // workers for w in range(workers + 1)]
-            procs = [subprocess.Popen([sys.executable, os.path.abspath(__file__), kind, str(bounds[w]), str(bounds[w + 1]), tmp])
+            procs = [subprocess.Popen([sys.executable, os.path.abspath(__file__), kind, str(bounds[w]), str(bounds[w + 1]), tmp, str(N_POSES)])
                      for w in range(workers) if bounds[w + 1] > bounds[w]]
             for pr in procs:
                 if pr.wait() != 0:
@@ -80,10 +90,14 @@ def dense_dataset(workers=1, leader=True):
     return _dataset("dense", DENSE_CACHE, workers, leader)
 
 
-def local_map(poses, scans):
+def kitti_dataset(workers=1, leader=True):
+    return _dataset("kitti", KITTI_CACHE, workers, leader, N_POSES=KITTI_POSES)
+
+
+def local_map(poses, scans, keyframes=None):
     """front_end.cpp:348-424: key-frames transformed into the map frame (pose 0) and concatenated; the caller filters at 0.3."""
     P0inv = np.linalg.inv(poses[0])
-    parts = [synth.transform_points(P0inv @ poses[k], scans[k]) for k in MAP_KEYFRAMES]
+    parts = [synth.transform_points(P0inv @ poses[k], scans[k]) for k in (MAP_KEYFRAMES if keyframes is None else keyframes)]
     return np.ascontiguousarray(np.concatenate(parts, axis=0))
 
 
@@ -160,6 +174,6 @@ def pose_err(Ta, Tb):
 
 if __name__ == "__main__":
     _kind, _i0, _i1, _prefix = _sys.argv[1], int(_sys.argv[2]), int(_sys.argv[3]), _sys.argv[4]
-    _poses = synth.trajectory(N_POSES)
+    _poses = synth.trajectory(int(_sys.argv[5]) if len(_sys.argv) > 5 else N_POSES)
     for _i in range(_i0, _i1):
         np.save("%s.%d.npy" % (_prefix, _i), _gen_one(_kind, 1, _poses[_i], 100 + _i))
