@@ -468,16 +468,28 @@ def main():
                                   % (tgt_w.shape[0], gi_w["dim"][0], gi_w["dim"][1], gi_w["dim"][2], float(np.prod(gi_w["dim"])) * 16 / 1e6, gi_w["occupied"] * 80 / 1e6),
                       "target_voxels_valid": int(gi_w["valid"])}
         order = np.lexsort((np.floor(src_w[:, 0]), np.floor(src_w[:, 1]), np.floor(src_w[:, 2])))
-        for name, arr in (("random_order", src_w), ("cell_sorted", np.ascontiguousarray(src_w[order]))):
+        for name, arr in (("random_order_unsorted", src_w), ("random_order", src_w), ("cell_sorted", np.ascontiguousarray(src_w[order]))):
             d_sw = torch.from_numpy(arr).to(dev)
             torch.cuda.synchronize()
+            # "random_order": the library's default — it samples the cloud, finds it incoherent and walks a spatially ordered copy
+            # (csrc/source_sort.hip); "random_order_unsorted": that switched off, the raw cost of an incoherent walk
+            ndt_w.set_source_sort(0 if name == "random_order_unsorted" else 1)
             ndt_w.set_source(d_sw)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            ndt_w.set_source(d_sw)
+            torch.cuda.synchronize()
+            order_ms = (time.perf_counter() - t0) * 1e3
             (_, _, _, pairs_w, npts_w), ms_w = ndt_w.derivatives_timed(g_w, p_w, kind=0, repeat=20)
             Mw, kbar_w = int(npts_w), pairs_w / max(1.0, float(npts_w))
             alg_w = Mw * (16.0 + 4.0 * 27.0 + 48.0 * kbar_w)
             wide_probe[name] = {"us_per_launch": round(ms_w * 1e3, 1), "kbar": round(kbar_w, 3), "pairs_per_s": round(pairs_w / (ms_w * 1e-3), 0),
                                 "hbm_alg": {"achieved": round(alg_w / (ms_w * 1e-3) / 1e9, 1), "unit": "GB/s", "frac": round(alg_w / (ms_w * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)},
                                 "vector_f64": vector_f64(pairs_w, Mw, ms_w)}
+            if name == "random_order":
+                wide_probe[name]["walked_in_spatial_order"] = bool(ndt_w.source_sort_count()[1])
+                wide_probe[name]["order_ms_once_per_scan_match"] = round(order_ms, 3)
+                wide_probe[name]["us_per_launch_incl_ordering_over_31_passes"] = round(ms_w * 1e3 + order_ms * 1e3 / 31.0, 1)
             del d_sw
         ndt_w.close()
 

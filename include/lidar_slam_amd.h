@@ -271,6 +271,15 @@ int lsa_ndt_derivatives(lsa_ndt *ndt, const float T[16], const double p[6], int 
 int lsa_ndt_derivatives_timed(lsa_ndt *ndt, const float T[16], const double p[6], int kind, int repeat,
                               double out32[32], double *ms_per_pass);
 
+/* Large sources in arbitrary point order (a merged or shuffled cloud rather than a sensor sweep): the pass hands 14 consecutive
+ * points to a wave, and when those are not spatial neighbours every probe and voxel record pulls a cache line of its own (measured:
+ * 5 x the algorithmic traffic, twice the time at 2 M points).  For sources of >= 262144 points the library therefore looks at a
+ * sample of consecutive pairs and, if most are far apart, walks a spatially ordered copy instead (stable radix sort by 2 m Morton
+ * cell: deterministic; the result differs from the unsorted walk by f64 summation order only).  mode 0: never, 1: when the
+ * sample says so (default), 2: always.  The environment variable LSA_SOURCE_SORT sets the default. */
+int lsa_ndt_set_source_sort(lsa_ndt *ndt, int mode);
+int lsa_ndt_source_sort_count(lsa_ndt *ndt, uint64_t *count, int *last_was_sorted);
+
 /* ---- multi-GPU: source cloud sharded over ranks, target replicated ------------------------- */
 /* Called once per pass with a DEVICE buffer of n doubles (32) that must be summed in place over all
  * ranks (RCCL all-reduce over xGMI), enqueued on hip_stream; return 0 on success. */

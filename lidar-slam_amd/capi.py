@@ -172,6 +172,8 @@ def lib():
     L.lsa_pipeline_scan_match.argtypes = [vp, vp, sz, PVP, PSZ, PF, vp, vp, i, i, PF, C.POINTER(NdtStats), PSZ]
     L.lsa_ndt_armed_stats.argtypes = [vp, C.POINTER(NdtArmedStats), i]
     L.lsa_ndt_set_armed_patience.argtypes = [vp, C.c_double]
+    L.lsa_ndt_set_source_sort.argtypes = [vp, i]
+    L.lsa_ndt_source_sort_count.argtypes = [vp, C.POINTER(C.c_uint64), C.POINTER(i)]
     L.lsa_ndt_set_persistent.argtypes = [vp, i]
     L.lsa_ndt_align_counters.argtypes = [vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
     L.lsa_ndt_armed_timing.argtypes = [vp, C.POINTER(C.c_double), i]

@@ -312,6 +312,7 @@ extern "C" void lsa_ndt_destroy(lsa_ndt *h) {
   h->dense.release();
   if (h->mail) { if (h->mail_is_device) (void)hipFree(h->mail); else (void)hipHostFree(h->mail); }
   h->align_rows.release(); h->align_flags.release(); h->h_result.release(); h->align_stamps.release(); h->h_gave_up.release(); h->src_keep.release();
+  h->sort_keys.release(); h->sort_idx.release(); h->sort_small.release(); h->sort_tmp.release(); h->d_source_sorted.release();
   h->d_source_own.release(); h->h_stage.release(); h->partials.release(); h->d_out.release(); h->h_out.release(); h->h_partials.release();
   delete h;
 }
@@ -339,9 +340,8 @@ extern "C" int lsa_ndt_set_source_device(lsa_ndt *h, const float *d_xyzw, size_t
   int rc = check(h);
   if (rc) return rc;
   if (n && !d_xyzw) return lsa_fail(h->ctx, LSA_ERR_INVALID, "set_source: null points");
-  h->d_source = (const float4 *)d_xyzw;
   h->n_source = n;
-  return LSA_OK;
+  return ndt_source_order(h, (const float4 *)d_xyzw, n, &h->d_source);
 }
 
 extern "C" int lsa_ndt_set_source(lsa_ndt *h, const void *src, size_t n, size_t stride) {
@@ -351,9 +351,8 @@ extern "C" int lsa_ndt_set_source(lsa_ndt *h, const void *src, size_t n, size_t 
   if (n) {
     if ((rc = upload_points(h, src, n, stride, SIZE_MAX, h->d_source_own))) return rc;
   }
-  h->d_source = h->d_source_own.p;
   h->n_source = n;
-  return LSA_OK;
+  return ndt_source_order(h, h->d_source_own.p, n, &h->d_source);
 }
 
 extern "C" int lsa_ndt_derivatives(lsa_ndt *h, const float T[16], const double p[6], int kind, double out32[32]) {
@@ -397,8 +396,8 @@ extern "C" int lsa_ndt_scan_match_device(lsa_ndt *h, const float *d_src_xyzw, si
   int rc = check_keep(h);  // a kernel this handle left parked for exactly this call stays
   if (rc) return rc;
   if (n && !d_src_xyzw) return lsa_fail(h->ctx, LSA_ERR_INVALID, "ScanMatch: null points");
-  h->d_source = (const float4 *)d_src_xyzw;
   h->n_source = n;
+  if ((rc = ndt_source_order(h, (const float4 *)d_src_xyzw, n, &h->d_source))) return rc;
   if (!predict_pose || !result_pose) return lsa_fail(h->ctx, LSA_ERR_INVALID, "ScanMatch: null pose");
   return scan_match_common(h, predict_pose, result_pose, stats);
 }

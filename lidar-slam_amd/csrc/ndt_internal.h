@@ -50,6 +50,15 @@ struct lsa_ndt {
   int (*ext_materialize)(void *) = nullptr;
   void *ext_user = nullptr;
 
+  // spatial ordering of large incoherent sources (source_sort.hip): 0 never, 1 when a sample says the cloud is incoherent
+  // (default), 2 always (>= 262144 points)
+  int source_sort_mode = getenv("LSA_SOURCE_SORT") ? atoi(getenv("LSA_SOURCE_SORT")) : 1;
+  bool source_sorted = false;
+  unsigned long long n_source_sorts = 0;
+  DevBuf<unsigned> sort_keys, sort_idx, sort_small;
+  DevBuf<char> sort_tmp;
+  DevBuf<float4> d_source_sorted;
+
   // source
   DevBuf<float4> d_source_own;
   const float4 *d_source = nullptr;
@@ -125,6 +134,7 @@ int ndt_adopt_external(lsa_ndt *h, const double *rec, const float4 *dense, const
                        int (*materialize)(void *), void *user);
 void ndt_touch_external(lsa_ndt *h, size_t n_target);   // the owner changed the table's contents in place
 int ndt_materialize(lsa_ndt *h);                         // no-op unless the table is external
+int ndt_source_order(lsa_ndt *h, const float4 *d_src, size_t n, const float4 **d_use);   // source_sort.hip
 int ndt_build_grid(lsa_ndt *h, const float4 *d_pts, size_t n);
 bool ndt_carry_scope(lsa_ndt *h, bool on);   // ndt_api.hip: carry between the scans of a batch; returns the previous setting
 void ndt_release_parked(lsa_ndt *h);

@@ -163,6 +163,15 @@ class NDTRegistrationHip(RegistrationInterface):
         return dict(passes=int(out[0]), post_us=out[1] / n, post_to_rows_us=out[2] / n, rows_to_post_us=out[3] / n,
                     dev_wait_us=out[4] / n, dev_body_us=out[5] / n)
 
+    def set_source_sort(self, mode):
+        """0 never, 1 when a sample says a >= 262144-point source is spatially incoherent (default), 2 always."""
+        self.ctx.check(capi.lib().lsa_ndt_set_source_sort(self.h, int(mode)))
+
+    def source_sort_count(self):
+        n, last = C.c_uint64(0), C.c_int(0)
+        self.ctx.check(capi.lib().lsa_ndt_source_sort_count(self.h, C.byref(n), C.byref(last)))
+        return n.value, bool(last.value)
+
     def set_persistent(self, on):
         """ScanMatch as ONE persistent launch (opt-in: measured no faster) instead of one launch per derivative
         pass, the default (lsa_ndt_set_persistent)."""

@@ -174,6 +174,50 @@ def test_cfg5_pass_properties_at_full_size(ctx, oracle, big):
     n.close()
 
 
+def test_incoherent_source_is_walked_in_spatial_order(ctx, oracle, big):
+    """A 2,097,152-point source in RANDOM order (csrc/source_sort.hip): the library's sample of consecutive pairs calls it
+    incoherent and the passes walk a spatially ordered copy — same pairs, sums equal to the unsorted walk up to f64 summation
+    order, reproducible bit for bit run to run (stable sort) — while the sensor-ordered cloud is left alone."""
+    import torch
+    target, src5, guess = big
+    n = registration.NDTRegistrationHip(ctx, 1.0, 0.1, 0.0, 30, 0.55)
+    n.SetInputTarget(torch.from_numpy(target).cuda())
+    p = oracle.matrix_to_pose(guess)
+    d_s = torch.from_numpy(src5).cuda()
+    n.set_source(d_s)
+    assert n.source_sort_count() == (0, False)            # a sweep is coherent: not touched
+    ref = n.derivatives(guess, p, 0)
+    perm = np.random.RandomState(3).permutation(src5.shape[0])
+    d_r = torch.from_numpy(np.ascontiguousarray(src5[perm])).cuda()
+    n.set_source_sort(0)
+    n.set_source(d_r)
+    plain = n.derivatives(guess, p, 0)
+    assert n.source_sort_count() == (0, False)
+    n.set_source_sort(1)
+    n.set_source(d_r)
+    assert n.source_sort_count() == (1, True)             # the sample found it incoherent
+    a = n.derivatives(guess, p, 0)
+    n.set_source(d_r)
+    b = n.derivatives(guess, p, 0)
+    assert a[0] == b[0] and np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2])        # deterministic order
+    for other in (plain, ref):                            # same points, same pairs, another order of the same f64 sums
+        assert int(a[3]) == int(other[3]) and int(a[4]) == int(other[4]) == 2097152
+        assert abs(a[0] - other[0]) <= 1e-11 * abs(other[0])
+        assert np.max(np.abs(a[1] - other[1])) <= 1e-9 * np.max(np.abs(other[1]))
+        assert np.max(np.abs(a[2] - other[2])) <= 1e-10 * np.max(np.abs(other[2]))
+    # through ScanMatch too, and a small cloud is never touched
+    _, T = n.ScanMatch(d_r, guess)
+    assert n.source_sort_count()[1] is True and np.linalg.norm(T[:3, 3] - guess[:3, 3]) < 0.2
+    n.ScanMatch(d_r[:100000], guess)
+    assert n.source_sort_count()[1] is False
+    n.set_source_sort(2)
+    n.set_source(d_s)
+    assert n.source_sort_count()[1] is True               # mode 2: always
+    with pytest.raises(capi.LsaError):
+        n.set_source_sort(3)
+    n.close()
+
+
 def test_filter_properties_at_2m_points(ctx, big):
     import torch
     target, _, _ = big
