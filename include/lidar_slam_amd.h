@@ -227,6 +227,8 @@ typedef struct {
   uint64_t expired;       /* parked kernels found to have left before the next ScanMatch came (cancelled and relaunched) */
   double rows_wait_max_us;/* longest time from a pass's parameters being posted / its kernel launched to its last row taken */
   int32_t parked;         /* 1 while this handle has a kernel parked on its context's stream */
+  int32_t pad;
+  uint64_t deferred;      /* final passes of a ScanMatch that a batch did not wait for (collected behind the next scan's first mail) */
 } lsa_ndt_armed_stats_t;
 int lsa_ndt_armed_stats(lsa_ndt *ndt, lsa_ndt_armed_stats_t *out, int reset);
 /* diagnostics / tests: how long an armed kernel waits for its mail before it leaves by itself (default 300 us; [1, 1e5]) */
@@ -327,6 +329,13 @@ void lsa_ndt_gauss_constants(float res, float outlier_ratio, double *d1, double 
  * the sequential calls.  d_filtered_a / _b: two device buffers of max(n_points) float4 each.  rank / world: (0, 1) on one
  * GPU; with world > 1 the rank registers its contiguous shard of every filtered scan and the NDT handle must carry the
  * all-reduce (lsa_ndt_set_allreduce / _rccl).  stats and n_filtered may be NULL.
+ * Inside the batch the library also overlaps ACROSS scans what the reference's own arithmetic leaves independent: with the trial
+ * loop of the line search dead, the step length and the convergence test (NormalDistributionsTransform.cpp:379-381) of a Newton
+ * iteration are known before the derivatives at the new pose are evaluated (:696-698), so the pose of scan k is final BEFORE its
+ * last derivative pass; that pass — it only feeds stats[k].score / trans_probability / pairs_per_pass — is posted, not waited
+ * for, and its sums complete stats[k] behind the first pass of scan k + 1 (the last scan's before the call returns).  Every pass
+ * runs, every number returned is the sequential call's (tests/test_gpu_parity.py); a third filtered-cloud buffer, owned by the
+ * filter handle, keeps the filter of scan k + 2 off the cloud that pass still reads.  LSA_NO_DEFER=1 switches it off.
  * ------------------------------------------------------------------------------------------- */
 int lsa_pipeline_scan_match(lsa_voxel_filter *frame_filter, lsa_ndt *ndt, size_t count, const float *const *d_scans_xyzw,
                             const size_t *n_points, const float *predict_poses, float *d_filtered_a, float *d_filtered_b,

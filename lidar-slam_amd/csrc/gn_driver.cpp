@@ -20,6 +20,10 @@
 #include "gn_math.h"
 #include "lidar_slam_amd.h"
 
+int lsa_gn_solve_defer(lsa_pass_eval_fn eval, int (*defer)(void *, const float[16], const double[6], int), void *user, float res, float step_size, float trans_eps,
+                       int max_iter, float outlier_ratio, int mode, const float predict_pose[16], float result_pose[16], lsa_ndt_stats *stats,
+                       double *trace_rows, int trace_cap, int *trace_n, double *pairs_before_deferred);
+
 namespace {
 
 inline void unpack_h(const double *out32, double H[6][6]) {
@@ -131,6 +135,14 @@ bool update_interval(double &a_l, double &f_l, double &g_l, double &a_u, double 
 
 struct Driver {
   lsa_pass_eval_fn eval;
+  // Optional (library-internal callers): enqueue a pass WITHOUT waiting for its sums; non-zero = cannot, evaluate it the ordinary
+  // way.  Used for the one pass per ScanMatch whose sums the iteration never reads: with the trial loop of the line search
+  // dead, the step length and with it the convergence test (:379-381) are known BEFORE the derivatives at the new pose are
+  // (computeStepLengthMT evaluates them at :696-698 all the same); when that test ends the iteration, the pass only feeds
+  // the statistics (score, transformation probability, pair count), which the caller completes when the sums arrive.
+  int (*defer)(void *user, const float T[16], const double p[6], int kind) = nullptr;
+  bool deferred = false;
+  int iterations_so_far = 0;
   void *user;
   double step_size, trans_eps;
   int max_iter;
@@ -190,6 +202,13 @@ struct Driver {
     double x_t[6];
     for (int i = 0; i < 6; i++) x_t[i] = x[i] + dir[i] * a_t;
     lsa_pose_to_matrix(x_t, T);
+    // (interval_converged: the loop below will not run, a_t is this call's result whatever the pass says)
+    if (defer && interval_converged && (iterations_so_far > max_iter || (iterations_so_far && std::fabs(a_t) < trans_eps)) &&
+        defer(user, T, x_t, 0) == 0) {
+      passes++;
+      deferred = true;
+      return a_t;
+    }
     if (!pass(x_t, 0)) return NAN;
     trace_row(x_t, a_t, 0);
     double phi_t = -score, d_phi_t = 0;
@@ -296,10 +315,22 @@ extern "C" int lsa_gn_solve_mode(lsa_pass_eval_fn eval, void *user, float res, f
 extern "C" int lsa_gn_solve_trace(lsa_pass_eval_fn eval, void *user, float res, float step_size, float trans_eps, int max_iter,
                                   float outlier_ratio, int mode, const float predict_pose[16], float result_pose[16], lsa_ndt_stats *stats,
                                   double *trace_rows, int trace_cap, int *trace_n) {
+  return lsa_gn_solve_defer(eval, nullptr, user, res, step_size, trans_eps, max_iter, outlier_ratio, mode, predict_pose, result_pose, stats, trace_rows, trace_cap,
+                            trace_n, nullptr);
+}
+
+// library-internal form (ndt_api.hip): `defer` as documented in Driver; *pairs_before_deferred >= 0 on return iff the last pass was
+// deferred — then stats->score / trans_probability / pairs_per_pass are NOT final: the caller completes them from the pass's 32
+// sums (score = out[0], trans_probability = out[0] / out[29], pairs_per_pass = (*pairs_before_deferred + out[28]) / passes)
+int lsa_gn_solve_defer(lsa_pass_eval_fn eval, int (*defer)(void *, const float[16], const double[6], int), void *user, float res, float step_size, float trans_eps,
+                       int max_iter, float outlier_ratio, int mode, const float predict_pose[16], float result_pose[16], lsa_ndt_stats *stats,
+                       double *trace_rows, int trace_cap, int *trace_n, double *pairs_before_deferred) {
   (void)res; (void)outlier_ratio;  // the evaluator owns d1/d2; kept in the signature to mirror the plugin ctor
+  if (pairs_before_deferred) *pairs_before_deferred = -1.0;
   if (!eval || !predict_pose || !result_pose) return LSA_ERR_INVALID;
   Driver d;
   d.eval = eval; d.user = user; d.mode = mode;
+  d.defer = (trace_rows || !pairs_before_deferred) ? nullptr : defer;   // (a trace wants every pass's score as it happens)
   d.trace = trace_rows; d.trace_cap = trace_cap; d.trace_n = trace_n;
   if (trace_n) *trace_n = 0;
   d.step_size = step_size; d.trans_eps = trans_eps; d.max_iter = max_iter;  // float -> double like the plugin (:14-22)
@@ -324,6 +355,7 @@ extern "C" int lsa_gn_solve_trace(lsa_pass_eval_fn eval, void *user, float res, 
       goto done;
     }
     for (int i = 0; i < 6; i++) delta[i] /= nrm;
+    d.iterations_so_far = iterations;
     nrm = d.step_length(p, delta, nrm, d.step_size, d.trans_eps / 2);
     if (nrm != nrm) return d.rc ? d.rc : LSA_ERR_HIP;
     for (int i = 0; i < 6; i++) { delta[i] *= nrm; p[i] = p[i] + delta[i]; }
@@ -344,5 +376,6 @@ done:
     memcpy(stats->final_p, p, sizeof(p));
     stats->gpu_ms = 0;
   }
+  if (d.deferred && pairs_before_deferred) *pairs_before_deferred = d.pairs_total;
   return LSA_OK;
 }

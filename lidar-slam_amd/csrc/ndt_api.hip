@@ -7,6 +7,9 @@
 #include <vector>
 
 int ndt_fitness(lsa_ndt *h, float *score);  // ndt_fitness.hip
+int lsa_gn_solve_defer(lsa_pass_eval_fn eval, int (*defer)(void *, const float[16], const double[6], int), void *user, float res, float step_size, float trans_eps,
+                       int max_iter, float outlier_ratio, int mode, const float predict_pose[16], float result_pose[16], lsa_ndt_stats *stats,
+                       double *trace_rows, int trace_cap, int *trace_n, double *pairs_before_deferred);   // gn_driver.cpp
 
 namespace {
 
@@ -65,6 +68,149 @@ unsigned armed_headroom(const lsa_ndt *h, unsigned g) {
   return want < cap ? want : (g < cap ? cap : g);
 }
 
+int run_pass(lsa_ndt *h, const float T[16], const double p[6], int kind, double out32[32]);
+int collect_pending(lsa_ndt *h);
+
+// ---- armed pass, first half: this pass's kernel is already waiting on the device — enqueued behind the previous pass, or left
+// parked by the previous ScanMatch — or is launched now; post its parameters and enqueue the kernel of the NEXT pass behind it
+struct ArmedPosted {
+  unsigned long long seq;
+  unsigned g;
+  bool kept;
+  std::chrono::steady_clock::time_point at0, at1;
+};
+int armed_post(lsa_ndt *h, const PassParams &P, ArmedPosted *ap) {
+  int rc;
+  const unsigned g = ndt_pass_grid(h, h->n_source, 0);
+  volatile unsigned long long *gave_up = h->h_gave_up.p ? reinterpret_cast<volatile unsigned long long *>(h->h_gave_up.p) : nullptr;
+  if (h->armed_outstanding && (h->armed_grid < g || h->armed_gen != h->target_gen || (gave_up && *gave_up == h->armed_seq))) {
+    if (gave_up && *gave_up == h->armed_seq) h->armed_expired++;
+    armed_cancel(h);   // parked for another table / too small a grid, or it has already left: not usable
+  }
+  unsigned long long seq = h->armed_seq;
+  // A deferred final pass still to be collected sits in the mailbox slot and the row-buffer half of ITS parity.  Normally the
+  // next pass has the other one (consecutive numbers); after a cancel in between the numbers skip one and the two would share:
+  // take the deferred pass's rows first.
+  if (h->pending.on && ((h->pending.seq ^ seq) & 1ull) == 0ull && (rc = collect_pending(h))) return rc;
+  if (!h->armed_outstanding && (rc = ndt_launch_armed(h, P, seq, armed_headroom(h, g), h->armed_patience_us))) return rc;
+  // (after the first armed pass of this ScanMatch the kernels hold their first tiles from the kept copy)
+  static const bool no_keep = getenv("LSA_NO_KEEP") != nullptr;   // A/B switch for measurements (scratch: ab_match.py)
+  ap->kept = !no_keep && h->keep_match == h->match_id && h->keep_n == h->n_source;
+  ap->at0 = std::chrono::steady_clock::now();
+  ndt_mail_post(reinterpret_cast<PassMail *>(h->mail), &P, seq, false, h->d_source, h->n_source, g, ap->kept);
+  ap->at1 = std::chrono::steady_clock::now();
+  h->armed_seq = seq + 1;
+  h->armed_outstanding = false;
+  if ((rc = ndt_launch_armed(h, P, seq + 1, armed_headroom(h, g), h->armed_patience_us))) return rc;
+  h->armed_outstanding = true;
+  h->armed_grid = armed_headroom(h, g);
+  h->armed_gen = h->target_gen;
+  h->armed_passes++;
+  ap->seq = seq; ap->g = g;
+  return LSA_OK;
+}
+
+// ---- second half: take the rows of armed pass `seq` as they arrive.  *redo = true (and LSA_OK): the pass did not run
+// (completely); the caller evaluates it the ordinary way.  Every outcome other than the plain one is counted.
+int armed_take(lsa_ndt *h, const ArmedPosted &ap, double out32[32], bool *redo) {
+  lsa_context *ctx = h->ctx;
+  *redo = false;
+  const unsigned long long seq = ap.seq;
+  const unsigned g = ap.g;
+  volatile unsigned long long *gave_up = reinterpret_cast<volatile unsigned long long *>(h->h_gave_up.p);
+  const double *rows = ndt_armed_rows(h, seq);
+  bool ok = !h->no_row_polling && ndt_reduce_partials_host(rows, g, ndt_armed_row_key(seq), kArmedRowLimitMs, out32, gave_up, seq);
+  {
+    const double w = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - ap.at1).count();
+    if (w > h->rows_wait_max_us) h->rows_wait_max_us = w;
+  }
+  if (!ok) {
+    // rows missing.  Either a workgroup of the kernel ran out of patience before the mail came (this thread was held up;
+    // EVERY workgroup that leaves says so in *gave_up, so the wait above ends at once instead of at its limit), or the rows
+    // are slow (limit), or polling is switched off: let everything enqueued drain, look again, and if the pass really did
+    // not run (completely) do it the ordinary way, unarmed for the rest of this ScanMatch.
+    const bool left = gave_up && *gave_up == seq;
+    if (left) h->armed_gave_up_seen++;
+    armed_cancel(h);
+    LSA_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    h->unsynced = 0;
+    if (ndt_reduce_partials_host(rows, g, ndt_armed_row_key(seq), 0.0, out32)) {
+      // complete after all: the rows were slow (counted as late), or only a workgroup of the launch's head-room — one that
+      // has no row to deliver — ran out of patience while the others took the mail (counted above)
+      if (!h->no_row_polling && !left) h->armed_late++;
+      return LSA_OK;
+    }
+    h->armed_scope = false;
+    h->armed_fallbacks++;
+    *redo = true;
+    return LSA_OK;
+  }
+  {  // diagnostics (lsa_ndt_armed_timing)
+    const auto at2 = std::chrono::steady_clock::now();
+    h->at_passes += 1;
+    h->at_post_us += std::chrono::duration<double, std::micro>(ap.at1 - ap.at0).count();
+    h->at_post_to_rows_us += std::chrono::duration<double, std::micro>(at2 - ap.at1).count();
+    if (h->at_have_last) h->at_rows_to_post_us += std::chrono::duration<double, std::micro>(ap.at0 - h->at_last_rows).count();
+    h->at_last_rows = at2; h->at_have_last = true;
+    const unsigned long long st = (unsigned long long)out32[30];   // sum over the workgroups of (wait << 20) + body
+    h->at_dev_wait_ticks += (double)(st >> 20) / (double)g;
+    h->at_dev_body_ticks += (double)(st & 0xfffffull) / (double)g;
+  }
+  h->unsynced += 2;
+  return LSA_OK;
+}
+
+// ---- deferred final pass (see gn_driver.cpp: Driver::defer).  Inside a batch (lsa_pipeline_scan_match) the last pass of a
+// ScanMatch — whose sums only complete the statistics — is posted like any armed pass but NOT waited for: the call returns
+// with the pose, the pass runs while the host moves on, and its rows are taken behind the first mail of the next ScanMatch
+// (or at the batch's end), when the statistics of the previous scan are completed.  The mailbox and the row buffer have two
+// halves by sequence parity for exactly this overlap (ndt_derivatives.hip).
+int collect_pending(lsa_ndt *h) {
+  if (!h->pending.on) return LSA_OK;
+  lsa_ndt::Pending pd = h->pending;
+  h->pending.on = false;
+  ArmedPosted ap;
+  ap.seq = pd.seq; ap.g = pd.g; ap.kept = true; ap.at0 = ap.at1 = pd.posted;
+  double out32[32];
+  bool redo = false;
+  const bool have_last = h->at_have_last;
+  h->at_have_last = false;   // (host-side gaps across a deferred pass mean nothing)
+  int rc = armed_take(h, ap, out32, &redo);
+  h->at_have_last = have_last && !redo;
+  if (rc) return rc;
+  if (redo) {  // the ordinary way, on the cloud and at the pose the pass was for
+    const float4 *src = h->d_source;
+    const size_t n = h->n_source;
+    h->d_source = pd.d_source; h->n_source = pd.n_source;
+    rc = run_pass(h, pd.T, pd.p, 0, out32);
+    h->d_source = src; h->n_source = n;
+    if (rc) return rc;
+  }
+  if (pd.stats) {
+    pd.stats->score = out32[0];
+    pd.stats->trans_probability = out32[29] > 0 ? out32[0] / out32[29] : 0;
+    pd.stats->pairs_per_pass = pd.passes ? (pd.pairs_before + out32[28]) / pd.passes : 0;
+  }
+  h->deferred_passes++;
+  return LSA_OK;
+}
+
+int defer_trampoline(void *user, const float T[16], const double p[6], int kind) {
+  lsa_ndt *h = (lsa_ndt *)user;
+  if (kind != 0 || !h->defer_final || h->pending.on || !(h->armed_scope && h->mail && ndt_pass_host_reduce(h, 0))) return 1;
+  PassParams P;
+  ndt_make_pass_params(h, T, p, &P);
+  ArmedPosted ap;
+  if (armed_post(h, P, &ap)) return 1;
+  lsa_ndt::Pending &pd = h->pending;
+  pd.on = true;
+  pd.seq = ap.seq; pd.g = ap.g; pd.posted = ap.at1;
+  memcpy(pd.T, T, sizeof(pd.T)); memcpy(pd.p, p, sizeof(pd.p));
+  pd.d_source = h->d_source; pd.n_source = h->n_source;
+  pd.stats = nullptr; pd.pairs_before = 0; pd.passes = 0;   // completed by scan_match_common once the driver has returned
+  return 0;
+}
+
 // one pass, synchronous: kernel(s) -> [all-reduce] -> D2H of 32 doubles
 int run_pass(lsa_ndt *h, const float T[16], const double p[6], int kind, double out32[32]) {
   lsa_context *ctx = h->ctx;
@@ -72,73 +218,17 @@ int run_pass(lsa_ndt *h, const float T[16], const double p[6], int kind, double 
   ndt_make_pass_params(h, T, p, &P);
   int rc;
   if (h->armed_scope && kind == 0 && h->mail && ndt_pass_host_reduce(h, 0)) {
-    // armed: this pass's kernel is already waiting on the device — enqueued behind the previous pass, or left parked by
-    // the previous ScanMatch — or is launched now; post its parameters, enqueue the kernel of the NEXT pass behind it, then
-    // take the rows as they arrive
-    const unsigned g = ndt_pass_grid(h, h->n_source, 0);
-    volatile unsigned long long *gave_up = h->h_gave_up.p ? reinterpret_cast<volatile unsigned long long *>(h->h_gave_up.p) : nullptr;
-    if (h->armed_outstanding && (h->armed_grid < g || h->armed_gen != h->target_gen || (gave_up && *gave_up == h->armed_seq))) {
-      if (gave_up && *gave_up == h->armed_seq) h->armed_expired++;
-      armed_cancel(h);   // parked for another table / too small a grid, or it has already left: not usable
-    }
-    unsigned long long seq = h->armed_seq;
-    if (!h->armed_outstanding) {
-      if ((rc = ndt_launch_armed(h, P, seq, armed_headroom(h, g), h->armed_patience_us))) return rc;
-      gave_up = reinterpret_cast<volatile unsigned long long *>(h->h_gave_up.p);
-    }
-    // (after the first armed pass of this ScanMatch the kernels hold their first tiles from the kept copy)
-    static const bool no_keep = getenv("LSA_NO_KEEP") != nullptr;   // A/B switch for measurements (scratch: ab_match.py)
-    const bool kept = !no_keep && h->keep_match == h->match_id && h->keep_n == h->n_source;
-    const auto at0 = std::chrono::steady_clock::now();
-    ndt_mail_post(reinterpret_cast<PassMail *>(h->mail), &P, seq, false, h->d_source, h->n_source, g, kept);
-    const auto at1 = std::chrono::steady_clock::now();
-    h->armed_seq = seq + 1;
-    h->armed_outstanding = false;
-    if ((rc = ndt_launch_armed(h, P, seq + 1, armed_headroom(h, g), h->armed_patience_us))) return rc;
-    h->armed_outstanding = true;
-    h->armed_grid = armed_headroom(h, g);
-    h->armed_gen = h->target_gen;
-    h->armed_passes++;
-    bool ok = !h->no_row_polling && ndt_reduce_partials_host(h->h_partials.p, g, ndt_armed_row_key(seq), kArmedRowLimitMs, out32, gave_up, seq);
-    {
-      const double w = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - at1).count();
-      if (w > h->rows_wait_max_us) h->rows_wait_max_us = w;
-    }
-    if (!ok) {
-      // rows missing.  Either a workgroup of the kernel ran out of patience before the mail came (this thread was held up;
-      // EVERY workgroup that leaves says so in *gave_up, so the wait above ends at once instead of at its limit), or the rows
-      // are slow (limit), or polling is switched off: let everything enqueued drain, look again, and if the pass really did
-      // not run (completely) do it the ordinary way, unarmed for the rest of this ScanMatch.  Each outcome is counted.
-      const bool left = gave_up && *gave_up == seq;
-      if (left) h->armed_gave_up_seen++;
-      armed_cancel(h);
-      LSA_HIP(ctx, hipStreamSynchronize(ctx->stream));
-      h->unsynced = 0;
-      if (ndt_reduce_partials_host(h->h_partials.p, g, ndt_armed_row_key(seq), 0.0, out32)) {
-        // complete after all: the rows were slow (counted as late), or only a workgroup of the launch's head-room — one that
-        // has no row to deliver — ran out of patience while the others took the mail (counted above)
-        if (!h->no_row_polling && !left) h->armed_late++;
-        return LSA_OK;
-      }
-      h->armed_scope = false;
-      h->armed_fallbacks++;
-      return run_pass(h, T, p, kind, out32);
-    }
-    {  // diagnostics (lsa_ndt_armed_timing)
-      const auto at2 = std::chrono::steady_clock::now();
-      h->at_passes += 1;
-      h->at_post_us += std::chrono::duration<double, std::micro>(at1 - at0).count();
-      h->at_post_to_rows_us += std::chrono::duration<double, std::micro>(at2 - at1).count();
-      if (h->at_have_last) h->at_rows_to_post_us += std::chrono::duration<double, std::micro>(at0 - h->at_last_rows).count();
-      h->at_last_rows = at2; h->at_have_last = true;
-      const unsigned long long st = (unsigned long long)out32[30];   // sum over the workgroups of (wait << 20) + body
-      h->at_dev_wait_ticks += (double)(st >> 20) / (double)g;
-      h->at_dev_body_ticks += (double)(st & 0xfffffull) / (double)g;
-    }
-    h->unsynced += 2;
-    if (!kept) { h->keep_match = h->match_id; h->keep_n = h->n_source; }   // that pass kept its first tiles
+    ArmedPosted ap;
+    if ((rc = armed_post(h, P, &ap))) return rc;
+    // the previous ScanMatch's deferred final pass: its kernel ran in front of this pass's, its rows are (being) delivered
+    if (h->pending.on && (rc = collect_pending(h))) return rc;
+    bool redo = false;
+    if ((rc = armed_take(h, ap, out32, &redo))) return rc;
+    if (redo) return run_pass(h, T, p, kind, out32);
+    if (!ap.kept) { h->keep_match = h->match_id; h->keep_n = h->n_source; }   // that pass kept its first tiles
     return LSA_OK;
   }
+  if (h->pending.on && (rc = collect_pending(h))) return rc;
   if (ndt_pass_host_reduce(h, kind)) {
     unsigned g = 0;
     unsigned long long key = 0;
@@ -197,7 +287,7 @@ int check(lsa_ndt *h) {
   if (!h) return LSA_ERR_INVALID;
   hipError_t e = lsa_enter(h->ctx);
   if (e != hipSuccess) return lsa_fail(h->ctx, LSA_ERR_NO_DEVICE, "hipSetDevice(%d): %s", h->ctx->device, hipGetErrorString(e));
-  return LSA_OK;
+  return collect_pending(h);   // (a deferred final pass reads the source and the table: nothing may change under it)
 }
 
 // entry of the ScanMatch calls: like check(), but a kernel this very handle left parked stays (the call is what it waits for)
@@ -237,8 +327,17 @@ int scan_match_common(lsa_ndt *h, const float predict_pose[16], float result_pos
   // a kernel this handle left parked (check_keep kept it for this call) that the call will NOT feed — an all-reduce was
   // installed meanwhile, the source is empty, there is no mailbox — would hold the ordinary passes back for its whole patience
   if (!h->armed_scope) armed_cancel(h);
-  rc = lsa_gn_solve_trace(eval_trampoline, h, h->resolution, h->step_size, h->trans_eps, h->max_iter, h->outlier_ratio, h->mode, predict_pose, result_pose, &st,
-                              h->trace_rows, h->trace_cap, h->trace_n);
+  if (h->pending.on && !h->armed_scope && (rc = collect_pending(h))) return rc;
+  double pairs_before = -1.0;
+  rc = lsa_gn_solve_defer(eval_trampoline, (h->defer_final && h->armed_scope) ? defer_trampoline : nullptr, h, h->resolution, h->step_size, h->trans_eps, h->max_iter,
+                          h->outlier_ratio, h->mode, predict_pose, result_pose, &st, h->trace_rows, h->trace_cap, h->trace_n, &pairs_before);
+  if (!rc && h->pending.on && pairs_before >= 0) {   // the last pass was deferred: its sums complete *stats later (collect_pending)
+    h->pending.stats = stats;
+    h->pending.pairs_before = pairs_before;
+    h->pending.passes = st.passes;
+  } else if (h->pending.on && (rc || pairs_before < 0)) {
+    (void)collect_pending(h);   // (posted by a solve that then failed: do not leave it dangling)
+  }
   if (h->armed_scope) {
     h->armed_scope = false;
     // The kernel enqueued for the pass that never came: cancelled — or, when scans follow each other on this handle and
@@ -304,6 +403,8 @@ extern "C" int lsa_ndt_set_dense_limit(lsa_ndt *h, long long max_cells) {
 extern "C" void lsa_ndt_destroy(lsa_ndt *h) {
   if (!h) return;
   (void)lsa_enter(h->ctx);
+  h->pending.stats = nullptr;
+  (void)collect_pending(h);
   armed_cancel(h);
   (void)hipStreamSynchronize(h->ctx->stream);
   ndt_fitness_release(h);
@@ -449,8 +550,10 @@ extern "C" int lsa_ndt_armed_stats(lsa_ndt *h, lsa_ndt_armed_stats_t *out, int r
     out->expired = h->armed_expired;
     out->rows_wait_max_us = h->rows_wait_max_us;
     out->parked = (h->armed_outstanding && h->ctx->unpark_arg == h) ? 1 : 0;
+    out->pad = 0;
+    out->deferred = h->deferred_passes;
   }
-  if (reset) { h->armed_passes = h->armed_cancels = h->armed_fallbacks = h->armed_late = h->rows_late = h->armed_gave_up_seen = h->armed_expired = 0; h->rows_wait_max_us = 0; }
+  if (reset) { h->armed_passes = h->armed_cancels = h->armed_fallbacks = h->armed_late = h->rows_late = h->armed_gave_up_seen = h->armed_expired = h->deferred_passes = 0; h->rows_wait_max_us = 0; }
   return LSA_OK;
 }
 
@@ -492,6 +595,14 @@ void ndt_prearm(lsa_ndt *h) {
   ctx->unpark = armed_cancel_cb;
   ctx->unpark_arg = h;
 }
+
+// internal (pipeline.cpp): inside a batch the final pass of every ScanMatch may be deferred; returns the previous setting
+bool ndt_defer_scope(lsa_ndt *h, bool on) {
+  const bool prev = h->defer_final;
+  h->defer_final = on && getenv("LSA_NO_DEFER") == nullptr;
+  return prev;
+}
+int ndt_collect_deferred(lsa_ndt *h) { return collect_pending(h); }
 
 // internal: release a kernel this handle has left parked (the batch is over and nobody is known to follow)
 void ndt_release_parked(lsa_ndt *h) { armed_cancel(h); }

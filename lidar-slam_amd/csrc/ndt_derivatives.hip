@@ -46,6 +46,7 @@ __global__ __launch_bounds__(kBlockD, pass_waves(KIND)) void k_ndt_pass(const fl
 }  // namespace
 
 constexpr unsigned kHostReduceMaxBlocks = 1024;
+constexpr size_t kHostRowsDoubles = (size_t)2 * kHostReduceMaxBlocks * kOutDoubles;   // two halves (ndt_armed_rows)
 
 // ---- armed pass: the NEXT pass's kernel is launched before its parameters exist -------------------------------------
 // A pass kernel at KITTI size is ~5 us of work behind ~3 us of host launch call and ~4.5 us until its first wave runs, and
@@ -157,8 +158,11 @@ __global__ __launch_bounds__(kBlockD, pass_waves(0)) void k_ndt_pass_armed(PassP
 }
 }  // namespace
 
-// host: post the dynamic parameters of pass `seq` (or its cancellation) into the mailbox
-void ndt_mail_post(PassMail *mail, const PassParams *P, unsigned long long seq, bool cancel, const void *d_src, size_t n, unsigned vgrid, bool kept) {
+// host: post the dynamic parameters of pass `seq` (or its cancellation) into the mailbox.  The mailbox has TWO slots, taken by
+// the parity of the sequence number: the final pass of one ScanMatch may still be on its way when the first mail of the next is
+// posted (deferred final pass, ndt_api.hip), and a mail must never be overwritten before every workgroup it is for has taken it.
+void ndt_mail_post(PassMail *mail_base, const PassParams *P, unsigned long long seq, bool cancel, const void *d_src, size_t n, unsigned vgrid, bool kept) {
+  PassMail *mail = mail_base + (seq & 1ull);
   if (cancel) {
     __atomic_store_n(&mail->seq, seq | kMailCancel, __ATOMIC_RELEASE);
     _mm_sfence();
@@ -187,25 +191,29 @@ void ndt_mail_post(PassMail *mail, const PassParams *P, unsigned long long seq, 
 int ndt_launch_armed(lsa_ndt *h, const PassParams &P, unsigned long long seq, unsigned grid, double patience_us) {
   lsa_context *ctx = h->ctx;
   int rc;
-  if ((rc = h->h_partials.reserve(ctx, (size_t)kHostReduceMaxBlocks * kOutDoubles))) return rc;
+  if ((rc = h->h_partials.reserve(ctx, kHostRowsDoubles))) return rc;
   if (!h->h_gave_up.p) {
     if ((rc = h->h_gave_up.reserve(ctx, 8))) return rc;
     memset(h->h_gave_up.p, 0, 8 * sizeof(double));
   }
   // first-tile points kept from pass to pass (k_ndt_pass_armed): sized once for the largest armed grid, never moved
   if (!h->src_keep.p && (rc = h->src_keep.reserve(ctx, (size_t)kHostReduceMaxBlocks * kWaves * kTilePts))) return rc;
-  const PassMail *mail = reinterpret_cast<const PassMail *>(h->mail);
+  const PassMail *mail = reinterpret_cast<const PassMail *>(h->mail) + (seq & 1ull);   // the slot of this sequence number's parity
+  double *rows = ndt_armed_rows(h, seq);                                                   // ... and its half of the row buffer
   const unsigned long long ticks = (unsigned long long)(patience_us * 100.0);
   unsigned long long *gu = reinterpret_cast<unsigned long long *>(h->h_gave_up.p);
   if (h->use_dense)
-    hipLaunchKernelGGL((k_ndt_pass_armed<true>), dim3(grid), dim3(kBlockD), 0, ctx->stream, P, h->words.p, ndt_dense(h), ndt_rec(h), h->h_partials.p, mail, seq, ticks, gu, h->src_keep.p, (unsigned)h->src_keep.cap);
+    hipLaunchKernelGGL((k_ndt_pass_armed<true>), dim3(grid), dim3(kBlockD), 0, ctx->stream, P, h->words.p, ndt_dense(h), ndt_rec(h), rows, mail, seq, ticks, gu, h->src_keep.p, (unsigned)h->src_keep.cap);
   else
-    hipLaunchKernelGGL((k_ndt_pass_armed<false>), dim3(grid), dim3(kBlockD), 0, ctx->stream, P, h->words.p, ndt_dense(h), ndt_rec(h), h->h_partials.p, mail, seq, ticks, gu, h->src_keep.p, (unsigned)h->src_keep.cap);
+    hipLaunchKernelGGL((k_ndt_pass_armed<false>), dim3(grid), dim3(kBlockD), 0, ctx->stream, P, h->words.p, ndt_dense(h), ndt_rec(h), rows, mail, seq, ticks, gu, h->src_keep.p, (unsigned)h->src_keep.cap);
   LSA_HIP(ctx, hipGetLastError());
   return LSA_OK;
 }
 
 unsigned long long ndt_armed_row_key(unsigned long long seq) { return mail_key(seq) | 1ull; }
+// rows of the armed pass `seq`: the half of the host-mapped row buffer that belongs to its parity (two consecutive passes never
+// share rows: the deferred final pass of a ScanMatch and the first pass of the next are in flight together)
+double *ndt_armed_rows(lsa_ndt *h, unsigned long long seq) { return h->h_partials.p + (size_t)(seq & 1ull) * kHostReduceMaxBlocks * kOutDoubles; }
 
 namespace {
 
@@ -363,7 +371,7 @@ int ndt_enqueue_pass_host(lsa_ndt *h, const PassParams &P, int kind, unsigned *g
   lsa_context *ctx = h->ctx;
   unsigned g = ndt_pass_grid(h, h->n_source, kind);
   int rc;
-  if ((rc = h->h_partials.reserve(ctx, (size_t)kHostReduceMaxBlocks * kOutDoubles))) return rc;
+  if ((rc = h->h_partials.reserve(ctx, kHostRowsDoubles))) return rc;
   const uint4 *words = h->words.p;
   const double *rec = ndt_rec(h);
   double *dst = h->h_partials.p;  // pinned + mapped: the same pointer is valid on the device

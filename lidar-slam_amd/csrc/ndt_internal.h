@@ -113,6 +113,23 @@ struct lsa_ndt {
   unsigned long long armed_late = 0, rows_late = 0, armed_gave_up_seen = 0, armed_expired = 0;
   double rows_wait_max_us = 0;
 
+  // deferred final pass of a ScanMatch inside a batch (ndt_api.hip: collect_pending)
+  struct Pending {
+    bool on = false;
+    unsigned long long seq = 0;
+    unsigned g = 0;
+    float T[16];
+    double p[6];
+    const float4 *d_source = nullptr;
+    size_t n_source = 0;
+    lsa_ndt_stats *stats = nullptr;   // the caller's statistics block the pass completes (may be null)
+    double pairs_before = 0;
+    int passes = 0;
+    std::chrono::steady_clock::time_point posted;
+  } pending;
+  bool defer_final = false;            // set by lsa_pipeline_scan_match for the duration of a batch
+  unsigned long long deferred_passes = 0;
+
   // multi-GPU
   lsa_allreduce_fn allreduce = nullptr;
   void *allreduce_user = nullptr;
@@ -136,6 +153,8 @@ void ndt_touch_external(lsa_ndt *h, size_t n_target);   // the owner changed the
 int ndt_materialize(lsa_ndt *h);                         // no-op unless the table is external
 int ndt_source_order(lsa_ndt *h, const float4 *d_src, size_t n, const float4 **d_use);   // source_sort.hip
 int ndt_build_grid(lsa_ndt *h, const float4 *d_pts, size_t n);
+bool ndt_defer_scope(lsa_ndt *h, bool on);   // ndt_api.hip: the final pass of every ScanMatch of a batch may be deferred
+int ndt_collect_deferred(lsa_ndt *h);
 bool ndt_carry_scope(lsa_ndt *h, bool on);   // ndt_api.hip: carry between the scans of a batch; returns the previous setting
 void ndt_release_parked(lsa_ndt *h);
 int ndt_count_valid(lsa_ndt *h);

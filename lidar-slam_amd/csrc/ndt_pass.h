@@ -28,6 +28,7 @@ struct PassMail;
 void ndt_mail_post(PassMail *mail, const PassParams *P, unsigned long long seq, bool cancel, const void *d_src, size_t n, unsigned vgrid, bool kept = false);
 int ndt_launch_armed(lsa_ndt *h, const PassParams &P, unsigned long long seq, unsigned grid, double patience_us);
 unsigned long long ndt_armed_row_key(unsigned long long seq);
+double *ndt_armed_rows(lsa_ndt *h, unsigned long long seq);
 bool ndt_fetch_row_host(const double *row, unsigned long long key, double limit_ms, unsigned long long out32[32],
                         const volatile unsigned long long *abort_word = nullptr, unsigned long long abort_value = 0);
 bool ndt_reduce_partials_host(const double *partials, unsigned nb, unsigned long long key, double limit_ms, double out32[32],

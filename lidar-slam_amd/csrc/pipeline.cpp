@@ -8,6 +8,9 @@
 bool ndt_carry_scope(lsa_ndt *h, bool on);   // ndt_api.hip
 void ndt_release_parked(lsa_ndt *h);
 void ndt_prearm(lsa_ndt *h);
+bool ndt_defer_scope(lsa_ndt *h, bool on);
+int ndt_collect_deferred(lsa_ndt *h);
+float *lsa_voxel_filter_pipe_buffer(lsa_voxel_filter *f, size_t n);
 void lsa_voxel_filter_retire_begin(lsa_voxel_filter *f);
 void lsa_voxel_filter_retire_end(lsa_voxel_filter *f);
 int lsa_voxel_filter_apply_device_async_here(lsa_voxel_filter *f, const float *d_in_xyzw, size_t n, float *d_out_xyzw);   // voxel_filter.hip
@@ -19,7 +22,13 @@ extern "C" int lsa_pipeline_scan_match(lsa_voxel_filter *frame_filter, lsa_ndt *
     return LSA_ERR_INVALID;
   if (world < 1 || rank < 0 || rank >= world) return LSA_ERR_INVALID;
   if (count == 0) return LSA_OK;
-  float *buf[2] = {d_filtered_a, d_filtered_b};
+  // THREE filtered-cloud buffers in rotation (the caller's two and one the filter handle owns): the final derivative pass of
+  // scan k may still be reading its source when the filter of scan k + 2 is enqueued (deferred final pass, ndt_api.hip) — with
+  // two buffers that filter would write the very cloud the pass reads.
+  size_t n_max = 0;
+  for (size_t k = 0; k < count; k++) n_max = n_points[k] > n_max ? n_points[k] : n_max;
+  float *buf[3] = {d_filtered_a, d_filtered_b, lsa_voxel_filter_pipe_buffer(frame_filter, n_max)};
+  const size_t nbuf = buf[2] ? 3 : 2;
   int rc = lsa_voxel_filter_apply_device_async_here(frame_filter, d_scans_xyzw[0], n_points[0], buf[0]);
   if (rc) return rc;
   // Between the scans of the batch the next ScanMatch is known to follow at once and nothing else uses the NDT's stream, so
@@ -27,14 +36,18 @@ extern "C" int lsa_pipeline_scan_match(lsa_voxel_filter *frame_filter, lsa_ndt *
   // cancelled (unless the caller opted into the carry himself): the batch returns with nothing spinning on the stream.
   ndt_prearm(ndt);   // the first pass's kernel, enqueued while the first filter runs
   const bool carry_user = ndt_carry_scope(ndt, true);
+  // ... and the LAST derivative pass of every ScanMatch — whose sums only complete the statistics, the pose is final before it —
+  // is posted but not waited for: it runs while the host moves on to the next scan and is collected behind that scan's first
+  // mail (behind the last scan: before this call returns).  Needs the third buffer.
+  const bool defer_user = ndt_defer_scope(ndt, nbuf == 3);
   struct Restore {
-    lsa_ndt *h; bool prev;
-    ~Restore() { (void)ndt_carry_scope(h, prev); if (!prev) ndt_release_parked(h); }
-  } restore{ndt, carry_user};
+    lsa_ndt *h; bool prev, prev_defer;
+    ~Restore() { (void)ndt_collect_deferred(h); (void)ndt_defer_scope(h, prev_defer); (void)ndt_carry_scope(h, prev); if (!prev) ndt_release_parked(h); }
+  } restore{ndt, carry_user, defer_user};
   for (size_t k = 0; k < count; k++) {
     size_t m = 0;
     if ((rc = lsa_voxel_filter_wait(frame_filter, &m))) return rc;
-    if (k + 1 < count && (rc = lsa_voxel_filter_apply_device_async(frame_filter, d_scans_xyzw[k + 1], n_points[k + 1], buf[(k + 1) & 1]))) return rc;
+    if (k + 1 < count && (rc = lsa_voxel_filter_apply_device_async(frame_filter, d_scans_xyzw[k + 1], n_points[k + 1], buf[(k + 1) % nbuf]))) return rc;
     // multi-GPU: this rank's contiguous shard of the filtered source; the all-reduce callback installed on
     // the NDT handle sums the per-rank normal equations
     if (k + 1 == count) {
@@ -42,7 +55,7 @@ extern "C" int lsa_pipeline_scan_match(lsa_voxel_filter *frame_filter, lsa_ndt *
       lsa_voxel_filter_retire_begin(frame_filter);   // nothing more to filter: the helper thread retires the filter's stream meanwhile
     }
     size_t lo = (m * (size_t)rank) / (size_t)world, hi = (m * (size_t)(rank + 1)) / (size_t)world;
-    rc = lsa_ndt_scan_match_device(ndt, buf[k & 1] + 4 * lo, hi - lo, predict_poses + 16 * k, result_poses + 16 * k, stats ? stats + k : nullptr);
+    rc = lsa_ndt_scan_match_device(ndt, buf[k % nbuf] + 4 * lo, hi - lo, predict_poses + 16 * k, result_poses + 16 * k, stats ? stats + k : nullptr);
     if (k + 1 == count) lsa_voxel_filter_retire_end(frame_filter);
     if (rc) {  // leave no filter in flight behind an error
       if (k + 1 < count) { size_t dummy; (void)lsa_voxel_filter_wait(frame_filter, &dummy); }

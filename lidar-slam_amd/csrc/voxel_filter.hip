@@ -19,6 +19,7 @@ struct lsa_voxel_filter {
   float leaf[3] = {0, 0, 0};
   VoxelIndex vi;
   DevBuf<float4> d_in, d_out;
+  DevBuf<float4> d_pipe;   // third output buffer of lsa_pipeline_scan_match (beside the caller's two)
   PinnedBuf<float> h_stage;
   // asynchronous call in flight (lsa_voxel_filter_apply_device_async .. lsa_voxel_filter_wait)
   bool pending = false;
@@ -218,6 +219,12 @@ int lsa_voxel_filter_apply_device_async_here(lsa_voxel_filter *f, const float *d
   return LSA_OK;
 }
 
+// internal (pipeline.cpp): a device buffer of n points owned by this handle (grow-only)
+float *lsa_voxel_filter_pipe_buffer(lsa_voxel_filter *f, size_t n) {
+  if (!f || f->d_pipe.reserve(f->ctx, n ? n : 1, 1.1)) return nullptr;
+  return (float *)f->d_pipe.p;
+}
+
 // internal (pipeline.cpp): see job kind 3.  _begin posts it to the helper thread, _end waits for it.
 void lsa_voxel_filter_retire_begin(lsa_voxel_filter *f) {
   if (!f || f->pending || !f->worker_started) return;
@@ -284,7 +291,7 @@ extern "C" void lsa_voxel_filter_destroy(lsa_voxel_filter *f) {
   (void)lsa_enter(f->ctx);
   (void)hipStreamSynchronize(f->ctx->stream);
   if (f->stream2) { (void)hipStreamSynchronize(f->stream2); (void)hipStreamDestroy(f->stream2); (void)hipEventDestroy(f->ev2); }
-  f->vi.release(); f->d_in.release(); f->d_out.release(); f->h_stage.release();
+  f->vi.release(); f->d_in.release(); f->d_out.release(); f->d_pipe.release(); f->h_stage.release();
   delete f;
 }
 

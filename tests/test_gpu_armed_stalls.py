@@ -102,6 +102,34 @@ def test_nothing_parked_by_default_and_batch_cancels_behind_its_last_scan(rig):
     n.close()
 
 
+def test_deferred_final_pass_completes_every_statistic(rig):
+    """Inside a batch the last derivative pass of a ScanMatch is posted but not waited for (the pose does not depend on it);
+    its sums complete the scan's statistics behind the next scan's first mail.  A batch long enough to pass the library's
+    periodic stream wait (which cancels the parked kernel and makes the sequence numbers skip one: the deferred pass and the
+    next pass would then share a mailbox slot and a row-buffer half) must return, scan for scan, the poses AND statistics of
+    plain sequential calls; no pass may be lost or redone."""
+    n = _ndt(rig)
+    plain = _ndt(rig)
+    plain.set_armed(False)
+    ref = []
+    for d_s, g in zip(rig["d_src"], rig["guesses"]):
+        _, T = plain.ScanMatch(d_s, g)
+        ref.append((T, dict(plain.last_stats)))
+    plain.close()
+    idx = [i % 9 for i in range(700)]
+    Ts, sts, nfs = registration.pipeline_scan_match(rig["ff"], n, [rig["d_raw"][i] for i in idx], [rig["guesses"][i] for i in idx], rig["bufs"])
+    s = n.armed_stats()
+    assert s["deferred"] >= 650 and s["fallbacks"] == 0 and s["late"] == 0 and s["gave_up_seen"] == 0 and s["parked"] == 0, s
+    assert s["cancels"] >= 3          # the periodic stream wait did occur (every 512 armed passes)
+    for i, T, st in zip(idx, Ts, sts):
+        Tr, sr = ref[i]
+        assert np.array_equal(T, Tr)
+        for key in ("iterations", "passes", "ls_iterations", "converged", "score", "trans_probability", "pairs_per_pass"):
+            assert st[key] == sr[key], (i, key, st[key], sr[key])
+        assert np.array_equal(st["final_p"], sr["final_p"])
+    n.close()
+
+
 @pytest.mark.parametrize("carry", [False, True], ids=["default", "carry_opt_in"])
 def test_batch_idle_then_standalone_scan_matches(rig, carry):
     """The driver's sequence: batches, an idle gap longer than the patience, then 50 plain ScanMatch calls."""

@@ -384,7 +384,7 @@ def test_pipeline_batch_equals_sequential_calls(oracle, scene):
         f = ff.filter_device(d_scans[i]).clone()
         torch.cuda.synchronize()
         _, T = ndt.ScanMatch(f, guesses[i])
-        seq.append((T, f.shape[0], ndt.last_stats["passes"]))
+        seq.append((T, f.shape[0], ndt.last_stats["passes"], dict(ndt.last_stats)))
     L = capi.lib()
     L.lsa_pipeline_scan_match.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t), C.POINTER(C.c_float),
                                           C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_float), C.POINTER(capi.NdtStats), C.POINTER(C.c_size_t)]
@@ -402,6 +402,13 @@ def test_pipeline_batch_equals_sequential_calls(oracle, scene):
     for i in range(6):
         assert int(nf[i]) == seq[i][1] and st[i].passes == seq[i][2]
         assert np.array_equal(capi.from_colmajor(out[i]), seq[i][0])
+        # the statistics too: inside a batch the final derivative pass of a ScanMatch is not waited for (it only feeds them);
+        # its sums complete the block behind the next scan's first mail, or before the batch returns
+        ref_st = seq[i][3]
+        got = st[i].as_dict()
+        for key in ("iterations", "ls_iterations", "converged", "score", "trans_probability", "pairs_per_pass"):
+            assert got[key] == ref_st[key], (i, key, got[key], ref_st[key])
+        assert np.array_equal(got["final_p"], ref_st["final_p"])
     # argument checking
     assert L.lsa_pipeline_scan_match(ff.h, ndt.h, n, ptrs, nn, capi.fptr(pred), bufs[0].data_ptr(), bufs[1].data_ptr(), 2, 2, capi.fptr(out), st, nf) != 0
     ndt.close(); ff.close(); ctx.close(); ctx_f.close()
