@@ -405,7 +405,29 @@ def main():
         us_armed = (at.get("dev_wait_us", 0.0) + at.get("dev_body_us", 0.0)) if at.get("passes") else None
         us_roof = us_armed if us_armed else ms * 1e3
         achieved_roof = alg_bytes / (us_roof * 1e-6) / 1e9
+        # what rocprofv3's kernel trace of the same command says for that kernel (committed summary under profiles/; the traced run
+        # is slower on the host side — the tracer sits in every API call — so its kernels wait longer for their mail than here)
+        rocprof_avg = None
+        for pname in ("r03_final_bench_kernel_stats.csv", "r03_a_bench_kernel_stats.csv"):
+            ppath = os.path.join(ROOT, "profiles", pname)
+            if os.path.exists(ppath):
+                try:
+                    import csv
+                    for row in csv.DictReader(open(ppath)):
+                        if "k_ndt_pass_armed<true>" in row["Name"]:
+                            rocprof_avg = {"file": "profiles/" + pname, "dispatches": int(row["Calls"]), "avg_us": round(float(row["AverageNs"]) / 1e3, 3)}
+                            break
+                except Exception:
+                    rocprof_avg = None
+                if rocprof_avg:
+                    break
+        if rocprof_avg:
+            rocprof_avg["frac_at_this_duration"] = round(alg_bytes / (rocprof_avg["avg_us"] * 1e-6) / 1e9 / HBM_PEAK_GBS, 5)
+            rocprof_avg["why_longer_than_us_per_launch"] = ("a dispatch's begin -> end also holds the launch ramp / drain (~2 us), the dispatches that end by a cancel or "
+                                                            "run out of patience (up to 300 us each) count too, and in the traced run the host — hence every mail — is slower: "
+                                                            "that run's own device stamps are in profiles/*_bench_traced_run.json (roofline.armed)")
         roofline = {"bound": "hbm", "kernel": "k_ndt_pass_armed<true>" if us_armed else "k_ndt_pass<0, true>",
+                    "rocprof_kernel_trace": rocprof_avg,
                     "achieved": round(achieved_roof, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": round(achieved_roof / HBM_PEAK_GBS, 5), "traffic": traffic, "us_per_launch": round(us_roof, 3),
                     "armed": {"passes_timed": at.get("passes"), "dev_wait_us": round(at.get("dev_wait_us", 0.0), 3), "dev_body_us": round(at.get("dev_body_us", 0.0), 3),
