@@ -76,12 +76,15 @@ __device__ __forceinline__ void nn_visit_row(const NNView &g, int xa, int xb, in
 // rows — that cannot hold a point closer than min(gate_d2, best so far) are skipped without touching memory: the cube
 // of rings shrinks to the sphere that matters (about half the cells), which is what bounds a query with no neighbour.
 constexpr int kPhasedMaxRing = 2;
+// seed_hit (optional, instead of seed_slot): a hit the caller has already evaluated — e.g. against another grid over the same
+// points; its `slot` is passed through untouched unless a better point of THIS grid replaces it.
 template <int SUB>
 __device__ __forceinline__ NNHit nn_nearest_sub(const NNView &g, float qx, float qy, float qz, int max_ring, int sub, float gate_d2 = INFINITY,
-                                                unsigned seed_slot = 0xffffffffu) {
+                                                unsigned seed_slot = 0xffffffffu, const NNHit *seed_hit = nullptr) {
   const CellMap &m = g.map;
   NNHit h;
   h.d2 = INFINITY; h.id = 0xffffffffu; h.x = h.y = h.z = 0.0f; h.slot = 0u;
+  if (seed_hit) h = *seed_hit;
   // seed_slot: a point of the sorted array known to be a good guess (the neighbour found for this query one ICP iteration
   // ago).  It is treated as already visited, which changes nothing in the answer — every cell that could hold a closer
   // (or equally close, lower-index) point is still searched — but shrinks the sphere the search has to cover from the
