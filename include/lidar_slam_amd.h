@@ -441,6 +441,16 @@ int lsa_front_end_set_init_pose(lsa_front_end *fe, const float pose[16]);
 int lsa_front_end_update(lsa_front_end *fe, const void *cloud, size_t n, size_t stride, size_t w_off, float pose_out[16],
                          lsa_front_end_stats *stats);
 int lsa_front_end_update_device(lsa_front_end *fe, const float *d_xyzw, size_t n, float pose_out[16], lsa_front_end_stats *stats);
+/* `count` Updates in one call — a recorded drive being replayed, or a sensor queue that has backed up: the loop
+ * front_end_flow.cpp:44-66 runs over its cloud_data_buff_ (while (HasData()) { ValidData(); UpdateLaserOdometry(); }).  The
+ * frame filter of scan k + 1 runs on a second stream while scan k is registered and the local map updated (it needs no pose);
+ * within the call the next pass's kernel stays parked between two ScanMatches and a ScanMatch's final derivative pass, which
+ * only completes its statistics, is collected behind the next scan's first pass (as in lsa_pipeline_scan_match).  Poses,
+ * key-frame decisions, local map and statistics are those of `count` calls of lsa_front_end_update_device, bit for bit.
+ * d_scans_xyzw[k]: device cloud of n_points[k] points, complete or produced on this context's stream, untouched until the call
+ * returns; poses_out: 16 floats per scan; stats: `count` records or NULL.  On an error the scans before it have been applied. */
+int lsa_front_end_update_batch_device(lsa_front_end *fe, size_t count, const float *const *d_scans_xyzw, const size_t *n_points, float *poses_out,
+                                      lsa_front_end_stats *stats);
 /* the NDT handle the front end owns (for GetFitnessScore / introspection); do not destroy it */
 lsa_ndt *lsa_front_end_registration(lsa_front_end *fe);
 /* Incremental local map (default ON; 0 or the environment variable LSA_FE_INCREMENTAL=0 selects the full rebuild).

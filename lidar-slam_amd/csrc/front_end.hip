@@ -116,6 +116,10 @@ struct lsa_front_end {
   lsa_front_end_config cfg{};
   lsa_voxel_filter *frame_filter = nullptr, *map_filter = nullptr;
   lsa_ndt *ndt = nullptr;
+  // lsa_front_end_update_batch_device: a second context (stream) with a frame filter of its own, three filtered clouds in rotation
+  lsa_context *ctx_b = nullptr;
+  lsa_voxel_filter *frame_filter_b = nullptr;
+  DevBuf<float4> d_batch[3];
   std::deque<KeyFrame *> frames;
   std::vector<KeyFrame *> pool;
   DevBuf<float4> d_in, d_filtered, d_map, d_map_f;
@@ -136,6 +140,12 @@ struct lsa_front_end {
 
 void lsa_voxel_filter_set_scale_floor(lsa_voxel_filter *f, unsigned long long n);   // voxel_filter.hip
 void ndt_set_scale_floor(lsa_ndt *h, unsigned long long n);                         // ndt_grid.hip
+bool ndt_carry_scope(lsa_ndt *h, bool on);                                          // ndt_api.hip
+void ndt_release_parked(lsa_ndt *h);
+void ndt_prearm(lsa_ndt *h);
+bool ndt_defer_scope(lsa_ndt *h, bool on);
+int ndt_collect_deferred(lsa_ndt *h);
+int lsa_voxel_filter_apply_device_async_here(lsa_voxel_filter *f, const float *d_in_xyzw, size_t n, float *d_out_xyzw);   // voxel_filter.hip
 
 namespace {
 // The local map buffer is `local_frame_num` slots of slot_cap points; a key-frame's transformed cloud lives in its slot
@@ -298,10 +308,52 @@ int fe_add_key_frame(lsa_front_end *fe, const float4 *d_cloud, size_t n, const f
   return fe_rebuild_map(fe, kf, evicted, d_cloud, reset_w);
 }
 
+// Everything of Update behind the frame filter.  `st` is the CALLER's record and is written in place: inside a batch the
+// registration may complete st->ndt after this returns (deferred final pass, ndt_api.hip).
+int fe_update_filtered(lsa_front_end *fe, const float4 *d_cloud, size_t n, const float4 *src, size_t n_src, float pose_out[16], lsa_front_end_stats *st,
+                       bool batch) {
+  int rc;
+  memset(st, 0, sizeof(*st));
+  st->filtered_points = (int64_t)n_src;
+  if (fe->frames.empty()) {  // first frame: key-frame 0 at the init pose, raw intensities kept (:203-218)
+    if (batch) lsa_ctx_unpark(fe->ctx);
+    if ((rc = fe_add_key_frame(fe, d_cloud, n, fe->init_pose, false))) return rc;
+    memcpy(pose_out, fe->init_pose, 16 * sizeof(float));
+    memcpy(fe->last_pose, fe->init_pose, sizeof(fe->last_pose));
+    memcpy(fe->predict_pose, fe->init_pose, sizeof(fe->predict_pose));
+    memcpy(fe->last_kf_pose, fe->init_pose, sizeof(fe->last_kf_pose));
+    identity16(fe->step_pose);
+    st->key_frame = 1;
+  } else {
+    float cur[16];
+    if (fe->incremental && !fe->lm_off && (rc = fe_lm_settle(fe))) return rc;
+    if ((rc = lsa_ndt_scan_match_device(fe->ndt, (const float *)src, n_src, fe->predict_pose, cur, &st->ndt))) return rc;
+    memcpy(pose_out, cur, sizeof(cur));
+    float inv_last[16];
+    if (mat4_inverse(fe->last_pose, inv_last)) mat4_mul(inv_last, cur, fe->step_pose);  // :238
+    mat4_mul(cur, fe->step_pose, fe->predict_pose);                                      // :239
+    memcpy(fe->last_pose, cur, sizeof(cur));                                             // :240
+    float l1 = std::fabs(fe->last_kf_pose[12] - cur[12]) + std::fabs(fe->last_kf_pose[13] - cur[13]) + std::fabs(fe->last_kf_pose[14] - cur[14]);
+    if (l1 > fe->cfg.key_frame_distance) {  // :243-245
+      // inside a batch the next pass's kernel is parked on the stream: the local-map kernels go in front of its successor
+      if (batch) lsa_ctx_unpark(fe->ctx);
+      // the reference resets every point's static weight to 1.0 before storing a later key-frame (:304-306)
+      if ((rc = fe_add_key_frame(fe, d_cloud, n, cur, fe->cfg.reset_intensity != 0))) return rc;
+      memcpy(fe->last_kf_pose, cur, sizeof(cur));
+      st->key_frame = 1;
+      // ... and that successor is enqueued behind them at once: its launch and dispatch pass while the map is updated
+      if (batch && fe->lm_adopted) ndt_prearm(fe->ndt);
+    }
+  }
+  fe->frames_seen++;
+  st->local_map_frames = (int32_t)fe->frames.size();
+  st->local_map_points = (int64_t)fe->map_points;
+  st->target_points = (int64_t)fe->target_points;
+  return LSA_OK;
+}
+
 int fe_update_device(lsa_front_end *fe, const float4 *d_cloud, size_t n, float pose_out[16], lsa_front_end_stats *stats) {
   lsa_context *ctx = fe->ctx;
-  lsa_front_end_stats st;
-  memset(&st, 0, sizeof(st));
   int rc;
   // frame filter (:106-107)
   const float4 *src = d_cloud;
@@ -313,37 +365,64 @@ int fe_update_device(lsa_front_end *fe, const float4 *d_cloud, size_t n, float p
     if (rc == LSA_OK) { src = fe->d_filtered.p; n_src = V; }
     else if (rc != LSA_ERR_RANGE) return rc;
   }
-  st.filtered_points = (int64_t)n_src;
-  if (fe->frames.empty()) {  // first frame: key-frame 0 at the init pose, raw intensities kept (:203-218)
-    if ((rc = fe_add_key_frame(fe, d_cloud, n, fe->init_pose, false))) return rc;
-    memcpy(pose_out, fe->init_pose, 16 * sizeof(float));
-    memcpy(fe->last_pose, fe->init_pose, sizeof(fe->last_pose));
-    memcpy(fe->predict_pose, fe->init_pose, sizeof(fe->predict_pose));
-    memcpy(fe->last_kf_pose, fe->init_pose, sizeof(fe->last_kf_pose));
-    identity16(fe->step_pose);
-    st.key_frame = 1;
-  } else {
-    float cur[16];
-    if (fe->incremental && !fe->lm_off && (rc = fe_lm_settle(fe))) return rc;
-    if ((rc = lsa_ndt_scan_match_device(fe->ndt, (const float *)src, n_src, fe->predict_pose, cur, &st.ndt))) return rc;
-    memcpy(pose_out, cur, sizeof(cur));
-    float inv_last[16];
-    if (mat4_inverse(fe->last_pose, inv_last)) mat4_mul(inv_last, cur, fe->step_pose);  // :238
-    mat4_mul(cur, fe->step_pose, fe->predict_pose);                                      // :239
-    memcpy(fe->last_pose, cur, sizeof(cur));                                             // :240
-    float l1 = std::fabs(fe->last_kf_pose[12] - cur[12]) + std::fabs(fe->last_kf_pose[13] - cur[13]) + std::fabs(fe->last_kf_pose[14] - cur[14]);
-    if (l1 > fe->cfg.key_frame_distance) {  // :243-245
-      // the reference resets every point's static weight to 1.0 before storing a later key-frame (:304-306)
-      if ((rc = fe_add_key_frame(fe, d_cloud, n, cur, fe->cfg.reset_intensity != 0))) return rc;
-      memcpy(fe->last_kf_pose, cur, sizeof(cur));
-      st.key_frame = 1;
+  lsa_front_end_stats local;
+  return fe_update_filtered(fe, d_cloud, n, src, n_src, pose_out, stats ? stats : &local, false);
+}
+
+// A run of scans (replay of a recorded drive, or a sensor queue that has backed up) through Update with the frame filter of
+// scan k + 1 running on a second context's stream while scan k is registered and, on key-frames, while the local map is
+// updated — the pose-independent part of the next Update overlaps the pose-dependent part of this one.  Inside the run the
+// next pass's kernel stays parked between two ScanMatches and the final derivative pass of a ScanMatch, which only completes
+// the statistics, is collected behind the next scan's first mail (both as in lsa_pipeline_scan_match).  Poses, key-frame
+// decisions, maps and statistics are those of `count` single Updates, bit for bit.
+int fe_update_batch(lsa_front_end *fe, size_t count, const float *const *d_scans, const size_t *n_points, float *poses_out, lsa_front_end_stats *stats) {
+  lsa_context *ctx = fe->ctx;
+  int rc;
+  if (!fe->cfg.use_frame_filter) {  // nothing to overlap
+    for (size_t k = 0; k < count; k++)
+      if ((rc = fe_update_device(fe, (const float4 *)d_scans[k], n_points[k], poses_out + 16 * k, stats ? stats + k : nullptr))) return rc;
+    return LSA_OK;
+  }
+  if (!fe->ctx_b) {
+    if ((rc = lsa_context_create(&fe->ctx_b, ctx->device, nullptr))) return lsa_fail(ctx, rc, "lsa_front_end_update_batch_device: second context: %s", lsa_last_global_error());
+    if ((rc = lsa_voxel_filter_create(&fe->frame_filter_b, fe->ctx_b, fe->cfg.frame_leaf[0], fe->cfg.frame_leaf[1], fe->cfg.frame_leaf[2]))) return rc;
+  }
+  size_t n_max = 1;
+  for (size_t k = 0; k < count; k++) n_max = std::max(n_max, n_points[k]);
+  // before the reserves (they may free a buffer): neither stream may still read the old ones
+  if (fe->d_batch[0].cap < n_max) {
+    LSA_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    LSA_HIP(ctx, hipStreamSynchronize(fe->ctx_b->stream));
+    for (int b = 0; b < 3; b++)
+      if ((rc = fe->d_batch[b].reserve(ctx, n_max, 1.25))) return rc;
+  }
+  lsa_voxel_filter *ff = fe->frame_filter_b;
+  // the scans were produced on the caller's stream = this context's (lidar_slam_amd.h): the second stream starts behind it
+  LSA_HIP(ctx, hipEventRecord(ctx->ev1, ctx->stream));
+  LSA_HIP(ctx, hipStreamWaitEvent(fe->ctx_b->stream, ctx->ev1, 0));
+  if ((rc = lsa_voxel_filter_apply_device_async_here(ff, d_scans[0], n_points[0], (float *)fe->d_batch[0].p))) return lsa_fail(ctx, rc, "%s", lsa_last_error(fe->ctx_b));
+  const bool carry_user = ndt_carry_scope(fe->ndt, true);
+  const bool defer_user = ndt_defer_scope(fe->ndt, true);
+  struct Restore {
+    lsa_ndt *h; bool prev, prev_defer;
+    ~Restore() { (void)ndt_collect_deferred(h); (void)ndt_defer_scope(h, prev_defer); (void)ndt_carry_scope(h, prev); if (!prev) ndt_release_parked(h); }
+  } restore{fe->ndt, carry_user, defer_user};
+  lsa_front_end_stats local;
+  for (size_t k = 0; k < count; k++) {
+    size_t m = 0;
+    rc = lsa_voxel_filter_wait(ff, &m);
+    const float4 *src = fe->d_batch[k % 3].p;
+    if (rc == LSA_ERR_RANGE) { src = (const float4 *)d_scans[k]; m = n_points[k]; rc = LSA_OK; }   // PCL passes the input through
+    if (rc) return lsa_fail(ctx, rc, "%s", lsa_last_error(fe->ctx_b));
+    if (k + 1 < count && (rc = lsa_voxel_filter_apply_device_async(ff, d_scans[k + 1], n_points[k + 1], (float *)fe->d_batch[(k + 1) % 3].p)))
+      return lsa_fail(ctx, rc, "%s", lsa_last_error(fe->ctx_b));
+    rc = fe_update_filtered(fe, (const float4 *)d_scans[k], n_points[k], src, m, poses_out + 16 * k, stats ? stats + k : &local, true);
+    if (!stats && (rc == LSA_OK)) rc = ndt_collect_deferred(fe->ndt);   // (`local` is about to be reused)
+    if (rc) {  // leave no filter in flight behind an error
+      if (k + 1 < count) { size_t dummy; (void)lsa_voxel_filter_wait(ff, &dummy); }
+      return rc;
     }
   }
-  fe->frames_seen++;
-  st.local_map_frames = (int32_t)fe->frames.size();
-  st.local_map_points = (int64_t)fe->map_points;
-  st.target_points = (int64_t)fe->target_points;
-  if (stats) *stats = st;
   return LSA_OK;
 }
 }  // namespace
@@ -379,6 +458,10 @@ extern "C" void lsa_front_end_destroy(lsa_front_end *fe) {
   lsa_voxel_filter_destroy(fe->frame_filter);
   lsa_voxel_filter_destroy(fe->map_filter);
   lsa_ndt_destroy(fe->ndt);
+  if (fe->ctx_b) (void)hipStreamSynchronize(fe->ctx_b->stream);
+  lsa_voxel_filter_destroy(fe->frame_filter_b);
+  for (int b = 0; b < 3; b++) fe->d_batch[b].release();
+  if (fe->ctx_b) lsa_context_destroy(fe->ctx_b);
   delete fe;
 }
 
@@ -392,6 +475,16 @@ extern "C" int lsa_front_end_update_device(lsa_front_end *fe, const float *d_xyz
   if (!fe || !pose_out || (n && !d_xyzw)) return fe ? lsa_fail(fe->ctx, LSA_ERR_INVALID, "lsa_front_end_update_device: null argument") : LSA_ERR_INVALID;
   LSA_HIP(fe->ctx, lsa_enter(fe->ctx));
   return fe_update_device(fe, (const float4 *)d_xyzw, n, pose_out, stats);
+}
+
+extern "C" int lsa_front_end_update_batch_device(lsa_front_end *fe, size_t count, const float *const *d_scans_xyzw, const size_t *n_points, float *poses_out,
+                                                 lsa_front_end_stats *stats) {
+  if (!fe || (count && (!d_scans_xyzw || !n_points || !poses_out))) return fe ? lsa_fail(fe->ctx, LSA_ERR_INVALID, "lsa_front_end_update_batch_device: null argument") : LSA_ERR_INVALID;
+  for (size_t k = 0; k < count; k++)
+    if (n_points[k] && !d_scans_xyzw[k]) return lsa_fail(fe->ctx, LSA_ERR_INVALID, "lsa_front_end_update_batch_device: scan %zu is null", k);
+  if (count == 0) return LSA_OK;
+  LSA_HIP(fe->ctx, lsa_enter(fe->ctx));
+  return fe_update_batch(fe, count, d_scans_xyzw, n_points, poses_out, stats);
 }
 
 extern "C" int lsa_front_end_update(lsa_front_end *fe, const void *cloud, size_t n, size_t stride, size_t w_off, float pose_out[16],

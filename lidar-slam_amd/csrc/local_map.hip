@@ -16,6 +16,8 @@
 //                           dirty counters.
 #include "local_map.h"
 
+#include <chrono>
+
 #include "ndt_cell_dev.h"
 
 namespace {
@@ -728,8 +730,13 @@ int lm_check(LocalMap &lm) {
   if (!lm.pending) return 0;
   const LmStatus &s = *lm.h_status.p;
   if (__atomic_load_n(&lm.h_status.p->epoch, __ATOMIC_ACQUIRE) != lm.epoch) {
-    // the caller's ordering guarantee did not hold (it should): make sure
-    (void)hipStreamSynchronize(lm.ctx->stream);
+    // The update is still running (a batch of Updates filters on another stream, so nothing has ordered the host behind it):
+    // its last kernel writes the epoch, ~60 us after the key-frame.  Past any plausible run time: ask the runtime.
+    const auto t0 = std::chrono::steady_clock::now();
+    while (__atomic_load_n(&lm.h_status.p->epoch, __ATOMIC_ACQUIRE) != lm.epoch) {
+      __builtin_ia32_pause();
+      if (std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(5)) { (void)hipStreamSynchronize(lm.ctx->stream); break; }
+    }
   }
   lm.pending = false;
   if (s.overflow) return 2;

@@ -61,6 +61,8 @@ class FrontEndHip:
         L.lsa_front_end_set_init_pose.argtypes = [C.c_void_p, C.POINTER(C.c_float)]
         L.lsa_front_end_update.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, C.c_size_t, C.POINTER(C.c_float), C.POINTER(FrontEndStats)]
         L.lsa_front_end_update_device.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.POINTER(C.c_float), C.POINTER(FrontEndStats)]
+        L.lsa_front_end_update_batch_device.argtypes = [C.c_void_p, C.c_size_t, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t), C.POINTER(C.c_float),
+                                                        C.POINTER(FrontEndStats)]
         L.lsa_front_end_registration.argtypes = [C.c_void_p]
         L.lsa_front_end_registration.restype = C.c_void_p
         L.lsa_front_end_set_incremental.argtypes = [C.c_void_p, C.c_int]
@@ -95,6 +97,25 @@ class FrontEndHip:
         self.last_stats = dict(key_frame=st.key_frame, local_map_frames=st.local_map_frames, filtered_points=st.filtered_points,
                                local_map_points=st.local_map_points, target_points=st.target_points, ndt=st.ndt.as_dict())
         return True, capi.from_colmajor(out)
+
+    def UpdateBatch(self, clouds):  # noqa: N802
+        """A run of scans (CUDA float32 tensors (n, 4)) through Update in ONE library call with the next scan's frame filter
+        overlapped (lsa_front_end_update_batch_device).  Returns (poses [count, 4, 4], list of per-scan stats dicts)."""
+        from .registration import check_points_tensor
+        count = len(clouds)
+        for c in clouds:
+            check_points_tensor(c, "FrontEnd.UpdateBatch")
+        self._keep = list(clouds)
+        ptrs = (C.c_void_p * max(count, 1))(*[c.data_ptr() for c in clouds])
+        ns = (C.c_size_t * max(count, 1))(*[c.shape[0] for c in clouds])
+        out = np.zeros((max(count, 1), 16), dtype=np.float32)
+        st = (FrontEndStats * max(count, 1))()
+        self.ctx.check(capi.lib().lsa_front_end_update_batch_device(self.h, count, ptrs, ns, capi.fptr(out), st))
+        stats = [dict(key_frame=s.key_frame, local_map_frames=s.local_map_frames, filtered_points=s.filtered_points,
+                      local_map_points=s.local_map_points, target_points=s.target_points, ndt=s.ndt.as_dict()) for s in st[:count]]
+        if count:
+            self.last_stats = stats[-1]
+        return np.stack([capi.from_colmajor(out[k]) for k in range(count)]) if count else np.zeros((0, 4, 4), np.float32), stats
 
     def set_incremental(self, on):
         """Incremental local map (default) or the full rebuild of filter output + voxel table on every key-frame."""

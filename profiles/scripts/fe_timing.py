@@ -35,3 +35,18 @@ for rep in range(4):
         rep, "incremental" if rep >= 2 else "full rebuild", kf.sum(), np.median(times[~kf][2:]), np.median(times[kf][1:]), times[1:].sum(), N - 1, (N - 1) / times[1:].sum() * 1e3, err,
         fe.last_stats["local_map_points"], fe.last_stats["target_points"]), flush=True)
     fe.close()
+# the same drive as ONE run of lsa_front_end_update_batch_device (next scan's frame filter overlapped, parked passes, deferred
+# final pass): twice, the second on warm buffers
+for rep in range(3):
+    fe = front_end.FrontEndHip(ctx)
+    fe.SetInitPose(poses[0].astype(np.float32))
+    fe.UpdateBatch(d_scans[:1])
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    Ts, sts = fe.UpdateBatch(d_scans[1:])
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    err = np.linalg.norm(Ts[-1][:3, 3] - poses[N - 1][:3, 3])
+    print("batch rep %d: %d scans in %.2f ms = %.0f scans/s (%d key-frames); end drift %.3f m; counters %s" % (
+        rep, N - 1, dt * 1e3, (N - 1) / dt, sum(s["key_frame"] for s in sts), err, fe.map_counters()), flush=True)
+    fe.close()

@@ -207,6 +207,68 @@ def test_incremental_local_map_equals_full_rebuild(scene):
     fe_i.close(); fe_f.close(); ctx_i.close(); ctx_f.close()
 
 
+def _flat(d, prefix=""):
+    """a stats dict (nested, with arrays) as a flat {name: tuple of floats / scalar} for exact comparison"""
+    out = {}
+    for k, v in d.items():
+        if isinstance(v, dict):
+            out.update(_flat(v, prefix + k + "."))
+        elif hasattr(v, "tolist"):
+            out[prefix + k] = tuple(np.asarray(v).ravel().tolist())
+        elif isinstance(v, (list, tuple)):
+            out[prefix + k] = tuple(v)
+        else:
+            out[prefix + k] = v
+    out.pop("ndt.gpu_ms", None)   # (a timing, not a result)
+    return out
+
+
+def test_update_batch_equals_single_updates(scene):
+    """lsa_front_end_update_batch_device (a run of scans in one call: next scan's frame filter on a second stream, next pass
+    parked between ScanMatches, final derivative pass collected late) against the same scans through single Updates: the bar is
+    BITS — poses, key-frame decisions, every statistic, and the incremental map's table after the run.  The drive covers the
+    first frame, the unfiltered phase, the switch to the filtered map, evictions; the batch is cut into runs of uneven length
+    (1, 2, 7, ...) so that a run starts and ends in every phase, and single Updates are mixed in between the runs."""
+    import torch
+    N = 44
+    poses = synth.trajectory(N, step=1.1)
+    scans = [synth.gen_scan(scene, poses[i], seed=1200 + i, beams=32, az_steps=900) for i in range(N)]
+    cfg = front_end.default_config()
+    cfg.local_frame_num = 12
+    ctx_b, ctx_s = capi.Context(0), capi.Context(0)
+    fe_b = front_end.FrontEndHip(ctx_b, cfg)
+    fe_s = front_end.FrontEndHip(ctx_s, cfg)
+    d = [torch.from_numpy(np.ascontiguousarray(s)).cuda() for s in scans]
+    torch.cuda.synchronize()
+    ref_T, ref_st = [], []
+    for i in range(N):
+        _, T = fe_s.Update(d[i])
+        ref_T.append(T); ref_st.append(fe_s.last_stats)
+    cuts = [0, 1, 3, 10, 11, 12, 25, 26, 40, N]   # runs [0,1) [1,3) [3,10) single 10, single 11, [12,25) single 25, [26,40) [40,N)
+    got_T, got_st = [], []
+    for a, b in zip(cuts[:-1], cuts[1:]):
+        if b - a == 1 and a in (10, 11, 25):
+            _, T = fe_b.Update(d[a])
+            got_T.append(T); got_st.append(fe_b.last_stats)
+        else:
+            Ts, sts = fe_b.UpdateBatch(d[a:b])
+            got_T += list(Ts); got_st += sts
+    assert len(got_T) == N
+    n_kf = 0
+    for i in range(N):
+        assert np.array_equal(got_T[i], ref_T[i]), (i, got_T[i] - ref_T[i])
+        assert _flat(got_st[i]) == _flat(ref_st[i]), (i, got_st[i], ref_st[i])
+        n_kf += ref_st[i]["key_frame"]
+    assert n_kf >= 18 and ref_st[-1]["local_map_frames"] == 12
+    assert ref_st[5]["ndt"]["iterations"] > 0 and ref_st[5]["ndt"]["score"] != 0
+    vb, vs = fe_b.map_verify(), fe_s.map_verify()
+    assert vb["mismatches"] == 0 and vb == vs, (vb, vs)
+    # an empty run is a no-op; a run after it continues the drive
+    Ts, sts = fe_b.UpdateBatch([])
+    assert Ts.shape == (0, 4, 4) and sts == []
+    fe_b.close(); fe_s.close(); ctx_b.close(); ctx_s.close()
+
+
 def test_kitti_directory_example(scene, tmp_path):
     """examples/run_kitti_odometry.py end to end: KITTI-format .bin files in a directory -> front end -> poses file in the
     KITTI odometry format; the trajectory matches the drive the scans were generated on."""
