@@ -521,6 +521,39 @@ def main():
 
     # ---- a second, KITTI-residential-shaped workload through the same pipeline (workloads.dense_dataset: front gardens, hedges,
     # trees with volumetric crowns, second-row buildings; 100 m range): brackets the headline's bare street.  Extra key, rank 0.
+    def front_end_drive(lsa_fe, ctx, d_all, poses_drive):
+        """The drive through FrontEnd::Update twice over: scan by scan (one library call per scan, nothing overlapped between
+        scans), and as ONE run of lsa_front_end_update_batch_device (next scan's frame filter on a second stream).  Same poses,
+        bit for bit, asserted here."""
+        import torch
+        for _rep in range(2):   # the first drive sizes every buffer
+            fe = lsa_fe.FrontEndHip(ctx)
+            fe.SetInitPose(poses_drive[0].astype(np.float32))
+            n_kf = 0
+            t0 = time.perf_counter()
+            for d_one in d_all:
+                _, T_fe = fe.Update(d_one)
+                n_kf += int(fe.last_stats["key_frame"])
+            torch.cuda.synchronize()
+            dt_fe = time.perf_counter() - t0
+            cnt_fe = fe.map_counters()
+            fe.close()
+        for _rep in range(2):
+            fe = lsa_fe.FrontEndHip(ctx)
+            fe.SetInitPose(poses_drive[0].astype(np.float32))
+            t0 = time.perf_counter()
+            T_b, st_b = fe.UpdateBatch(d_all)
+            torch.cuda.synchronize()
+            dt_b = time.perf_counter() - t0
+            fe.close()
+        if not np.array_equal(T_b[-1], T_fe) or sum(int(x["key_frame"]) for x in st_b) != n_kf:
+            raise RuntimeError("front end: the batch run and the scan-by-scan run disagree")
+        return {"scans": len(d_all), "key_frames": n_kf, "value": round(len(d_all) / dt_fe, 1), "unit": "scans/s",
+                "ms_per_scan": round(dt_fe / len(d_all) * 1e3, 4),
+                "one_run": {"value": round(len(d_all) / dt_b, 1), "unit": "scans/s", "ms_per_scan": round(dt_b / len(d_all) * 1e3, 4),
+                            "what": "the same drive as one lsa_front_end_update_batch_device call; final pose identical to the scan-by-scan run"},
+                "end_drift_m": round(float(np.linalg.norm(T_fe[:3, 3] - poses_drive[len(d_all) - 1][:3, 3])), 4), "local_map": cnt_fe}
+
     def second_workload(label, poses_d, scans_d, keyframes, tests, with_oracle=False, with_front_end=False):
         """Another scene through the same Filter -> ScanMatch pipeline: local map of `keyframes` (filtered at 0.3 m), the `tests`
         scans with the constant-velocity guess + prediction error of the headline."""
@@ -600,21 +633,7 @@ def main():
             from lidar_slam_amd import front_end as lsa_fe
             d_all = [torch.from_numpy(np.ascontiguousarray(sc)).to(dev) for sc in scans_d]
             torch.cuda.synchronize()
-            for _rep in range(2):
-                fe = lsa_fe.FrontEndHip(ctx)
-                fe.SetInitPose(poses_d[0].astype(np.float32))
-                n_kf = 0
-                t0 = time.perf_counter()
-                for d_one in d_all:
-                    _, T_fe = fe.Update(d_one)
-                    n_kf += int(fe.last_stats["key_frame"])
-                torch.cuda.synchronize()
-                dt_fe = time.perf_counter() - t0
-                cnt_fe = fe.map_counters()
-                fe.close()
-            key["front_end_loop"] = {"scans": len(d_all), "key_frames": n_kf, "value": round(len(d_all) / dt_fe, 1), "unit": "scans/s",
-                                     "ms_per_scan": round(dt_fe / len(d_all) * 1e3, 4),
-                                     "end_drift_m": round(float(np.linalg.norm(T_fe[:3, 3] - poses_d[len(d_all) - 1][:3, 3])), 4), "local_map": cnt_fe}
+            key["front_end_loop"] = front_end_drive(lsa_fe, ctx, d_all, poses_d)
             del d_all
         ndt_d.close()
         del d_sc, d_map_d
@@ -784,21 +803,8 @@ def main():
         from lidar_slam_amd import front_end as lsa_fe
         d_all = [torch.from_numpy(np.ascontiguousarray(sc)).to(dev) for sc in scans]
         torch.cuda.synchronize()
-        for _rep in range(2):   # the first drive sizes every buffer
-            fe = lsa_fe.FrontEndHip(ctx)
-            fe.SetInitPose(poses[0].astype(np.float32))
-            n_kf = 0
-            t0 = time.perf_counter()
-            for d_sc in d_all:
-                _, T_fe = fe.Update(d_sc)
-                n_kf += int(fe.last_stats["key_frame"])
-            torch.cuda.synchronize()
-            dt_fe = time.perf_counter() - t0
-            drift = float(np.linalg.norm(T_fe[:3, 3] - poses[len(d_all) - 1][:3, 3]))
-            fe.close()
-        front_end_loop = {"scans": len(d_all), "key_frames": n_kf, "value": round(len(d_all) / dt_fe, 1), "unit": "scans/s",
-                          "ms_per_scan": round(dt_fe / len(d_all) * 1e3, 4), "end_drift_m": round(drift, 4),
-                          "note": "device-resident FrontEnd::Update loop incl. key-frame work (local map of <= 20 key-frames, 0.3 m map filter, voxel table)"}
+        front_end_loop = front_end_drive(lsa_fe, ctx, d_all, poses)
+        front_end_loop["note"] = "device-resident FrontEnd::Update loop incl. key-frame work (local map of <= 20 key-frames, 0.3 m map filter, voxel table)"
         del d_all
 
     # ---- BASELINE.json configs[2]: point-to-plane ICP (the second RegistrationInterface plugin, lsa_icp_* in its point-to-plane

@@ -442,7 +442,7 @@ int lsa_front_end_update(lsa_front_end *fe, const void *cloud, size_t n, size_t 
                          lsa_front_end_stats *stats);
 int lsa_front_end_update_device(lsa_front_end *fe, const float *d_xyzw, size_t n, float pose_out[16], lsa_front_end_stats *stats);
 /* `count` Updates in one call — a recorded drive being replayed, or a sensor queue that has backed up: the loop
- * front_end_flow.cpp:44-66 runs over its cloud_data_buff_ (while (HasData()) { ValidData(); UpdateLaserOdometry(); }).  The
+ * front_end_flow.cpp:18-36 runs over its cloud_data_buff_ (while (HasData()) { ValidData(); UpdateLaserOdometry(); }).  The
  * frame filter of scan k + 1 runs on a second stream while scan k is registered and the local map updated (it needs no pose);
  * within the call the next pass's kernel stays parked between two ScanMatches and a ScanMatch's final derivative pass, which
  * only completes its statistics, is collected behind the next scan's first pass (as in lsa_pipeline_scan_match).  Poses,
