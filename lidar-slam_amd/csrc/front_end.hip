@@ -218,6 +218,7 @@ int fe_lm_settle(lsa_front_end *fe) {
   if (!fe->cfg.use_frame_filter) (void)hipStreamSynchronize(fe->ctx->stream);   // (nothing else ordered the host behind the update)
   const int c = lm_check(fe->lm);
   if (fe->lm.filtered && fe->lm_adopted) fe->target_points = (size_t)(fe->lm.h_status.p->live_f > 0 ? fe->lm.h_status.p->live_f : 0);
+  if (c) lsa_ctx_unpark(fe->ctx);   // (inside a batch the next pass's kernel is already parked: the repair goes in front of its successor)
   if (c == 2) return fe_lm_rebuild(fe, fe->lm.filtered);
   if (c == 1) {
     int rc = lm_refit_window(fe->lm);
