@@ -52,6 +52,7 @@ struct IcpParams {
   float T[12];   // row-major 3x4 current pose
   float gate;    // max_correspond_distance_ compared with the SQUARED distance (sic)
   int use_coarse;  // iterations after the first, when the coarse grid exists: far queries search it
+  int allow_skip;  // iterations after the first: a query whose old neighbour is provably still the answer does not search
 };
 
 // original index -> slot of the fine grid's cell-sorted array
@@ -64,26 +65,55 @@ __global__ __launch_bounds__(kBlock) void k_slot_of_id(const float4 *__restrict_
 // iteration is farther than a fine cell — or that had none — searches the COARSE grid (one phased step covers the gate); the
 // others the fine one.  ONE call site: the grid is selected per lane (a second inlined instance of the ring search next to the 27
 // f64 accumulators spills).
-__device__ __forceinline__ NNHit icp_search(const NNView &Gf, const NNView &Gc, const unsigned *__restrict__ slot_of_id, int use_coarse, float qx, float qy,
-                                            float qz, int sub, float gate, unsigned seed_slot) {
+//
+// SKIPPED searches.  ICPRegistrationManual runs a fixed 30 iterations and the pose stops moving long before the last one; a
+// query then asks for the neighbour it already has.  Every search therefore leaves, beside the neighbour, a PROOF RADIUS: the
+// query's position q_ref and a lower bound D on the distance from q_ref to every OTHER target point (the runner-up among the
+// points it visited, or the radius of the sphere it covered — the search looks kSkipWiden farther than the answer alone needs,
+// nn_nearest_sub<.., TRACK>).  One iteration later the query sits at q, m = |q - q_ref| away; every other point is at least D - m
+// from it, so when the old neighbour is still closer than that — by a margin far above the f32 rounding of the distances — it
+// IS the exact nearest neighbour (strictly: no tie can arise) and no cell is looked at.  Likewise a query that had nothing
+// within the gate has nothing within it now while D - m stays beyond the gate.  The answer is the one the full search returns;
+// `LSA_ICP_NO_SKIP=1` runs every search for the A/B (tests/test_gpu_icp_fitness.py).
+constexpr float kSkipWiden = 0.10f;
+struct IcpQueryState {
+  unsigned prev;   // cell-sorted slot of the neighbour found last (0xffffffff: none)
+  float4 ref;      // xyz: the query's position when it last SEARCHED, w: the proof radius D
+};
+__device__ __forceinline__ NNHit icp_search(const NNView &Gf, const NNView &Gc, const unsigned *__restrict__ slot_of_id, int use_coarse, int allow_skip,
+                                            float qx, float qy, float qz, int sub, float gate, IcpQueryState &st, bool *searched) {
   NNHit seed;
   seed.d2 = INFINITY; seed.id = 0xffffffffu; seed.x = seed.y = seed.z = 0.0f; seed.slot = 0u;
+  const unsigned seed_slot = st.prev;
   if (seed_slot < Gf.n_sorted) {
     const float4 t = Gf.sorted[seed_slot];
     const float ex = lsa_fsub(qx, t.x), ey = lsa_fsub(qy, t.y), ez = lsa_fsub(qz, t.z);
     seed.d2 = lsa_fadd(lsa_fadd(lsa_fmul(ex, ex), lsa_fmul(ey, ey)), lsa_fmul(ez, ez));
     seed.id = __float_as_uint(t.w); seed.x = t.x; seed.y = t.y; seed.z = t.z; seed.slot = seed_slot;
   }
+  *searched = false;
+  if (allow_skip) {
+    const float mx = qx - st.ref.x, my = qy - st.ref.y, mz = qz - st.ref.z;
+    // the old bound carried to the new position, less a margin of 1 mm + 2^-18 of the coordinates' magnitude (an f32 distance
+    // between points of this magnitude is off by ~2^-22 of it)
+    const float lb = st.ref.w - sqrtf(mx * mx + my * my + mz * mz) - (1.0e-3f + 3.8e-6f * (fabsf(qx) + fabsf(qy) + fabsf(qz)));
+    if (seed.id != 0xffffffffu && sqrtf(seed.d2) < lb) return seed;              // still the nearest, and alone at that distance
+    if ((seed.id == 0xffffffffu || seed.d2 > gate) && lb * lb > gate && lb > 0.0f) return seed;   // nothing within the gate (the caller drops the pair)
+  }
+  *searched = true;
   const bool far = use_coarse && !(seed.d2 <= Gf.cell * Gf.cell);   // (no seed: d2 = inf -> far)
   NNView G = Gf;
   if (far) G = Gc;
-  NNHit hit = nn_nearest_sub<kSub>(G, qx, qy, qz, far ? 2 : kGateRings, sub, gate, 0xffffffffu, &seed);
-  if (far && hit.id != 0xffffffffu) hit.slot = slot_of_id[hit.id];
+  float others = 0.0f;
+  NNHit hit = nn_nearest_sub<kSub, true>(G, qx, qy, qz, far ? 2 : kGateRings, sub, gate, 0xffffffffu, &seed, kSkipWiden, &others);
+  if (far && hit.id != 0xffffffffu && hit.id != seed.id) hit.slot = slot_of_id[hit.id];
+  st.prev = hit.id == 0xffffffffu ? 0xffffffffu : hit.slot;
+  st.ref = make_float4(qx, qy, qz, others);
   return hit;
 }
 
 __global__ __launch_bounds__(kBlock) void k_icp_pass(const float4 *__restrict__ src, size_t n, IcpParams P, NNView G, NNView Gc, const unsigned *__restrict__ slot_of_id,
-                                                     unsigned *__restrict__ prev, double *__restrict__ partials, unsigned long long key) {
+                                                     unsigned *__restrict__ prev, float4 *__restrict__ qref, double *__restrict__ partials, unsigned long long key) {
   double acc[27];
 #pragma unroll
   for (int k = 0; k < 27; k++) acc[k] = 0.0;
@@ -97,8 +127,12 @@ __global__ __launch_bounds__(kBlock) void k_icp_pass(const float4 *__restrict__ 
     float qy = lsa_fadd(lsa_fadd(lsa_fadd(lsa_fmul(P.T[4], s.x), lsa_fmul(P.T[5], s.y)), lsa_fmul(P.T[6], s.z)), P.T[7]);
     float qz = lsa_fadd(lsa_fadd(lsa_fadd(lsa_fmul(P.T[8], s.x), lsa_fmul(P.T[9], s.y)), lsa_fmul(P.T[10], s.z)), P.T[11]);
     if (!lsa_finite3(qx, qy, qz)) continue;
-    NNHit hit = icp_search(G, Gc, slot_of_id, P.use_coarse, qx, qy, qz, sub, P.gate, prev[i]);
-    if (sub == 0) prev[i] = hit.id == 0xffffffffu ? 0xffffffffu : hit.slot;  // next iteration's seed (all kSub lanes have read theirs)
+    IcpQueryState st;
+    st.prev = prev[i];
+    st.ref = P.allow_skip ? qref[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+    bool searched;
+    NNHit hit = icp_search(G, Gc, slot_of_id, P.use_coarse, P.allow_skip, qx, qy, qz, sub, P.gate, st, &searched);
+    if (sub == 0 && searched) { prev[i] = st.prev; qref[i] = st.ref; }  // next iteration's seed and proof (all kSub lanes have read theirs)
     if (sub != 0) continue;  // lane 0 of the group carries the point into the sums
     float best = hit.d2, bx = hit.x, by = hit.y, bz = hit.z;
     unsigned best_id = hit.id;
@@ -200,7 +234,7 @@ __global__ __launch_bounds__(kBlock) void k_slot_normals(const float4 *__restric
 
 // out32: [1..6] B = -sum J r, [7..27] H = sum J^T J upper triangle, [28] #pairs, [29] #finite source points
 __global__ __launch_bounds__(kBlock) void k_plane_pass(const float4 *__restrict__ src, size_t n, IcpParams P, NNView G, NNView Gc, const unsigned *__restrict__ slot_of_id,
-                                                       unsigned *__restrict__ prev, const float4 *__restrict__ slot_normals,
+                                                       unsigned *__restrict__ prev, float4 *__restrict__ qref, const float4 *__restrict__ slot_normals,
                                                        double *__restrict__ partials, unsigned long long key) {
   double acc[27];
 #pragma unroll
@@ -215,8 +249,12 @@ __global__ __launch_bounds__(kBlock) void k_plane_pass(const float4 *__restrict_
     float qy = lsa_fadd(lsa_fadd(lsa_fadd(lsa_fmul(P.T[4], s.x), lsa_fmul(P.T[5], s.y)), lsa_fmul(P.T[6], s.z)), P.T[7]);
     float qz = lsa_fadd(lsa_fadd(lsa_fadd(lsa_fmul(P.T[8], s.x), lsa_fmul(P.T[9], s.y)), lsa_fmul(P.T[10], s.z)), P.T[11]);
     if (!lsa_finite3(qx, qy, qz)) continue;
-    NNHit hit = icp_search(G, Gc, slot_of_id, P.use_coarse, qx, qy, qz, sub, P.gate, prev[i]);
-    if (sub == 0) prev[i] = hit.id == 0xffffffffu ? 0xffffffffu : hit.slot;  // next iteration's seed (all kSub lanes have read theirs)
+    IcpQueryState st;
+    st.prev = prev[i];
+    st.ref = P.allow_skip ? qref[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+    bool searched;
+    NNHit hit = icp_search(G, Gc, slot_of_id, P.use_coarse, P.allow_skip, qx, qy, qz, sub, P.gate, st, &searched);
+    if (sub == 0 && searched) { prev[i] = st.prev; qref[i] = st.ref; }  // next iteration's seed and proof (all kSub lanes have read theirs)
     if (sub != 0) continue;  // lane 0 of the group carries the point into the sums
     if (hit.id == 0xffffffffu || hit.d2 > P.gate) continue;  // P.gate = max_correspond_dis^2 in this mode
     float4 nv = slot_normals[hit.slot];
@@ -409,6 +447,8 @@ struct lsa_icp {
   NNGrid grid_c;
   DevBuf<unsigned> slot_of_id;
   bool no_coarse = getenv("LSA_ICP_NO_COARSE") != nullptr;
+  bool no_skip = getenv("LSA_ICP_NO_SKIP") != nullptr;
+  DevBuf<float4> qref;    // per source point: where it last searched and how far every other target point was (icp_search)
   VoxelIndex vi_n;                                  // plane mode: voxel grid the normals come from
   DevBuf<float4> cell_normals, slot_normals;        // per occupied voxel / per cell-sorted target point
   float normal_leaf = 1.0f;
@@ -550,6 +590,7 @@ int icp_match_manual(lsa_icp *h, const float4 *d_src, size_t n, const float pred
   if ((rc = h->h_out.reserve(ctx, kOut))) return rc;
   if ((rc = h->h_partials.reserve(ctx, (size_t)kHostRows * kOut))) return rc;
   if ((rc = h->prev.reserve(ctx, n ? n : 1, 1.25))) return rc;
+  if ((rc = h->qref.reserve(ctx, n ? n : 1, 1.25))) return rc;
   LSA_HIP(ctx, hipMemsetAsync(h->prev.p, 0xff, (n ? n : 1) * sizeof(unsigned), ctx->stream));  // no seeds: the first iteration searches cold
   NNView G = nn_view(h->grid);
   const bool coarse = h->grid_c.built && h->grid_c.use_dense && h->slot_of_id.p;
@@ -557,16 +598,17 @@ int icp_match_manual(lsa_icp *h, const float4 *d_src, size_t n, const float pred
   for (int it = 0; it < h->max_iter; it++) {
     IcpParams P;
     P.use_coarse = (coarse && it > 0) ? 1 : 0;   // the first iteration searches cold: no seed says who is far
+    P.allow_skip = (!h->no_skip && it > 0) ? 1 : 0;   // ... and leaves every query's proof radius
     for (int r = 0; r < 3; r++) {
       for (int c = 0; c < 3; c++) P.T[r * 4 + c] = R[r * 3 + c];
       P.T[r * 4 + 3] = t[r];
     }
     if (h->mode == LSA_ICP_MODE_PLANE) {
       P.gate = h->max_corr * h->max_corr;
-      hipLaunchKernelGGL(k_plane_pass, dim3(g), dim3(kBlock), 0, ctx->stream, d_src, n, P, G, Gc, h->slot_of_id.p, h->prev.p, h->slot_normals.p, icp_partials_dst(h, g), icp_next_key(h, g));
+      hipLaunchKernelGGL(k_plane_pass, dim3(g), dim3(kBlock), 0, ctx->stream, d_src, n, P, G, Gc, h->slot_of_id.p, h->prev.p, h->qref.p, h->slot_normals.p, icp_partials_dst(h, g), icp_next_key(h, g));
     } else {
       P.gate = h->max_corr;
-      hipLaunchKernelGGL(k_icp_pass, dim3(g), dim3(kBlock), 0, ctx->stream, d_src, n, P, G, Gc, h->slot_of_id.p, h->prev.p, icp_partials_dst(h, g), icp_next_key(h, g));
+      hipLaunchKernelGGL(k_icp_pass, dim3(g), dim3(kBlock), 0, ctx->stream, d_src, n, P, G, Gc, h->slot_of_id.p, h->prev.p, h->qref.p, icp_partials_dst(h, g), icp_next_key(h, g));
     }
     if ((rc = icp_fetch_sums(h, g))) return rc;
     const double *o = h->h_out.p;
@@ -789,7 +831,7 @@ extern "C" void lsa_icp_destroy(lsa_icp *h) {
   (void)lsa_enter(h->ctx);
   (void)hipStreamSynchronize(h->ctx->stream);
   h->grid.release(); h->grid_c.release(); h->slot_of_id.release(); h->vi_n.release(); h->cell_normals.release(); h->slot_normals.release(); h->d_target.release(); h->d_source_own.release(); h->d_work.release();
-  h->partials.release(); h->d_out.release(); h->h_out.release(); h->h_partials.release(); h->h_stage.release(); h->prev.release();
+  h->partials.release(); h->d_out.release(); h->h_out.release(); h->h_partials.release(); h->h_stage.release(); h->prev.release(); h->qref.release();
   delete h;
 }
 

@@ -14,7 +14,9 @@ struct NNHit {
 
 // compare the query with the points sorted[a, b) of one cell.  Four points per step, their loads issued together: a cell
 // holds a handful of points and a load-compare-load chain would cost one memory round trip per point.
-__device__ __forceinline__ void nn_visit_range(const NNView &g, unsigned a, unsigned b, float qx, float qy, float qz, NNHit &h) {
+// TRACK: `sec` follows the smallest squared distance among the visited points OTHER than the best one (see nn_nearest_sub).
+template <bool TRACK = false>
+__device__ __forceinline__ void nn_visit_range(const NNView &g, unsigned a, unsigned b, float qx, float qy, float qz, NNHit &h, float &sec) {
   for (unsigned k0 = a; k0 < b; k0 += 4) {
     float4 t[4];
 #pragma unroll
@@ -25,22 +27,33 @@ __device__ __forceinline__ void nn_visit_range(const NNView &g, unsigned a, unsi
       float ex = lsa_fsub(qx, t[u].x), ey = lsa_fsub(qy, t[u].y), ez = lsa_fsub(qz, t[u].z);
       float d = lsa_fadd(lsa_fadd(lsa_fmul(ex, ex), lsa_fmul(ey, ey)), lsa_fmul(ez, ez));  // FLANN L2_Simple, f32
       unsigned id = __float_as_uint(t[u].w);
-      if (d < h.d2 || (d == h.d2 && id < h.id)) { h.d2 = d; h.id = id; h.x = t[u].x; h.y = t[u].y; h.z = t[u].z; h.slot = k0 + u; }
+      if (d < h.d2 || (d == h.d2 && id < h.id)) {
+        if (TRACK) sec = fminf(sec, h.d2);   // the best so far becomes a runner-up (+inf when there was none)
+        h.d2 = d; h.id = id; h.x = t[u].x; h.y = t[u].y; h.z = t[u].z; h.slot = k0 + u;
+      } else if (TRACK && id != h.id) {      // (the seed is met again in its cell: not a runner-up of itself)
+        sec = fminf(sec, d);
+      }
     }
   }
 }
+__device__ __forceinline__ void nn_visit_range(const NNView &g, unsigned a, unsigned b, float qx, float qy, float qz, NNHit &h) {
+  float unused = INFINITY;
+  nn_visit_range<false>(g, a, b, qx, qy, qz, h, unused);
+}
 
 // visit the points of one occupied cell given its bitmap word (already loaded)
-__device__ __forceinline__ void nn_visit_bit(const NNView &g, int cell, uint32_t w, float qx, float qy, float qz, NNHit &h) {
+template <bool TRACK = false>
+__device__ __forceinline__ void nn_visit_bit(const NNView &g, int cell, uint32_t w, float qx, float qy, float qz, NNHit &h, float &sec) {
   uint32_t bit = 1u << (cell & 31);
   unsigned rank = g.prefix[cell >> 5] + __popc(w & (bit - 1u));
-  nn_visit_range(g, g.start[rank], g.start[rank + 1], qx, qy, qz, h);
+  nn_visit_range<TRACK>(g, g.start[rank], g.start[rank + 1], qx, qy, qz, h, sec);
 }
 
 // visit the occupied cells among x in [xa, xb] (clipped by the caller) of row (iy, iz); only_ends: just xa and xb.
 // Cells of a row are consecutive bits, so an EMPTY stretch costs one or two bitmap words instead of a load per cell —
 // what a query with no neighbour nearby spends its time on.
-__device__ __forceinline__ void nn_visit_row(const NNView &g, int xa, int xb, int iy, int iz, bool only_ends, float qx, float qy, float qz, NNHit &h) {
+template <bool TRACK = false>
+__device__ __forceinline__ void nn_visit_row(const NNView &g, int xa, int xb, int iy, int iz, bool only_ends, float qx, float qy, float qz, NNHit &h, float &sec) {
   const CellMap &m = g.map;
   const int base = iy * m.dim[0] + iz * m.dim[0] * m.dim[1];
   const int ca = base + xa, cb = base + xb;
@@ -59,7 +72,7 @@ __device__ __forceinline__ void nn_visit_row(const NNView &g, int xa, int xb, in
     while (bitsel) {
       int b = __ffs(bitsel) - 1;
       bitsel &= bitsel - 1;
-      nn_visit_bit(g, (wi << 5) + b, w, qx, qy, qz, h);
+      nn_visit_bit<TRACK>(g, (wi << 5) + b, w, qx, qy, qz, h, sec);
     }
   }
 }
@@ -78,10 +91,24 @@ __device__ __forceinline__ void nn_visit_row(const NNView &g, int xa, int xb, in
 constexpr int kPhasedMaxRing = 2;
 // seed_hit (optional, instead of seed_slot): a hit the caller has already evaluated — e.g. against another grid over the same
 // points; its `slot` is passed through untouched unless a better point of THIS grid replaces it.
-template <int SUB>
+//
+// TRACK (ICP's search-skipping, icp.hip): inside the rings the search walks anyway, cells are ruled out against
+// min(gate, best) + `widen` metres instead of min(gate, best), and *others_lb receives a lower bound, in metres, of the distance
+// from the query to every target point other than the returned one: the runner-up among the visited points, the widened reach,
+// or the rings' own coverage, whichever is smallest.  The answer itself is the same point either way.
+template <int SUB, bool TRACK = false>
 __device__ __forceinline__ NNHit nn_nearest_sub(const NNView &g, float qx, float qy, float qz, int max_ring, int sub, float gate_d2 = INFINITY,
-                                                unsigned seed_slot = 0xffffffffu, const NNHit *seed_hit = nullptr) {
+                                                unsigned seed_slot = 0xffffffffu, const NNHit *seed_hit = nullptr, float widen = 0.0f,
+                                                float *others_lb = nullptr) {
   const CellMap &m = g.map;
+  float sec = INFINITY;
+  const float gate_r = TRACK ? sqrtf(gate_d2) : 0.0f;
+  // squared radius beyond which a cell cannot matter
+  auto reach2 = [&](float best_d2) -> float {
+    if (!TRACK) return fminf(gate_d2, best_d2);
+    const float r = fminf(gate_r, sqrtf(best_d2)) + widen;
+    return r * r;
+  };
   NNHit h;
   h.d2 = INFINITY; h.id = 0xffffffffu; h.x = h.y = h.z = 0.0f; h.slot = 0u;
   if (seed_hit) h = *seed_hit;
@@ -117,6 +144,8 @@ __device__ __forceinline__ NNHit nn_nearest_sub(const NNView &g, float qx, float
   int far0 = max(abs(c0), abs(m.dim[0] - 1 - c0)), far1 = max(abs(c1), abs(m.dim[1] - 1 - c1)), far2 = max(abs(c2), abs(m.dim[2] - 1 - c2));
   int rho_end = max(far0, max(far1, far2));  // last ring that touches the grid
   if (max_ring < rho_end) rho_end = max_ring;
+  // (no ring at all when the grid begins beyond max_ring: everything is at least rho0 - 1 + umin cells away)
+  float lb_last = rho0 > rho_end ? ((float)(rho0 - 1) + umin) * g.cell - kSlack : 0.0f;
   for (int rho = rho0; rho <= rho_end; rho++) {
     if (g.dense && rho <= kPhasedMaxRing) {
       // PHASED ring (dense per-cell {first slot, #points} table).  The lanes of a wave run in lockstep, so a loop that
@@ -136,7 +165,7 @@ __device__ __forceinline__ NNHit nn_nearest_sub(const NNView &g, float qx, float
       if (fused) rho = 1;          // ... and the highest; the termination test below then speaks for ring 1
       const int w = 2 * rho + 1, ww = w * w, ncube = ww * w;
       const float inv_w = 1.0f / (float)w, inv_ww = 1.0f / (float)ww;
-      const float bound2 = fminf(gate_d2, h.d2);  // fixed for the ring: conservative
+      const float bound2 = reach2(h.d2);  // fixed for the ring: conservative
       for (int base = 0; base < ncube; base += SUB * kSlots) {
         uint2 ent[kSlots];
 #pragma unroll
@@ -164,7 +193,7 @@ __device__ __forceinline__ NNHit nn_nearest_sub(const NNView &g, float qx, float
           uint2 e = ent[0];
 #pragma unroll
           for (int j = 1; j < kSlots; j++) e = (k == j) ? ent[j] : e;
-          nn_visit_range(g, e.x, e.x + e.y, qx, qy, qz, h);
+          nn_visit_range<TRACK>(g, e.x, e.x + e.y, qx, qy, qz, h, sec);
         }
       }
     } else {
@@ -175,7 +204,7 @@ __device__ __forceinline__ NNHit nn_nearest_sub(const NNView &g, float qx, float
       for (int iy = yc0; iy <= yc1; iy++) {
         if (SUB != 1 && ((turn++) & (SUB - 1)) != sub) continue;
         // lower bound of the distance from the query to this row / its cells (exact slab distances, see above)
-        const float bound2 = fminf(gate_d2, h.d2);
+        const float bound2 = reach2(h.d2);
         const float gy = iy > c1 ? (float)(iy - c1) - uy : (iy < c1 ? (float)(c1 - iy - 1) + uy : 0.0f);
         const float gz = iz > c2 ? (float)(iz - c2) - uz : (iz < c2 ? (float)(c2 - iz - 1) + uz : 0.0f);
         const float my = fmaxf(gy * g.cell - kSlack, 0.0f), mz = fmaxf(gz * g.cell - kSlack, 0.0f);
@@ -192,15 +221,15 @@ __device__ __forceinline__ NNHit nn_nearest_sub(const NNView &g, float qx, float
             xa = max(xc0, c0 - nl);
             xb = min(xc1, c0 + nr);
           }
-          if (xa <= xb) nn_visit_row(g, xa, xb, iy, iz, false, qx, qy, qz, h);
+          if (xa <= xb) nn_visit_row<TRACK>(g, xa, xb, iy, iz, false, qx, qy, qz, h, sec);
         } else {
           // an inner row contributes only the two end cells x0, x1 (when inside the grid and close enough)
           const float ml = fmaxf(((float)(rho - 1) + ux) * g.cell - kSlack, 0.0f), mr = fmaxf(((float)rho - ux) * g.cell - kSlack, 0.0f);
           const bool in0 = x0 >= 0 && x0 < m.dim[0] && ryz2 + ml * ml <= bound2;
           const bool in1 = x1 >= 0 && x1 < m.dim[0] && x1 != x0 && ryz2 + mr * mr <= bound2;
-          if (in0 && in1) nn_visit_row(g, x0, x1, iy, iz, true, qx, qy, qz, h);
-          else if (in0) nn_visit_row(g, x0, x0, iy, iz, true, qx, qy, qz, h);
-          else if (in1) nn_visit_row(g, x1, x1, iy, iz, true, qx, qy, qz, h);
+          if (in0 && in1) nn_visit_row<TRACK>(g, x0, x1, iy, iz, true, qx, qy, qz, h, sec);
+          else if (in0) nn_visit_row<TRACK>(g, x0, x0, iy, iz, true, qx, qy, qz, h, sec);
+          else if (in1) nn_visit_row<TRACK>(g, x1, x1, iy, iz, true, qx, qy, qz, h, sec);
         }
       }
     }
@@ -210,15 +239,27 @@ __device__ __forceinline__ NNHit nn_nearest_sub(const NNView &g, float qx, float
         NNHit o;
         o.d2 = __shfl_xor(h.d2, off, 64); o.id = __shfl_xor(h.id, off, 64);
         o.x = __shfl_xor(h.x, off, 64); o.y = __shfl_xor(h.y, off, 64); o.z = __shfl_xor(h.z, off, 64); o.slot = __shfl_xor(h.slot, off, 64);
+        if (TRACK) {  // the group's runner-up: either lane's, or the loser of the two bests when they are different points
+          const float osec = __shfl_xor(sec, off, 64);
+          sec = fminf(sec, osec);
+          if (o.id != h.id) sec = fminf(sec, fmaxf(o.d2, h.d2));
+        }
         if (o.d2 < h.d2 || (o.d2 == h.d2 && o.id < h.id)) h = o;
       }
     }
     // every cell not visited yet differs from the query's by more than rho along some axis, i.e. lies at least
     // (rho + umin) cells away
     float lb = ((float)rho + umin) * g.cell - kSlack;
+    if (TRACK) lb_last = lb;   // (the rings end where the answer is proven: `widen` never opens a ring of its own)
     if (h.id != 0xffffffffu && lb > 0.0f && h.d2 <= lb * lb) break;
     // ... and nothing farther than the gate is wanted at all
     if (lb > 0.0f && gate_d2 < lb * lb) break;
+  }
+  if (TRACK && others_lb) {
+    // a point that was not visited lies in a cell ruled out against the reach (at least the final one: the reach only
+    // shrinks), or beyond the last ring
+    const float reach = fminf(gate_r, sqrtf(h.d2)) + widen;
+    *others_lb = fminf(fminf(sqrtf(sec), reach), fmaxf(lb_last, 0.0f));
   }
   return h;
 }

@@ -17,5 +17,6 @@ for mode, name in ((capi.ICP_MODE_MANUAL, "manual"), (capi.ICP_MODE_PLANE, "plan
         for s, g in zip(srcs, guesses):
             torch.cuda.synchronize(); t0 = time.perf_counter(); _, T = icp.ScanMatch(s, g); ts.append(time.perf_counter() - t0)
             if rep == 0: Ts.append(T)
-    print(name, "coarse grid for far queries" if not os.environ.get("LSA_ICP_NO_COARSE") else "fine grid only", "median ms per 30-iteration ScanMatch %.4f" % (np.median(ts) * 1e3), "checksum %.9f" % float(sum(T.astype(np.float64).sum() for T in Ts)))
+    print(name, "coarse grid for far queries" if not os.environ.get("LSA_ICP_NO_COARSE") else "fine grid only",
+          "every search run" if os.environ.get("LSA_ICP_NO_SKIP") else "proven searches skipped", "median ms per 30-iteration ScanMatch %.4f" % (np.median(ts) * 1e3), "checksum %.9f" % float(sum(T.astype(np.float64).sum() for T in Ts)))
     icp.close()

@@ -252,6 +252,37 @@ def test_cfg3_bench_scans_match_oracle(ctx, oracle, cfg2):
     icp.close(); pl.close()
 
 
+def test_icp_skipped_searches_change_nothing(ctx, cfg2, monkeypatch):
+    """From the second ICP iteration on a query whose old neighbour is PROVABLY still the nearest (proof radius left by its last
+    search, csrc/icp.hip icp_search) does not search.  The bar is BITS against the build that runs every search
+    (LSA_ICP_NO_SKIP=1): final poses and correspondence counts of ICPMANUAL and point-to-plane on the nine bench scans — from the
+    bench's guess and from a guess 0.6 m / 2 deg off, where the pose keeps moving for many iterations and queries change
+    neighbours — and the normal equations after 1, 2, 3 and 7 iterations (a wrong neighbour anywhere would change the sums)."""
+    tgt8 = synth.to_xyzi32(cfg2["map_f"])
+    off = synth.pose_matrix(0.5, -0.3, 0.05, 0.004, -0.003, 0.035).astype(np.float32)
+    runs = {}
+    for label in ("skip", "full"):
+        if label == "full":
+            monkeypatch.setenv("LSA_ICP_NO_SKIP", "1")
+        out = []
+        for mode in (capi.ICP_MODE_MANUAL, capi.ICP_MODE_PLANE):
+            for iters in (30, 1, 2, 3, 7):
+                icp = registration.ICPRegistrationHip(ctx, 2.0, iters, mode=mode)
+                icp.SetInputTarget(tgt8)
+                for k, (src, guess) in enumerate(zip(cfg2["srcs"], cfg2["guesses"])):
+                    if iters != 30 and k > 2:
+                        break
+                    s8 = synth.to_xyzi32(src)
+                    for g in (guess, (guess @ off).astype(np.float32)):
+                        _, T = icp.ScanMatch(s8, g)
+                        out.append((T.copy(), int(icp.last_stats["correspondences"])))
+                icp.close()
+        runs[label] = out
+    assert len(runs["skip"]) == len(runs["full"]) > 40
+    for i, ((Ta, ca), (Tb, cb)) in enumerate(zip(runs["skip"], runs["full"])):
+        assert ca == cb and np.array_equal(Ta, Tb), (i, ca, cb, Ta - Tb)
+
+
 # --------------------------------------------------------------------------------------------- cfg4 (BASELINE.json configs[3])
 @pytest.fixture(scope="module")
 def cfg4(cfg2):
