@@ -390,6 +390,15 @@ int lsa_icp_create(lsa_icp **out, lsa_context *ctx, float max_correspond_dis, in
 /* ICPRegistration::SetRegistrationParam's setEuclideanFitnessEpsilon / setTransformationEpsilon (icp_registration.cpp:30-33) */
 int lsa_icp_set_criteria(lsa_icp *icp, float euclid_eps, float trans_eps);
 int lsa_icp_get_stats(lsa_icp *icp, lsa_icp_stats *stats);
+/* ICPMANUAL / point-to-plane modes, last ScanMatch: from the second iteration on a source point whose old neighbour is provably
+ * still the nearest does not search (csrc/icp.hip; LSA_ICP_NO_SKIP=1 runs every search, same results).  searches / queries:
+ * totals over the iterations; per_iteration[i] (up to cap entries, *n_iterations of them exist): source points that searched in
+ * iteration i.  Any pointer may be NULL. */
+int lsa_icp_search_counts(lsa_icp *icp, uint64_t *searches, uint64_t *queries, uint32_t *per_iteration, size_t cap, size_t *n_iterations);
+/* diagnostics: the per-source-point search state of the last ScanMatch, copied to the host — prev_out[i]: position of point i's
+ * neighbour in the handle's cell-sorted target (0xffffffff: none); qref_out[4 i .. 4 i + 3]: where the point last searched (xyz,
+ * map frame) and the proof radius it left (metres) */
+int lsa_icp_query_state(lsa_icp *icp, uint32_t *prev_out, float *qref_out, size_t n);
 /* plane mode: edge of the voxels the target normals are estimated in (call before SetInputTarget) */
 int lsa_icp_set_normal_leaf(lsa_icp *icp, float leaf);
 void lsa_icp_destroy(lsa_icp *icp);

@@ -34,6 +34,7 @@
 #include "ndt_pass.h"
 
 #include <cmath>
+#include <vector>
 
 namespace {
 constexpr int kBlock = 256;
@@ -71,7 +72,7 @@ __global__ __launch_bounds__(kBlock) void k_slot_of_id(const float4 *__restrict_
 // query's position q_ref and a lower bound D on the distance from q_ref to every OTHER target point (the runner-up among the
 // points it visited, or the radius of the sphere it covered — the search looks kSkipWiden farther than the answer alone needs,
 // nn_nearest_sub<.., TRACK>).  One iteration later the query sits at q, m = |q - q_ref| away; every other point is at least D - m
-// from it, so when the old neighbour is still closer than that — by a margin far above the f32 rounding of the distances — it
+// from it, so when the old neighbour is still closer than that — by a margin 40 times the f32 rounding of the distances — it
 // IS the exact nearest neighbour (strictly: no tie can arise) and no cell is looked at.  Likewise a query that had nothing
 // within the gate has nothing within it now while D - m stays beyond the gate.  The answer is the one the full search returns;
 // `LSA_ICP_NO_SKIP=1` runs every search for the A/B (tests/test_gpu_icp_fitness.py).
@@ -94,11 +95,14 @@ __device__ __forceinline__ NNHit icp_search(const NNView &Gf, const NNView &Gc, 
   *searched = false;
   if (allow_skip) {
     const float mx = qx - st.ref.x, my = qy - st.ref.y, mz = qz - st.ref.z;
-    // the old bound carried to the new position, less a margin of 1 mm + 2^-18 of the coordinates' magnitude (an f32 distance
-    // between points of this magnitude is off by ~2^-22 of it)
-    const float lb = st.ref.w - sqrtf(mx * mx + my * my + mz * mz) - (1.0e-3f + 3.8e-6f * (fabsf(qx) + fabsf(qy) + fabsf(qz)));
-    if (seed.id != 0xffffffffu && sqrtf(seed.d2) < lb) return seed;              // still the nearest, and alone at that distance
-    if ((seed.id == 0xffffffffu || seed.d2 > gate) && lb * lb > gate && lb > 0.0f) return seed;   // nothing within the gate (the caller drops the pair)
+    // The old bound carried to the new position.  Every quantity here is a DISTANCE computed from f32 differences, each
+    // correctly rounded relative to itself (not to the coordinates' magnitude), so the computed values are off by a few 2^-24 of
+    // themselves; the margin is 1e-5 of them (+ 1 um) — 40 times that.  (The bounds that come from cell geometry carry the
+    // grid's own 1 mm slack already, nn_grid_dev.h.)
+    const float mm = sqrtf(mx * mx + my * my + mz * mz);
+    const float lb = st.ref.w - mm - 1.0e-5f * (st.ref.w + mm) - 1.0e-6f;
+    if (seed.id != 0xffffffffu && sqrtf(seed.d2) * (1.0f + 1.0e-5f) < lb) return seed;   // still the nearest, and alone at that distance
+    if ((seed.id == 0xffffffffu || seed.d2 > gate) && lb > 0.0f && lb * lb > gate * (1.0f + 4.0e-5f)) return seed;   // nothing within the gate (the caller drops the pair)
   }
   *searched = true;
   const bool far = use_coarse && !(seed.d2 <= Gf.cell * Gf.cell);   // (no seed: d2 = inf -> far)
@@ -112,17 +116,60 @@ __device__ __forceinline__ NNHit icp_search(const NNView &Gf, const NNView &Gc, 
   return hit;
 }
 
+// The 32 columns of a workgroup row ([0] unused, [1..6] B, [7..27] H upper triangle, [28] #pairs, [29] #finite source points,
+// [30] #queries that ran a search)
+// are accumulated by the kSub = 4 lanes that share a query: column c lives in lane (c & 3) of the group, accumulator c >> 2 —
+// eight f64 registers per lane instead of 27 + 2 in the group's first lane, and a wave reduction of 4 steps x 8 values instead
+// of 6 x 29 (3.3 us at the tail of every pass).  Per column the values meet in the order they met before (the group's own
+// running sum, then the groups pairwise at distances 32, 16, 8, 4): same bits.
+__device__ __forceinline__ void icp_accumulate(double (&acc)[8], const double (&term)[32], int sub) {
+#pragma unroll
+  for (int j = 0; j < 8; j++) {
+    const double a = (sub & 1) ? term[4 * j + 1] : term[4 * j], b = (sub & 1) ? term[4 * j + 3] : term[4 * j + 2];
+    acc[j] += (sub & 2) ? b : a;
+  }
+}
+
+// one column's term: the owning lane adds it, the others add +0.0 (which leaves a sum that started at +0.0 as it is)
+__device__ __forceinline__ void icp_add_column(double (&acc)[8], int col /* compile-time */, int sub, double v) {
+  acc[col >> 2] += (sub == (col & 3)) ? v : 0.0;
+}
+
+// wave reduction of the per-lane columns, block sum, check-worded row (tail of k_icp_pass / k_plane_pass)
+__device__ __forceinline__ void icp_store_row(double (&acc)[8], double *__restrict__ partials, unsigned long long key) {
+  __shared__ double sm[kBlock / 64][kOut];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int off = 32; off >= kSub; off >>= 1) {
+    double t[8];
+#pragma unroll
+    for (int j = 0; j < 8; j++) t[j] = __shfl_down(acc[j], off, 64);
+#pragma unroll
+    for (int j = 0; j < 8; j++) acc[j] += t[j];
+  }
+  if (lane < kSub) {
+#pragma unroll
+    for (int j = 0; j < 8; j++) sm[wave][4 * j + lane] = acc[j];
+  }
+  __syncthreads();
+  if (threadIdx.x < kOut) {
+    double v = 0.0;
+    for (int w = 0; w < kBlock / 64; w++) v += sm[w][threadIdx.x];
+    lsa_store_row32(partials + (size_t)blockIdx.x * kOut, (int)threadIdx.x, v, key);
+  }
+}
+
 __global__ __launch_bounds__(kBlock) void k_icp_pass(const float4 *__restrict__ src, size_t n, IcpParams P, NNView G, NNView Gc, const unsigned *__restrict__ slot_of_id,
                                                      unsigned *__restrict__ prev, float4 *__restrict__ qref, double *__restrict__ partials, unsigned long long key) {
-  double acc[27];
+  static_assert(kSub == 4, "the column-to-lane mapping of icp_accumulate assumes four lanes per query");
+  double acc[8];
 #pragma unroll
-  for (int k = 0; k < 27; k++) acc[k] = 0.0;
-  unsigned ncorr = 0, npts = 0;
+  for (int k = 0; k < 8; k++) acc[k] = 0.0;
   const int sub = threadIdx.x & (kSub - 1);  // kSub adjacent lanes share one source point's neighbour search
   for (size_t i = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) / kSub; i < n; i += (size_t)gridDim.x * blockDim.x / kSub) {
     float4 s = src[i];
     if (!lsa_finite3(s.x, s.y, s.z)) continue;  // pcl::isFinite(ori_point) (:141)
-    if (sub == 0) npts++;
+    if (sub == 1) acc[7] += 1.0;                // column 29: finite source points
     float qx = lsa_fadd(lsa_fadd(lsa_fadd(lsa_fmul(P.T[0], s.x), lsa_fmul(P.T[1], s.y)), lsa_fmul(P.T[2], s.z)), P.T[3]);
     float qy = lsa_fadd(lsa_fadd(lsa_fadd(lsa_fmul(P.T[4], s.x), lsa_fmul(P.T[5], s.y)), lsa_fmul(P.T[6], s.z)), P.T[7]);
     float qz = lsa_fadd(lsa_fadd(lsa_fadd(lsa_fmul(P.T[8], s.x), lsa_fmul(P.T[9], s.y)), lsa_fmul(P.T[10], s.z)), P.T[11]);
@@ -133,11 +180,10 @@ __global__ __launch_bounds__(kBlock) void k_icp_pass(const float4 *__restrict__ 
     bool searched;
     NNHit hit = icp_search(G, Gc, slot_of_id, P.use_coarse, P.allow_skip, qx, qy, qz, sub, P.gate, st, &searched);
     if (sub == 0 && searched) { prev[i] = st.prev; qref[i] = st.ref; }  // next iteration's seed and proof (all kSub lanes have read theirs)
-    if (sub != 0) continue;  // lane 0 of the group carries the point into the sums
+    if (sub == 2 && searched) acc[7] += 1.0;    // column 30: queries that searched (lsa_icp_search_counts)
     float best = hit.d2, bx = hit.x, by = hit.y, bz = hit.z;
     unsigned best_id = hit.id;
-    if (best_id == 0xffffffffu || best > P.gate) continue;  // :147
-    ncorr++;
+    if (best_id == 0xffffffffu || best > P.gate) continue;  // :147 (the same decision in all kSub lanes)
     float e0 = lsa_fsub(qx, bx), e1 = lsa_fsub(qy, by), e2 = lsa_fsub(qz, bz);
     // J = [I | A], A = -R * hat(p) in f32 (:156-159); hat(p) = [[0,-z,y],[z,0,-x],[-y,x,0]]
     float A[3][3];
@@ -149,12 +195,13 @@ __global__ __launch_bounds__(kBlock) void k_icp_pass(const float4 *__restrict__ 
       A[r][2] = lsa_fadd(lsa_fmul(nr0, s.y), lsa_fmul(nr1, -s.x));
     }
     double ed[3] = {e0, e1, e2};
+    double term[32];
+    term[0] = 0.0;
     // B = -J^T e
-    acc[0] -= ed[0]; acc[1] -= ed[1]; acc[2] -= ed[2];
+    term[1] = -ed[0]; term[2] = -ed[1]; term[3] = -ed[2];
 #pragma unroll
-    for (int a = 0; a < 3; a++) acc[3 + a] -= (double)A[0][a] * ed[0] + (double)A[1][a] * ed[1] + (double)A[2][a] * ed[2];
+    for (int a = 0; a < 3; a++) term[4 + a] = -((double)A[0][a] * ed[0] + (double)A[1][a] * ed[1] + (double)A[2][a] * ed[2]);
     // H = J^T J upper triangle: [I, A; A^T, A^T A]
-    int k = 6;
 #pragma unroll
     for (int a = 0; a < 6; a++)
 #pragma unroll
@@ -163,29 +210,13 @@ __global__ __launch_bounds__(kBlock) void k_icp_pass(const float4 *__restrict__ 
         if (a < 3 && b < 3) v = (a == b) ? 1.0 : 0.0;
         else if (a < 3) v = (double)A[a][b - 3];
         else v = (double)A[0][a - 3] * A[0][b - 3] + (double)A[1][a - 3] * A[1][b - 3] + (double)A[2][a - 3] * A[2][b - 3];
-        acc[k++] += v;
+        term[7 + a * 6 - (a * (a - 1)) / 2 + (b - a)] = v;
       }
+    term[28] = 1.0;  // a pair
+    term[29] = 0.0; term[30] = 0.0; term[31] = 0.0;
+    icp_accumulate(acc, term, sub);
   }
-  __shared__ double sm[kBlock / 64][kOut];
-  int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  {
-    double red[29];
-#pragma unroll
-    for (int k = 0; k < 27; k++) red[k] = acc[k];
-    red[27] = (double)ncorr; red[28] = (double)npts;
-    lsa_wave_sum_n<29>(red);   // all 29 sums step by step together (see lsa_wave_sum_n)
-    if (lane == 0) {
-#pragma unroll
-      for (int k = 0; k < 27; k++) sm[wave][1 + k] = red[k];
-      sm[wave][0] = 0.0; sm[wave][28] = red[27]; sm[wave][29] = red[28]; sm[wave][30] = 0.0; sm[wave][31] = 0.0;
-    }
-  }
-  __syncthreads();
-  if (threadIdx.x < kOut) {
-    double v = 0.0;
-    for (int w = 0; w < kBlock / 64; w++) v += sm[w][threadIdx.x];
-    lsa_store_row32(partials + (size_t)blockIdx.x * kOut, (int)threadIdx.x, v, key);
-  }
+  icp_store_row(acc, partials, key);
 }
 
 // ---- point-to-plane extension --------------------------------------------------------------------------------------
@@ -236,15 +267,14 @@ __global__ __launch_bounds__(kBlock) void k_slot_normals(const float4 *__restric
 __global__ __launch_bounds__(kBlock) void k_plane_pass(const float4 *__restrict__ src, size_t n, IcpParams P, NNView G, NNView Gc, const unsigned *__restrict__ slot_of_id,
                                                        unsigned *__restrict__ prev, float4 *__restrict__ qref, const float4 *__restrict__ slot_normals,
                                                        double *__restrict__ partials, unsigned long long key) {
-  double acc[27];
+  double acc[8];
 #pragma unroll
-  for (int k = 0; k < 27; k++) acc[k] = 0.0;
-  unsigned ncorr = 0, npts = 0;
+  for (int k = 0; k < 8; k++) acc[k] = 0.0;
   const int sub = threadIdx.x & (kSub - 1);  // kSub adjacent lanes share one source point's neighbour search
   for (size_t i = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) / kSub; i < n; i += (size_t)gridDim.x * blockDim.x / kSub) {
     float4 s = src[i];
     if (!lsa_finite3(s.x, s.y, s.z)) continue;
-    if (sub == 0) npts++;
+    if (sub == 1) acc[7] += 1.0;                // column 29: finite source points
     float qx = lsa_fadd(lsa_fadd(lsa_fadd(lsa_fmul(P.T[0], s.x), lsa_fmul(P.T[1], s.y)), lsa_fmul(P.T[2], s.z)), P.T[3]);
     float qy = lsa_fadd(lsa_fadd(lsa_fadd(lsa_fmul(P.T[4], s.x), lsa_fmul(P.T[5], s.y)), lsa_fmul(P.T[6], s.z)), P.T[7]);
     float qz = lsa_fadd(lsa_fadd(lsa_fadd(lsa_fmul(P.T[8], s.x), lsa_fmul(P.T[9], s.y)), lsa_fmul(P.T[10], s.z)), P.T[11]);
@@ -252,14 +282,17 @@ __global__ __launch_bounds__(kBlock) void k_plane_pass(const float4 *__restrict_
     IcpQueryState st;
     st.prev = prev[i];
     st.ref = P.allow_skip ? qref[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+    // the old neighbour's normal travels with the old neighbour (one round trip instead of two when the search is skipped)
+    const unsigned seed_slot = st.prev;
+    const float4 nv_seed = seed_slot < G.n_sorted ? slot_normals[seed_slot] : make_float4(0.f, 0.f, 0.f, 0.f);
     bool searched;
     NNHit hit = icp_search(G, Gc, slot_of_id, P.use_coarse, P.allow_skip, qx, qy, qz, sub, P.gate, st, &searched);
     if (sub == 0 && searched) { prev[i] = st.prev; qref[i] = st.ref; }  // next iteration's seed and proof (all kSub lanes have read theirs)
-    if (sub != 0) continue;  // lane 0 of the group carries the point into the sums
-    if (hit.id == 0xffffffffu || hit.d2 > P.gate) continue;  // P.gate = max_correspond_dis^2 in this mode
-    float4 nv = slot_normals[hit.slot];
+    if (sub == 2 && searched) acc[7] += 1.0;    // column 30: queries that searched (lsa_icp_search_counts)
+    if (hit.id == 0xffffffffu || hit.d2 > P.gate) continue;  // P.gate = max_correspond_dis^2 in this mode (the same decision in all kSub lanes)
+    float4 nv = nv_seed;
+    if (hit.slot != seed_slot) nv = slot_normals[hit.slot];
     if (nv.w == 0.0f) continue;
-    ncorr++;
     float e0 = lsa_fsub(qx, hit.x), e1 = lsa_fsub(qy, hit.y), e2 = lsa_fsub(qz, hit.z);
     float r = lsa_fadd(lsa_fadd(lsa_fmul(nv.x, e0), lsa_fmul(nv.y, e1)), lsa_fmul(nv.z, e2));
     float J[6] = {nv.x, nv.y, nv.z, 0.f, 0.f, 0.f};
@@ -275,34 +308,16 @@ __global__ __launch_bounds__(kBlock) void k_plane_pass(const float4 *__restrict_
     }
 #pragma unroll
     for (int c = 0; c < 3; c++) J[3 + c] = lsa_fadd(lsa_fadd(lsa_fmul(nv.x, A[0][c]), lsa_fmul(nv.y, A[1][c])), lsa_fmul(nv.z, A[2][c]));
-    int k = 6;
+    const double Jd[6] = {J[0], J[1], J[2], J[3], J[4], J[5]}, rd = r;
 #pragma unroll
     for (int a = 0; a < 6; a++) {
-      acc[a] -= (double)J[a] * (double)r;
+      icp_add_column(acc, 1 + a, sub, -(Jd[a] * rd));
 #pragma unroll
-      for (int b = a; b < 6; b++) acc[k++] += (double)J[a] * (double)J[b];
+      for (int b = a; b < 6; b++) icp_add_column(acc, 7 + a * 6 - (a * (a - 1)) / 2 + (b - a), sub, Jd[a] * Jd[b]);
     }
+    icp_add_column(acc, 28, sub, 1.0);  // a pair
   }
-  __shared__ double sm[kBlock / 64][kOut];
-  int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  {
-    double red[29];
-#pragma unroll
-    for (int k = 0; k < 27; k++) red[k] = acc[k];
-    red[27] = (double)ncorr; red[28] = (double)npts;
-    lsa_wave_sum_n<29>(red);   // all 29 sums step by step together (see lsa_wave_sum_n)
-    if (lane == 0) {
-#pragma unroll
-      for (int k = 0; k < 27; k++) sm[wave][1 + k] = red[k];
-      sm[wave][0] = 0.0; sm[wave][28] = red[27]; sm[wave][29] = red[28]; sm[wave][30] = 0.0; sm[wave][31] = 0.0;
-    }
-  }
-  __syncthreads();
-  if (threadIdx.x < kOut) {
-    double v = 0.0;
-    for (int w = 0; w < kBlock / 64; w++) v += sm[w][threadIdx.x];
-    lsa_store_row32(partials + (size_t)blockIdx.x * kOut, (int)threadIdx.x, v, key);
-  }
+  icp_store_row(acc, partials, key);
 }
 
 struct T12 { float v[12]; };
@@ -449,6 +464,8 @@ struct lsa_icp {
   bool no_coarse = getenv("LSA_ICP_NO_COARSE") != nullptr;
   bool no_skip = getenv("LSA_ICP_NO_SKIP") != nullptr;
   DevBuf<float4> qref;    // per source point: where it last searched and how far every other target point was (icp_search)
+  std::vector<uint32_t> searches_per_iter;   // last ScanMatch (manual / plane modes): queries that searched, per iteration
+  uint64_t n_searches = 0, n_queries = 0;
   VoxelIndex vi_n;                                  // plane mode: voxel grid the normals come from
   DevBuf<float4> cell_normals, slot_normals;        // per occupied voxel / per cell-sorted target point
   float normal_leaf = 1.0f;
@@ -595,6 +612,8 @@ int icp_match_manual(lsa_icp *h, const float4 *d_src, size_t n, const float pred
   NNView G = nn_view(h->grid);
   const bool coarse = h->grid_c.built && h->grid_c.use_dense && h->slot_of_id.p;
   NNView Gc = coarse ? nn_view(h->grid_c) : G;
+  h->searches_per_iter.clear();
+  h->n_searches = h->n_queries = 0;
   for (int it = 0; it < h->max_iter; it++) {
     IcpParams P;
     P.use_coarse = (coarse && it > 0) ? 1 : 0;   // the first iteration searches cold: no seed says who is far
@@ -612,6 +631,8 @@ int icp_match_manual(lsa_icp *h, const float4 *d_src, size_t n, const float pred
     }
     if ((rc = icp_fetch_sums(h, g))) return rc;
     const double *o = h->h_out.p;
+    h->searches_per_iter.push_back((uint32_t)o[30]);
+    h->n_searches += (uint64_t)o[30]; h->n_queries += (uint64_t)o[29];
     float H[36], B[6];
     int k = 7;
     for (int a = 0; a < 6; a++) B[a] = (float)o[1 + a];
@@ -848,6 +869,29 @@ extern "C" int lsa_icp_set_input_target(lsa_icp *h, const void *pts, size_t n, s
   if (!n || !pts || stride < 12) return lsa_fail(h->ctx, LSA_ERR_INVALID, "ICP SetInputTarget: bad points / stride");
   if ((rc = icp_upload(h, pts, n, stride, h->d_target))) return rc;
   return icp_build(h, h->d_target.p, n);
+}
+
+extern "C" int lsa_icp_search_counts(lsa_icp *h, uint64_t *searches, uint64_t *queries, uint32_t *per_iteration, size_t cap, size_t *n_iterations) {
+  if (!h) return LSA_ERR_INVALID;
+  if (searches) *searches = h->n_searches;
+  if (queries) *queries = h->n_queries;
+  if (n_iterations) *n_iterations = h->searches_per_iter.size();
+  if (per_iteration)
+    for (size_t i = 0; i < cap && i < h->searches_per_iter.size(); i++) per_iteration[i] = h->searches_per_iter[i];
+  return LSA_OK;
+}
+
+// diagnostics (tests, profiles/scripts): the per-query search state the last ScanMatch left on the device, copied to the host —
+// prev[i]: cell-sorted slot of source point i's neighbour (0xffffffff: none), qref[4 i ..]: where it last searched + proof radius
+extern "C" int lsa_icp_query_state(lsa_icp *h, uint32_t *prev_out, float *qref_out, size_t n) {
+  if (!h || !prev_out || !qref_out) return LSA_ERR_INVALID;
+  lsa_context *ctx = h->ctx;
+  LSA_HIP(ctx, lsa_enter(ctx));
+  if (n > h->prev.cap || n > h->qref.cap) return lsa_fail(ctx, LSA_ERR_INVALID, "lsa_icp_query_state: %zu points asked for, the last ScanMatch had fewer", n);
+  LSA_HIP(ctx, hipMemcpyAsync(prev_out, h->prev.p, n * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+  LSA_HIP(ctx, hipMemcpyAsync(qref_out, h->qref.p, n * sizeof(float4), hipMemcpyDeviceToHost, ctx->stream));
+  LSA_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return LSA_OK;
 }
 
 extern "C" int lsa_icp_scan_match_device(lsa_icp *h, const float *d_src_xyzw, size_t n, const float predict_pose[16], float result_pose[16]) {

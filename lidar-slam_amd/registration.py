@@ -237,6 +237,13 @@ class ICPRegistrationHip(RegistrationInterface):
         self.ctx.check(capi.lib().lsa_icp_get_stats(self.h, C.byref(st)))
         return dict(iterations=st.iterations, converged=st.converged, correspondences=st.correspondences, mse=st.mse)
 
+    def search_counts(self):
+        """Last ScanMatch (ICPMANUAL / point-to-plane): (searches, queries, per-iteration list) — lsa_icp_search_counts."""
+        a, b, n = C.c_uint64(0), C.c_uint64(0), C.c_size_t(0)
+        per = (C.c_uint32 * 256)()
+        self.ctx.check(capi.lib().lsa_icp_search_counts(self.h, C.byref(a), C.byref(b), per, 256, C.byref(n)))
+        return int(a.value), int(b.value), [int(x) for x in per[: min(n.value, 256)]]
+
     def SetInputTarget(self, input_target):  # noqa: N802
         if _is_tensor(input_target):
             check_points_tensor(input_target, "SetInputTarget")

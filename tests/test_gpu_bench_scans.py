@@ -281,6 +281,25 @@ def test_icp_skipped_searches_change_nothing(ctx, cfg2, monkeypatch):
     assert len(runs["skip"]) == len(runs["full"]) > 40
     for i, ((Ta, ca), (Tb, cb)) in enumerate(zip(runs["skip"], runs["full"])):
         assert ca == cb and np.array_equal(Ta, Tb), (i, ca, cb, Ta - Tb)
+    # ... and searches ARE skipped: every query searches in the first iteration, a few per cent of them once the pose has settled
+    # (lsa_icp_search_counts); with LSA_ICP_NO_SKIP every query searches in every iteration
+    monkeypatch.delenv("LSA_ICP_NO_SKIP")
+    s8 = synth.to_xyzi32(cfg2["srcs"][0])
+    for mode, settled in ((capi.ICP_MODE_MANUAL, 0.05), (capi.ICP_MODE_PLANE, 0.01)):
+        icp = registration.ICPRegistrationHip(ctx, 2.0, 30, mode=mode)
+        icp.SetInputTarget(tgt8)
+        icp.ScanMatch(s8, cfg2["guesses"][0])
+        searches, queries, per = icp.search_counts()
+        assert len(per) == 30 and per[0] * 30 == queries and sum(per) == searches, (per, queries)
+        assert per[-1] <= settled * per[0] and searches < 0.3 * queries, (mode, per)
+        icp.close()
+    monkeypatch.setenv("LSA_ICP_NO_SKIP", "1")
+    icp = registration.ICPRegistrationHip(ctx, 2.0, 5)
+    icp.SetInputTarget(tgt8)
+    icp.ScanMatch(s8, cfg2["guesses"][0])
+    searches, queries, per = icp.search_counts()
+    assert searches == queries and len(set(per)) == 1
+    icp.close()
 
 
 # --------------------------------------------------------------------------------------------- cfg4 (BASELINE.json configs[3])
