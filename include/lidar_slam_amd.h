@@ -395,6 +395,11 @@ int lsa_icp_get_stats(lsa_icp *icp, lsa_icp_stats *stats);
  * totals over the iterations; per_iteration[i] (up to cap entries, *n_iterations of them exist): source points that searched in
  * iteration i.  Any pointer may be NULL. */
 int lsa_icp_search_counts(lsa_icp *icp, uint64_t *searches, uint64_t *queries, uint32_t *per_iteration, size_t cap, size_t *n_iterations);
+/* ICPMANUAL / point-to-plane modes launch the kernel of iteration k + 1 while iteration k runs; it takes its pose by mail
+ * (csrc/icp.hip, "armed passes"; LSA_ICP_NO_ARMED=1: one launch per iteration, same results).  armed_passes: iterations run that
+ * way since the handle was created; fallbacks: iterations whose armed kernel delivered no rows and that were run again the
+ * ordinary way — never silent. */
+int lsa_icp_armed_counts(lsa_icp *icp, uint64_t *armed_passes, uint64_t *fallbacks);
 /* diagnostics: the per-source-point search state of the last ScanMatch, copied to the host — prev_out[i]: position of point i's
  * neighbour in the handle's cell-sorted target (0xffffffff: none); qref_out[4 i .. 4 i + 3]: where the point last searched (xyz,
  * map frame) and the proof radius it left (metres) */

@@ -33,6 +33,8 @@
 #include "nn_grid_dev.h"
 #include "ndt_pass.h"
 
+#include <immintrin.h>
+
 #include <cmath>
 #include <vector>
 
@@ -159,12 +161,13 @@ __device__ __forceinline__ void icp_store_row(double (&acc)[8], double *__restri
   }
 }
 
-__global__ __launch_bounds__(kBlock) void k_icp_pass(const float4 *__restrict__ src, size_t n, IcpParams P, NNView G, NNView Gc, const unsigned *__restrict__ slot_of_id,
-                                                     unsigned *__restrict__ prev, float4 *__restrict__ qref, double *__restrict__ partials, unsigned long long key) {
+// One Gauss-Newton pass of ICPMANUAL (PLANE = false) or of the point-to-plane extension (PLANE = true) over this workgroup's
+// share of the source points: the columns of its row, spread over the lanes as icp_accumulate describes.
+template <bool PLANE>
+__device__ __forceinline__ void icp_gn_body(const float4 *__restrict__ src, size_t n, const IcpParams &P, const NNView &G, const NNView &Gc,
+                                            const unsigned *__restrict__ slot_of_id, unsigned *__restrict__ prev, float4 *__restrict__ qref,
+                                            const float4 *__restrict__ slot_normals, double (&acc)[8]) {
   static_assert(kSub == 4, "the column-to-lane mapping of icp_accumulate assumes four lanes per query");
-  double acc[8];
-#pragma unroll
-  for (int k = 0; k < 8; k++) acc[k] = 0.0;
   const int sub = threadIdx.x & (kSub - 1);  // kSub adjacent lanes share one source point's neighbour search
   for (size_t i = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) / kSub; i < n; i += (size_t)gridDim.x * blockDim.x / kSub) {
     float4 s = src[i];
@@ -177,45 +180,153 @@ __global__ __launch_bounds__(kBlock) void k_icp_pass(const float4 *__restrict__ 
     IcpQueryState st;
     st.prev = prev[i];
     st.ref = P.allow_skip ? qref[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+    // (plane) the old neighbour's normal travels with the old neighbour: one round trip instead of two when the search is skipped
+    const unsigned seed_slot = st.prev;
+    float4 nv_seed = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (PLANE && seed_slot < G.n_sorted) nv_seed = slot_normals[seed_slot];
     bool searched;
     NNHit hit = icp_search(G, Gc, slot_of_id, P.use_coarse, P.allow_skip, qx, qy, qz, sub, P.gate, st, &searched);
     if (sub == 0 && searched) { prev[i] = st.prev; qref[i] = st.ref; }  // next iteration's seed and proof (all kSub lanes have read theirs)
     if (sub == 2 && searched) acc[7] += 1.0;    // column 30: queries that searched (lsa_icp_search_counts)
-    float best = hit.d2, bx = hit.x, by = hit.y, bz = hit.z;
-    unsigned best_id = hit.id;
-    if (best_id == 0xffffffffu || best > P.gate) continue;  // :147 (the same decision in all kSub lanes)
-    float e0 = lsa_fsub(qx, bx), e1 = lsa_fsub(qy, by), e2 = lsa_fsub(qz, bz);
-    // J = [I | A], A = -R * hat(p) in f32 (:156-159); hat(p) = [[0,-z,y],[z,0,-x],[-y,x,0]]
-    float A[3][3];
+    // manual: sqdist > max_correspond_distance_ (:147); plane: P.gate = max_correspond_dis^2.  The same decision in all kSub lanes.
+    if (hit.id == 0xffffffffu || hit.d2 > P.gate) continue;
+    if (PLANE) {
+      float4 nv = nv_seed;
+      if (hit.slot != seed_slot) nv = slot_normals[hit.slot];
+      if (nv.w == 0.0f) continue;
+      float e0 = lsa_fsub(qx, hit.x), e1 = lsa_fsub(qy, hit.y), e2 = lsa_fsub(qz, hit.z);
+      float r = lsa_fadd(lsa_fadd(lsa_fmul(nv.x, e0), lsa_fmul(nv.y, e1)), lsa_fmul(nv.z, e2));
+      float J[6] = {nv.x, nv.y, nv.z, 0.f, 0.f, 0.f};
+      // A = -R * hat(p) in f32 as the manual plugin forms it; J[3 + c] = n . A[:, c]
+      float A[3][3];
 #pragma unroll
-    for (int r = 0; r < 3; r++) {
-      float nr0 = -P.T[r * 4 + 0], nr1 = -P.T[r * 4 + 1], nr2 = -P.T[r * 4 + 2];
-      A[r][0] = lsa_fadd(lsa_fmul(nr1, s.z), lsa_fmul(nr2, -s.y));
-      A[r][1] = lsa_fadd(lsa_fmul(nr0, -s.z), lsa_fmul(nr2, s.x));
-      A[r][2] = lsa_fadd(lsa_fmul(nr0, s.y), lsa_fmul(nr1, -s.x));
-    }
-    double ed[3] = {e0, e1, e2};
-    double term[32];
-    term[0] = 0.0;
-    // B = -J^T e
-    term[1] = -ed[0]; term[2] = -ed[1]; term[3] = -ed[2];
-#pragma unroll
-    for (int a = 0; a < 3; a++) term[4 + a] = -((double)A[0][a] * ed[0] + (double)A[1][a] * ed[1] + (double)A[2][a] * ed[2]);
-    // H = J^T J upper triangle: [I, A; A^T, A^T A]
-#pragma unroll
-    for (int a = 0; a < 6; a++)
-#pragma unroll
-      for (int b = a; b < 6; b++) {
-        double v;
-        if (a < 3 && b < 3) v = (a == b) ? 1.0 : 0.0;
-        else if (a < 3) v = (double)A[a][b - 3];
-        else v = (double)A[0][a - 3] * A[0][b - 3] + (double)A[1][a - 3] * A[1][b - 3] + (double)A[2][a - 3] * A[2][b - 3];
-        term[7 + a * 6 - (a * (a - 1)) / 2 + (b - a)] = v;
+      for (int rr = 0; rr < 3; rr++) {
+        float nr0 = -P.T[rr * 4 + 0], nr1 = -P.T[rr * 4 + 1], nr2 = -P.T[rr * 4 + 2];
+        // row rr of (-R) times hat(p) = [[0,-z,y],[z,0,-x],[-y,x,0]], summed left to right like the oracle
+        A[rr][0] = lsa_fadd(lsa_fadd(lsa_fmul(nr0, 0.0f), lsa_fmul(nr1, s.z)), lsa_fmul(nr2, -s.y));
+        A[rr][1] = lsa_fadd(lsa_fadd(lsa_fmul(nr0, -s.z), lsa_fmul(nr1, 0.0f)), lsa_fmul(nr2, s.x));
+        A[rr][2] = lsa_fadd(lsa_fadd(lsa_fmul(nr0, s.y), lsa_fmul(nr1, -s.x)), lsa_fmul(nr2, 0.0f));
       }
-    term[28] = 1.0;  // a pair
-    term[29] = 0.0; term[30] = 0.0; term[31] = 0.0;
-    icp_accumulate(acc, term, sub);
+#pragma unroll
+      for (int c = 0; c < 3; c++) J[3 + c] = lsa_fadd(lsa_fadd(lsa_fmul(nv.x, A[0][c]), lsa_fmul(nv.y, A[1][c])), lsa_fmul(nv.z, A[2][c]));
+      // out32: [1..6] B = -sum J r, [7..27] H = sum J^T J upper triangle
+      const double Jd[6] = {J[0], J[1], J[2], J[3], J[4], J[5]}, rd = r;
+#pragma unroll
+      for (int a = 0; a < 6; a++) {
+        icp_add_column(acc, 1 + a, sub, -(Jd[a] * rd));
+#pragma unroll
+        for (int b = a; b < 6; b++) icp_add_column(acc, 7 + a * 6 - (a * (a - 1)) / 2 + (b - a), sub, Jd[a] * Jd[b]);
+      }
+      icp_add_column(acc, 28, sub, 1.0);  // a pair
+    } else {
+      float e0 = lsa_fsub(qx, hit.x), e1 = lsa_fsub(qy, hit.y), e2 = lsa_fsub(qz, hit.z);
+      // J = [I | A], A = -R * hat(p) in f32 (:156-159); hat(p) = [[0,-z,y],[z,0,-x],[-y,x,0]]
+      float A[3][3];
+#pragma unroll
+      for (int r = 0; r < 3; r++) {
+        float nr0 = -P.T[r * 4 + 0], nr1 = -P.T[r * 4 + 1], nr2 = -P.T[r * 4 + 2];
+        A[r][0] = lsa_fadd(lsa_fmul(nr1, s.z), lsa_fmul(nr2, -s.y));
+        A[r][1] = lsa_fadd(lsa_fmul(nr0, -s.z), lsa_fmul(nr2, s.x));
+        A[r][2] = lsa_fadd(lsa_fmul(nr0, s.y), lsa_fmul(nr1, -s.x));
+      }
+      double ed[3] = {e0, e1, e2};
+      double term[32];
+      term[0] = 0.0;
+      // B = -J^T e
+      term[1] = -ed[0]; term[2] = -ed[1]; term[3] = -ed[2];
+#pragma unroll
+      for (int a = 0; a < 3; a++) term[4 + a] = -((double)A[0][a] * ed[0] + (double)A[1][a] * ed[1] + (double)A[2][a] * ed[2]);
+      // H = J^T J upper triangle: [I, A; A^T, A^T A]
+#pragma unroll
+      for (int a = 0; a < 6; a++)
+#pragma unroll
+        for (int b = a; b < 6; b++) {
+          double v;
+          if (a < 3 && b < 3) v = (a == b) ? 1.0 : 0.0;
+          else if (a < 3) v = (double)A[a][b - 3];
+          else v = (double)A[0][a - 3] * A[0][b - 3] + (double)A[1][a - 3] * A[1][b - 3] + (double)A[2][a - 3] * A[2][b - 3];
+          term[7 + a * 6 - (a * (a - 1)) / 2 + (b - a)] = v;
+        }
+      term[28] = 1.0;  // a pair
+      term[29] = 0.0; term[30] = 0.0; term[31] = 0.0;
+      icp_accumulate(acc, term, sub);
+    }
   }
+}
+
+template <bool PLANE>
+__global__ __launch_bounds__(kBlock) void k_gn_pass(const float4 *__restrict__ src, size_t n, IcpParams P, NNView G, NNView Gc, const unsigned *__restrict__ slot_of_id,
+                                                    unsigned *__restrict__ prev, float4 *__restrict__ qref, const float4 *__restrict__ slot_normals,
+                                                    double *__restrict__ partials, unsigned long long key) {
+  double acc[8];
+#pragma unroll
+  for (int k = 0; k < 8; k++) acc[k] = 0.0;
+  icp_gn_body<PLANE>(src, n, P, G, Gc, slot_of_id, prev, qref, slot_normals, acc);
+  icp_store_row(acc, partials, key);
+}
+
+// ARMED passes (the mechanism of the NDT passes, ndt_derivatives.hip, in its plainest form: ICPMANUAL runs a FIXED number of
+// iterations, so every armed kernel gets its mail and nothing is ever cancelled or left parked).  The kernel of iteration k + 1
+// is enqueued while iteration k runs; it starts when k's kernel ends and its first wave waits, resident, for the pose — 12 floats
+// + the two flags, posted by the host into fine-grained device memory once it has solved iteration k's normal equations.
+// Launch call and launch-to-first-wave latency (~8 us of a ~20 us iteration) leave the critical path.
+struct IcpMail {
+  unsigned long long words[7];   // [0..5] T (12 floats), [6] bit 0 use_coarse, bit 1 allow_skip
+  unsigned long long check;      // key ^ XOR_c rotl-mix(word_c)
+  unsigned long long seq;        // the pass these words are for
+  unsigned long long pad[7];
+};
+static_assert(sizeof(IcpMail) == 128, "one mail slot = one 128-byte line");
+
+template <bool PLANE>
+__global__ __launch_bounds__(kBlock) void k_gn_pass_armed(const float4 *__restrict__ src, size_t n, float gate, NNView G, NNView Gc,
+                                                          const unsigned *__restrict__ slot_of_id, unsigned *__restrict__ prev, float4 *__restrict__ qref,
+                                                          const float4 *__restrict__ slot_normals, double *__restrict__ partials, unsigned long long key,
+                                                          const IcpMail *mail, unsigned long long seq, unsigned long long patience_ticks,
+                                                          unsigned long long *gave_up /* host-mapped */) {
+  __shared__ unsigned long long s_mail[8];
+  __shared__ int s_go;
+  if (threadIdx.x < 64) {
+    const int lane = threadIdx.x;
+    const unsigned long long *mw = reinterpret_cast<const unsigned long long *>(mail);
+    const unsigned long long t0 = wall_clock64();
+    int go = 0;
+    for (;;) {
+      // one round trip per look: words, check word and sequence number together; the payload is taken if it is whole
+      const unsigned long long w = lane < 9 ? __hip_atomic_load(mw + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) : 0ull;
+      unsigned long long x = lane < 7 ? lsa_row_mix(w, lane) : 0ull;
+#pragma unroll
+      for (int off = 4; off > 0; off >>= 1) x ^= __shfl_xor(x, off, 64);
+      const unsigned long long chk = __shfl(w, 7, 64), sq = __shfl(w, 8, 64), x0 = __shfl(x, 0, 64);
+      if (sq == seq && (x0 ^ key) == chk) {
+        if (lane < 7) s_mail[lane] = w;
+        go = 1;
+        break;
+      }
+      if (wall_clock64() - t0 > patience_ticks) {   // nobody posted: leave and say so (the host then runs the pass the ordinary way)
+        if (lane == 0) __hip_atomic_store(gave_up, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        break;
+      }
+      __builtin_amdgcn_s_sleep(1);
+    }
+    if (lane == 0) s_go = go;
+  }
+  __syncthreads();
+  if (!s_go) return;
+  IcpParams P;
+  {
+    const float *tf = reinterpret_cast<const float *>(s_mail);
+#pragma unroll
+    for (int k = 0; k < 12; k++) P.T[k] = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(tf[k])));
+    const int flags = __builtin_amdgcn_readfirstlane((int)(unsigned)s_mail[6]);
+    P.use_coarse = flags & 1;
+    P.allow_skip = (flags >> 1) & 1;
+    P.gate = gate;
+  }
+  double acc[8];
+#pragma unroll
+  for (int k = 0; k < 8; k++) acc[k] = 0.0;
+  icp_gn_body<PLANE>(src, n, P, G, Gc, slot_of_id, prev, qref, slot_normals, acc);
   icp_store_row(acc, partials, key);
 }
 
@@ -261,63 +372,6 @@ __global__ __launch_bounds__(kBlock) void k_slot_normals(const float4 *__restric
     if (w & bit) out = normals[nprefix[cell >> 5] + __popc(w & (bit - 1u))];
   }
   slot_normals[i] = out;
-}
-
-// out32: [1..6] B = -sum J r, [7..27] H = sum J^T J upper triangle, [28] #pairs, [29] #finite source points
-__global__ __launch_bounds__(kBlock) void k_plane_pass(const float4 *__restrict__ src, size_t n, IcpParams P, NNView G, NNView Gc, const unsigned *__restrict__ slot_of_id,
-                                                       unsigned *__restrict__ prev, float4 *__restrict__ qref, const float4 *__restrict__ slot_normals,
-                                                       double *__restrict__ partials, unsigned long long key) {
-  double acc[8];
-#pragma unroll
-  for (int k = 0; k < 8; k++) acc[k] = 0.0;
-  const int sub = threadIdx.x & (kSub - 1);  // kSub adjacent lanes share one source point's neighbour search
-  for (size_t i = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) / kSub; i < n; i += (size_t)gridDim.x * blockDim.x / kSub) {
-    float4 s = src[i];
-    if (!lsa_finite3(s.x, s.y, s.z)) continue;
-    if (sub == 1) acc[7] += 1.0;                // column 29: finite source points
-    float qx = lsa_fadd(lsa_fadd(lsa_fadd(lsa_fmul(P.T[0], s.x), lsa_fmul(P.T[1], s.y)), lsa_fmul(P.T[2], s.z)), P.T[3]);
-    float qy = lsa_fadd(lsa_fadd(lsa_fadd(lsa_fmul(P.T[4], s.x), lsa_fmul(P.T[5], s.y)), lsa_fmul(P.T[6], s.z)), P.T[7]);
-    float qz = lsa_fadd(lsa_fadd(lsa_fadd(lsa_fmul(P.T[8], s.x), lsa_fmul(P.T[9], s.y)), lsa_fmul(P.T[10], s.z)), P.T[11]);
-    if (!lsa_finite3(qx, qy, qz)) continue;
-    IcpQueryState st;
-    st.prev = prev[i];
-    st.ref = P.allow_skip ? qref[i] : make_float4(0.f, 0.f, 0.f, 0.f);
-    // the old neighbour's normal travels with the old neighbour (one round trip instead of two when the search is skipped)
-    const unsigned seed_slot = st.prev;
-    const float4 nv_seed = seed_slot < G.n_sorted ? slot_normals[seed_slot] : make_float4(0.f, 0.f, 0.f, 0.f);
-    bool searched;
-    NNHit hit = icp_search(G, Gc, slot_of_id, P.use_coarse, P.allow_skip, qx, qy, qz, sub, P.gate, st, &searched);
-    if (sub == 0 && searched) { prev[i] = st.prev; qref[i] = st.ref; }  // next iteration's seed and proof (all kSub lanes have read theirs)
-    if (sub == 2 && searched) acc[7] += 1.0;    // column 30: queries that searched (lsa_icp_search_counts)
-    if (hit.id == 0xffffffffu || hit.d2 > P.gate) continue;  // P.gate = max_correspond_dis^2 in this mode (the same decision in all kSub lanes)
-    float4 nv = nv_seed;
-    if (hit.slot != seed_slot) nv = slot_normals[hit.slot];
-    if (nv.w == 0.0f) continue;
-    float e0 = lsa_fsub(qx, hit.x), e1 = lsa_fsub(qy, hit.y), e2 = lsa_fsub(qz, hit.z);
-    float r = lsa_fadd(lsa_fadd(lsa_fmul(nv.x, e0), lsa_fmul(nv.y, e1)), lsa_fmul(nv.z, e2));
-    float J[6] = {nv.x, nv.y, nv.z, 0.f, 0.f, 0.f};
-    // A = -R * hat(p) in f32 as the manual plugin forms it; J[3 + c] = n . A[:, c]
-    float A[3][3];
-#pragma unroll
-    for (int rr = 0; rr < 3; rr++) {
-      float nr0 = -P.T[rr * 4 + 0], nr1 = -P.T[rr * 4 + 1], nr2 = -P.T[rr * 4 + 2];
-      // row rr of (-R) times hat(p) = [[0,-z,y],[z,0,-x],[-y,x,0]], summed left to right like the oracle
-      A[rr][0] = lsa_fadd(lsa_fadd(lsa_fmul(nr0, 0.0f), lsa_fmul(nr1, s.z)), lsa_fmul(nr2, -s.y));
-      A[rr][1] = lsa_fadd(lsa_fadd(lsa_fmul(nr0, -s.z), lsa_fmul(nr1, 0.0f)), lsa_fmul(nr2, s.x));
-      A[rr][2] = lsa_fadd(lsa_fadd(lsa_fmul(nr0, s.y), lsa_fmul(nr1, -s.x)), lsa_fmul(nr2, 0.0f));
-    }
-#pragma unroll
-    for (int c = 0; c < 3; c++) J[3 + c] = lsa_fadd(lsa_fadd(lsa_fmul(nv.x, A[0][c]), lsa_fmul(nv.y, A[1][c])), lsa_fmul(nv.z, A[2][c]));
-    const double Jd[6] = {J[0], J[1], J[2], J[3], J[4], J[5]}, rd = r;
-#pragma unroll
-    for (int a = 0; a < 6; a++) {
-      icp_add_column(acc, 1 + a, sub, -(Jd[a] * rd));
-#pragma unroll
-      for (int b = a; b < 6; b++) icp_add_column(acc, 7 + a * 6 - (a * (a - 1)) / 2 + (b - a), sub, Jd[a] * Jd[b]);
-    }
-    icp_add_column(acc, 28, sub, 1.0);  // a pair
-  }
-  icp_store_row(acc, partials, key);
 }
 
 struct T12 { float v[12]; };
@@ -464,6 +518,13 @@ struct lsa_icp {
   bool no_coarse = getenv("LSA_ICP_NO_COARSE") != nullptr;
   bool no_skip = getenv("LSA_ICP_NO_SKIP") != nullptr;
   DevBuf<float4> qref;    // per source point: where it last searched and how far every other target point was (icp_search)
+  // armed passes (k_gn_pass_armed): two mail slots in fine-grained device memory (host-coherent memory where there is no large
+  // BAR), the word a kernel that ran out of patience reports to, counters
+  void *mail = nullptr;
+  bool mail_tried = false, mail_is_device = false;
+  bool no_armed = getenv("LSA_ICP_NO_ARMED") != nullptr || getenv("LSA_NO_ARMED") != nullptr;
+  PinnedBuf<unsigned long long> h_gave_up;
+  uint64_t armed_passes = 0, armed_fallbacks = 0;
   std::vector<uint32_t> searches_per_iter;   // last ScanMatch (manual / plane modes): queries that searched, per iteration
   uint64_t n_searches = 0, n_queries = 0;
   VoxelIndex vi_n;                                  // plane mode: voxel grid the normals come from
@@ -567,7 +628,7 @@ unsigned long long icp_next_key(lsa_icp *h, unsigned g) {
 }
 
 // brings the 32 sums of `g` partial rows to h->h_out
-int icp_fetch_sums(lsa_icp *h, unsigned g) {
+int icp_fetch_sums(lsa_icp *h, unsigned g, bool may_sync = true) {
   lsa_context *ctx = h->ctx;
   LSA_HIP(ctx, hipGetLastError());
   if (g <= kHostRows) {
@@ -578,7 +639,7 @@ int icp_fetch_sums(lsa_icp *h, unsigned g) {
       h->unsynced = 0;
       if (!ndt_reduce_partials_host(h->h_partials.p, g, h->row_key, 0.0, h->h_out.p))
         return lsa_fail(ctx, LSA_ERR_HIP, "ICP pass: workgroup rows incomplete after the kernel finished");
-    } else if (++h->unsynced >= 256) {  // let the runtime retire its commands now and then
+    } else if (++h->unsynced >= 256 && may_sync) {  // let the runtime retire its commands now and then (not with an armed kernel waiting on the stream)
       LSA_HIP(ctx, hipStreamSynchronize(ctx->stream));
       h->unsynced = 0;
     }
@@ -590,6 +651,43 @@ int icp_fetch_sums(lsa_icp *h, unsigned g) {
   LSA_HIP(ctx, hipStreamSynchronize(ctx->stream));
   return LSA_OK;
 }
+
+int icp_mail_ensure(lsa_icp *h) {
+  if (h->mail || h->mail_tried) return LSA_OK;
+  h->mail_tried = true;
+  lsa_context *ctx = h->ctx;
+  hipDeviceProp_t prop;
+  void *m = nullptr;
+  if (hipGetDeviceProperties(&prop, ctx->device) == hipSuccess && prop.isLargeBar && hipExtMallocWithFlags(&m, 4096, hipDeviceMallocFinegrained) == hipSuccess) {
+    h->mail = m; h->mail_is_device = true;
+  } else if (hipHostMalloc(&m, 4096, hipHostMallocMapped | hipHostMallocCoherent) == hipSuccess) {
+    h->mail = m; h->mail_is_device = false;
+  } else {
+    (void)hipGetLastError();
+    return LSA_OK;  // no mailbox: one launch per iteration, the ordinary way
+  }
+  int rc = h->h_gave_up.reserve(ctx, 8);
+  if (rc) return rc;
+  LSA_HIP(ctx, hipMemsetAsync(h->mail, 0, 4096, ctx->stream));
+  LSA_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return LSA_OK;
+}
+
+void icp_mail_post(IcpMail *base, unsigned long long seq, unsigned long long key, const IcpParams &P) {
+  IcpMail *m = base + (seq & 1ull);   // two slots by parity: the mail of pass k stays whole while the kernel of pass k + 1 is already resident
+  unsigned long long w[7];
+  memcpy(w, P.T, 12 * sizeof(float));
+  w[6] = (P.use_coarse ? 1ull : 0ull) | (P.allow_skip ? 2ull : 0ull);
+  unsigned long long x = 0;
+  for (int c = 0; c < 7; c++) x ^= lsa_row_mix(w[c], c);
+  for (int c = 0; c < 7; c++) m->words[c] = w[c];
+  m->check = x ^ key;
+  _mm_sfence();   // payload before the sequence number (the BAR mapping may be write-combining)
+  __atomic_store_n(&m->seq, seq, __ATOMIC_RELEASE);
+  _mm_sfence();
+}
+
+constexpr double kIcpPatienceUs = 300.0, kIcpArmedRowLimitMs = 2.0;
 
 int icp_match_manual(lsa_icp *h, const float4 *d_src, size_t n, const float predict[16], float result[16]) {
   lsa_context *ctx = h->ctx;
@@ -614,22 +712,65 @@ int icp_match_manual(lsa_icp *h, const float4 *d_src, size_t n, const float pred
   NNView Gc = coarse ? nn_view(h->grid_c) : G;
   h->searches_per_iter.clear();
   h->n_searches = h->n_queries = 0;
+  const bool plane = h->mode == LSA_ICP_MODE_PLANE;
+  // armed passes: iteration 0 is launched with its parameters; from then on the kernel of iteration k + 1 is enqueued while k
+  // runs and takes its pose by mail
+  bool armed = !h->no_armed && g <= kHostRows && h->max_iter > 1;
+  if (armed && (rc = icp_mail_ensure(h))) return rc;
+  armed = armed && h->mail;
+  const float gate = plane ? h->max_corr * h->max_corr : h->max_corr;
+  unsigned long long seq_next = 0, key_next = 0;   // the armed kernel in flight, if any
+  auto launch_plain = [&](const IcpParams &P) {
+    if (plane) hipLaunchKernelGGL(k_gn_pass<true>, dim3(g), dim3(kBlock), 0, ctx->stream, d_src, n, P, G, Gc, h->slot_of_id.p, h->prev.p, h->qref.p, h->slot_normals.p, icp_partials_dst(h, g), icp_next_key(h, g));
+    else hipLaunchKernelGGL(k_gn_pass<false>, dim3(g), dim3(kBlock), 0, ctx->stream, d_src, n, P, G, Gc, h->slot_of_id.p, h->prev.p, h->qref.p, (const float4 *)nullptr, icp_partials_dst(h, g), icp_next_key(h, g));
+  };
+  auto launch_armed = [&]() {
+    const unsigned long long current = h->row_key;   // (the key of the pass whose rows are being waited for stays)
+    (void)icp_next_key(h, g);
+    seq_next = h->pass_seq; key_next = h->row_key;
+    h->row_key = current;
+    const IcpMail *slot = reinterpret_cast<const IcpMail *>(h->mail) + (seq_next & 1ull);
+    const unsigned long long ticks = (unsigned long long)(kIcpPatienceUs * 100.0);
+    if (plane) hipLaunchKernelGGL(k_gn_pass_armed<true>, dim3(g), dim3(kBlock), 0, ctx->stream, d_src, n, gate, G, Gc, h->slot_of_id.p, h->prev.p, h->qref.p, h->slot_normals.p, h->h_partials.p, key_next, slot, seq_next, ticks, h->h_gave_up.p);
+    else hipLaunchKernelGGL(k_gn_pass_armed<false>, dim3(g), dim3(kBlock), 0, ctx->stream, d_src, n, gate, G, Gc, h->slot_of_id.p, h->prev.p, h->qref.p, (const float4 *)nullptr, h->h_partials.p, key_next, slot, seq_next, ticks, h->h_gave_up.p);
+  };
   for (int it = 0; it < h->max_iter; it++) {
     IcpParams P;
     P.use_coarse = (coarse && it > 0) ? 1 : 0;   // the first iteration searches cold: no seed says who is far
     P.allow_skip = (!h->no_skip && it > 0) ? 1 : 0;   // ... and leaves every query's proof radius
+    P.gate = gate;
     for (int r = 0; r < 3; r++) {
       for (int c = 0; c < 3; c++) P.T[r * 4 + c] = R[r * 3 + c];
       P.T[r * 4 + 3] = t[r];
     }
-    if (h->mode == LSA_ICP_MODE_PLANE) {
-      P.gate = h->max_corr * h->max_corr;
-      hipLaunchKernelGGL(k_plane_pass, dim3(g), dim3(kBlock), 0, ctx->stream, d_src, n, P, G, Gc, h->slot_of_id.p, h->prev.p, h->qref.p, h->slot_normals.p, icp_partials_dst(h, g), icp_next_key(h, g));
-    } else {
-      P.gate = h->max_corr;
-      hipLaunchKernelGGL(k_icp_pass, dim3(g), dim3(kBlock), 0, ctx->stream, d_src, n, P, G, Gc, h->slot_of_id.p, h->prev.p, h->qref.p, icp_partials_dst(h, g), icp_next_key(h, g));
+    bool fetched = false;
+    if (armed && it > 0) {
+      // this iteration's kernel is resident (or about to be): hand it the pose, enqueue its successor, take its rows
+      const unsigned long long seq = seq_next, key = key_next;
+      icp_mail_post(reinterpret_cast<IcpMail *>(h->mail), seq, key, P);
+      if (it + 1 < h->max_iter) launch_armed();
+      LSA_HIP(ctx, hipGetLastError());
+      h->armed_passes++;
+      if (ndt_reduce_partials_host(h->h_partials.p, g, key, kIcpArmedRowLimitMs, h->h_out.p, h->h_gave_up.p, seq)) {
+        fetched = true;
+        if (++h->unsynced >= 256) {  // let the runtime retire its commands now and then: behind the LAST kernel only, nothing may be parked
+          if (it + 1 == h->max_iter) { LSA_HIP(ctx, hipStreamSynchronize(ctx->stream)); h->unsynced = 0; }
+        }
+      } else {
+        // its rows did not come (it ran out of patience, or something held the stream): drain the stream — the successor, which
+        // will get no mail, leaves after its patience — look once more, and go on one launch per iteration
+        LSA_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        h->unsynced = 0;
+        h->armed_fallbacks++;
+        armed = false;
+        fetched = ndt_reduce_partials_host(h->h_partials.p, g, key, 0.0, h->h_out.p);
+      }
     }
-    if ((rc = icp_fetch_sums(h, g))) return rc;
+    if (!fetched) {
+      launch_plain(P);
+      if (armed && it + 1 < h->max_iter) launch_armed();   // (iteration 0)
+      if ((rc = icp_fetch_sums(h, g, /*may_sync=*/!armed))) return rc;
+    }
     const double *o = h->h_out.p;
     h->searches_per_iter.push_back((uint32_t)o[30]);
     h->n_searches += (uint64_t)o[30]; h->n_queries += (uint64_t)o[29];
@@ -852,7 +993,8 @@ extern "C" void lsa_icp_destroy(lsa_icp *h) {
   (void)lsa_enter(h->ctx);
   (void)hipStreamSynchronize(h->ctx->stream);
   h->grid.release(); h->grid_c.release(); h->slot_of_id.release(); h->vi_n.release(); h->cell_normals.release(); h->slot_normals.release(); h->d_target.release(); h->d_source_own.release(); h->d_work.release();
-  h->partials.release(); h->d_out.release(); h->h_out.release(); h->h_partials.release(); h->h_stage.release(); h->prev.release(); h->qref.release();
+  h->partials.release(); h->d_out.release(); h->h_out.release(); h->h_partials.release(); h->h_stage.release(); h->prev.release(); h->qref.release(); h->h_gave_up.release();
+  if (h->mail) { if (h->mail_is_device) (void)hipFree(h->mail); else (void)hipHostFree(h->mail); }
   delete h;
 }
 
@@ -878,6 +1020,13 @@ extern "C" int lsa_icp_search_counts(lsa_icp *h, uint64_t *searches, uint64_t *q
   if (n_iterations) *n_iterations = h->searches_per_iter.size();
   if (per_iteration)
     for (size_t i = 0; i < cap && i < h->searches_per_iter.size(); i++) per_iteration[i] = h->searches_per_iter[i];
+  return LSA_OK;
+}
+
+extern "C" int lsa_icp_armed_counts(lsa_icp *h, uint64_t *armed_passes, uint64_t *fallbacks) {
+  if (!h) return LSA_ERR_INVALID;
+  if (armed_passes) *armed_passes = h->armed_passes;
+  if (fallbacks) *fallbacks = h->armed_fallbacks;
   return LSA_OK;
 }
 

@@ -237,6 +237,12 @@ class ICPRegistrationHip(RegistrationInterface):
         self.ctx.check(capi.lib().lsa_icp_get_stats(self.h, C.byref(st)))
         return dict(iterations=st.iterations, converged=st.converged, correspondences=st.correspondences, mse=st.mse)
 
+    def armed_counts(self):
+        """(iterations run as armed passes, iterations that had to be run again the ordinary way) since the handle was created."""
+        a, b = C.c_uint64(0), C.c_uint64(0)
+        self.ctx.check(capi.lib().lsa_icp_armed_counts(self.h, C.byref(a), C.byref(b)))
+        return int(a.value), int(b.value)
+
     def search_counts(self):
         """Last ScanMatch (ICPMANUAL / point-to-plane): (searches, queries, per-iteration list) — lsa_icp_search_counts."""
         a, b, n = C.c_uint64(0), C.c_uint64(0), C.c_size_t(0)

@@ -19,5 +19,5 @@ for mode, name in ((capi.ICP_MODE_MANUAL, "manual"), (capi.ICP_MODE_PLANE, "plan
             if rep == 0: Ts.append(T)
     print(name, "coarse grid for far queries" if not os.environ.get("LSA_ICP_NO_COARSE") else "fine grid only",
           "every search run" if os.environ.get("LSA_ICP_NO_SKIP") else "proven searches skipped", "median ms per 30-iteration ScanMatch %.4f" % (np.median(ts) * 1e3), "checksum %.9f" % float(sum(T.astype(np.float64).sum() for T in Ts)))
-    print("   searches per iteration of the last ScanMatch:", icp.search_counts())
+    print("   searches per iteration of the last ScanMatch:", icp.search_counts(), " armed passes / fallbacks:", icp.armed_counts())
     icp.close()

@@ -264,6 +264,7 @@ def test_icp_skipped_searches_change_nothing(ctx, cfg2, monkeypatch):
     for label in ("skip", "full"):
         if label == "full":
             monkeypatch.setenv("LSA_ICP_NO_SKIP", "1")
+            monkeypatch.setenv("LSA_ICP_NO_ARMED", "1")   # ... and one launch per iteration instead of the armed passes
         out = []
         for mode in (capi.ICP_MODE_MANUAL, capi.ICP_MODE_PLANE):
             for iters in (30, 1, 2, 3, 7):
@@ -276,6 +277,8 @@ def test_icp_skipped_searches_change_nothing(ctx, cfg2, monkeypatch):
                     for g in (guess, (guess @ off).astype(np.float32)):
                         _, T = icp.ScanMatch(s8, g)
                         out.append((T.copy(), int(icp.last_stats["correspondences"])))
+                armed_passes, fallbacks = icp.armed_counts()
+                assert fallbacks == 0 and (armed_passes > 0) == (label == "skip" and iters > 1), (label, iters, armed_passes, fallbacks)
                 icp.close()
         runs[label] = out
     assert len(runs["skip"]) == len(runs["full"]) > 40
@@ -284,6 +287,7 @@ def test_icp_skipped_searches_change_nothing(ctx, cfg2, monkeypatch):
     # ... and searches ARE skipped: every query searches in the first iteration, a few per cent of them once the pose has settled
     # (lsa_icp_search_counts); with LSA_ICP_NO_SKIP every query searches in every iteration
     monkeypatch.delenv("LSA_ICP_NO_SKIP")
+    monkeypatch.delenv("LSA_ICP_NO_ARMED")
     s8 = synth.to_xyzi32(cfg2["srcs"][0])
     for mode, settled in ((capi.ICP_MODE_MANUAL, 0.05), (capi.ICP_MODE_PLANE, 0.01)):
         icp = registration.ICPRegistrationHip(ctx, 2.0, 30, mode=mode)
