@@ -825,13 +825,21 @@ def main():
             else:
                 icp_orc.build(ref=False)
                 map8 = synth.to_xyzi32(d_map_f.cpu().numpy())
+        icp_m = registration.ICPRegistrationHip(ctx, 2.0, 30)   # ICPMANUAL (the reference's own plugin) on the same scans: timing only here,
+        icp_m.SetInputTarget(d_map_f.contiguous())             # its parity is tests/test_gpu_bench_scans.py::test_cfg3_bench_scans_match_oracle
+        t_icp_m, searches, queries = [], 0, 0
         for k in range(len(d_scans)):
             f_k = frame_filter.filter_device(d_scans[k]).clone()
             torch.cuda.synchronize()
             t0 = time.perf_counter()
             _, T_icp = icp.ScanMatch(f_k, guesses[k])
             t_icp.append(time.perf_counter() - t0)
+            sc = icp.search_counts()
+            searches += sc[0]; queries += sc[1]
             e_icp.append(pose_err(T_icp, truths[k]))
+            t0 = time.perf_counter()
+            icp_m.ScanMatch(f_k, guesses[k])
+            t_icp_m.append(time.perf_counter() - t0)
             if icp_orc is not None:
                 T_o, _ = icp_orc.icp_plane(map8, synth.to_xyzi32(f_k.cpu().numpy()), guesses[k], 2.0, 30, 1.0)
                 e_icp_orc.append(pose_err(T_icp, T_o))
@@ -842,7 +850,11 @@ def main():
         if e_icp_orc:
             eo = np.array(e_icp_orc)
             icp_plane["pose_rmse_vs_oracle"] = {"t_m": float(np.sqrt(np.mean(eo[:, 0] ** 2))), "r_rad": float(np.sqrt(np.mean(eo[:, 1] ** 2))), "scans": len(eo)}
-        icp.close()
+        ap, af = icp.armed_counts()
+        icp_plane["neighbour_searches"] = {"run": searches, "of": queries, "armed_iterations": ap, "armed_fallbacks": af,
+                                           "note": "a query whose old neighbour is provably still the nearest does not search (csrc/icp.hip); same bits as with every search run"}
+        icp_plane["icpmanual_ms_per_scan_match"] = round(float(np.median(t_icp_m)) * 1e3, 4)
+        icp.close(); icp_m.close()
 
     # ---- CPU baseline: the oracle (single thread) on a bounded sample of the same scans; also the pose check
     progress("CPU baseline + pose checks")
