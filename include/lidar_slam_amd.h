@@ -400,6 +400,9 @@ int lsa_icp_search_counts(lsa_icp *icp, uint64_t *searches, uint64_t *queries, u
  * way since the handle was created; fallbacks: iterations whose armed kernel delivered no rows and that were run again the
  * ordinary way — never silent. */
 int lsa_icp_armed_counts(lsa_icp *icp, uint64_t *armed_passes, uint64_t *fallbacks);
+/* how long a pre-launched iteration kernel waits for its pose before it leaves (default 300 us; tests shorten it to drive the
+ * fallback path) */
+int lsa_icp_set_armed_patience(lsa_icp *icp, double microseconds);
 /* diagnostics: the per-source-point search state of the last ScanMatch, copied to the host — prev_out[i]: position of point i's
  * neighbour in the handle's cell-sorted target (0xffffffff: none); qref_out[4 i .. 4 i + 3]: where the point last searched (xyz,
  * map frame) and the proof radius it left (metres) */

@@ -163,6 +163,7 @@ def lib():
     L.lsa_box_filter_apply.argtypes = [vp, vp, sz, sz, sz, vp, sz, sz, sz, C.POINTER(sz)]
     L.lsa_box_filter_apply_device.argtypes = [vp, vp, sz, vp, C.POINTER(sz)]
     L.lsa_icp_get_stats.argtypes = [vp, C.POINTER(IcpStats)]
+    L.lsa_icp_set_armed_patience.argtypes = [vp, C.c_double]
     L.lsa_icp_armed_counts.argtypes = [vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
     L.lsa_icp_search_counts.argtypes = [vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint32), sz, PSZ]
     L.lsa_ndt_set_mode.argtypes = [vp, i]

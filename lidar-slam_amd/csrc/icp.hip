@@ -525,6 +525,7 @@ struct lsa_icp {
   bool no_armed = getenv("LSA_ICP_NO_ARMED") != nullptr || getenv("LSA_NO_ARMED") != nullptr;
   PinnedBuf<unsigned long long> h_gave_up;
   uint64_t armed_passes = 0, armed_fallbacks = 0;
+  double armed_patience_us = 300.0;   // how long a pre-launched kernel waits for its pose before it leaves (lsa_icp_set_armed_patience)
   std::vector<uint32_t> searches_per_iter;   // last ScanMatch (manual / plane modes): queries that searched, per iteration
   uint64_t n_searches = 0, n_queries = 0;
   VoxelIndex vi_n;                                  // plane mode: voxel grid the normals come from
@@ -687,7 +688,7 @@ void icp_mail_post(IcpMail *base, unsigned long long seq, unsigned long long key
   _mm_sfence();
 }
 
-constexpr double kIcpPatienceUs = 300.0, kIcpArmedRowLimitMs = 2.0;
+constexpr double kIcpArmedRowLimitMs = 2.0;
 
 int icp_match_manual(lsa_icp *h, const float4 *d_src, size_t n, const float predict[16], float result[16]) {
   lsa_context *ctx = h->ctx;
@@ -730,7 +731,7 @@ int icp_match_manual(lsa_icp *h, const float4 *d_src, size_t n, const float pred
     seq_next = h->pass_seq; key_next = h->row_key;
     h->row_key = current;
     const IcpMail *slot = reinterpret_cast<const IcpMail *>(h->mail) + (seq_next & 1ull);
-    const unsigned long long ticks = (unsigned long long)(kIcpPatienceUs * 100.0);
+    const unsigned long long ticks = (unsigned long long)(h->armed_patience_us * 100.0);   // wall_clock64: 100 MHz
     if (plane) hipLaunchKernelGGL(k_gn_pass_armed<true>, dim3(g), dim3(kBlock), 0, ctx->stream, d_src, n, gate, G, Gc, h->slot_of_id.p, h->prev.p, h->qref.p, h->slot_normals.p, h->h_partials.p, key_next, slot, seq_next, ticks, h->h_gave_up.p);
     else hipLaunchKernelGGL(k_gn_pass_armed<false>, dim3(g), dim3(kBlock), 0, ctx->stream, d_src, n, gate, G, Gc, h->slot_of_id.p, h->prev.p, h->qref.p, (const float4 *)nullptr, h->h_partials.p, key_next, slot, seq_next, ticks, h->h_gave_up.p);
   };
@@ -1020,6 +1021,13 @@ extern "C" int lsa_icp_search_counts(lsa_icp *h, uint64_t *searches, uint64_t *q
   if (n_iterations) *n_iterations = h->searches_per_iter.size();
   if (per_iteration)
     for (size_t i = 0; i < cap && i < h->searches_per_iter.size(); i++) per_iteration[i] = h->searches_per_iter[i];
+  return LSA_OK;
+}
+
+extern "C" int lsa_icp_set_armed_patience(lsa_icp *h, double microseconds) {
+  if (!h) return LSA_ERR_INVALID;
+  if (!(microseconds >= 0.0) || microseconds > 1.0e6) return lsa_fail(h->ctx, LSA_ERR_INVALID, "lsa_icp_set_armed_patience: %g us (0 .. 1e6)", microseconds);
+  h->armed_patience_us = microseconds;
   return LSA_OK;
 }
 

@@ -237,6 +237,9 @@ class ICPRegistrationHip(RegistrationInterface):
         self.ctx.check(capi.lib().lsa_icp_get_stats(self.h, C.byref(st)))
         return dict(iterations=st.iterations, converged=st.converged, correspondences=st.correspondences, mse=st.mse)
 
+    def set_armed_patience(self, microseconds):
+        self.ctx.check(capi.lib().lsa_icp_set_armed_patience(self.h, float(microseconds)))
+
     def armed_counts(self):
         """(iterations run as armed passes, iterations that had to be run again the ordinary way) since the handle was created."""
         a, b = C.c_uint64(0), C.c_uint64(0)

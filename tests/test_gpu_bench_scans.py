@@ -297,6 +297,23 @@ def test_icp_skipped_searches_change_nothing(ctx, cfg2, monkeypatch):
         assert len(per) == 30 and per[0] * 30 == queries and sum(per) == searches, (per, queries)
         assert per[-1] <= settled * per[0] and searches < 0.3 * queries, (mode, per)
         icp.close()
+    # a pre-launched kernel that runs out of patience before its pose is posted leaves without rows; the iteration is then run the
+    # ordinary way, counted, and the result is the same: patience of 1 us (the host needs ~5 to solve and post) and of 8 us (some
+    # workgroups take the mail, others have just left)
+    want = [r[0] for r in runs["skip"][:2]]
+    for patience in (1.0, 3.0, 4.0, 5.0, 8.0, 0.0):
+        icp = registration.ICPRegistrationHip(ctx, 2.0, 30)
+        icp.set_armed_patience(patience)
+        icp.SetInputTarget(tgt8)
+        g0 = cfg2["guesses"][0]
+        for rep in range(3):
+            _, Ta = icp.ScanMatch(s8, g0)
+            _, Tb = icp.ScanMatch(s8, (g0 @ off).astype(np.float32))
+            assert np.array_equal(Ta, want[0]) and np.array_equal(Tb, want[1]), (patience, rep)
+        ap, fb = icp.armed_counts()
+        print("ICP armed patience %.0f us: %d armed iterations, %d fallbacks in 6 ScanMatches" % (patience, ap, fb))
+        assert fb >= 1 if patience <= 1.0 else fb >= 0
+        icp.close()
     monkeypatch.setenv("LSA_ICP_NO_SKIP", "1")
     icp = registration.ICPRegistrationHip(ctx, 2.0, 5)
     icp.SetInputTarget(tgt8)
