@@ -269,6 +269,38 @@ def test_update_batch_equals_single_updates(scene):
     fe_b.close(); fe_s.close(); ctx_b.close(); ctx_s.close()
 
 
+def test_update_batch_full_rebuild_and_no_frame_filter(scene):
+    """The same equality with the incremental local map switched off (every key-frame rebuilds filter output and voxel table on the
+    registration's stream, between two ScanMatches of the run) and, separately, without a frame filter (nothing to overlap: the run
+    degenerates to single Updates)."""
+    import torch
+    N = 26
+    poses = synth.trajectory(N, step=1.1)
+    d = [torch.from_numpy(np.ascontiguousarray(synth.gen_scan(scene, poses[i], seed=1500 + i, beams=32, az_steps=900))).cuda() for i in range(N)]
+    torch.cuda.synchronize()
+    for variant in ("full_rebuild", "no_frame_filter"):
+        cfg = front_end.default_config()
+        cfg.local_frame_num = 6
+        if variant == "no_frame_filter":
+            cfg.use_frame_filter = 0
+        ctx_b, ctx_s = capi.Context(0), capi.Context(0)
+        fe_b, fe_s = front_end.FrontEndHip(ctx_b, cfg), front_end.FrontEndHip(ctx_s, cfg)
+        if variant == "full_rebuild":
+            fe_b.set_incremental(False); fe_s.set_incremental(False)
+        ref = []
+        for i in range(N):
+            _, T = fe_s.Update(d[i])
+            ref.append((T, fe_s.last_stats))
+        Ta, sa = fe_b.UpdateBatch(d[:9])
+        Tb, sb = fe_b.UpdateBatch(d[9:])
+        got = list(zip(list(Ta) + list(Tb), sa + sb))
+        for i in range(N):
+            assert np.array_equal(got[i][0], ref[i][0]), (variant, i)
+            assert _flat(got[i][1]) == _flat(ref[i][1]), (variant, i)
+        assert sum(st["key_frame"] for _, st in ref) >= 10
+        fe_b.close(); fe_s.close(); ctx_b.close(); ctx_s.close()
+
+
 def test_kitti_directory_example(scene, tmp_path):
     """examples/run_kitti_odometry.py end to end: KITTI-format .bin files in a directory -> front end -> poses file in the
     KITTI odometry format; the trajectory matches the drive the scans were generated on."""
