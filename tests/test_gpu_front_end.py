@@ -320,9 +320,11 @@ def test_kitti_directory_example(scene, tmp_path):
             s[5, 1] = np.nan   # the reader's removeNaN path
         cloud_io.write_kitti_bin(str(vdir / ("%06d.bin" % i)), s)
     out = tmp_path / "poses.txt"
-    got = ex.run(str(vdir), str(out), log=lambda *a: None)
+    got = ex.run(str(vdir), str(out), log=lambda *a: None, batch=3)   # runs of 3, 3, 2 scans
     rows = np.loadtxt(str(out))
     assert rows.shape == (8, 12) and len(got) == 8
+    one_by_one = ex.run(str(vdir), str(tmp_path / "poses1.txt"), log=lambda *a: None, batch=1)
+    assert all(np.array_equal(a, b) for a, b in zip(got, one_by_one))
     T_last = np.eye(4)
     T_last[:3, :] = rows[-1].reshape(3, 4)
     T_true = np.linalg.inv(poses[0]) @ poses[-1]
