@@ -113,6 +113,27 @@ def main():
         if rank == 0:
             print("[bench %6.1fs] %s" % (time.time() - t_start, msg), file=sys.stderr, flush=True)
 
+    extras_failed = {}
+
+    class guarded:
+        """An extra key's section: a failure in it is recorded under "extras_failed" in the JSON line and on stderr — the headline
+        line is printed whatever happens to an extra.  (Single-process sections only: a rank that skipped a collective would
+        hang the others.)"""
+        def __init__(self, name):
+            self.name = name
+
+        def __enter__(self):
+            return self
+
+        def __exit__(self, et, ev, tb):
+            if et is not None and issubclass(et, Exception):
+                import traceback
+                extras_failed[self.name] = "%s: %s" % (et.__name__, ev)
+                print("[bench] section '%s' failed: %s: %s" % (self.name, et.__name__, ev), file=sys.stderr, flush=True)
+                traceback.print_tb(tb, file=sys.stderr)
+                return True
+            return False
+
     t_start = time.time()
     _load_pkg()
     from lidar_slam_amd import workloads as wl
@@ -450,74 +471,76 @@ def main():
         capi.lib().lsa_matrix_to_pose(capi.fptr(capi.colmajor(g5)), capi.dptr(p5))
         return torch.from_numpy(tgt5).to(dev), torch.from_numpy(src5).to(dev), g5, p5
 
-    progress("cfg5 probe")
-    roofline_cfg5 = None
-    if rank == 0 and world == 1 and not args.no_large:
-        d_t5, d_s5, g5, p5 = make_cfg5()
-        torch.cuda.synchronize()
-        ndt5 = registration.NDTRegistrationHip(ctx, 1.0, 0.1, 0.0, 30, 0.55)
-        ndt5.SetInputTarget(d_t5)
-        ndt5.set_source(d_s5)
-        (_, _, _, pairs5, npts5), ms5 = ndt5.derivatives_timed(g5, p5, kind=0, repeat=20)
-        M5, kbar5 = int(npts5), pairs5 / max(1.0, float(npts5))
-        alg5 = M5 * (16.0 + 4.0 * 27.0 + 48.0 * kbar5)
-        roofline_cfg5 = {"workload": "cfg5: k_ndt_pass<0>, 2,097,152-point source vs 2 M-point target (res 1.0 m)", "bound": "hbm",
-                         "achieved": round(alg5 / (ms5 * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(alg5 / (ms5 * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "us_per_launch": round(ms5 * 1e3, 1),
-                         "alg_bytes_per_launch": int(alg5), "source_points": M5, "kbar": round(kbar5, 3),
-                         "pairs_per_s": round(pairs5 / (ms5 * 1e-3), 0), "vector_f64": vector_f64(pairs5, M5, ms5)}
-        # BASELINE.json configs[4] in full: the 30-iteration align of the 2 M-point scan (eps 0 -> runs to max_iter)
-        ndt5.ScanMatch(d_s5, g5)
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        ndt5.ScanMatch(d_s5, g5)
-        torch.cuda.synchronize()
-        roofline_cfg5["align_ms"] = round((time.perf_counter() - t0) * 1e3, 3)
-        roofline_cfg5["align_iterations"] = int(ndt5.last_stats["iterations"])
-        roofline_cfg5["align_passes"] = int(ndt5.last_stats["passes"])
-        ndt5.close()
-        del d_t5, d_s5
+    with guarded("cfg5 probe"):
+        progress("cfg5 probe")
+        roofline_cfg5 = None
+        if rank == 0 and world == 1 and not args.no_large:
+            d_t5, d_s5, g5, p5 = make_cfg5()
+            torch.cuda.synchronize()
+            ndt5 = registration.NDTRegistrationHip(ctx, 1.0, 0.1, 0.0, 30, 0.55)
+            ndt5.SetInputTarget(d_t5)
+            ndt5.set_source(d_s5)
+            (_, _, _, pairs5, npts5), ms5 = ndt5.derivatives_timed(g5, p5, kind=0, repeat=20)
+            M5, kbar5 = int(npts5), pairs5 / max(1.0, float(npts5))
+            alg5 = M5 * (16.0 + 4.0 * 27.0 + 48.0 * kbar5)
+            roofline_cfg5 = {"workload": "cfg5: k_ndt_pass<0>, 2,097,152-point source vs 2 M-point target (res 1.0 m)", "bound": "hbm",
+                             "achieved": round(alg5 / (ms5 * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                             "frac": round(alg5 / (ms5 * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "us_per_launch": round(ms5 * 1e3, 1),
+                             "alg_bytes_per_launch": int(alg5), "source_points": M5, "kbar": round(kbar5, 3),
+                             "pairs_per_s": round(pairs5 / (ms5 * 1e-3), 0), "vector_f64": vector_f64(pairs5, M5, ms5)}
+            # BASELINE.json configs[4] in full: the 30-iteration align of the 2 M-point scan (eps 0 -> runs to max_iter)
+            ndt5.ScanMatch(d_s5, g5)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            ndt5.ScanMatch(d_s5, g5)
+            torch.cuda.synchronize()
+            roofline_cfg5["align_ms"] = round((time.perf_counter() - t0) * 1e3, 3)
+            roofline_cfg5["align_iterations"] = int(ndt5.last_stats["iterations"])
+            roofline_cfg5["align_passes"] = int(ndt5.last_stats["passes"])
+            ndt5.close()
+            del d_t5, d_s5
 
     # ---- the same kernel against a target that cannot live in a 4 MiB per-XCD L2 (wide_map: >= 100 k valid voxels over
     # +-160 m, a 26 MB dense probe table + ~10 MB of records), cfg5-sized source in RANDOM order (adversarial) and sorted by
     # cell (what a sweeping sensor delivers): where the "table is cache resident" claim can fail.  Extra key, rank 0.
-    progress("wide-map probe")
-    wide_probe = None
-    if rank == 0 and world == 1 and not args.no_large:
-        tgt_w, src_w, g_w = wl.wide_map()
-        p_w = np.zeros(6)
-        capi.lib().lsa_matrix_to_pose(capi.fptr(capi.colmajor(g_w)), capi.dptr(p_w))
-        ndt_w = registration.NDTRegistrationHip(ctx, 1.0, 0.1, 0.0, 30, 0.55)
-        ndt_w.SetInputTarget(torch.from_numpy(tgt_w).to(dev))
-        gi_w = ndt_w.grid_info()
-        wide_probe = {"workload": "wide_map: %d-point target over +-160 m, dense probe table %d x %d x %d cells (%.1f MB) + %.1f MB of records; 2,097,152-point source"
-                                  % (tgt_w.shape[0], gi_w["dim"][0], gi_w["dim"][1], gi_w["dim"][2], float(np.prod(gi_w["dim"])) * 16 / 1e6, gi_w["occupied"] * 80 / 1e6),
-                      "target_voxels_valid": int(gi_w["valid"])}
-        order = np.lexsort((np.floor(src_w[:, 0]), np.floor(src_w[:, 1]), np.floor(src_w[:, 2])))
-        for name, arr in (("random_order_unsorted", src_w), ("random_order", src_w), ("cell_sorted", np.ascontiguousarray(src_w[order]))):
-            d_sw = torch.from_numpy(arr).to(dev)
-            torch.cuda.synchronize()
-            # "random_order": the library's default — it samples the cloud, finds it incoherent and walks a spatially ordered copy
-            # (csrc/source_sort.hip); "random_order_unsorted": that switched off, the raw cost of an incoherent walk
-            ndt_w.set_source_sort(0 if name == "random_order_unsorted" else 1)
-            ndt_w.set_source(d_sw)
-            torch.cuda.synchronize()
-            t0 = time.perf_counter()
-            ndt_w.set_source(d_sw)
-            torch.cuda.synchronize()
-            order_ms = (time.perf_counter() - t0) * 1e3
-            (_, _, _, pairs_w, npts_w), ms_w = ndt_w.derivatives_timed(g_w, p_w, kind=0, repeat=20)
-            Mw, kbar_w = int(npts_w), pairs_w / max(1.0, float(npts_w))
-            alg_w = Mw * (16.0 + 4.0 * 27.0 + 48.0 * kbar_w)
-            wide_probe[name] = {"us_per_launch": round(ms_w * 1e3, 1), "kbar": round(kbar_w, 3), "pairs_per_s": round(pairs_w / (ms_w * 1e-3), 0),
-                                "hbm_alg": {"achieved": round(alg_w / (ms_w * 1e-3) / 1e9, 1), "unit": "GB/s", "frac": round(alg_w / (ms_w * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)},
-                                "vector_f64": vector_f64(pairs_w, Mw, ms_w)}
-            if name == "random_order":
-                wide_probe[name]["walked_in_spatial_order"] = bool(ndt_w.source_sort_count()[1])
-                wide_probe[name]["order_ms_once_per_scan_match"] = round(order_ms, 3)
-                wide_probe[name]["us_per_launch_incl_ordering_over_31_passes"] = round(ms_w * 1e3 + order_ms * 1e3 / 31.0, 1)
-            del d_sw
-        ndt_w.close()
+    with guarded("wide-map probe"):
+        progress("wide-map probe")
+        wide_probe = None
+        if rank == 0 and world == 1 and not args.no_large:
+            tgt_w, src_w, g_w = wl.wide_map()
+            p_w = np.zeros(6)
+            capi.lib().lsa_matrix_to_pose(capi.fptr(capi.colmajor(g_w)), capi.dptr(p_w))
+            ndt_w = registration.NDTRegistrationHip(ctx, 1.0, 0.1, 0.0, 30, 0.55)
+            ndt_w.SetInputTarget(torch.from_numpy(tgt_w).to(dev))
+            gi_w = ndt_w.grid_info()
+            wide_probe = {"workload": "wide_map: %d-point target over +-160 m, dense probe table %d x %d x %d cells (%.1f MB) + %.1f MB of records; 2,097,152-point source"
+                                      % (tgt_w.shape[0], gi_w["dim"][0], gi_w["dim"][1], gi_w["dim"][2], float(np.prod(gi_w["dim"])) * 16 / 1e6, gi_w["occupied"] * 80 / 1e6),
+                          "target_voxels_valid": int(gi_w["valid"])}
+            order = np.lexsort((np.floor(src_w[:, 0]), np.floor(src_w[:, 1]), np.floor(src_w[:, 2])))
+            for name, arr in (("random_order_unsorted", src_w), ("random_order", src_w), ("cell_sorted", np.ascontiguousarray(src_w[order]))):
+                d_sw = torch.from_numpy(arr).to(dev)
+                torch.cuda.synchronize()
+                # "random_order": the library's default — it samples the cloud, finds it incoherent and walks a spatially ordered copy
+                # (csrc/source_sort.hip); "random_order_unsorted": that switched off, the raw cost of an incoherent walk
+                ndt_w.set_source_sort(0 if name == "random_order_unsorted" else 1)
+                ndt_w.set_source(d_sw)
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                ndt_w.set_source(d_sw)
+                torch.cuda.synchronize()
+                order_ms = (time.perf_counter() - t0) * 1e3
+                (_, _, _, pairs_w, npts_w), ms_w = ndt_w.derivatives_timed(g_w, p_w, kind=0, repeat=20)
+                Mw, kbar_w = int(npts_w), pairs_w / max(1.0, float(npts_w))
+                alg_w = Mw * (16.0 + 4.0 * 27.0 + 48.0 * kbar_w)
+                wide_probe[name] = {"us_per_launch": round(ms_w * 1e3, 1), "kbar": round(kbar_w, 3), "pairs_per_s": round(pairs_w / (ms_w * 1e-3), 0),
+                                    "hbm_alg": {"achieved": round(alg_w / (ms_w * 1e-3) / 1e9, 1), "unit": "GB/s", "frac": round(alg_w / (ms_w * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)},
+                                    "vector_f64": vector_f64(pairs_w, Mw, ms_w)}
+                if name == "random_order":
+                    wide_probe[name]["walked_in_spatial_order"] = bool(ndt_w.source_sort_count()[1])
+                    wide_probe[name]["order_ms_once_per_scan_match"] = round(order_ms, 3)
+                    wide_probe[name]["us_per_launch_incl_ordering_over_31_passes"] = round(ms_w * 1e3 + order_ms * 1e3 / 31.0, 1)
+                del d_sw
+            ndt_w.close()
 
     # ---- a second, KITTI-residential-shaped workload through the same pipeline (workloads.dense_dataset: front gardens, hedges,
     # trees with volumetric crowns, second-row buildings; 100 m range): brackets the headline's bare street.  Extra key, rank 0.
@@ -639,20 +662,21 @@ def main():
         del d_sc, d_map_d
         return key
 
-    progress("dense workload")
-    dense_key = None
-    kitti_key = None
-    if rank == 0 and world == 1 and not dist_mode:
-        poses_d, scans_d = wl.dense_dataset(workers)
-        dense_key = second_workload("dense: residential street (gardens, hedges, trees, second-row buildings; 100 m range) through the same Filter -> ScanMatch pipeline",
-                                    poses_d, scans_d, MAP_KEYFRAMES, TEST_SCANS)
-        del poses_d, scans_d
-        progress("KITTI-shaped workload")
-        poses_k, scans_k = wl.kitti_dataset(workers)
-        kitti_key = second_workload("kitti_shaped: residential street on rolling terrain with vegetation and distant blocks, HDL-64E beam table, 120 m range, 50-pose drive; "
-                                    "local map = the reference's full window of 20 key-frames (front_end.yaml local_frame_num), filtered at 0.3 m",
-                                    poses_k, scans_k, wl.KITTI_MAP_KEYFRAMES, wl.KITTI_TEST_SCANS, with_oracle=True, with_front_end=True)
-        del poses_k, scans_k
+    with guarded("dense workload"):
+        progress("dense workload")
+        dense_key = None
+        kitti_key = None
+        if rank == 0 and world == 1 and not dist_mode:
+            poses_d, scans_d = wl.dense_dataset(workers)
+            dense_key = second_workload("dense: residential street (gardens, hedges, trees, second-row buildings; 100 m range) through the same Filter -> ScanMatch pipeline",
+                                        poses_d, scans_d, MAP_KEYFRAMES, TEST_SCANS)
+            del poses_d, scans_d
+            progress("KITTI-shaped workload")
+            poses_k, scans_k = wl.kitti_dataset(workers)
+            kitti_key = second_workload("kitti_shaped: residential street on rolling terrain with vegetation and distant blocks, HDL-64E beam table, 120 m range, 50-pose drive; "
+                                        "local map = the reference's full window of 20 key-frames (front_end.yaml local_frame_num), filtered at 0.3 m",
+                                        poses_k, scans_k, wl.KITTI_MAP_KEYFRAMES, wl.KITTI_TEST_SCANS, with_oracle=True, with_front_end=True)
+            del poses_k, scans_k
 
     # ---- N > 1: the exchange step at the size it is meant for (BASELINE.json configs[3] / [4]): the 2,097,152-point source
     # sharded over the ranks against the replicated 2 M-point target, ONE all-reduce of the 32-double block per pass.
@@ -728,195 +752,199 @@ def main():
     # KITTI-sized pass occupies ~120 of 256 CUs for 8 us and the stream is bound by launch / completion latency, so
     # independent streams (several sensors, loop-closure candidates, offline re-mapping) interleave.  A SINGLE sensor stream
     # cannot use this — scan k+1's prediction needs scan k's pose (front_end.cpp:238-240) — so it is an extra key, never `value`.
-    progress("concurrent streams")
-    concurrent = None
-    if rank == 0 and world == 1 and not dist_mode and args.streams > 1:
-        import threading
-        S = args.streams
+    with guarded("concurrent streams"):
+        progress("concurrent streams")
+        concurrent = None
+        if rank == 0 and world == 1 and not dist_mode and args.streams > 1:
+            import threading
+            S = args.streams
 
-        class _Pipe:
-            def __init__(self, sid):
-                self.sid = sid
-                self.ctx, self.ctx_f = capi.Context(dev_index, None), capi.Context(dev_index, None)
-                self.ff = cloud_filter.VoxelFilterHip(self.ctx_f, 0.5, 0.5, 0.5)
-                self.ndt = registration.NDTRegistrationHip(self.ctx, **NDT_PARAMS)
-                self.ndt.SetInputTarget(d_map_f.contiguous())
-                self.ctx.synchronize()
-                self.buf = [torch.empty_like(d_filt2[0]) for _ in range(2)]
+            class _Pipe:
+                def __init__(self, sid):
+                    self.sid = sid
+                    self.ctx, self.ctx_f = capi.Context(dev_index, None), capi.Context(dev_index, None)
+                    self.ff = cloud_filter.VoxelFilterHip(self.ctx_f, 0.5, 0.5, 0.5)
+                    self.ndt = registration.NDTRegistrationHip(self.ctx, **NDT_PARAMS)
+                    self.ndt.SetInputTarget(d_map_f.contiguous())
+                    self.ctx.synchronize()
+                    self.buf = [torch.empty_like(d_filt2[0]) for _ in range(2)]
 
-            def prep(self, count):
-                idx = [(i + self.sid) % ns for i in range(count)]
-                self.idx, self.count = idx, count
-                self.ptrs = (C.c_void_p * count)(*[d_scans[k].data_ptr() for k in idx])
-                self.nn = (C.c_size_t * count)(*[d_scans[k].shape[0] for k in idx])
-                self.pred = np.ascontiguousarray(guess_cm[idx])
-                self.out = np.zeros((count, 16), dtype=np.float32)
-                self.st = (capi.NdtStats * count)()
-                self.nf = (C.c_size_t * count)()
+                def prep(self, count):
+                    idx = [(i + self.sid) % ns for i in range(count)]
+                    self.idx, self.count = idx, count
+                    self.ptrs = (C.c_void_p * count)(*[d_scans[k].data_ptr() for k in idx])
+                    self.nn = (C.c_size_t * count)(*[d_scans[k].shape[0] for k in idx])
+                    self.pred = np.ascontiguousarray(guess_cm[idx])
+                    self.out = np.zeros((count, 16), dtype=np.float32)
+                    self.st = (capi.NdtStats * count)()
+                    self.nf = (C.c_size_t * count)()
 
-            def run(self):
-                self.rc = L.lsa_pipeline_scan_match(self.ff.h, self.ndt.h, self.count, self.ptrs, self.nn, capi.fptr(self.pred), self.buf[0].data_ptr(),
-                                                    self.buf[1].data_ptr(), 0, 1, capi.fptr(self.out), self.st, self.nf)
+                def run(self):
+                    self.rc = L.lsa_pipeline_scan_match(self.ff.h, self.ndt.h, self.count, self.ptrs, self.nn, capi.fptr(self.pred), self.buf[0].data_ptr(),
+                                                        self.buf[1].data_ptr(), 0, 1, capi.fptr(self.out), self.st, self.nf)
 
-            def close(self):
-                self.ndt.close(); self.ff.close(); self.ctx_f.close(); self.ctx.close()
+                def close(self):
+                    self.ndt.close(); self.ff.close(); self.ctx_f.close(); self.ctx.close()
 
-        pipes = [_Pipe(sid) for sid in range(S)]
+            pipes = [_Pipe(sid) for sid in range(S)]
 
-        def go(count):
+            def go(count):
+                for p_ in pipes:
+                    p_.prep(count)
+                bar = threading.Barrier(S + 1)
+
+                def work(p_):
+                    bar.wait(); p_.run(); bar.wait()
+                th = [threading.Thread(target=work, args=(p_,)) for p_ in pipes]
+                for t_ in th:
+                    t_.start()
+                torch.cuda.synchronize()
+                bar.wait(); t0 = time.perf_counter(); bar.wait()
+                dt_ = time.perf_counter() - t0
+                for t_ in th:
+                    t_.join()
+                for p_ in pipes:
+                    if p_.rc:
+                        p_.ctx_f.check(p_.rc)
+                return dt_
+            go(int(min(args.ramp_seconds, 0.5) * 8000)); go(max(1, args.warmup))
+            dt_s = go(args.steps)
+            # every stream must reproduce, bit for bit, what the single stream produced for the same scans
+            same = all(np.array_equal(capi.from_colmajor(p_.out[i]), results[p_.idx[i]][0]) for p_ in pipes for i in range(max(0, p_.count - ns), p_.count)
+                       if p_.idx[i] in results)
+            concurrent = {"streams": S, "steps_per_stream": args.steps, "value": round(S * args.steps / dt_s, 2), "unit": "scans/s",
+                          "ms_per_step_per_stream": round(dt_s / args.steps * 1e3, 4), "poses_identical_to_single_stream": bool(same),
+                          "note": "S independent scan streams on one GPU, one host thread + one helper thread each; not applicable to a single sensor stream"}
             for p_ in pipes:
-                p_.prep(count)
-            bar = threading.Barrier(S + 1)
-
-            def work(p_):
-                bar.wait(); p_.run(); bar.wait()
-            th = [threading.Thread(target=work, args=(p_,)) for p_ in pipes]
-            for t_ in th:
-                t_.start()
-            torch.cuda.synchronize()
-            bar.wait(); t0 = time.perf_counter(); bar.wait()
-            dt_ = time.perf_counter() - t0
-            for t_ in th:
-                t_.join()
-            for p_ in pipes:
-                if p_.rc:
-                    p_.ctx_f.check(p_.rc)
-            return dt_
-        go(int(min(args.ramp_seconds, 0.5) * 8000)); go(max(1, args.warmup))
-        dt_s = go(args.steps)
-        # every stream must reproduce, bit for bit, what the single stream produced for the same scans
-        same = all(np.array_equal(capi.from_colmajor(p_.out[i]), results[p_.idx[i]][0]) for p_ in pipes for i in range(max(0, p_.count - ns), p_.count)
-                   if p_.idx[i] in results)
-        concurrent = {"streams": S, "steps_per_stream": args.steps, "value": round(S * args.steps / dt_s, 2), "unit": "scans/s",
-                      "ms_per_step_per_stream": round(dt_s / args.steps * 1e3, 4), "poses_identical_to_single_stream": bool(same),
-                      "note": "S independent scan streams on one GPU, one host thread + one helper thread each; not applicable to a single sensor stream"}
-        for p_ in pipes:
-            p_.close()
+                p_.close()
 
     # ---- the caller of the hot path, end to end: lsa_front_end_* = FrontEnd::Update with the sliding local
     # map kept in HBM (front_end.cpp:88-424) over the 30 scans of the drive, scan after scan with NO overlap between scans (the
     # prediction of scan k+1 needs the pose of scan k): frame filter + ScanMatch every scan, and on every key-frame (2 m) the
     # local-map rebuild, its 0.3 m filter and the voxel table.  Extra key, rank 0.
-    progress("front-end loop")
-    front_end_loop = None
-    if rank == 0 and world == 1 and not dist_mode:
-        from lidar_slam_amd import front_end as lsa_fe
-        d_all = [torch.from_numpy(np.ascontiguousarray(sc)).to(dev) for sc in scans]
-        torch.cuda.synchronize()
-        front_end_loop = front_end_drive(lsa_fe, ctx, d_all, poses)
-        front_end_loop["note"] = "device-resident FrontEnd::Update loop incl. key-frame work (local map of <= 20 key-frames, 0.3 m map filter, voxel table)"
-        del d_all
+    with guarded("front-end loop"):
+        progress("front-end loop")
+        front_end_loop = None
+        if rank == 0 and world == 1 and not dist_mode:
+            from lidar_slam_amd import front_end as lsa_fe
+            d_all = [torch.from_numpy(np.ascontiguousarray(sc)).to(dev) for sc in scans]
+            torch.cuda.synchronize()
+            front_end_loop = front_end_drive(lsa_fe, ctx, d_all, poses)
+            front_end_loop["note"] = "device-resident FrontEnd::Update loop incl. key-frame work (local map of <= 20 key-frames, 0.3 m map filter, voxel table)"
+            del d_all
 
     # ---- BASELINE.json configs[2]: point-to-plane ICP (the second RegistrationInterface plugin, lsa_icp_* in its point-to-plane
     # mode; 30 iterations, max correspondence distance 2 m, normals from the target's 1 m voxels) on the same scans against the
     # same local map.  Extra key, rank 0.
-    progress("point-to-plane ICP")
-    icp_plane = None
-    if rank == 0 and world == 1 and not dist_mode:
-        icp = registration.ICPRegistrationHip(ctx, 2.0, 30, mode=capi.ICP_MODE_PLANE)
-        icp.SetInputTarget(d_map_f.contiguous())
-        t_icp, e_icp, e_icp_orc = [], [], []
-        icp_orc = None
-        if not args.no_cpu_baseline:   # the oracle's point-to-plane restatement on the same scans (the checker, not timed)
-            sys.path.insert(0, os.path.join(ROOT, "oracle"))
-            import oracle_py as icp_orc
-            if _under_profiler() and not os.path.exists(os.path.join(ROOT, "oracle", "liblsa_oracle.so")):
-                icp_orc = None
-            else:
-                icp_orc.build(ref=False)
-                map8 = synth.to_xyzi32(d_map_f.cpu().numpy())
-        icp_m = registration.ICPRegistrationHip(ctx, 2.0, 30)   # ICPMANUAL (the reference's own plugin) on the same scans: timing only here,
-        icp_m.SetInputTarget(d_map_f.contiguous())             # its parity is tests/test_gpu_bench_scans.py::test_cfg3_bench_scans_match_oracle
-        t_icp_m, searches, queries = [], 0, 0
-        for k in range(len(d_scans)):
-            f_k = frame_filter.filter_device(d_scans[k]).clone()
-            torch.cuda.synchronize()
-            t0 = time.perf_counter()
-            _, T_icp = icp.ScanMatch(f_k, guesses[k])
-            t_icp.append(time.perf_counter() - t0)
-            sc = icp.search_counts()
-            searches += sc[0]; queries += sc[1]
-            e_icp.append(pose_err(T_icp, truths[k]))
-            t0 = time.perf_counter()
-            icp_m.ScanMatch(f_k, guesses[k])
-            t_icp_m.append(time.perf_counter() - t0)
-            if icp_orc is not None:
-                T_o, _ = icp_orc.icp_plane(map8, synth.to_xyzi32(f_k.cpu().numpy()), guesses[k], 2.0, 30, 1.0)
-                e_icp_orc.append(pose_err(T_icp, T_o))
-        e_icp = np.array(e_icp)
-        icp_plane = {"workload": "cfg3: point-to-plane ICP, 30 iterations, same scans / local map as the headline", "scans": len(t_icp),
-                     "ms_per_scan_match": round(float(np.median(t_icp)) * 1e3, 4), "value": round(1.0 / float(np.median(t_icp)), 1), "unit": "scans/s",
-                     "pose_rmse_vs_truth": {"t_m": float(np.sqrt(np.mean(e_icp[:, 0] ** 2))), "r_rad": float(np.sqrt(np.mean(e_icp[:, 1] ** 2)))}}
-        if e_icp_orc:
-            eo = np.array(e_icp_orc)
-            icp_plane["pose_rmse_vs_oracle"] = {"t_m": float(np.sqrt(np.mean(eo[:, 0] ** 2))), "r_rad": float(np.sqrt(np.mean(eo[:, 1] ** 2))), "scans": len(eo)}
-        ap, af = icp.armed_counts()
-        icp_plane["neighbour_searches"] = {"run": searches, "of": queries, "armed_iterations": ap, "armed_fallbacks": af,
-                                           "note": "a query whose old neighbour is provably still the nearest does not search (csrc/icp.hip); same bits as with every search run"}
-        icp_plane["icpmanual_ms_per_scan_match"] = round(float(np.median(t_icp_m)) * 1e3, 4)
-        icp.close(); icp_m.close()
+    with guarded("point-to-plane ICP"):
+        progress("point-to-plane ICP")
+        icp_plane = None
+        if rank == 0 and world == 1 and not dist_mode:
+            icp = registration.ICPRegistrationHip(ctx, 2.0, 30, mode=capi.ICP_MODE_PLANE)
+            icp.SetInputTarget(d_map_f.contiguous())
+            t_icp, e_icp, e_icp_orc = [], [], []
+            icp_orc = None
+            if not args.no_cpu_baseline:   # the oracle's point-to-plane restatement on the same scans (the checker, not timed)
+                sys.path.insert(0, os.path.join(ROOT, "oracle"))
+                import oracle_py as icp_orc
+                if _under_profiler() and not os.path.exists(os.path.join(ROOT, "oracle", "liblsa_oracle.so")):
+                    icp_orc = None
+                else:
+                    icp_orc.build(ref=False)
+                    map8 = synth.to_xyzi32(d_map_f.cpu().numpy())
+            icp_m = registration.ICPRegistrationHip(ctx, 2.0, 30)   # ICPMANUAL (the reference's own plugin) on the same scans: timing only here,
+            icp_m.SetInputTarget(d_map_f.contiguous())             # its parity is tests/test_gpu_bench_scans.py::test_cfg3_bench_scans_match_oracle
+            t_icp_m, searches, queries = [], 0, 0
+            for k in range(len(d_scans)):
+                f_k = frame_filter.filter_device(d_scans[k]).clone()
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                _, T_icp = icp.ScanMatch(f_k, guesses[k])
+                t_icp.append(time.perf_counter() - t0)
+                sc = icp.search_counts()
+                searches += sc[0]; queries += sc[1]
+                e_icp.append(pose_err(T_icp, truths[k]))
+                t0 = time.perf_counter()
+                icp_m.ScanMatch(f_k, guesses[k])
+                t_icp_m.append(time.perf_counter() - t0)
+                if icp_orc is not None:
+                    T_o, _ = icp_orc.icp_plane(map8, synth.to_xyzi32(f_k.cpu().numpy()), guesses[k], 2.0, 30, 1.0)
+                    e_icp_orc.append(pose_err(T_icp, T_o))
+            e_icp = np.array(e_icp)
+            icp_plane = {"workload": "cfg3: point-to-plane ICP, 30 iterations, same scans / local map as the headline", "scans": len(t_icp),
+                         "ms_per_scan_match": round(float(np.median(t_icp)) * 1e3, 4), "value": round(1.0 / float(np.median(t_icp)), 1), "unit": "scans/s",
+                         "pose_rmse_vs_truth": {"t_m": float(np.sqrt(np.mean(e_icp[:, 0] ** 2))), "r_rad": float(np.sqrt(np.mean(e_icp[:, 1] ** 2)))}}
+            if e_icp_orc:
+                eo = np.array(e_icp_orc)
+                icp_plane["pose_rmse_vs_oracle"] = {"t_m": float(np.sqrt(np.mean(eo[:, 0] ** 2))), "r_rad": float(np.sqrt(np.mean(eo[:, 1] ** 2))), "scans": len(eo)}
+            ap, af = icp.armed_counts()
+            icp_plane["neighbour_searches"] = {"run": searches, "of": queries, "armed_iterations": ap, "armed_fallbacks": af,
+                                               "note": "a query whose old neighbour is provably still the nearest does not search (csrc/icp.hip); same bits as with every search run"}
+            icp_plane["icpmanual_ms_per_scan_match"] = round(float(np.median(t_icp_m)) * 1e3, 4)
+            icp.close(); icp_m.close()
 
     # ---- CPU baseline: the oracle (single thread) on a bounded sample of the same scans; also the pose check
-    progress("CPU baseline + pose checks")
-    cpu_baseline = None
-    pose_rmse = None
-    pose_rmse_pcl = None
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        sys.path.insert(0, os.path.join(ROOT, "oracle"))
-        import oracle_py
-        if _under_profiler() and not os.path.exists(os.path.join(ROOT, "oracle", "liblsa_oracle_fast.so")):
-            raise SystemExit("bench.py under a profiler: build the oracle first (python -c 'import __graft_entry__ as g; g.build()') "
-                             "or pass --no-cpu-baseline; it is not built from a process whose GPU is already initialised")
-        oracle_py.build(ref=False)
-        o = oracle_py.Oracle(fast=True)
-        ondt = oracle_py.OracleNDT(fast=True, **NDT_PARAMS)
-        ondt.set_input_target(synth.to_xyzi32(d_map_f.cpu().numpy()))
-        n_done, t_cpu, errs = 0, 0.0, []
-        i = 0
-        while t_cpu < args.cpu_seconds and n_done < 5000:
-            k = i % len(TEST_SCANS)
-            raw = synth.to_xyzi32(scans[TEST_SCANS[k]])
-            t0 = time.perf_counter()
-            filt, _ = o.voxel_filter(raw, 0.5)
-            Tref, st = ondt.scan_match(synth.to_xyzi32(filt), guesses[k])
-            t_cpu += time.perf_counter() - t0
-            n_done += 1
-            if k in results and i < len(TEST_SCANS):
-                errs.append(pose_err(results[k][0], Tref))
-            i += 1
-        cpu_baseline = {"value": round(n_done / t_cpu, 3), "unit": "scans/s", "cores": 1, "kind": "port",
-                        "sample": "%d scans (VoxelFilter 0.5 + NDT align) of the same workload, oracle -O3, 1 thread, %.1f s" % (n_done, t_cpu)}
-        if errs:
-            e = np.array(errs)
-            pose_rmse = {"t_m": float(np.sqrt(np.mean(e[:, 0] ** 2))), "r_rad": float(np.sqrt(np.mean(e[:, 1] ** 2))), "scans": len(errs)}
-        # the metric says "RMSE vs PCL": PCL itself is absent, so the closest statement available is the
-        # PCL-SEMANTICS mode of the HIP path (the "NDT" plugin's arithmetic) against the oracle's restatement of it, on the
-        # same scans (both unpinned against real PCL)
-        ndt_p = registration.NDTRegistrationHip(ctx, pcl_mode=True, **NDT_PARAMS)
-        ndt_p.SetInputTarget(d_map_f.contiguous())
-        ondt_p = oracle_py.OracleNDT(fast=True, pcl_mode=True, **NDT_PARAMS)
-        ondt_p.set_input_target(synth.to_xyzi32(d_map_f.cpu().numpy()))
-        errs_p, capped = [], []
-        for k in range(len(TEST_SCANS)):
-            filt, _ = o.voxel_filter(synth.to_xyzi32(scans[TEST_SCANS[k]]), 0.5)
-            f8 = synth.to_xyzi32(filt)
-            Tref, st_ref = ondt_p.scan_match(f8, guesses[k])
-            _, Tg = ndt_p.ScanMatch(f8, guesses[k])
-            hit_cap = st_ref["iterations"] > NDT_PARAMS["max_iter"] or ndt_p.last_stats["iterations"] > NDT_PARAMS["max_iter"]
-            (capped if hit_cap else errs_p).append(pose_err(Tg, Tref))
-        ndt_p.close()
-        e = np.array(errs_p) if errs_p else np.zeros((0, 2))
-        c = np.array(capped) if capped else np.zeros((0, 2))
-        pose_rmse_pcl = {"t_m": float(np.sqrt(np.mean(e[:, 0] ** 2))) if len(e) else None,
-                         "r_rad": float(np.sqrt(np.mean(e[:, 1] ** 2))) if len(e) else None, "scans": len(errs_p),
-                         "scans_at_iteration_cap": len(capped), "max_t_m_at_iteration_cap": float(c[:, 0].max()) if len(c) else None,
-                         "note": "HIP PCL-semantics mode vs the oracle's PCL-semantics restatement, each on its OWN voxel table (real PCL is not "
-                                 "available). Cause of the capped scans (pinned by tests/test_gpu_bench_scans.py): PCL's zero-seeded covariances "
-                                 "make this map's voxels 3 cm thin, the 8 cm prediction error starts outside the Newton basin, the Hessian is "
-                                 "indefinite along the path and every step is the clamped 0.1 (the oracle alone behaves the same); such an "
-                                 "iteration is non-contractive, so the 1e-12-level pose gap the two covariance formulas leave after the first "
-                                 "step grows, via one-ulp flips of f32-transformed points, to centimetres. With IDENTICAL tables HIP and oracle "
-                                 "agree to 1e-14 on every pass of every scan, capped ones included"}
+    with guarded("CPU baseline + pose checks"):
+        progress("CPU baseline + pose checks")
+        cpu_baseline = None
+        pose_rmse = None
+        pose_rmse_pcl = None
+        if rank == 0 and world == 1 and not args.no_cpu_baseline:
+            sys.path.insert(0, os.path.join(ROOT, "oracle"))
+            import oracle_py
+            if _under_profiler() and not os.path.exists(os.path.join(ROOT, "oracle", "liblsa_oracle_fast.so")):
+                raise SystemExit("bench.py under a profiler: build the oracle first (python -c 'import __graft_entry__ as g; g.build()') "
+                                 "or pass --no-cpu-baseline; it is not built from a process whose GPU is already initialised")
+            oracle_py.build(ref=False)
+            o = oracle_py.Oracle(fast=True)
+            ondt = oracle_py.OracleNDT(fast=True, **NDT_PARAMS)
+            ondt.set_input_target(synth.to_xyzi32(d_map_f.cpu().numpy()))
+            n_done, t_cpu, errs = 0, 0.0, []
+            i = 0
+            while t_cpu < args.cpu_seconds and n_done < 5000:
+                k = i % len(TEST_SCANS)
+                raw = synth.to_xyzi32(scans[TEST_SCANS[k]])
+                t0 = time.perf_counter()
+                filt, _ = o.voxel_filter(raw, 0.5)
+                Tref, st = ondt.scan_match(synth.to_xyzi32(filt), guesses[k])
+                t_cpu += time.perf_counter() - t0
+                n_done += 1
+                if k in results and i < len(TEST_SCANS):
+                    errs.append(pose_err(results[k][0], Tref))
+                i += 1
+            cpu_baseline = {"value": round(n_done / t_cpu, 3), "unit": "scans/s", "cores": 1, "kind": "port",
+                            "sample": "%d scans (VoxelFilter 0.5 + NDT align) of the same workload, oracle -O3, 1 thread, %.1f s" % (n_done, t_cpu)}
+            if errs:
+                e = np.array(errs)
+                pose_rmse = {"t_m": float(np.sqrt(np.mean(e[:, 0] ** 2))), "r_rad": float(np.sqrt(np.mean(e[:, 1] ** 2))), "scans": len(errs)}
+            # the metric says "RMSE vs PCL": PCL itself is absent, so the closest statement available is the
+            # PCL-SEMANTICS mode of the HIP path (the "NDT" plugin's arithmetic) against the oracle's restatement of it, on the
+            # same scans (both unpinned against real PCL)
+            ndt_p = registration.NDTRegistrationHip(ctx, pcl_mode=True, **NDT_PARAMS)
+            ndt_p.SetInputTarget(d_map_f.contiguous())
+            ondt_p = oracle_py.OracleNDT(fast=True, pcl_mode=True, **NDT_PARAMS)
+            ondt_p.set_input_target(synth.to_xyzi32(d_map_f.cpu().numpy()))
+            errs_p, capped = [], []
+            for k in range(len(TEST_SCANS)):
+                filt, _ = o.voxel_filter(synth.to_xyzi32(scans[TEST_SCANS[k]]), 0.5)
+                f8 = synth.to_xyzi32(filt)
+                Tref, st_ref = ondt_p.scan_match(f8, guesses[k])
+                _, Tg = ndt_p.ScanMatch(f8, guesses[k])
+                hit_cap = st_ref["iterations"] > NDT_PARAMS["max_iter"] or ndt_p.last_stats["iterations"] > NDT_PARAMS["max_iter"]
+                (capped if hit_cap else errs_p).append(pose_err(Tg, Tref))
+            ndt_p.close()
+            e = np.array(errs_p) if errs_p else np.zeros((0, 2))
+            c = np.array(capped) if capped else np.zeros((0, 2))
+            pose_rmse_pcl = {"t_m": float(np.sqrt(np.mean(e[:, 0] ** 2))) if len(e) else None,
+                             "r_rad": float(np.sqrt(np.mean(e[:, 1] ** 2))) if len(e) else None, "scans": len(errs_p),
+                             "scans_at_iteration_cap": len(capped), "max_t_m_at_iteration_cap": float(c[:, 0].max()) if len(c) else None,
+                             "note": "HIP PCL-semantics mode vs the oracle's PCL-semantics restatement, each on its OWN voxel table (real PCL is not "
+                                     "available). Cause of the capped scans (pinned by tests/test_gpu_bench_scans.py): PCL's zero-seeded covariances "
+                                     "make this map's voxels 3 cm thin, the 8 cm prediction error starts outside the Newton basin, the Hessian is "
+                                     "indefinite along the path and every step is the clamped 0.1 (the oracle alone behaves the same); such an "
+                                     "iteration is non-contractive, so the 1e-12-level pose gap the two covariance formulas leave after the first "
+                                     "step grows, via one-ulp flips of f32-transformed points, to centimetres. With IDENTICAL tables HIP and oracle "
+                                     "agree to 1e-14 on every pass of every scan, capped ones included"}
 
     if rank == 0:
         st_list = [results[k][1] for k in sorted(results)]
