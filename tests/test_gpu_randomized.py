@@ -89,3 +89,61 @@ def test_ndt_random_sweep(ctx, oracle):
         assert np.max(np.abs(g_g - g_o)) <= 1e-7 * max(1.0, np.max(np.abs(g_o)))
         assert np.max(np.abs(H_g - H_sym)) <= 1e-7 * max(1.0, np.max(np.abs(H_sym)))
         n.close()
+
+
+def test_icp_skip_and_armed_random_sweep(ctx, monkeypatch):
+    """The two ICP mechanisms that must not change a bit (csrc/icp.hip: searches skipped on a proof radius, iterations launched
+    ahead and fed by mail) on awkward inputs: targets with exact DUPLICATES (ties that only the index breaks), with points on a
+    regular lattice (many equidistant neighbours), tiny clouds, sources partly far outside the target's grid, NaN rows, large
+    coordinates, motions from nothing to metres.  Bar: the pose and the correspondence count of every case equal, bit for bit,
+    those of the build that runs every search with one launch per iteration."""
+    def cases():
+        rng = np.random.RandomState(4242)
+        for case in range(28):
+            nt = int(rng.choice([40, 300, 5000, 30000]))
+            offset = rng.choice([0.0, -400.0, 900.0]) * rng.uniform(0.5, 1.0, 3)
+            if case % 4 == 1:   # lattice: every interior query has several exactly equidistant candidates at some point
+                gx = np.arange(int(round(nt ** (1 / 3.0))) + 2, dtype=np.float64) * 0.5
+                tg = np.stack(np.meshgrid(gx, gx, gx[:4]), axis=-1).reshape(-1, 3) + offset
+                tgt = np.concatenate([tg.astype(np.float32), np.ones((tg.shape[0], 1), np.float32)], axis=1)
+            else:
+                scale = rng.choice([0.3, 2.0, 12.0]) * np.array([1.0, rng.uniform(0.3, 1.0), rng.uniform(0.05, 0.5)])
+                tgt = _cloud(rng, nt, scale, offset, dup=0.4 if case % 4 == 0 else 0.0)
+            ns = int(rng.choice([1, 5, 64, 700, 6000]))
+            src = tgt[rng.randint(0, tgt.shape[0], ns)].copy()
+            src[:, :3] += rng.normal(0.0, rng.choice([0.0, 0.02, 0.4]), (ns, 3)).astype(np.float32)
+            if case % 3 == 0:   # a third of the source far outside the target
+                k = max(1, ns // 3)
+                src[:k, :3] += np.float32(rng.choice([30.0, 500.0]))
+            if case % 5 == 0 and ns > 3:
+                src[rng.randint(0, ns, 2), rng.randint(0, 3)] = np.nan
+            ang = rng.choice([0.0, 0.002, 0.05])
+            guess = synth.pose_matrix(*(rng.normal(0, rng.choice([0.0, 0.05, 0.8]), 3)), 0.0, 0.0, rng.normal(0, ang)).astype(np.float32)
+            yield case, synth.to_xyzi32(tgt), synth.to_xyzi32(src), guess, float(rng.choice([0.5, 2.0, 6.0])), int(rng.choice([2, 9, 30]))
+
+    def run():
+        out = []
+        for case, tgt, src, guess, gate, iters in cases():
+            for mode in (capi.ICP_MODE_MANUAL, capi.ICP_MODE_PLANE):
+                icp = registration.ICPRegistrationHip(ctx, gate, iters, mode=mode)
+                icp.SetInputTarget(tgt)
+                _, T = icp.ScanMatch(src, guess)
+                out.append((case, mode, T.copy(), float(icp.last_stats["correspondences"]), icp.search_counts()[:2], icp.armed_counts()))
+                icp.close()
+        return out
+
+    fast = run()
+    monkeypatch.setenv("LSA_ICP_NO_SKIP", "1")
+    monkeypatch.setenv("LSA_ICP_NO_ARMED", "1")
+    plain = run()
+    assert len(fast) == len(plain) == 56
+    skipped = 0
+    for a, b in zip(fast, plain):
+        assert a[0] == b[0] and a[1] == b[1]
+        same = np.array_equal(a[2], b[2]) or (np.isnan(a[2]).any() and np.array_equal(np.isnan(a[2]), np.isnan(b[2])))
+        assert same and a[3] == b[3], (a[0], a[1], a[2] - b[2], a[3], b[3])
+        # (a fallback is legitimate here — case 12 packs 30 000 target points into a few cells, an iteration takes milliseconds and
+        # the armed rows' 2 ms limit hands it to the ordinary path — but it is counted, and never more than once per ScanMatch)
+        assert b[4][0] == b[4][1] and a[5][1] <= 1 and b[5] == (0, 0), (a[0], a[4], b[4], a[5], b[5])
+        skipped += a[4][1] - a[4][0]
+    assert skipped > 0 and sum(a[5][0] for a in fast) > 100
