@@ -102,6 +102,9 @@ __device__ __forceinline__ NNHit icp_search(const NNView &Gf, const NNView &Gc, 
     // themselves; the margin is 1e-5 of them (+ 1 um) — 40 times that.  (The bounds that come from cell geometry carry the
     // grid's own 1 mm slack already, nn_grid_dev.h.)
     const float mm = sqrtf(mx * mx + my * my + mz * mz);
+    // the very position the last search was run from (the pose has stopped moving in f32): the same query has the same answer,
+    // ties included — the one case the proof below cannot make, and the one query in thousands that would search for ever
+    if (mx == 0.0f && my == 0.0f && mz == 0.0f) return seed;
     const float lb = st.ref.w - mm - 1.0e-5f * (st.ref.w + mm) - 1.0e-6f;
     if (seed.id != 0xffffffffu && sqrtf(seed.d2) * (1.0f + 1.0e-5f) < lb) return seed;   // still the nearest, and alone at that distance
     if ((seed.id == 0xffffffffu || seed.d2 > gate) && lb > 0.0f && lb * lb > gate * (1.0f + 4.0e-5f)) return seed;   // nothing within the gate (the caller drops the pair)
