@@ -556,7 +556,7 @@ def main():
             t0 = time.perf_counter()
             for d_one in d_all:
                 _, T_fe = fe.Update(d_one)
-                n_kf += int(fe.last_stats["key_frame"])
+                n_kf += fe.last_key_frame
             torch.cuda.synchronize()
             dt_fe = time.perf_counter() - t0
             cnt_fe = fe.map_counters()

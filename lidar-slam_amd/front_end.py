@@ -73,7 +73,7 @@ class FrontEndHip:
         h = C.c_void_p()
         ctx.check(L.lsa_front_end_create(C.byref(h), ctx.h, C.byref(self.cfg)))
         self.h = h
-        self.last_stats = None
+        self._last_st, self._last_dict = None, None
 
     def SetInitPose(self, init_pose):  # noqa: N802
         p = capi.colmajor(init_pose)
@@ -94,9 +94,25 @@ class FrontEndHip:
             w_off = capi.w_offset(pts.shape[1])
             rc = capi.lib().lsa_front_end_update(self.h, pts.ctypes.data, pts.shape[0], pts.strides[0], w_off, capi.fptr(out), C.byref(st))
         self.ctx.check(rc)
-        self.last_stats = dict(key_frame=st.key_frame, local_map_frames=st.local_map_frames, filtered_points=st.filtered_points,
-                               local_map_points=st.local_map_points, target_points=st.target_points, ndt=st.ndt.as_dict())
+        self._last_st, self._last_dict = st, None   # (the dict is built when somebody asks for it: a few us per scan otherwise)
         return True, capi.from_colmajor(out)
+
+    @staticmethod
+    def _stats_dict(s):
+        return dict(key_frame=s.key_frame, local_map_frames=s.local_map_frames, filtered_points=s.filtered_points,
+                    local_map_points=s.local_map_points, target_points=s.target_points, ndt=s.ndt.as_dict())
+
+    @property
+    def last_stats(self):
+        """lsa_front_end_stats of the last scan as a dict (None before the first Update)"""
+        if self._last_dict is None and self._last_st is not None:
+            self._last_dict = self._stats_dict(self._last_st)
+        return self._last_dict
+
+    @property
+    def last_key_frame(self):
+        """1 if the last scan became a key-frame"""
+        return int(self._last_st.key_frame) if self._last_st is not None else 0
 
     def UpdateBatch(self, clouds):  # noqa: N802
         """A run of scans (CUDA float32 tensors (n, 4)) through Update in ONE library call with the next scan's frame filter
@@ -111,10 +127,9 @@ class FrontEndHip:
         out = np.zeros((max(count, 1), 16), dtype=np.float32)
         st = (FrontEndStats * max(count, 1))()
         self.ctx.check(capi.lib().lsa_front_end_update_batch_device(self.h, count, ptrs, ns, capi.fptr(out), st))
-        stats = [dict(key_frame=s.key_frame, local_map_frames=s.local_map_frames, filtered_points=s.filtered_points,
-                      local_map_points=s.local_map_points, target_points=s.target_points, ndt=s.ndt.as_dict()) for s in st[:count]]
+        stats = [self._stats_dict(s) for s in st[:count]]
         if count:
-            self.last_stats = stats[-1]
+            self._last_st, self._last_dict = st[count - 1], stats[-1]
         return np.stack([capi.from_colmajor(out[k]) for k in range(count)]) if count else np.zeros((0, 4, 4), np.float32), stats
 
     def set_incremental(self, on):
