@@ -140,7 +140,7 @@ __device__ __forceinline__ void icp_add_column(double (&acc)[8], int col /* comp
   acc[col >> 2] += (sub == (col & 3)) ? v : 0.0;
 }
 
-// wave reduction of the per-lane columns, block sum, check-worded row (tail of k_icp_pass / k_plane_pass)
+// wave reduction of the per-lane columns, block sum, check-worded row (tail of k_gn_pass / k_gn_pass_armed)
 __device__ __forceinline__ void icp_store_row(double (&acc)[8], double *__restrict__ partials, unsigned long long key) {
   __shared__ double sm[kBlock / 64][kOut];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
