@@ -301,6 +301,53 @@ def test_update_batch_full_rebuild_and_no_frame_filter(scene):
         fe_b.close(); fe_s.close(); ctx_b.close(); ctx_s.close()
 
 
+def test_update_batch_random_interleaving(scene):
+    """Runs of random length (1 .. 21 scans) mixed with single Updates and with the calls that disturb the state a run relies on —
+    GetFitnessScore on the front end's registration (materialises an ordinary table, the map is adopted again at the next
+    key-frame), map_verify (scratch builds on the same stream), switching the incremental map off and on — against the same drive
+    through single Updates: every pose equal, bit for bit, no armed pass redone or late."""
+    import ctypes as C
+    import torch
+    N = 70
+    poses = synth.trajectory(N, step=1.05)
+    d = [torch.from_numpy(np.ascontiguousarray(synth.gen_scan(scene, poses[i], seed=2500 + i, beams=32, az_steps=900))).cuda() for i in range(N)]
+    torch.cuda.synchronize()
+    L = capi.lib()
+    cfg = front_end.default_config()
+    cfg.local_frame_num = 12
+    ctx_s = capi.Context(0)
+    fe_s = front_end.FrontEndHip(ctx_s, cfg)
+    ref = [fe_s.Update(d[i])[1] for i in range(N)]
+    fe_s.close(); ctx_s.close()
+    rng = np.random.RandomState(5)
+    for trial in range(4):
+        ctx = capi.Context(0)
+        fe = front_end.FrontEndHip(ctx, cfg)
+        i, got = 0, []
+        while i < N:
+            k = min(int(rng.choice([1, 1, 2, 3, 5, 8, 13, 21])), N - i)
+            op = rng.randint(0, 6)
+            if k == 1 and op < 3:
+                got.append(fe.Update(d[i])[1])
+            else:
+                got += list(fe.UpdateBatch(d[i:i + k])[0])
+            i += k
+            if i > 2:
+                if op == 3:
+                    f = C.c_float(0)
+                    ctx.check(L.lsa_ndt_get_fitness_score(L.lsa_front_end_registration(fe.h), C.byref(f)))
+                elif op == 5 and fe.map_counters()["adopted"]:
+                    assert fe.map_verify()["mismatches"] == 0, (trial, i)
+                elif op == 2 and trial == 3:
+                    fe.set_incremental(False); fe.set_incremental(True)
+        for j in range(N):
+            assert np.array_equal(got[j], ref[j]), (trial, j)
+        st = capi.NdtArmedStats()
+        ctx.check(L.lsa_ndt_armed_stats(L.lsa_front_end_registration(fe.h), C.byref(st), 0))
+        assert st.fallbacks == 0 and st.rows_late == 0 and st.deferred > N // 2, st.as_dict()
+        fe.close(); ctx.close()
+
+
 def test_kitti_directory_example(scene, tmp_path):
     """examples/run_kitti_odometry.py end to end: KITTI-format .bin files in a directory -> front end -> poses file in the
     KITTI odometry format; the trajectory matches the drive the scans were generated on."""
