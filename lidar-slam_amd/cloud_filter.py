@@ -37,18 +37,27 @@ class VoxelFilterHip(CloudFilterInterface):
         self.h = h
 
     def Filter(self, input_cloud, filtered_cloud=None):  # noqa: N802
-        """Host path. Returns (True, filtered (m, 8) float32). `filtered_cloud` may be the input (viewer.cpp:207)."""
+        """Host path. Returns (True, filtered (m, 8) float32). `filtered_cloud` may be the input (viewer.cpp:207) or any (>= n, 8) array to write into."""
         pts = np.ascontiguousarray(input_cloud, dtype=np.float32)
         n = pts.shape[0]
         stride = pts.strides[0]
         w_off = capi.w_offset(pts.shape[1])
-        out = np.zeros((max(n, 1), 8), dtype=np.float32)
+        # `filtered_cloud`: the caller's own (>= n, 8) float32 array, as the reference's callers hand in their cloud object
+        # (front_end.cpp:106-107) — written in place, a view of its first m rows is returned.  Without one: a buffer kept across
+        # calls (a fresh 4 MB array per scan costs an mmap / munmap and its page faults), of which the filtered points are copied out.
+        own = (isinstance(filtered_cloud, np.ndarray) and filtered_cloud.dtype == np.float32 and filtered_cloud.ndim == 2 and filtered_cloud.shape[1] == 8
+               and filtered_cloud.shape[0] >= max(n, 1) and filtered_cloud.flags.c_contiguous and filtered_cloud.flags.writeable)
+        if own:
+            buf = filtered_cloud
+        else:
+            buf = getattr(self, "_out_buf", None)
+            if buf is None or buf.shape[0] < max(n, 1):
+                buf = self._out_buf = np.zeros((max(n, 1) + max(n, 1) // 4, 8), dtype=np.float32)
         n_out = C.c_size_t(0)
-        rc = capi.lib().lsa_voxel_filter_apply(self.h, pts.ctypes.data, n, stride, w_off, out.ctypes.data, n, capi.POINT_STRIDE, capi.W_OFF, C.byref(n_out))
-        if rc == capi.LSA_ERR_RANGE:
-            return True, out[: n_out.value]  # PCL warns and passes the input through; the plugin still returns true
-        self.ctx.check(rc)
-        return True, out[: n_out.value]
+        rc = capi.lib().lsa_voxel_filter_apply(self.h, pts.ctypes.data, n, stride, w_off, buf.ctypes.data, n, capi.POINT_STRIDE, capi.W_OFF, C.byref(n_out))
+        if rc != capi.LSA_ERR_RANGE:  # (range: PCL warns and passes the input through; the plugin still returns true)
+            self.ctx.check(rc)
+        return True, (buf[: n_out.value] if own else buf[: n_out.value].copy())
 
     def filter_device(self, d_in, d_out=None):
         """Device path: d_in a CUDA float32 tensor (n, 4) {x,y,z,intensity}; returns a view of d_out[:m]."""

@@ -347,7 +347,12 @@ extern "C" int lsa_voxel_filter_apply(lsa_voxel_filter *f, const void *in_pts, s
     return rc;
   }
   size_t V = 0;
-  rc = filter_device(f, f->d_in.p, n, f->d_out.p, &V);
+  // The filtered points go STRAIGHT into the pinned staging buffer (device-visible host memory: the finalize kernel's 16-byte
+  // stores cross the link as they are issued, ~120 KB for a KITTI scan) instead of into device memory and back through a copy
+  // command and a second wait (13 us).  The staging buffer is free by then — its uploads were ordered in front of the kernels —
+  // and visible to the host once the build's completion event has been waited for (vi_wait); a build that ends in the range
+  // error writes nothing, so the packed input the pass-through below reads is still there.
+  rc = filter_device(f, f->d_in.p, n, reinterpret_cast<float4 *>(f->h_stage.p), &V);
   if (rc == LSA_ERR_RANGE) {
     // PCL: warns and sets output = *input_
     if (out_pts != in_pts) {
@@ -365,11 +370,6 @@ extern "C" int lsa_voxel_filter_apply(lsa_voxel_filter *f, const void *in_pts, s
   }
   if (rc) return rc;
   if (V > out_cap) return lsa_fail(ctx, LSA_ERR_CAPACITY, "lsa_voxel_filter_apply: out_cap %zu < %zu voxels", out_cap, V);
-  if (V) {
-    // the staging buffer is free again (input already consumed on the stream once we synchronise)
-    LSA_HIP(ctx, hipMemcpyAsync(f->h_stage.p, f->d_out.p, V * sizeof(float4), hipMemcpyDeviceToHost, ctx->stream));
-  }
-  LSA_HIP(ctx, hipStreamSynchronize(ctx->stream));
   for (size_t i = 0; i < V; i++) {
     const float *p = f->h_stage.p + 4 * i;
     char *o = (char *)out_pts + i * out_stride;

@@ -41,7 +41,7 @@ class NDTRegistrationHip(RegistrationInterface):
         self.h = h
         if pcl_mode:  # stand in for the "NDT" plugin (ndt_registration.cpp, PCL semantics) instead of "NDTMANUAL"
             ctx.check(capi.lib().lsa_ndt_set_mode(h, capi.NDT_MODE_PCL))
-        self.last_stats = None
+        self._ls_struct, self._ls_dict = None, None
         self._cb = None
         self._keep = None
 
@@ -72,10 +72,21 @@ class NDTRegistrationHip(RegistrationInterface):
             if trace:
                 capi.lib().lsa_ndt_set_trace(self.h, None, 0, None)
         self.ctx.check(rc)
-        self.last_stats = st.as_dict()
+        self._ls_struct, self._ls_dict = st, None   # (the dict is built when somebody asks for it)
         if trace:
             self.last_stats["trace"] = tr[: min(ntr.value, 512)].copy()
         return True, capi.from_colmajor(out)
+
+    @property
+    def last_stats(self):
+        """lsa_ndt_stats of the last ScanMatch as a dict (None before the first)"""
+        if self._ls_dict is None and self._ls_struct is not None:
+            self._ls_dict = self._ls_struct.as_dict()
+        return self._ls_dict
+
+    @last_stats.setter
+    def last_stats(self, value):
+        self._ls_struct, self._ls_dict = None, value
 
     def _scan_match(self, input_source, guess, out, st):
         if _is_tensor(input_source):

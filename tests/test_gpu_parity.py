@@ -82,6 +82,13 @@ def test_voxel_filter_edge_cases(ctx, oracle):
     ctx.check(capi.lib().lsa_voxel_filter_apply(f.h, buf.ctypes.data, buf.shape[0], 32, 16, buf.ctypes.data, buf.shape[0], 32, 16, C.byref(n_out)))
     assert n_out.value == ref.shape[0]
     assert np.allclose(buf[: n_out.value][:, [0, 1, 2, 4]], ref, rtol=1e-6, atol=1e-6)
+    # the Python mirror with the caller's own output cloud (written in place, a view is returned), also with in == out
+    own = np.zeros((p8.shape[0], 8), dtype=np.float32)
+    ok, view = f.Filter(p8, own)
+    assert ok and view.base is own and view.shape[0] == ref.shape[0] and np.allclose(view[:, [0, 1, 2, 4]], ref, rtol=1e-6, atol=1e-6)
+    both = p8.copy()
+    ok, view = f.Filter(both, both)
+    assert ok and view.base is both and np.allclose(view[:, [0, 1, 2, 4]], ref, rtol=1e-6, atol=1e-6)
     # leaf too small for the extent: PCL warns and passes the input through
     tiny = cloud_filter.VoxelFilterHip(ctx, 1e-2, 1e-2, 1e-2)
     big = synth.to_xyzi32(np.array([[0, 0, 0, 1], [500, 500, 50, 1]], dtype=np.float32))
