@@ -315,11 +315,12 @@ extern "C" int lsa_voxel_filter_apply(lsa_voxel_filter *f, const void *in_pts, s
     return lsa_fail(ctx, LSA_ERR_INVALID, "point rows of %zu bytes cannot hold xyz + an intensity at offset %zu (pass SIZE_MAX for clouds without one)", in_stride, in_w_off);
   LSA_HIP(ctx, lsa_enter(ctx));
   int rc;
-  // the staging buffer may still be feeding an earlier async copy, and growing a buffer frees the old one: wait first
-  LSA_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  // growing a buffer frees the old one, which an earlier command might still use: wait first.  (Not otherwise: every earlier call
+  // on this handle returned behind its build's completion event, i.e. behind every copy out of / kernel store into the staging
+  // buffer, and nothing else touches it — the wait on an idle stream cost 3-5 us per scan.)
+  if (n * 4 > f->h_stage.cap || n > f->d_in.cap) LSA_HIP(ctx, hipStreamSynchronize(ctx->stream));
   if ((rc = f->h_stage.reserve(ctx, n * 4))) return rc;
   if ((rc = f->d_in.reserve(ctx, n, 1.25))) return rc;
-  if ((rc = f->d_out.reserve(ctx, n, 1.25))) return rc;
   // Host cloud -> device: packing 131 k rows of 32 B costs ~65 us on one core and the four 512 KB copies behind it another
   // ~35 us on one copy queue.  Large clouds are therefore split in two: the helper thread packs the second half and sends
   // it down a second copy queue while this thread does the same with the first half (measured: the data is resident
