@@ -566,11 +566,11 @@ def main():
             fe = lsa_fe.FrontEndHip(ctx)
             fe.SetInitPose(poses_drive[0].astype(np.float32))
             t0 = time.perf_counter()
-            T_b, st_b = fe.UpdateBatch(d_all)
+            T_b, kf_b = fe.UpdateBatch(d_all, stats="key_frame")
             torch.cuda.synchronize()
             dt_b = time.perf_counter() - t0
             fe.close()
-        if not np.array_equal(T_b[-1], T_fe) or sum(int(x["key_frame"]) for x in st_b) != n_kf:
+        if not np.array_equal(T_b[-1], T_fe) or sum(kf_b) != n_kf:
             raise RuntimeError("front end: the batch run and the scan-by-scan run disagree")
         return {"scans": len(d_all), "key_frames": n_kf, "value": round(len(d_all) / dt_fe, 1), "unit": "scans/s",
                 "ms_per_scan": round(dt_fe / len(d_all) * 1e3, 4),

@@ -114,9 +114,10 @@ class FrontEndHip:
         """1 if the last scan became a key-frame"""
         return int(self._last_st.key_frame) if self._last_st is not None else 0
 
-    def UpdateBatch(self, clouds):  # noqa: N802
+    def UpdateBatch(self, clouds, stats=True):  # noqa: N802
         """A run of scans (CUDA float32 tensors (n, 4)) through Update in ONE library call with the next scan's frame filter
-        overlapped (lsa_front_end_update_batch_device).  Returns (poses [count, 4, 4], list of per-scan stats dicts)."""
+        overlapped (lsa_front_end_update_batch_device).  Returns (poses [count, 4, 4], per-scan stats): a list of stats dicts, or —
+        stats="key_frame" — just the list of key-frame flags (a replay that only wants poses does not pay for `count` dicts)."""
         from .registration import check_points_tensor
         count = len(clouds)
         for c in clouds:
@@ -127,10 +128,12 @@ class FrontEndHip:
         out = np.zeros((max(count, 1), 16), dtype=np.float32)
         st = (FrontEndStats * max(count, 1))()
         self.ctx.check(capi.lib().lsa_front_end_update_batch_device(self.h, count, ptrs, ns, capi.fptr(out), st))
-        stats = [self._stats_dict(s) for s in st[:count]]
         if count:
-            self._last_st, self._last_dict = st[count - 1], stats[-1]
-        return np.stack([capi.from_colmajor(out[k]) for k in range(count)]) if count else np.zeros((0, 4, 4), np.float32), stats
+            self._last_st, self._last_dict = st[count - 1], None
+        poses = np.ascontiguousarray(out[:count].reshape(count, 4, 4).transpose(0, 2, 1))   # column-major 4x4s -> row-major
+        if stats == "key_frame":
+            return poses, [int(s.key_frame) for s in st[:count]]
+        return poses, [self._stats_dict(s) for s in st[:count]]
 
     def set_incremental(self, on):
         """Incremental local map (default) or the full rebuild of filter output + voxel table on every key-frame."""
