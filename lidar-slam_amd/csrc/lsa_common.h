@@ -38,6 +38,7 @@ inline hipError_t lsa_enter(lsa_context *ctx) {
 // derived from them (rows handed to the host as they arrive, the armed passes' mail) can never match what another handle
 // — destroyed, its pinned memory recycled — left behind.  Bit 63 stays clear (the mail's cancel flag); 2^36 numbers per handle.
 unsigned long long lsa_seq_base();
+size_t lsa_upload_chunk();   // points per host -> device copy command (lsa_upload_xyzw)
 
 void lsa_set_global_error(const char *fmt, ...);
 int lsa_fail(lsa_context *ctx, int code, const char *fmt, ...);

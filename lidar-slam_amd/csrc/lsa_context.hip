@@ -37,12 +37,17 @@ int lsa_fail(lsa_context *ctx, int code, const char *fmt, ...) {
 // Host points -> device float4: packed into the pinned staging buffer and copied in a few chunks, each copy enqueued as
 // soon as its chunk is packed, so the PCIe transfer of chunk k runs under the packing of chunk k + 1 (a 131 k-point scan:
 // ~70 us of packing with ~40 us of copy behind it instead of after it).  The caller owns the ordering of h_stage reuse.
+size_t lsa_upload_chunk() {
+  static const size_t c = getenv("LSA_UPLOAD_CHUNK") ? (size_t)atol(getenv("LSA_UPLOAD_CHUNK")) : 65536;   // points per copy command: 1 MB (two of a KITTI scan run side by side, one per copy queue: 115-118 us per host Filter against 119-123 with four of 512 KB)
+  return c < 1024 ? 1024 : c;
+}
+
 int lsa_upload_xyzw(lsa_context *ctx, const void *pts, size_t n, size_t stride, size_t w_off, float *h_stage, float4 *d_dst) {
   // an intensity offset that does not fit the row would read the next point (or past the buffer): (n,3) xyz rows have
   // no intensity and must say so with w_off == SIZE_MAX
   if (n && (stride < 12 || (w_off != SIZE_MAX && w_off + 4 > stride)))
     return lsa_fail(ctx, LSA_ERR_INVALID, "point rows of %zu bytes cannot hold xyz + an intensity at offset %zu (pass SIZE_MAX for clouds without one)", stride, w_off);
-  constexpr size_t kChunk = 32768;  // points: 512 KB per copy, few enough copies that their launch cost stays small
+  const size_t kChunk = lsa_upload_chunk();
   for (size_t off = 0; off < n; off += kChunk) {
     const size_t m = n - off < kChunk ? n - off : kChunk;
     lsa_pack_xyzw((const char *)pts + off * stride, m, stride, w_off, h_stage + 4 * off);

@@ -156,7 +156,7 @@ void filter_worker(lsa_voxel_filter *f) {
       // second half of a host cloud down the second copy queue.  The helper touches neither the context nor its error text
       // (the caller's thread may be writing it): stride / offset were validated by the caller, a HIP failure comes back as
       // a code in job_hip and the caller's thread reports it
-      constexpr size_t kChunk = 32768;
+      const size_t kChunk = lsa_upload_chunk();
       hipError_t e = hipSuccess;
       for (size_t off = 0; off < f->u_n && e == hipSuccess; off += kChunk) {
         const size_t m = f->u_n - off < kChunk ? f->u_n - off : kChunk, at = f->u_off + off;
