@@ -319,6 +319,12 @@ int lsa_gn_solve_trace(lsa_pass_eval_fn eval, void *user, float res, float step_
 /* pose helpers of that driver (f32 rigid transform <-> the reference's (t, Euler XYZ) chart) */
 void lsa_pose_to_matrix(const double p[6], float T[16]);
 void lsa_matrix_to_pose(const float T[16], double p[6]);
+/* Self-test hook (pure host arithmetic, no device): the f32 Eigen blocks of csrc/gn_math.h on caller-supplied inputs, so that
+ * the CPU tests can hold the PRODUCT's copy to the same reference fixtures as the oracle's (tests/golden/eigen_blocks.json).
+ * what 0: Transform<float,3,Affine>::rotation() (NormalDistributionsTransform.cpp:336), in 9 row-major -> out 9;
+ *      1: Matrix<float,6,6>::determinant() (icp_registration_manual.cpp:165), in 36 -> out 1;
+ *      2: inverse() and inverse() * B (:169), in 36 + 6 -> out 36 + 6;   3: Matrix3f product (:173), in 9 + 9 -> out 9. */
+int lsa_eigen_f32_selftest(int what, const float *in, float *out);
 void lsa_ndt_gauss_constants(float res, float outlier_ratio, double *d1, double *d2);
 
 /* ---------------------------------------------------------------------------------------------

@@ -126,6 +126,7 @@ def lib():
     L.lsa_pose_to_matrix.restype = None
     L.lsa_matrix_to_pose.argtypes = [PF, PD]
     L.lsa_matrix_to_pose.restype = None
+    L.lsa_eigen_f32_selftest.argtypes = [C.c_int, PF, PF]
     L.lsa_ndt_gauss_constants.argtypes = [f, f, PD, PD]
     L.lsa_ndt_gauss_constants.restype = None
     L.lsa_icp_create.argtypes = [PVP, vp, f, i, i]

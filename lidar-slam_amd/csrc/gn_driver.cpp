@@ -272,11 +272,17 @@ extern "C" void lsa_pose_to_matrix(const double p[6], float T[16]) {
 }
 
 extern "C" void lsa_matrix_to_pose(const float T[16], double p[6]) {
-  // p = (translation, rotation().eulerAngles(0, 1, 2)) (:331-337).  Eigen 3.2.92's eulerAngles folds the first
-  // angle into [0, pi] before negating, so a slightly negative roll comes back in the flipped chart
-  // (roll + pi, pi - pitch, yaw +- pi); the chart map is affine and norm preserving, the Newton iteration is
-  // unaffected.  The linear part is used directly (Transform::rotation()'s f32 polar step returns it to rounding).
-  auto M = [&](int r, int c) { return T[c * 4 + r]; };
+  // p = (translation, rotation().eulerAngles(0, 1, 2)) (:331-337).  Transform::rotation() is an f32 Jacobi-SVD polar factor of
+  // the linear part (gm::rotation_polar_f32: Eigen's own sequence of operations; it moves a pose that has been through f32
+  // products by an ulp or two, which the first pass's angle tables then see); the Euler angles are taken from ITS result.
+  // Eigen 3.2.92's eulerAngles folds the first angle into [0, pi] before negating, so a slightly negative roll comes back
+  // in the flipped chart (roll + pi, pi - pitch, yaw +- pi); the chart map is affine and norm preserving, the Newton
+  // iteration is unaffected.
+  float L[9], Rm[9];
+  for (int r = 0; r < 3; r++)
+    for (int c = 0; c < 3; c++) L[r * 3 + c] = T[c * 4 + r];
+  gm::rotation_polar_f32(L, Rm);
+  auto M = [&](int r, int c) { return Rm[r * 3 + c]; };
   float r0 = atan2f(M(1, 2), M(2, 2));
   float c2 = sqrtf(M(0, 0) * M(0, 0) + M(0, 1) * M(0, 1));
   float r1;
@@ -288,8 +294,19 @@ extern "C" void lsa_matrix_to_pose(const float T[16], double p[6]) {
   }
   float s1 = sinf(r0), c1 = cosf(r0);
   float r2 = atan2f(s1 * M(2, 0) - c1 * M(1, 0), c1 * M(1, 1) - s1 * M(2, 1));
-  p[0] = M(0, 3); p[1] = M(1, 3); p[2] = M(2, 3);
+  p[0] = T[12]; p[1] = T[13]; p[2] = T[14];
   p[3] = -r0; p[4] = -r1; p[5] = -r2;
+}
+
+// tests (CPU): the f32 Eigen blocks of gn_math.h on caller-supplied inputs.  what: 0 rotation_polar_f32 (in 9 -> out 9), 1 determinant
+// (in 36 -> out 1), 2 inverse and inverse * B (in 36 + 6 -> out 36 + 6), 3 Matrix3f product (in 9 + 9 -> out 9).  Pure host arithmetic.
+extern "C" int lsa_eigen_f32_selftest(int what, const float *in, float *out) {
+  if (!in || !out) return LSA_ERR_INVALID;
+  if (what == 0) { gm::rotation_polar_f32(in, out); return LSA_OK; }
+  if (what == 1) { gm::Lu6f f; gm::lu6f_factor(in, &f); out[0] = gm::lu6f_det(f); return LSA_OK; }
+  if (what == 2) { gm::Lu6f f; gm::lu6f_factor(in, &f); gm::lu6f_inverse(f, out); gm::mul66f_vec(out, in + 36, out + 36); return LSA_OK; }
+  if (what == 3) { gm::mul3f_eigen(in, in + 9, out); return LSA_OK; }
+  return LSA_ERR_INVALID;
 }
 
 extern "C" void lsa_ndt_gauss_constants(float res, float outlier_ratio_f, double *d1, double *d2) {

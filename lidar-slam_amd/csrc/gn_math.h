@@ -230,6 +230,183 @@ GM_HD inline bool pose_to_matrix(const double p[6], float T[16]) {
   return ok;
 }
 
+// ------------------------------------------------------------------------------------------------ matrix -> pose, f32 Eigen blocks
+// The f32 Eigen calls the reference makes around the hot loops, operation by operation in Eigen 3.2.92's order (the
+// reference vendors it: lidar_localization/third_party/eigen3); oracle/eigen_f32_oracle.c holds the checker's copy of the
+// same restatement, and that one is pinned bit for bit against the vendored Eigen compiled in place (oracle/ref_blocks.cpp,
+// tests/golden/eigen_blocks.json); tests/test_cabi_cpu.py holds THESE to the same fixtures through lsa_matrix_to_pose /
+// lsa_eigen_f32_selftest.
+//
+// Eigen reduces a fixed-size 3-term sum as t0 + (t1 + t2) (Core/Redux.h, unrolled by halves) — not left to right.
+GM_HD inline float dot3_eigen(float a0, float b0, float a1, float b1, float a2, float b2) {
+#pragma clang fp contract(off)
+  return a0 * b0 + (a1 * b1 + a2 * b2);
+}
+GM_HD inline void rot_pair(float *x, float *y, float c, float s) {   // Jacobi/Jacobi.h:418-426
+#pragma clang fp contract(off)
+  const float xi = *x, yi = *y;
+  *x = c * xi + s * yi;
+  *y = -s * xi + c * yi;
+}
+// Transform<float,3,Affine>::rotation() (NormalDistributionsTransform.cpp:336; Eigen Geometry/Transform.h:1059-1074): two-sided
+// JacobiSVD<Matrix3f> of the linear part (SVD/JacobiSVD.h:676-780), x = det(U V^T), R = (U with column 0 / x) V^T.  Row-major.
+GM_HD inline void rotation_polar_f32(const float L[9], float R[9]) {
+#pragma clang fp contract(off)
+  float W[3][3], U[3][3], V[3][3];
+  float scale = 0.0f;
+  for (int k = 0; k < 9; k++) { const float a = __builtin_fabsf(L[k]); if (a > scale) scale = a; }
+  if (scale == 0.0f) scale = 1.0f;
+  for (int r = 0; r < 3; r++)
+    for (int c = 0; c < 3; c++) { W[r][c] = L[r * 3 + c] / scale; U[r][c] = V[r][c] = (r == c) ? 1.0f : 0.0f; }
+  const float precision = 2.0f * FLT_EPSILON, consider_as_zero = 2.0f * 0x1p-149f;
+  bool finished = false;
+  for (int sweep = 0; !finished && sweep < 64; sweep++) {   // (Eigen loops until a sweep changes nothing: 2-5 sweeps; NaN input ends it at once)
+    finished = true;
+    for (int p = 1; p < 3; p++)
+      for (int q = 0; q < p; q++) {
+        const float ap = __builtin_fabsf(W[p][p]), aq = __builtin_fabsf(W[q][q]);
+        float thr = precision * (ap < aq ? aq : ap);
+        thr = consider_as_zero < thr ? thr : consider_as_zero;
+        if (!(__builtin_fabsf(W[p][q]) > thr || __builtin_fabsf(W[q][p]) > thr)) continue;
+        finished = false;
+        // real_2x2_jacobi_svd (:408-435)
+        float m00 = W[p][p], m01 = W[p][q], m10 = W[q][p], m11 = W[q][q];
+        float c1 = 1.0f, s1 = 0.0f;
+        const float t = m00 + m11, d = m10 - m01;
+        if (d != 0.0f) {
+          const float u = t / d;
+          const float tmp = __builtin_sqrtf(1.0f + u * u);
+          s1 = 1.0f / tmp;
+          c1 = u / tmp;
+        }
+        if (!(c1 == 1.0f && s1 == 0.0f)) { rot_pair(&m00, &m10, c1, s1); rot_pair(&m01, &m11, c1, s1); }
+        // JacobiRotation::makeJacobi(m00, m01, m11) (Jacobi/Jacobi.h:80-113)
+        float cr = 1.0f, sr = 0.0f;
+        if (m01 != 0.0f) {
+          const float tau = (m00 - m11) / (2.0f * __builtin_fabsf(m01));
+          const float w = __builtin_sqrtf(tau * tau + 1.0f);
+          const float tt = tau > 0.0f ? 1.0f / (tau + w) : 1.0f / (tau - w);
+          const float sign_t = tt > 0.0f ? 1.0f : -1.0f;
+          const float n = 1.0f / __builtin_sqrtf(tt * tt + 1.0f);
+          sr = -sign_t * (m01 / __builtin_fabsf(m01)) * __builtin_fabsf(tt) * n;
+          cr = n;
+        }
+        const float s2 = -sr;                                             // j_right.transpose()
+        const float cl = c1 * cr - s1 * s2, sl = c1 * s2 + s1 * cr;       // j_left = rot1 * j_right.transpose()
+        if (!(cl == 1.0f && sl == 0.0f)) {
+          for (int i = 0; i < 3; i++) rot_pair(&W[p][i], &W[q][i], cl, sl);
+          for (int i = 0; i < 3; i++) rot_pair(&U[i][p], &U[i][q], cl, sl);
+        }
+        if (!(cr == 1.0f && s2 == 0.0f)) {
+          for (int i = 0; i < 3; i++) rot_pair(&W[i][p], &W[i][q], cr, s2);
+          for (int i = 0; i < 3; i++) rot_pair(&V[i][p], &V[i][q], cr, s2);
+        }
+      }
+  }
+  float sv[3];
+  for (int i = 0; i < 3; i++) {
+    const float a = __builtin_fabsf(W[i][i]);
+    sv[i] = a;
+    if (a != 0.0f) { const float f = W[i][i] / a; for (int r = 0; r < 3; r++) U[r][i] *= f; }
+  }
+  for (int i = 0; i < 3; i++) sv[i] *= scale;
+  for (int i = 0; i < 3; i++) {   // descending order, the first maximum wins
+    int pos = i;
+    for (int k = i + 1; k < 3; k++) if (sv[k] > sv[pos]) pos = k;
+    if (sv[pos] == 0.0f) break;
+    if (pos != i) {
+      const float ts = sv[i]; sv[i] = sv[pos]; sv[pos] = ts;
+      for (int r = 0; r < 3; r++) { const float tu = U[r][i]; U[r][i] = U[r][pos]; U[r][pos] = tu; const float tv = V[r][i]; V[r][i] = V[r][pos]; V[r][pos] = tv; }
+    }
+  }
+  float M[3][3];
+  for (int i = 0; i < 3; i++)
+    for (int j = 0; j < 3; j++) M[i][j] = dot3_eigen(U[i][0], V[j][0], U[i][1], V[j][1], U[i][2], V[j][2]);
+  // LU/Determinant.h: bruteforce_det3_helper(0,1,2) - helper(1,0,2) + helper(2,0,1)
+  const float x = M[0][0] * (M[1][1] * M[2][2] - M[1][2] * M[2][1]) - M[0][1] * (M[1][0] * M[2][2] - M[1][2] * M[2][0]) +
+                  M[0][2] * (M[1][0] * M[2][1] - M[1][1] * M[2][0]);
+  for (int r = 0; r < 3; r++) U[r][0] /= x;
+  for (int i = 0; i < 3; i++)
+    for (int j = 0; j < 3; j++) R[i * 3 + j] = dot3_eigen(U[i][0], V[j][0], U[i][1], V[j][1], U[i][2], V[j][2]);
+}
+
+// Matrix<float,6,6>::determinant() / inverse() / inverse() * B as ICPRegistrationManual calls them
+// (lidar_localization/src/models/registration/icp_registration_manual.cpp:165-169): PartialPivLU (LU/PartialPivLU.h:331-385, unblocked
+// for sizes <= 16), determinant = sign * diagonal().prod() reduced by halves, inverse = solve(Identity) by the column-oriented
+// triangular solves of Core/products/TriangularSolverMatrix.h:95-118 (b = (x_i *= 1 / u_ii); r -= b * l).  Row-major.
+struct Lu6f {
+  float lu[6][6];
+  int trans[6];
+  int nt;
+};
+GM_HD inline void lu6f_factor(const float A[36], Lu6f *f) {
+#pragma clang fp contract(off)
+  f->nt = 0;
+  for (int r = 0; r < 6; r++) for (int c = 0; c < 6; c++) f->lu[r][c] = A[r * 6 + c];
+  for (int k = 0; k < 6; k++) {
+    int piv = k;
+    float big = __builtin_fabsf(f->lu[k][k]);
+    for (int r = k + 1; r < 6; r++) if (__builtin_fabsf(f->lu[r][k]) > big) { big = __builtin_fabsf(f->lu[r][k]); piv = r; }
+    f->trans[k] = piv;
+    if (big != 0.0f) {
+      if (piv != k) { for (int c = 0; c < 6; c++) { const float t = f->lu[k][c]; f->lu[k][c] = f->lu[piv][c]; f->lu[piv][c] = t; } f->nt++; }
+      for (int r = k + 1; r < 6; r++) f->lu[r][k] /= f->lu[k][k];
+    }
+    for (int r = k + 1; r < 6; r++)
+      for (int c = k + 1; c < 6; c++) f->lu[r][c] -= f->lu[r][k] * f->lu[k][c];
+  }
+}
+GM_HD inline float lu6f_det(const Lu6f &f) {
+#pragma clang fp contract(off)
+  const float p = (f.lu[0][0] * (f.lu[1][1] * f.lu[2][2])) * (f.lu[3][3] * (f.lu[4][4] * f.lu[5][5]));
+  return ((f.nt & 1) ? -1.0f : 1.0f) * p;
+}
+GM_HD inline void lu6f_inverse(const Lu6f &f, float Hi[36]) {
+#pragma clang fp contract(off)
+  float X[6][6];
+  for (int r = 0; r < 6; r++) for (int c = 0; c < 6; c++) X[r][c] = (r == c) ? 1.0f : 0.0f;
+  for (int k = 0; k < 6; k++)
+    if (f.trans[k] != k) for (int c = 0; c < 6; c++) { const float t = X[k][c]; X[k][c] = X[f.trans[k]][c]; X[f.trans[k]][c] = t; }
+  for (int i = 0; i < 6; i++)
+    for (int j = 0; j < 6; j++) {
+      const float b = X[i][j];
+      for (int s = i + 1; s < 6; s++) X[s][j] -= b * f.lu[s][i];
+    }
+  for (int i = 5; i >= 0; i--) {
+    const float a = 1.0f / f.lu[i][i];
+    for (int j = 0; j < 6; j++) {
+      const float b = (X[i][j] *= a);
+      for (int s = 0; s < i; s++) X[s][j] -= b * f.lu[s][i];
+    }
+  }
+  for (int r = 0; r < 6; r++) for (int c = 0; c < 6; c++) Hi[r * 6 + c] = X[r][c];
+}
+GM_HD inline void mul66f_vec(const float Hi[36], const float B[6], float out[6]) {
+#pragma clang fp contract(off)
+  for (int r = 0; r < 6; r++) {
+    const float *h = Hi + r * 6;
+    out[r] = (h[0] * B[0] + (h[1] * B[1] + h[2] * B[2])) + (h[3] * B[3] + (h[4] * B[4] + h[5] * B[5]));
+  }
+}
+// delta_x = Hessian.inverse() * B unless Hessian.determinant() == 0 (:165-169); returns the determinant
+GM_HD inline float solve6f_eigen(const float H[36], const float B[6], float d[6]) {
+  Lu6f f;
+  lu6f_factor(H, &f);
+  const float det = lu6f_det(f);
+  if (det == 0.0f) return det;
+  float Hi[36];
+  lu6f_inverse(f, Hi);
+  mul66f_vec(Hi, B, d);
+  return det;
+}
+// Matrix3f * Matrix3f (rotation_matrix_ *= delta_rotation.matrix(), :173), row-major; out may alias A
+GM_HD inline void mul3f_eigen(const float A[9], const float B[9], float out[9]) {
+  float r[9];
+  for (int i = 0; i < 3; i++)
+    for (int j = 0; j < 3; j++) r[i * 3 + j] = dot3_eigen(A[i * 3], B[j], A[i * 3 + 1], B[3 + j], A[i * 3 + 2], B[6 + j]);
+  for (int k = 0; k < 9; k++) out[k] = r[k];
+}
+
 // ------------------------------------------------------------------------------------------------ angle derivatives
 // computeAngleDerivatives (:523-645), including the |angle| < 10e-5 snap; ja = j_ang_a..h (:551-581), ha = h_ang_a2, a3,
 // b2, b3, c2, c3, d1, d2, d3, e1, e2, e3, f1, f2, f3 (:584-642)

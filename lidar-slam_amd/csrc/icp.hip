@@ -32,6 +32,7 @@
 #include "eig3_dev.h"
 #include "nn_grid_dev.h"
 #include "ndt_pass.h"
+#include "gn_math.h"
 
 #include <immintrin.h>
 
@@ -450,38 +451,6 @@ __global__ __launch_bounds__(1024) void k_reduce32(const double *__restrict__ pa
   if (rl == 0) out[col] = sm[0][col];
 }
 
-// f32 partial-pivot LU: determinant and inverse of the 6x6 (Eigen's Matrix<float,6,6>::determinant()/inverse() both go
-// through PartialPivLU for sizes > 4)
-float lu6_inverse(const float A[36], float inv[36]) {
-  float M[6][12];
-  for (int r = 0; r < 6; r++)
-    for (int c = 0; c < 6; c++) { M[r][c] = A[r * 6 + c]; M[r][6 + c] = (r == c) ? 1.0f : 0.0f; }
-  float det = 1.0f;
-  for (int k = 0; k < 6; k++) {
-    int piv = k;
-    float mv = std::fabs(M[k][k]);
-    for (int r = k + 1; r < 6; r++)
-      if (std::fabs(M[r][k]) > mv) { mv = std::fabs(M[r][k]); piv = r; }
-    if (mv == 0.0f) return 0.0f;
-    if (piv != k) {
-      for (int c = 0; c < 12; c++) std::swap(M[k][c], M[piv][c]);
-      det = -det;
-    }
-    det *= M[k][k];
-    float ip = 1.0f / M[k][k];
-    for (int c = 0; c < 12; c++) M[k][c] *= ip;
-    for (int r = 0; r < 6; r++)
-      if (r != k) {
-        float f = M[r][k];
-        if (f != 0.0f)
-          for (int c = 0; c < 12; c++) M[r][c] -= f * M[k][c];
-      }
-  }
-  for (int r = 0; r < 6; r++)
-    for (int c = 0; c < 6; c++) inv[r * 6 + c] = M[r][6 + c];
-  return det;
-}
-
 // Sophus::SO3f::exp(omega).matrix(): unit quaternion, then Eigen's Quaternion::toRotationMatrix, all f32
 void so3_exp(const float w[3], float R[9]) {
   float theta_sq = w[0] * w[0] + w[1] * w[1] + w[2] * w[2];
@@ -783,21 +752,14 @@ int icp_match_manual(lsa_icp *h, const float4 *d_src, size_t n, const float pred
     for (int a = 0; a < 6; a++) B[a] = (float)o[1 + a];
     for (int a = 0; a < 6; a++)
       for (int b = a; b < 6; b++) { H[a * 6 + b] = H[b * 6 + a] = (float)o[k]; k++; }
-    float Hi[36];
-    float det = lu6_inverse(H, Hi);
-    if (det == 0.0f) continue;  // :165
+    // Hessian.determinant() == 0 -> continue; delta_x = Hessian.inverse() * B; rotation_matrix_ *= exp(delta) (:165-173): Eigen's
+    // own f32 operation order (gn_math.h; the checker's copy is pinned against the reference's vendored Eigen)
     float d[6];
-    for (int a = 0; a < 6; a++) {
-      float s = 0;
-      for (int b = 0; b < 6; b++) s += Hi[a * 6 + b] * B[b];
-      d[a] = s;
-    }
+    if (gm::solve6f_eigen(H, B, d) == 0.0f) continue;  // :165
     t[0] += d[0]; t[1] += d[1]; t[2] += d[2];
-    float dR[9], Rn[9];
+    float dR[9];
     so3_exp(d + 3, dR);
-    for (int r = 0; r < 3; r++)
-      for (int c = 0; c < 3; c++) Rn[r * 3 + c] = (R[r * 3 + 0] * dR[0 * 3 + c] + R[r * 3 + 1] * dR[1 * 3 + c]) + R[r * 3 + 2] * dR[2 * 3 + c];
-    memcpy(R, Rn, sizeof(R));
+    gm::mul3f_eigen(R, dR, R);
   }
   for (int r = 0; r < 3; r++) {
     for (int c = 0; c < 3; c++) T[c * 4 + r] = R[r * 3 + c];

@@ -7,10 +7,11 @@
  * lidar_localization/cmake/PCL.cmake:1; sophus via "sophus/se3.hpp", no version):
  *   pcl::KdTreeFLANN::nearestKSearch(k=1)  -> exact 1-NN, SQUARED L2 distance in f32
  *   Sophus::SO3f::hat / exp                -> textbook hat; exp via unit quaternion
- *   Eigen 6x6 f32 determinant / inverse    -> partial-pivot LU in f32
+ * In the tree and PINNED bit for bit (vendored Eigen 3.2.92 compiled in place, oracle/_ref; eigen_f32_oracle.c):
+ *   Eigen 6x6 f32 determinant / inverse / inverse * B, Matrix3f products, the per-point J / J^T J / J^T e expressions
  * Quirk kept (:147): the SQUARED NN distance is compared with the un-squared threshold.
- * PARITY STATUS: UNPINNED (f32 summation order inside Eigen/FLANN is not reproducible from text;
- * tests compare with a float tolerance, see tests/test_icp_*.py).
+ * PARITY STATUS: the Eigen arithmetic is pinned; the loop around it, the kd-tree's tie order and SO3::exp are restated
+ * from text and UNPINNED (tests compare with a float tolerance, see tests/test_gpu_icp_fitness.py).
  */
 #include "lsa_oracle.h"
 
@@ -79,25 +80,14 @@ static int nn_query(const nn_grid *g, const float q[3], float gate, float *sqd_o
   return best;
 }
 
-/* f32 partial-pivot LU: returns det, writes inverse */
-static float lu6_inverse(const float A[36], float inv[36]) {
-  float M[6][12];
-  for (int r = 0; r < 6; r++) for (int c = 0; c < 6; c++) { M[r][c] = A[r * 6 + c]; M[r][6 + c] = (r == c) ? 1.0f : 0.0f; }
-  float det = 1.0f;
-  for (int k = 0; k < 6; k++) {
-    int piv = k; float mv = fabsf(M[k][k]);
-    for (int r = k + 1; r < 6; r++) if (fabsf(M[r][k]) > mv) { mv = fabsf(M[r][k]); piv = r; }
-    if (mv == 0.0f) return 0.0f;
-    if (piv != k) { for (int c = 0; c < 12; c++) { float t = M[k][c]; M[k][c] = M[piv][c]; M[piv][c] = t; } det = -det; }
-    det *= M[k][k];
-    float ip = 1.0f / M[k][k];
-    for (int c = 0; c < 12; c++) M[k][c] *= ip;
-    for (int r = 0; r < 6; r++) if (r != k) {
-      float f = M[r][k];
-      if (f != 0.0f) for (int c = 0; c < 12; c++) M[r][c] -= f * M[k][c];
-    }
-  }
-  for (int r = 0; r < 6; r++) for (int c = 0; c < 6; c++) inv[r * 6 + c] = M[r][6 + c];
+/* Eigen's Matrix<float,6,6>::determinant() == 0 test, inverse() and inverse() * B (:165-169): eigen_f32_oracle.c, pinned.
+ * Returns the determinant; d = H^-1 B when it is not zero. */
+static float solve6f(const float H[36], const float B[6], float d[6]) {
+  float det = orc_det6f(H);
+  if (det == 0.0f) return det;
+  float Hi[36];
+  orc_inv6f(H, Hi);
+  orc_mul66f_vec(Hi, B, d);
   return det;
 }
 
@@ -145,29 +135,14 @@ int orc_icp_manual(const void *tgt, size_t nt, size_t tstride, const void *src, 
       if (id < 0) continue; /* distances[0] > max_correspond_distance_ (:147, squared vs un-squared, sic) */
       const float *c = P(tgt, tstride, (size_t)id);
       float e[3] = {q[0] - c[0], q[1] - c[1], q[2] - c[2]};
-      float J[3][6];
-      memset(J, 0, sizeof(J));
-      J[0][0] = J[1][1] = J[2][2] = 1.0f;
-      float hat[9] = {0, -p[2], p[1], p[2], 0, -p[0], -p[1], p[0], 0};
-      for (int r = 0; r < 3; r++)
-        for (int cc = 0; cc < 3; cc++)
-          J[r][3 + cc] = ((-R[r * 3 + 0]) * hat[0 * 3 + cc] + (-R[r * 3 + 1]) * hat[1 * 3 + cc]) + (-R[r * 3 + 2]) * hat[2 * 3 + cc];
-      for (int a = 0; a < 6; a++) {
-        for (int b = 0; b < 6; b++) H[a * 6 + b] += (J[0][a] * J[0][b] + J[1][a] * J[1][b]) + J[2][a] * J[2][b];
-        B[a] += (-J[0][a]) * e[0] + (-J[1][a]) * e[1] + (-J[2][a]) * e[2];
-      }
+      orc_icp_acc(R, p, e, H, B); /* :156-162, Eigen's product association (pinned) */
     }
-    float Hi[36];
-    float det = lu6_inverse(H, Hi);
-    if (det == 0.0f) continue; /* :165 */
     float d[6];
-    for (int a = 0; a < 6; a++) { float s = 0; for (int b = 0; b < 6; b++) s += Hi[a * 6 + b] * B[b]; d[a] = s; }
+    if (solve6f(H, B, d) == 0.0f) continue; /* :165 */
     t[0] += d[0]; t[1] += d[1]; t[2] += d[2];
-    float dR[9], Rn[9];
+    float dR[9];
     so3_exp_f32(d + 3, dR);
-    for (int r = 0; r < 3; r++) for (int c = 0; c < 3; c++)
-      Rn[r * 3 + c] = (R[r * 3 + 0] * dR[0 * 3 + c] + R[r * 3 + 1] * dR[1 * 3 + c]) + R[r * 3 + 2] * dR[2 * 3 + c];
-    memcpy(R, Rn, sizeof(R));
+    orc_mul3f(R, dR, R); /* rotation_matrix_ *= delta_rotation.matrix() (:173) */
     for (int r = 0; r < 3; r++) { for (int c = 0; c < 3; c++) T[c * 4 + r] = R[r * 3 + c]; T[12 + r] = t[r]; }
   }
   nn_free(g);
@@ -290,19 +265,15 @@ int orc_icp_plane(const void *tgt, size_t nt, size_t tstride, const void *src, s
       }
       ncorr += 1;
     }
-    float H[36], B[6], Hi[36];
+    float H[36], B[6];
     for (int k = 0; k < 36; k++) H[k] = (float)Hd[k];
     for (int k = 0; k < 6; k++) B[k] = (float)Bd[k];
-    float det = lu6_inverse(H, Hi);
-    if (det == 0.0f) continue;
     float d[6];
-    for (int a = 0; a < 6; a++) { float s = 0; for (int b = 0; b < 6; b++) s += Hi[a * 6 + b] * B[b]; d[a] = s; }
+    if (solve6f(H, B, d) == 0.0f) continue;
     t[0] += d[0]; t[1] += d[1]; t[2] += d[2];
-    float dR[9], Rn[9];
+    float dR[9];
     so3_exp_f32(d + 3, dR);
-    for (int r2 = 0; r2 < 3; r2++) for (int c2 = 0; c2 < 3; c2++)
-      Rn[r2 * 3 + c2] = (R[r2 * 3 + 0] * dR[0 * 3 + c2] + R[r2 * 3 + 1] * dR[1 * 3 + c2]) + R[r2 * 3 + 2] * dR[2 * 3 + c2];
-    memcpy(R, Rn, sizeof(R));
+    orc_mul3f(R, dR, R);
     for (int r2 = 0; r2 < 3; r2++) { for (int c2 = 0; c2 < 3; c2++) T[c2 * 4 + r2] = R[r2 * 3 + c2]; T[12 + r2] = t[r2]; }
   }
   nn_free(g); ng_free(ng);

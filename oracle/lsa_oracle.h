@@ -16,8 +16,10 @@
  *   - What IS pinned against real reference code: the 3x3 symmetric
  *     eigen-solver (reference header SymmetricEigenSolver.h, compiled in place)
  *     and the vendored-Eigen building blocks the path calls (Matrix3d::inverse,
- *     JacobiSVD<6x6>::solve, eulerAngles(0,1,2), Translation*AngleAxis^3) — see
- *     oracle/_ref (built by oracle/Makefile) and tests/golden/eigen_blocks.json.
+ *     JacobiSVD<6x6>::solve, Transform::rotation() + eulerAngles(0,1,2),
+ *     Translation*AngleAxis^3, and ICPMANUAL's f32 determinant / inverse /
+ *     products) — see oracle/_ref (built by oracle/Makefile) and
+ *     tests/golden/eigen_blocks.json.
  *   - Everything else (grid build loops, radius search, derivative loops,
  *     More-Thuente control flow, PCL VoxelGrid, ICP) is restated from the
  *     reference text / published PCL 1.7 algorithm and is UNPINNED.
@@ -51,6 +53,15 @@ int orc_svd6_solve(const double H[36], const double b[6], double x[6]);
 void orc_pose_to_matrix(const double p[6], float T[16]);
 /* p = (translation, rotation.eulerAngles(0,1,2)) in f32 then widened (NS/...:331-337). */
 void orc_matrix_to_pose(const float T[16], double p[6]);
+/* The f32 Eigen calls of the path (eigen_f32_oracle.c; each pinned bit for bit by oracle/_ref, row-major 3x3 / 6x6):
+ * Transform<float,3,Affine>::rotation() (NS/...:336), Matrix<float,6,6>::determinant() / inverse() / inverse() * B,
+ * Matrix3f * Matrix3f and the per-point accumulation of S/models/registration/icp_registration_manual.cpp:156-176. */
+void orc_rotation_f32(const float L[9], float R[9]);
+float orc_det6f(const float H[36]);
+void orc_inv6f(const float H[36], float Hi[36]);
+void orc_mul66f_vec(const float Hi[36], const float B[6], float out[6]);
+void orc_mul3f(const float A[9], const float B[9], float out[9]);
+void orc_icp_acc(const float R[9], const float p[3], const float e[3], float H[36], float B[6]);
 /* pcl::transformPointCloud f32 semantics (PCL 1.7 common/impl/transforms.hpp). xyz only. */
 void orc_transform_point(const float T[16], const float in[3], float out[3]);
 

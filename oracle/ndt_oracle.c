@@ -8,7 +8,7 @@
  * plus the vendored-Eigen calls that path makes.  PARITY STATUS: the loops in this
  * file are UNPINNED (no reference fixtures exist, reference unbuildable here); the
  * numeric building blocks orc_eig3 / orc_inv3 / orc_svd6_solve / orc_pose_to_matrix /
- * orc_matrix_to_pose are pinned against real reference code by oracle/_ref.
+ * orc_matrix_to_pose (incl. the f32 polar step of Transform::rotation()) are pinned against real reference code by oracle/_ref.
  *
  * Build with -ffp-contract=off: the reference is built for baseline x86-64 (no FMA).
  */
@@ -257,12 +257,15 @@ void orc_pose_to_matrix(const double p[6], float T[16]) {
 }
 
 void orc_matrix_to_pose(const float T[16], double p[6]) {
-  /* NS/NormalDistributionsTransform.cpp:331-337. Transform::rotation() is an f32 SVD polar
-   * factor; for the orthonormal linear part the path feeds it, it returns that part to f32
-   * rounding, so the linear part is used directly (effect <= ~1e-6 rad on p0 only).
+  /* NS/NormalDistributionsTransform.cpp:331-337.  Transform::rotation() is an f32 two-sided Jacobi SVD polar factor of
+   * the linear part (orc_rotation_f32, eigen_f32_oracle.c: pinned bit for bit); the Euler angles are taken from ITS result.
    * Euler extraction: Eigen 3.2.92 Geometry/EulerAngles.h:35-101 with (a0,a1,a2)=(0,1,2):
    * odd=0, i=0, j=1, k=2, first angle folded into [0,pi] before the final negation. */
-#define M(r, c) T[(c) * 4 + (r)]
+  float L[9], Rm[9];
+  for (int r = 0; r < 3; r++)
+    for (int c = 0; c < 3; c++) L[r * 3 + c] = T[c * 4 + r];
+  orc_rotation_f32(L, Rm);
+#define M(r, c) Rm[(r) * 3 + (c)]
   float res0 = atan2f(M(1, 2), M(2, 2));
   float c2 = sqrtf(M(0, 0) * M(0, 0) + M(0, 1) * M(0, 1));
   float res1;
@@ -274,9 +277,9 @@ void orc_matrix_to_pose(const float T[16], double p[6]) {
   }
   float s1 = sinf(res0), c1 = cosf(res0);
   float res2 = atan2f(s1 * M(2, 0) - c1 * M(1, 0), c1 * M(1, 1) - s1 * M(2, 1));
-  p[0] = M(0, 3); p[1] = M(1, 3); p[2] = M(2, 3);
-  p[3] = -res0; p[4] = -res1; p[5] = -res2;
 #undef M
+  p[0] = T[12]; p[1] = T[13]; p[2] = T[14];
+  p[3] = -res0; p[4] = -res1; p[5] = -res2;
 }
 
 void orc_transform_point(const float T[16], const float in[3], float out[3]) {

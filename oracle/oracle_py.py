@@ -81,6 +81,13 @@ class Oracle:
         L.orc_pose_to_matrix.argtypes = [PD, PF]
         L.orc_matrix_to_pose.argtypes = [PF, PD]
         L.orc_transform_point.argtypes = [PF, PF, PF]
+        L.orc_rotation_f32.argtypes = [PF, PF]
+        L.orc_det6f.argtypes = [PF]
+        L.orc_det6f.restype = f
+        L.orc_inv6f.argtypes = [PF, PF]
+        L.orc_mul66f_vec.argtypes = [PF, PF, PF]
+        L.orc_mul3f.argtypes = [PF, PF, PF]
+        L.orc_icp_acc.argtypes = [PF, PF, PF, PF, PF]
         L.orc_dot3.argtypes = [PD, PD]
         L.orc_dot3.restype = d
         L.orc_mv3.argtypes = [PD, PD, PD]
@@ -167,6 +174,42 @@ class Oracle:
         p = np.zeros(6)
         self.L.orc_matrix_to_pose(_fp(Tc), _dp(p))
         return p
+
+    # f32 Eigen blocks of the path (eigen_f32_oracle.c), row-major
+    def rotation_f32(self, L):
+        L = np.ascontiguousarray(L, dtype=np.float32).reshape(9)
+        R = np.zeros(9, dtype=np.float32)
+        self.L.orc_rotation_f32(_fp(L), _fp(R))
+        return R.reshape(3, 3)
+
+    def det6f(self, H):
+        H = np.ascontiguousarray(H, dtype=np.float32).reshape(36)
+        return np.float32(self.L.orc_det6f(_fp(H)))
+
+    def inv6f(self, H, B):
+        H = np.ascontiguousarray(H, dtype=np.float32).reshape(36)
+        B = np.ascontiguousarray(B, dtype=np.float32).reshape(6)
+        Hi = np.zeros(36, dtype=np.float32)
+        d = np.zeros(6, dtype=np.float32)
+        self.L.orc_inv6f(_fp(H), _fp(Hi))
+        self.L.orc_mul66f_vec(_fp(Hi), _fp(B), _fp(d))
+        return Hi.reshape(6, 6), d
+
+    def mul3f(self, A, B):
+        A = np.ascontiguousarray(A, dtype=np.float32).reshape(9)
+        B = np.ascontiguousarray(B, dtype=np.float32).reshape(9)
+        o = np.zeros(9, dtype=np.float32)
+        self.L.orc_mul3f(_fp(A), _fp(B), _fp(o))
+        return o.reshape(3, 3)
+
+    def icp_acc(self, R, p, e):
+        R = np.ascontiguousarray(R, dtype=np.float32).reshape(9)
+        p = np.ascontiguousarray(p, dtype=np.float32).reshape(3)
+        e = np.ascontiguousarray(e, dtype=np.float32).reshape(3)
+        H = np.zeros(36, dtype=np.float32)
+        B = np.zeros(6, dtype=np.float32)
+        self.L.orc_icp_acc(_fp(R), _fp(p), _fp(e), _fp(H), _fp(B))
+        return H.reshape(6, 6), B
 
     def dot3(self, a, b):
         a = np.ascontiguousarray(a, dtype=np.float64)

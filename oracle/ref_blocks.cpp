@@ -17,6 +17,14 @@
 //   dot3  a(3) b(3)                        -> a.dot(b) (1)
 //   vlv   evecs(9 row-major) evals(3)      -> evecs * evals.asDiagonal() (as Matrix3d) * evecs.inverse()   (NS/VoxelGrid.cpp:300,317)
 //   covx  tmp_cov(9 row-major) pt_sum(3) n -> the covariance expression of NS/VoxelGrid.cpp:286,293-294
+// f32 blocks (round 4): what NormalDistributionsTransform.cpp:331-337 and icp_registration_manual.cpp:156-176 ask of Eigen
+//   rot3f  L(9 row-major)                  -> Transform<float,3,Affine>::rotation() of a transform whose linear part is L (9 row-major):
+//                                             the f32 JacobiSVD polar step in front of eulerAngles (NS/...:336)
+//   det6f  H(36 row-major)                 -> Matrix<float,6,6>::determinant() (1)                       (icp_registration_manual.cpp:165)
+//   inv6f  H(36 row-major) B(6)            -> Hessian.inverse() (36 row-major), then Hessian.inverse() * B (6)   (:169)
+//   mul3f  A(9 row-major) B(9 row-major)   -> A *= B (9 row-major), Matrix3f                             (:173)
+//   icpacc R(9 row-major) p(3) e(3)        -> J = [I | -R * hat(p)] (the hat matrix written out as data, Sophus is absent),
+//                                             then Hessian += J^T J (36 row-major) and B += -J^T e (6) from zero     (:156-162)
 #include <cstdio>
 #include <cstring>
 #include <iostream>
@@ -107,6 +115,47 @@ int main() {
       covariance = (tmp_cov - 2.0 * (pt_sum * centroid.transpose())) / point_num + centroid * centroid.transpose();
       covariance *= (point_num - 1.0) / point_num;
       for (int r = 0; r < 3; r++) for (int c = 0; c < 3; c++) out.push_back(covariance(r, c));
+    } else if (op == "rot3f" && in.size() == 9) {
+      Eigen::Transform<float, 3, Eigen::Affine, Eigen::ColMajor> tr;
+      tr.setIdentity();
+      for (int r = 0; r < 3; r++) for (int c = 0; c < 3; c++) tr.matrix()(r, c) = static_cast<float>(in[r * 3 + c]);
+      Eigen::Matrix3f R = tr.rotation();
+      for (int r = 0; r < 3; r++) for (int c = 0; c < 3; c++) out.push_back(R(r, c));
+    } else if (op == "det6f" && in.size() == 36) {
+      Eigen::Matrix<float, 6, 6> Hessian;
+      for (int r = 0; r < 6; r++) for (int c = 0; c < 6; c++) Hessian(r, c) = static_cast<float>(in[r * 6 + c]);
+      out.push_back(Hessian.determinant());
+    } else if (op == "inv6f" && in.size() == 42) {
+      Eigen::Matrix<float, 6, 6> Hessian;
+      Eigen::Matrix<float, 6, 1> B;
+      for (int r = 0; r < 6; r++) for (int c = 0; c < 6; c++) Hessian(r, c) = static_cast<float>(in[r * 6 + c]);
+      for (int r = 0; r < 6; r++) B(r) = static_cast<float>(in[36 + r]);
+      Eigen::Matrix<float, 6, 6> Hi = Hessian.inverse();
+      Eigen::Matrix<float, 6, 1> delta_x = Hessian.inverse() * B;
+      for (int r = 0; r < 6; r++) for (int c = 0; c < 6; c++) out.push_back(Hi(r, c));
+      for (int r = 0; r < 6; r++) out.push_back(delta_x(r));
+    } else if (op == "mul3f" && in.size() == 18) {
+      Eigen::Matrix3f A, Bm;
+      for (int r = 0; r < 3; r++) for (int c = 0; c < 3; c++) { A(r, c) = static_cast<float>(in[r * 3 + c]); Bm(r, c) = static_cast<float>(in[9 + r * 3 + c]); }
+      A *= Bm;
+      for (int r = 0; r < 3; r++) for (int c = 0; c < 3; c++) out.push_back(A(r, c));
+    } else if (op == "icpacc" && in.size() == 15) {
+      Eigen::Matrix3f rotation_matrix_, hat;
+      for (int r = 0; r < 3; r++) for (int c = 0; c < 3; c++) rotation_matrix_(r, c) = static_cast<float>(in[r * 3 + c]);
+      const float px = static_cast<float>(in[9]), py = static_cast<float>(in[10]), pz = static_cast<float>(in[11]);
+      hat << 0.f, -pz, py, pz, 0.f, -px, -py, px, 0.f;
+      Eigen::Vector3f err_dis(static_cast<float>(in[12]), static_cast<float>(in[13]), static_cast<float>(in[14]));
+      Eigen::Matrix<float, 6, 6> Hessian;
+      Eigen::Matrix<float, 6, 1> B;
+      Hessian.setZero();
+      B.setZero();
+      Eigen::Matrix<float, 3, 6> Jacobian(Eigen::Matrix<float, 3, 6>::Zero());
+      Jacobian.leftCols<3>() = Eigen::Matrix3f::Identity();
+      Jacobian.rightCols<3>() = -rotation_matrix_ * hat;
+      Hessian += Jacobian.transpose() * Jacobian;
+      B += -Jacobian.transpose() * err_dis;
+      for (int r = 0; r < 6; r++) for (int c = 0; c < 6; c++) out.push_back(Hessian(r, c));
+      for (int r = 0; r < 6; r++) out.push_back(B(r));
     } else {
       std::printf("ERR\n");
       continue;

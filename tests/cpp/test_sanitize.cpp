@@ -125,6 +125,68 @@ static void test_math() {
   }
 }
 
+// the f32 Eigen blocks (gn_math.h) against the oracle's copy (eigen_f32_oracle.c, which the golden fixtures pin to the
+// reference's vendored Eigen): same bits on random, degenerate and non-finite inputs, and no UB on any of them
+static void test_eigen_f32_blocks() {
+  std::mt19937 rng(11);
+  std::normal_distribution<float> N(0.f, 1.f);
+  long bad_rot = 0, bad_lu = 0, bad_mul = 0;
+  for (int t = 0; t < 20000; t++) {
+    float L[9], Ra[9], Rb[9];
+    // near-rotations (what the path feeds), general matrices, rank-deficient ones, zeros
+    float a = N(rng) * (t % 3 ? 0.2f : 2.f), b = N(rng) * 0.2f, c = N(rng) * (t % 5 ? 0.2f : 3.f);
+    float Rx[9] = {1, 0, 0, 0, std::cos(a), -std::sin(a), 0, std::sin(a), std::cos(a)};
+    float Ry[9] = {std::cos(b), 0, std::sin(b), 0, 1, 0, -std::sin(b), 0, std::cos(b)};
+    float Rz[9] = {std::cos(c), -std::sin(c), 0, std::sin(c), std::cos(c), 0, 0, 0, 1};
+    float Rxy[9];
+    gm::mul3f_eigen(Rx, Ry, Rxy);
+    gm::mul3f_eigen(Rxy, Rz, L);
+    if (t % 7 == 3) for (float &v : L) v += N(rng) * 1e-3f;
+    if (t % 97 == 5) for (float &v : L) v = N(rng);
+    if (t % 97 == 6) { for (float &v : L) v = 0.f; }
+    if (t % 97 == 7) { L[3] = L[0]; L[4] = L[1]; L[5] = L[2]; }
+    if (t % 997 == 8) L[4] = NAN;
+    gm::rotation_polar_f32(L, Ra);
+    orc_rotation_f32(L, Rb);
+    bad_rot += std::memcmp(Ra, Rb, sizeof(Ra)) != 0;
+    float H[36], B[6], da[6] = {0}, db[6] = {0}, Hi[36];
+    for (int r = 0; r < 6; r++) for (int k = 0; k < 6; k++) H[r * 6 + k] = 0.f;
+    int n = 6 + (t % 50);
+    for (int i = 0; i < n; i++) {
+      float J[6];
+      for (int k = 0; k < 6; k++) J[k] = N(rng) * (k < 3 ? 1.f : 20.f);
+      if (t % 11 == 4) J[4] = 0.f;   // a direction no correspondence constrains: exactly singular
+      for (int r = 0; r < 6; r++) for (int k = 0; k < 6; k++) H[r * 6 + k] += J[r] * J[k];
+    }
+    for (float &v : B) v = N(rng) * 50.f;
+    const float deta = gm::solve6f_eigen(H, B, da);
+    const float detb = orc_det6f(H);
+    if (detb != 0.0f) { orc_inv6f(H, Hi); orc_mul66f_vec(Hi, B, db); }
+    bad_lu += std::memcmp(&deta, &detb, sizeof(float)) != 0 || (detb != 0.0f && std::memcmp(da, db, sizeof(da)) != 0);
+    float A3[9], B3[9], Ma[9], Mb[9];
+    for (float &v : A3) v = N(rng);
+    for (float &v : B3) v = N(rng);
+    gm::mul3f_eigen(A3, B3, Ma);
+    orc_mul3f(A3, B3, Mb);
+    bad_mul += std::memcmp(Ma, Mb, sizeof(Ma)) != 0;
+  }
+  CHECK(bad_rot == 0, "rotation_polar_f32 differs from the oracle's on %ld inputs", bad_rot);
+  CHECK(bad_lu == 0, "6x6 f32 determinant / solve differ from the oracle's on %ld inputs", bad_lu);
+  CHECK(bad_mul == 0, "Matrix3f product differs from the oracle's on %ld inputs", bad_mul);
+  // lsa_matrix_to_pose == orc_matrix_to_pose on poses that have been through f32 products
+  long bad_pose = 0;
+  for (int t = 0; t < 5000; t++) {
+    double p[6] = {N(rng) * 30., N(rng) * 30., N(rng), N(rng) * (t % 4 ? 0.05 : 1.5), N(rng) * 0.05, N(rng) * (t % 3 ? 0.3 : 3.0)};
+    float T[16];
+    lsa_pose_to_matrix(p, T);
+    double pa[6], pb[6];
+    lsa_matrix_to_pose(T, pa);
+    orc_matrix_to_pose(T, pb);
+    bad_pose += std::memcmp(pa, pb, sizeof(pa)) != 0;
+  }
+  CHECK(bad_pose == 0, "lsa_matrix_to_pose differs from the oracle's on %ld poses", bad_pose);
+}
+
 static void test_driver_and_oracle() {
   auto tgt = street(1, 0.f, 0.f, 60000), raw = street(2, 0.6f, 0.01f, 40000);
   // oracle voxel filter (also exercises in-place / capacity handling)
@@ -247,6 +309,7 @@ static void test_pack_and_io() {
 
 int main() {
   test_math();
+  test_eigen_f32_blocks();
   test_pack_and_io();
   test_driver_and_oracle();
   if (g_fail) { std::printf("%d check(s) failed\n", g_fail); return 1; }

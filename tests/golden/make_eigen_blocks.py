@@ -119,6 +119,66 @@ def main():
         cx.append(S.reshape(-1).tolist() + s1.tolist() + [float(n)])
     fx["covx"] = {"in": cx, "out": run([fmt("covx", m) for m in cx])}
 
+    # ---- round 4: the f32 Eigen calls of NS/NormalDistributionsTransform.cpp:336 and icp_registration_manual.cpp:156-176
+    # (generated AFTER everything above so that the earlier blocks keep their inputs, draw for draw)
+    def rot(ang):
+        cx, sx, cy, sy, cz, sz = np.cos(ang[0]), np.sin(ang[0]), np.cos(ang[1]), np.sin(ang[1]), np.cos(ang[2]), np.sin(ang[2])
+        return (np.array([[1, 0, 0], [0, cx, -sx], [0, sx, cx]]) @ np.array([[cy, 0, sy], [0, 1, 0], [-sy, 0, cy]]) @
+                np.array([[cz, -sz, 0], [sz, cz, 0], [0, 0, 1]]))
+    rots = []
+    for k in range(96):
+        R = rot(rng.uniform(-0.3, 0.3, 3) if k % 3 else rng.uniform(-3.1, 3.1, 3)).astype(np.float32)
+        if k % 4 == 1:      # a pose that went through f32 products (predict = cur * step): orthonormal to a few ulp only
+            R = (R @ rot(rng.uniform(-0.02, 0.02, 3)).astype(np.float32)).astype(np.float32)
+        if k % 8 == 6:      # visibly non-orthonormal linear part: the polar step changes it
+            R = (R + rng.normal(size=(3, 3)) * 1e-3).astype(np.float32)
+        if k == 7:
+            R = np.eye(3, dtype=np.float32)
+        if k == 15:
+            R = rng.normal(size=(3, 3)).astype(np.float32)
+        if k == 23:
+            R = np.zeros((3, 3), dtype=np.float32); R[0, 1] = R[1, 2] = R[2, 0] = 1.0   # permutation: sorting of equal singular values
+        rots.append([float(v) for v in R.reshape(-1)])
+    fx["rot3f"] = {"in": rots, "out": run([fmt("rot3f", m) for m in rots])}
+    # ... and m2p on 4x4 matrices carrying those linear parts (the full :331-337 expression)
+    m2p2 = []
+    for m in rots:
+        R = np.array(m, dtype=np.float32).reshape(3, 3)
+        if not np.all(np.isfinite(R)) or abs(np.linalg.det(R.astype(np.float64))) < 0.5:
+            continue
+        T = np.eye(4, dtype=np.float32)
+        T[:3, :3] = R
+        T[:3, 3] = rng.uniform(-60, 60, 3).astype(np.float32)
+        m2p2.append([float(v) for v in T.T.reshape(-1)])
+    fx["m2p_f32svd"] = {"in": m2p2, "out": run([fmt("m2p", m) for m in m2p2])}
+
+    h6 = []
+    for k in range(48):
+        n = int(rng.randint(6, 4000))
+        J = (rng.normal(size=(n, 6)) * np.array([1, 1, 1, 20, 20, 20])).astype(np.float32)
+        H = (J.T @ J).astype(np.float32)
+        if k % 8 == 3:      # general, not symmetric
+            H = rng.normal(size=(6, 6)).astype(np.float32)
+        if k % 8 == 5:      # exactly singular: a zero row and column (a degenerate correspondence set) -> determinant() == 0
+            H[:, 4] = 0.0; H[4, :] = 0.0
+        if k % 16 == 7:     # pivoting needed in the first column
+            H = H[[2, 0, 1, 3, 5, 4], :]
+        B = (rng.normal(size=6) * 50).astype(np.float32)
+        h6.append([float(v) for v in H.reshape(-1)] + [float(v) for v in B])
+    fx["det6f"] = {"in": [m[:36] for m in h6], "out": run([fmt("det6f", m[:36]) for m in h6])}
+    reg = [m for m, d in zip(h6, fx["det6f"]["out"]) if d[0] != 0.0]     # the reference inverts only when det != 0 (:165-169)
+    fx["inv6f"] = {"in": reg, "out": run([fmt("inv6f", m) for m in reg])}
+    m3 = [[float(v) for v in np.concatenate([rot(rng.uniform(-3, 3, 3)).reshape(-1), rot(rng.uniform(-0.05, 0.05, 3)).reshape(-1)]).astype(np.float32)] for _ in range(32)]
+    m3 += [[float(v) for v in rng.normal(size=18).astype(np.float32)] for _ in range(16)]
+    fx["mul3f"] = {"in": m3, "out": run([fmt("mul3f", m) for m in m3])}
+    acc = []
+    for k in range(48):
+        R = rot(rng.uniform(-0.5, 0.5, 3)).astype(np.float32)
+        pt = (rng.normal(size=3) * np.array([30, 30, 2])).astype(np.float32)
+        e = (rng.normal(size=3) * 0.3).astype(np.float32)
+        acc.append([float(v) for v in np.concatenate([R.reshape(-1), pt, e])])
+    fx["icpacc"] = {"in": acc, "out": run([fmt("icpacc", m) for m in acc])}
+
     with open(os.path.join(HERE, "eigen_blocks.json"), "w") as f:
         json.dump(fx, f)
     print("wrote eigen_blocks.json:", {k: len(v["in"]) for k, v in fx.items()})

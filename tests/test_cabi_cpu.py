@@ -40,11 +40,37 @@ def test_pose_helpers_match_reference_eigen_fixtures():
         pa = np.array(p, dtype=np.float64)
         L.lsa_pose_to_matrix(capi.dptr(pa), capi.fptr(T))
         assert np.array_equal(T, np.array(out, dtype=np.float32))
-    for m, out in zip(fx["m2p"]["in"], fx["m2p"]["out"]):
-        T = np.array(m, dtype=np.float32)
-        p = np.zeros(6)
-        L.lsa_matrix_to_pose(capi.fptr(T), capi.dptr(p))
-        assert np.max(np.abs(p - np.array(out))) < 2e-6
+    # matrix -> pose goes through Transform::rotation()'s f32 polar step (gn_math.h: rotation_polar_f32): translation and the
+    # rotation matrix the angles are read from are Eigen's to the bit; the angles themselves pass through this host's atan2f
+    for name in ("m2p", "m2p_f32svd"):
+        for m, out in zip(fx[name]["in"], fx[name]["out"]):
+            T = np.array(m, dtype=np.float32)
+            p = np.zeros(6)
+            L.lsa_matrix_to_pose(capi.fptr(T), capi.dptr(p))
+            ref = np.array(out)
+            assert np.array_equal(p[:3], ref[:3])
+            assert np.all(np.abs(p[3:] - ref[3:]) <= 2 * np.spacing(np.abs(ref[3:]).astype(np.float32)).astype(np.float64)), (name, p, ref)
+
+
+def test_product_f32_eigen_blocks_match_reference_fixtures():
+    """csrc/gn_math.h's copy of the f32 Eigen calls (what lsa_matrix_to_pose and the ICPMANUAL host step run) against the fixtures the
+    reference's vendored Eigen produced: bit for bit."""
+    fx = json.load(open(os.path.join(HERE, "golden", "eigen_blocks.json")))
+    L = capi.lib()
+
+    def run(what, vals, n_out):
+        a = np.array(vals, dtype=np.float32)
+        o = np.zeros(n_out, dtype=np.float32)
+        assert L.lsa_eigen_f32_selftest(what, capi.fptr(a), capi.fptr(o)) == 0
+        return o
+    for m, out in zip(fx["rot3f"]["in"], fx["rot3f"]["out"]):
+        assert np.array_equal(run(0, m, 9), np.array(out, dtype=np.float32))
+    for m, out in zip(fx["det6f"]["in"], fx["det6f"]["out"]):
+        assert run(1, m, 1)[0] == np.float32(out[0])
+    for m, out in zip(fx["inv6f"]["in"], fx["inv6f"]["out"]):
+        assert np.array_equal(run(2, m, 42), np.array(out, dtype=np.float32))
+    for m, out in zip(fx["mul3f"]["in"], fx["mul3f"]["out"]):
+        assert np.array_equal(run(3, m, 9), np.array(out, dtype=np.float32))
 
 
 def test_gauss_constants_match_oracle():
