@@ -229,6 +229,9 @@ typedef struct {
   int32_t parked;         /* 1 while this handle has a kernel parked on its context's stream */
   int32_t pad;
   uint64_t deferred;      /* final passes of a ScanMatch that a batch did not wait for (collected behind the next scan's first mail) */
+  double host_gap_max_us; /* host-stall detector: the longest interval between two consecutive looks of the calling thread at the rows
+                           * it was waiting for (a look takes < 1 us), or from posting a pass to the first look.  >= 1000 means the OS
+                           * held the thread up for longer than that: late / redone passes beside such a value are the box's doing */
 } lsa_ndt_armed_stats_t;
 int lsa_ndt_armed_stats(lsa_ndt *ndt, lsa_ndt_armed_stats_t *out, int reset);
 /* diagnostics / tests: how long an armed kernel waits for its mail before it leaves by itself (default 300 us; [1, 1e5]) */
@@ -298,6 +301,21 @@ int lsa_rccl_comm_create(lsa_rccl_comm **out, lsa_context *ctx, const void *id12
 void lsa_rccl_comm_destroy(lsa_rccl_comm *comm);
 int lsa_ndt_set_allreduce_rccl(lsa_ndt *ndt, lsa_rccl_comm *comm);   /* comm == NULL clears it */
 int lsa_rccl_allreduce_f64(lsa_rccl_comm *comm, void *device_buf, size_t n_doubles);  /* in place, on the context's stream */
+/* The ICP plugins shard identically: the neighbour grid is replicated (every rank calls SetInputTarget with the
+ * whole target), each rank's ScanMatch gets its contiguous shard of the source, and the 32-double block of every iteration —
+ * ICPRegistrationManual's H and B (icp_registration_manual.cpp:161-162), the rigid fit's 17 sums in PCL mode — is summed over the
+ * ranks by the same callback (one all-reduce per iteration, on the context's stream); every rank then takes the identical host step.
+ * With it installed the iterations run one launch each (no armed kernels: every iteration ends in a collective).
+ * GetFitnessScore — of an NDT handle (either mode) or of the "ICP" plugin — sums {distance sum, point count} over the ranks the
+ * same way when the handle has an exchange step installed: one all-reduce of 2 doubles. */
+typedef struct lsa_icp lsa_icp;   /* (the ICP handle: section below) */
+int lsa_icp_set_allreduce(lsa_icp *icp, lsa_allreduce_fn fn, void *user);
+int lsa_icp_set_allreduce_rccl(lsa_icp *icp, lsa_rccl_comm *comm);   /* comm == NULL clears it */
+/* The host step of ICPMANUAL / the point-to-plane extension with a caller-supplied evaluator of an iteration's sums (what lsa_gn_solve
+ * is for NDT): eval fills out32 as the pass kernels do — [1..6] B = -J^T e, [7..27] the upper triangle of H = J^T J row by row,
+ * [28] correspondences — already summed over the ranks, for the pose T (column-major 4x4).  No device is touched. */
+typedef int (*lsa_icp_eval_fn)(void *user, const float T[16], double out32[32]);
+int lsa_icp_gn_solve(lsa_icp_eval_fn eval, void *user, int max_iter, const float predict_pose[16], float result_pose[16]);
 int lsa_rccl_comm_count(lsa_rccl_comm *comm, int *count);                              /* ncclCommCount: ranks the communicator spans */
 
 /* ---- host-side Newton / More-Thuente driver with a caller-supplied pass evaluator ---------- */
@@ -385,7 +403,7 @@ int lsa_yaw_init_cells(lsa_yaw_init *y, float *mu, float *sigma, int32_t *point_
 #define LSA_ICP_MODE_MANUAL 0
 #define LSA_ICP_MODE_PLANE 1
 #define LSA_ICP_MODE_PCL 2
-typedef struct lsa_icp lsa_icp;
+/* (typedef struct lsa_icp lsa_icp: declared above, beside the multi-GPU entry points) */
 typedef struct {
   int32_t iterations;      /* nr_iterations_ (manual mode: max_iter) */
   int32_t converged;       /* hasConverged() */
@@ -463,6 +481,10 @@ int lsa_front_end_set_init_pose(lsa_front_end *fe, const float pose[16]);
 /* FrontEnd::Update(cloud_data, cloud_pose): one scan in, its pose (map <- lidar, column-major) out */
 int lsa_front_end_update(lsa_front_end *fe, const void *cloud, size_t n, size_t stride, size_t w_off, float pose_out[16],
                          lsa_front_end_stats *stats);
+/* the same on a cloud already in device memory (packed x, y, z, w rows, produced on the context's stream).  When the scan becomes a
+ * key-frame the local map's update reads it on a stream of the map's own AFTER this call has returned, beside the caller's next scan
+ * (FrontEnd keeps the key-frame's cloud as well: front_end.cpp:375): leave the buffer unchanged until the next call on this handle
+ * has returned (or the device has been synchronised). */
 int lsa_front_end_update_device(lsa_front_end *fe, const float *d_xyzw, size_t n, float pose_out[16], lsa_front_end_stats *stats);
 /* `count` Updates in one call — a recorded drive being replayed, or a sensor queue that has backed up: the loop
  * front_end_flow.cpp:18-36 runs over its cloud_data_buff_ (while (HasData()) { ValidData(); UpdateLaserOdometry(); }).  The

@@ -38,12 +38,12 @@ class NdtArmedStats(C.Structure):
     """lsa_ndt_armed_stats_t"""
     _fields_ = [("passes", C.c_uint64), ("cancels", C.c_uint64), ("fallbacks", C.c_uint64), ("late", C.c_uint64), ("rows_late", C.c_uint64),
                 ("gave_up_seen", C.c_uint64), ("expired", C.c_uint64), ("rows_wait_max_us", C.c_double), ("parked", C.c_int32), ("pad", C.c_int32),
-                ("deferred", C.c_uint64)]
+                ("deferred", C.c_uint64), ("host_gap_max_us", C.c_double)]
 
     def as_dict(self):
         return dict(passes=self.passes, cancels=self.cancels, fallbacks=self.fallbacks, late=self.late, rows_late=self.rows_late,
                     gave_up_seen=self.gave_up_seen, expired=self.expired, rows_wait_max_us=round(self.rows_wait_max_us, 2), parked=self.parked,
-                    deferred=self.deferred)
+                    deferred=self.deferred, host_gap_max_us=round(self.host_gap_max_us, 2))
 
 
 class NdtStats(C.Structure):
@@ -67,6 +67,7 @@ class NdtStats(C.Structure):
 
 ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p)
 PASS_EVAL_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_double), C.c_int, C.POINTER(C.c_double))
+ICP_EVAL_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_double))
 
 _lib = None
 
@@ -121,6 +122,9 @@ def lib():
     L.lsa_ndt_derivatives.argtypes = [vp, PF, PD, i, PD]
     L.lsa_ndt_derivatives_timed.argtypes = [vp, PF, PD, i, i, PD, PD]
     L.lsa_ndt_set_allreduce.argtypes = [vp, ALLREDUCE_FN, vp]
+    L.lsa_icp_set_allreduce.argtypes = [vp, ALLREDUCE_FN, vp]
+    L.lsa_icp_set_allreduce_rccl.argtypes = [vp, vp]
+    L.lsa_icp_gn_solve.argtypes = [ICP_EVAL_FN, vp, i, PF, PF]
     L.lsa_gn_solve.argtypes = [PASS_EVAL_FN, vp, f, f, f, i, f, PF, PF, C.POINTER(NdtStats)]
     L.lsa_pose_to_matrix.argtypes = [PD, PF]
     L.lsa_pose_to_matrix.restype = None

@@ -131,6 +131,17 @@ struct lsa_front_end {
   // incremental local map (local_map.hip): the persistent sums of the window, updated key-frame by key-frame; the NDT handle
   // then runs on its records / dense table (an EXTERNAL table, ndt_internal.h) instead of a table rebuilt per key-frame
   LocalMap lm;
+  // The incremental map lives on a context (HIP stream) of its OWN.  A key-frame's update — three dependent launches, ~40 us — then
+  // runs beside whatever the registration's stream does next that does not need the map: in a scan-by-scan loop the NEXT scan's frame
+  // filter (which a shared stream made wait behind the update: that was the whole difference between a key-frame scan and an ordinary
+  // one), in a batch the tail of the deferred final pass and the release of the parked kernel.  The registration's stream is ordered
+  // behind the update by an event before anything on it reads the table (fe_map_join); what the update reads — the caller's scan, the
+  // slot's old points — is complete by then as far as the HOST knows (the frame filter that read the scan has been waited for).
+  lsa_context *ctx_m = nullptr;
+  hipEvent_t ev_map = nullptr, ev_in = nullptr;
+  bool map_inflight = false;   // an update has been enqueued on ctx_m's stream that the registration's stream is not yet ordered behind
+  DevBuf<float4> d_in_alt;     // lsa_front_end_update (host clouds): the upload alternates between two buffers (see there)
+  bool in_alt = false;
   bool incremental = getenv("LSA_FE_INCREMENTAL") ? atoi(getenv("LSA_FE_INCREMENTAL")) != 0 : true;
   bool lm_off = false;       // fell back to the full build for good (window / table limits, coordinates out of range)
   bool lm_adopted = false;   // the NDT handle currently runs on the local map's table
@@ -153,11 +164,29 @@ namespace {
 // slot of the frame it evicts — instead of re-transforming all 20.  The frames therefore sit in the buffer in slot order,
 // not in age order, with NaN padding behind each: the 0.3 m filter and the voxel table sum in exact fixed point, so their
 // results do not depend on the order of the points (and they skip non-finite ones).
+// which stream the local-map buffer is written on: the map's own while the incremental map is in use, the registration's otherwise
+hipStream_t fe_map_stream(lsa_front_end *fe) { return (fe->incremental && !fe->lm_off) ? fe->ctx_m->stream : fe->ctx->stream; }
+
+// order the registration's stream behind the map update in flight (before anything on it reads the table, the map buffer or a
+// key-frame's cloud); the host itself learns of the update's end from the status block (lm_check)
+int fe_map_join(lsa_front_end *fe) {
+  if (!fe->map_inflight) return LSA_OK;
+  LSA_HIP(fe->ctx, hipStreamWaitEvent(fe->ctx->stream, fe->ev_map, 0));
+  fe->map_inflight = false;
+  return LSA_OK;
+}
+// everything the map's stream holds has completed (host wait): the slow paths that read the map buffer on the registration's stream
+int fe_map_drain(lsa_front_end *fe) {
+  LSA_HIP(fe->ctx, hipStreamSynchronize(fe->ctx_m->stream));
+  fe->map_inflight = false;
+  return LSA_OK;
+}
+
 void fe_transform_into_slot(lsa_front_end *fe, KeyFrame *f) {
   T12 T;
   for (int r = 0; r < 3; r++)
     for (int c = 0; c < 4; c++) T.v[r * 4 + c] = f->pose[c * 4 + r];
-  hipLaunchKernelGGL(k_transform_slot, dim3(lsa_div_up(fe->slot_cap, kBlock)), dim3(kBlock), 0, fe->ctx->stream, f->pts.p, f->n, fe->slot_cap, T,
+  hipLaunchKernelGGL(k_transform_slot, dim3(lsa_div_up(fe->slot_cap, kBlock)), dim3(kBlock), 0, fe_map_stream(fe), f->pts.p, f->n, fe->slot_cap, T,
                      fe->d_map.p + (size_t)f->slot * fe->slot_cap);
 }
 
@@ -166,12 +195,14 @@ void fe_transform_into_slot(lsa_front_end *fe, KeyFrame *f) {
 // voxel table
 int fe_full_target(lsa_front_end *fe) {
   lsa_context *ctx = fe->ctx;
+  int rc;
+  // (the map buffer may have been written on the map's own stream: the build below reads it on the registration's)
+  if (fe->incremental && (rc = fe_map_drain(fe))) return rc;
   size_t sum = 0;
   for (KeyFrame *f : fe->frames) sum += f->n;
   const size_t total = fe->slot_cap * fe->frames.size();  // slots 0 .. size-1 are the occupied ones (see fe_add_key_frame)
   fe->lm_adopted = false;
   fe->n_full_builds++;
-  int rc;
   if ((int)fe->frames.size() < 10 || !fe->cfg.use_map_filter) {  // front_end.cpp:394-396: few key-frames -> unfiltered map
     fe->target_points = sum;
     return lsa_ndt_set_input_target_device(fe->ndt, (const float *)fe->d_map.p, total);
@@ -214,9 +245,10 @@ int fe_lm_rebuild(lsa_front_end *fe, bool filtered) {
 // the same stream came after them).  A valid voxel outside the dense window -> the window is re-fitted; tables filling up
 // -> rebuilt (larger).
 int fe_lm_settle(lsa_front_end *fe) {
+  int rc0;
+  if ((rc0 = fe_map_join(fe))) return rc0;
   if (!fe->lm.pending) return LSA_OK;
-  if (!fe->cfg.use_frame_filter) (void)hipStreamSynchronize(fe->ctx->stream);   // (nothing else ordered the host behind the update)
-  const int c = lm_check(fe->lm);
+  const int c = lm_check(fe->lm);   // (spins on the status block's epoch: the update's last kernel writes it)
   if (fe->lm.filtered && fe->lm_adopted) fe->target_points = (size_t)(fe->lm.h_status.p->live_f > 0 ? fe->lm.h_status.p->live_f : 0);
   if (c) lsa_ctx_unpark(fe->ctx);   // (inside a batch the next pass's kernel is already parked: the repair goes in front of its successor)
   if (c == 2) return fe_lm_rebuild(fe, fe->lm.filtered);
@@ -240,10 +272,18 @@ int fe_rebuild_map(lsa_front_end *fe, KeyFrame *added, bool evicted, const float
   // the steady state of the incremental map: ONE launch takes the caller's cloud, keeps the key-frame's copy of it, writes its
   // transformed points into the slot and swaps it for the evicted key-frame in the persistent sums
   const bool steady = fe->incremental && !fe->lm_off && !relayout && fe->lm.valid && want_filtered == fe->lm.filtered;
+  if (fe->incremental && !fe->lm_off) {
+    // the map's stream behind whatever the registration's stream still holds (the caller's own producer of this scan, if it has
+    // not been waited for by a frame filter; normally nothing: the event is complete when it is recorded)
+    lsa_ctx_unpark(ctx);   // (a kernel parked on the registration's stream — a caller who opted into the carry — would hold the event back)
+    LSA_HIP(ctx, hipEventRecord(fe->ev_in, ctx->stream));
+    LSA_HIP(ctx, hipStreamWaitEvent(fe->ctx_m->stream, fe->ev_in, 0));
+  }
   if (!steady && added->n)
-    hipLaunchKernelGGL(k_copy_w, dim3(lsa_div_up(added->n, kBlock)), dim3(kBlock), 0, ctx->stream, d_cloud, added->n, added->pts.p, reset_w ? 1 : 0);
+    hipLaunchKernelGGL(k_copy_w, dim3(lsa_div_up(added->n, kBlock)), dim3(kBlock), 0, fe_map_stream(fe), d_cloud, added->n, added->pts.p, reset_w ? 1 : 0);
   if (relayout) {  // first frame, or a cloud larger than any before: lay the buffer out anew
     fe->slot_cap = biggest + biggest / 8 + 1;
+    if ((rc = fe_map_drain(fe))) return rc;   // (the reserve may free the buffer an update in flight still writes)
     if ((rc = fe->d_map.reserve(ctx, fe->slot_cap * (size_t)fe->cfg.local_frame_num))) return rc;
     int k = 0;
     for (KeyFrame *f : fe->frames) { f->slot = k++; fe_transform_into_slot(fe, f); }
@@ -255,7 +295,7 @@ int fe_rebuild_map(lsa_front_end *fe, KeyFrame *added, bool evicted, const float
     if (fe->map_filter) lsa_voxel_filter_set_scale_floor(fe->map_filter, s);
     ndt_set_scale_floor(fe->ndt, s);
     fe->lm.valid = false;
-    if (fe->incremental && !fe->lm_off && (rc = lm_configure(fe->lm, ctx, fe->cfg.map_leaf, fe->cfg.ndt_res, /*pcl*/ 0, s))) return rc;
+    if (fe->incremental && !fe->lm_off && (rc = lm_configure(fe->lm, fe->ctx_m, fe->cfg.map_leaf, fe->cfg.ndt_res, /*pcl*/ 0, s))) return rc;
   }
   LSA_HIP(ctx, hipGetLastError());
   fe->map_points = sum;
@@ -275,6 +315,8 @@ int fe_rebuild_map(lsa_front_end *fe, KeyFrame *added, bool evicted, const float
     for (int c = 0; c < 4; c++) T[r * 4 + c] = added->pose[c * 4 + r];
   if ((rc = lm_swap(fe->lm, slot, fe->slot_cap, evicted, d_cloud, added->n, T, added->pts.p, reset_w))) return rc;
   if ((rc = lm_finish(fe->lm))) return rc;
+  LSA_HIP(ctx, hipEventRecord(fe->ev_map, fe->ctx_m->stream));
+  fe->map_inflight = true;
   if (!want_filtered) fe->target_points = sum;   // (filtered: the live-cell count arrives with the update's status)
   if (!fe->lm_adopted) return fe_lm_adopt(fe);
   ndt_touch_external(fe->ndt, fe->target_points);
@@ -336,13 +378,20 @@ int fe_update_filtered(lsa_front_end *fe, const float4 *d_cloud, size_t n, const
     memcpy(fe->last_pose, cur, sizeof(cur));                                             // :240
     float l1 = std::fabs(fe->last_kf_pose[12] - cur[12]) + std::fabs(fe->last_kf_pose[13] - cur[13]) + std::fabs(fe->last_kf_pose[14] - cur[14]);
     if (l1 > fe->cfg.key_frame_distance) {  // :243-245
-      // inside a batch the next pass's kernel is parked on the stream: the local-map kernels go in front of its successor
+      // Inside a batch: this ScanMatch's final derivative pass is still in flight (deferred, ndt_api.hip).  Should it have to be redone,
+      // the redo must see the table it was posted for, not the one the key-frame is about to change in place: take its rows first
+      // (they are as good as there: the pass was posted before the pose came back).  Then the next pass's parked kernel is released:
+      // the local-map kernels go in front of its successor.
+      if (batch && (rc = ndt_collect_deferred(fe->ndt))) return rc;
       if (batch) lsa_ctx_unpark(fe->ctx);
       // the reference resets every point's static weight to 1.0 before storing a later key-frame (:304-306)
       if ((rc = fe_add_key_frame(fe, d_cloud, n, cur, fe->cfg.reset_intensity != 0))) return rc;
       memcpy(fe->last_kf_pose, cur, sizeof(cur));
       st->key_frame = 1;
-      // ... and that successor is enqueued behind them at once: its launch and dispatch pass while the map is updated
+      // ... and that successor is enqueued at once, behind the event that ends the update on the map's stream: its launch and dispatch
+      // pass while the map is updated.  (A scan-by-scan caller's stream is ordered behind the update later, in front of the next
+      // ScanMatch: the next scan's frame filter goes first and runs beside the update.)
+      if (batch && (rc = fe_map_join(fe))) return rc;
       if (batch && fe->lm_adopted) ndt_prearm(fe->ndt);
     }
   }
@@ -424,7 +473,8 @@ int fe_update_batch(lsa_front_end *fe, size_t count, const float *const *d_scans
       return rc;
     }
   }
-  return LSA_OK;
+  // the caller's scans are his again when this returns: whatever he enqueues on his stream next comes behind the last map update
+  return fe_map_join(fe);
 }
 }  // namespace
 
@@ -442,6 +492,9 @@ extern "C" int lsa_front_end_create(lsa_front_end **out, lsa_context *ctx, const
   // every Update puts the frame filter (and, on key-frames, the local-map work) on this context's stream between two
   // ScanMatches: an armed kernel parked across them would only have to be released again
   if (!rc) rc = lsa_ndt_set_armed_carry(fe->ndt, 0);
+  if (!rc && (rc = lsa_context_create(&fe->ctx_m, ctx->device, nullptr))) rc = lsa_fail(ctx, rc, "lsa_front_end_create: the local map's context: %s", lsa_last_global_error());
+  if (!rc && (hipEventCreateWithFlags(&fe->ev_map, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&fe->ev_in, hipEventDisableTiming) != hipSuccess))
+    rc = lsa_fail(ctx, LSA_ERR_HIP, "lsa_front_end_create: hipEventCreate failed");
   if (rc) { lsa_front_end_destroy(fe); return rc; }
   identity16(fe->init_pose); identity16(fe->last_pose); identity16(fe->predict_pose); identity16(fe->step_pose); identity16(fe->last_kf_pose);
   *out = fe;
@@ -452,6 +505,7 @@ extern "C" void lsa_front_end_destroy(lsa_front_end *fe) {
   if (!fe) return;
   (void)lsa_enter(fe->ctx);
   (void)hipStreamSynchronize(fe->ctx->stream);
+  if (fe->ctx_m) (void)hipStreamSynchronize(fe->ctx_m->stream);
   for (KeyFrame *f : fe->frames) { f->pts.release(); delete f; }
   for (KeyFrame *f : fe->pool) { f->pts.release(); delete f; }
   fe->d_in.release(); fe->d_filtered.release(); fe->d_map.release(); fe->d_map_f.release(); fe->h_stage.release();
@@ -463,6 +517,10 @@ extern "C" void lsa_front_end_destroy(lsa_front_end *fe) {
   lsa_voxel_filter_destroy(fe->frame_filter_b);
   for (int b = 0; b < 3; b++) fe->d_batch[b].release();
   if (fe->ctx_b) lsa_context_destroy(fe->ctx_b);
+  if (fe->ev_map) (void)hipEventDestroy(fe->ev_map);
+  if (fe->ev_in) (void)hipEventDestroy(fe->ev_in);
+  fe->d_in_alt.release();
+  if (fe->ctx_m) lsa_context_destroy(fe->ctx_m);
   delete fe;
 }
 
@@ -495,10 +553,15 @@ extern "C" int lsa_front_end_update(lsa_front_end *fe, const void *cloud, size_t
   LSA_HIP(ctx, lsa_enter(ctx));
   int rc;
   LSA_HIP(ctx, hipStreamSynchronize(ctx->stream));  // before the reserves: they may free a buffer an earlier copy still reads
+  // The upload alternates between two device buffers: a key-frame's map update reads the scan on the map's own stream after this
+  // call has returned, and it is the NEXT call that sees that update complete (fe_lm_settle) — the one after it may overwrite.
+  DevBuf<float4> &din = fe->in_alt ? fe->d_in_alt : fe->d_in;
+  fe->in_alt = !fe->in_alt;
+  if (n > din.cap && (rc = fe_map_drain(fe))) return rc;   // (growing frees the old buffer)
   if ((rc = fe->h_stage.reserve(ctx, (n ? n : 1) * 4))) return rc;
-  if ((rc = fe->d_in.reserve(ctx, n ? n : 1, 1.25))) return rc;
-  if ((rc = lsa_upload_xyzw(ctx, cloud, n, stride, w_off, fe->h_stage.p, fe->d_in.p))) return rc;
-  return fe_update_device(fe, fe->d_in.p, n, pose_out, stats);
+  if ((rc = din.reserve(ctx, n ? n : 1, 1.25))) return rc;
+  if ((rc = lsa_upload_xyzw(ctx, cloud, n, stride, w_off, fe->h_stage.p, din.p))) return rc;
+  return fe_update_device(fe, din.p, n, pose_out, stats);
 }
 
 extern "C" lsa_ndt *lsa_front_end_registration(lsa_front_end *fe) { return fe ? fe->ndt : nullptr; }
@@ -508,13 +571,16 @@ extern "C" int lsa_front_end_set_incremental(lsa_front_end *fe, int on) {
   LSA_HIP(fe->ctx, lsa_enter(fe->ctx));
   const bool want = on != 0;
   if (want == fe->incremental) return LSA_OK;
+  int rc0;
+  if ((rc0 = fe_map_drain(fe))) return rc0;   // (the two settings write the map buffer on different streams)
+  LSA_HIP(fe->ctx, hipStreamSynchronize(fe->ctx->stream));
   fe->incremental = want;
   fe->lm.valid = false;
   fe->lm_off = false;
   // the target as the new setting builds it (same voxels either way: the two paths agree to the bit)
   if (fe->frames.empty()) return LSA_OK;
   if (!want) return fe->lm_adopted ? fe_full_target(fe) : LSA_OK;
-  int rc = lm_configure(fe->lm, fe->ctx, fe->cfg.map_leaf, fe->cfg.ndt_res, 0, fe->scale_n);
+  int rc = lm_configure(fe->lm, fe->ctx_m, fe->cfg.map_leaf, fe->cfg.ndt_res, 0, fe->scale_n);
   if (rc) return rc;
   return fe_lm_rebuild(fe, (int)fe->frames.size() >= 10 && fe->cfg.use_map_filter);
 }
@@ -548,6 +614,7 @@ extern "C" int lsa_front_end_map_verify(lsa_front_end *fe, uint64_t out[6]) {
     rc = lsa_ndt_set_input_target_device(sn, (const float *)fe->d_map.p, total);
   }
   unsigned long long res[4] = {0, 0, 0, 0};
+  if (!rc && hipStreamSynchronize(ctx->stream) != hipSuccess) rc = LSA_ERR_HIP;   // the scratch build (this stream) before the comparison (the map's)
   if (!rc) rc = lm_verify(fe->lm, sn->vi.cell_of_rank.p, sn->rec.p, sn->state.p, sn->vi.nocc, sn->vi.map, res);
   for (int k = 0; k < 4; k++) out[k] = res[k];
   lsa_ndt_destroy(sn);

@@ -506,6 +506,10 @@ struct lsa_icp {
   DevBuf<float4> d_target, d_source_own, d_work;
   DevBuf<double> partials, d_out;
   PinnedBuf<double> h_out, h_partials;
+  // multi-GPU ("ICP shards identically"): the source sharded over the ranks, the neighbour grid replicated, the
+  // 32-double block of every iteration summed in place over the ranks by this callback (one RCCL all-reduce per iteration)
+  lsa_allreduce_fn allreduce = nullptr;
+  void *allreduce_user = nullptr;
   unsigned long long pass_seq = 0, row_key = 0;  // check word of the rows of the pass in flight (0: plain rows)
   unsigned unsynced = 0;
   DevBuf<unsigned> prev;  // per source point: cell-sorted slot of the neighbour found one iteration ago (0xffffffff: none)
@@ -591,10 +595,12 @@ unsigned icp_grid_size(const lsa_icp *h, size_t n) {
 // Where the pass kernels write their workgroup rows: up to kHostRows rows go straight into host-mapped pinned memory and
 // the host adds them (fixed order) — no reduction launch, no copy; larger grids use the device reduction.
 constexpr unsigned kHostRows = 512;
-double *icp_partials_dst(lsa_icp *h, unsigned g) { return g <= kHostRows ? h->h_partials.p : h->partials.p; }
+// (with an exchange step installed the rows stay on the device: second stage -> all-reduce -> one copy)
+bool icp_host_rows(const lsa_icp *h, unsigned g) { return !h->allreduce && g <= kHostRows; }
+double *icp_partials_dst(lsa_icp *h, unsigned g) { return icp_host_rows(h, g) ? h->h_partials.p : h->partials.p; }
 // host-bound rows carry a check word (lsa_store_row32) so that the host can add them as they arrive; 0 = plain rows
 unsigned long long icp_next_key(lsa_icp *h, unsigned g) {
-  if (g > kHostRows) return h->row_key = 0ull;
+  if (!icp_host_rows(h, g)) return h->row_key = 0ull;
   unsigned long long key = (++h->pass_seq) * 0x9E3779B97F4A7C15ull;
   if (!key) key = (++h->pass_seq) * 0x9E3779B97F4A7C15ull;
   return h->row_key = key;
@@ -604,7 +610,7 @@ unsigned long long icp_next_key(lsa_icp *h, unsigned g) {
 int icp_fetch_sums(lsa_icp *h, unsigned g, bool may_sync = true) {
   lsa_context *ctx = h->ctx;
   LSA_HIP(ctx, hipGetLastError());
-  if (g <= kHostRows) {
+  if (icp_host_rows(h, g)) {
     // rows b, b + 32, ... accumulate in ascending b, then a 32-way tree (the order k_reduce32 uses), each row as soon as
     // its check word matches; a row that is 20 ms late is waited for the ordinary way
     if (!ndt_reduce_partials_host(h->h_partials.p, g, h->row_key, 20.0, h->h_out.p)) {
@@ -620,6 +626,10 @@ int icp_fetch_sums(lsa_icp *h, unsigned g, bool may_sync = true) {
   }
   hipLaunchKernelGGL(k_reduce32, dim3(1), dim3(1024), 0, ctx->stream, h->partials.p, (int)g, h->d_out.p);
   LSA_HIP(ctx, hipGetLastError());
+  if (h->allreduce) {  // the exchange step: this rank's 32 sums + every other rank's, in place, on the stream
+    int crc = h->allreduce(h->allreduce_user, h->d_out.p, kOut, (void *)ctx->stream);
+    if (crc) return lsa_fail(ctx, LSA_ERR_COLLECTIVE, "ICP: all-reduce callback returned %d", crc);
+  }
   LSA_HIP(ctx, hipMemcpyAsync(h->h_out.p, h->d_out.p, kOut * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
   LSA_HIP(ctx, hipStreamSynchronize(ctx->stream));
   return LSA_OK;
@@ -662,6 +672,25 @@ void icp_mail_post(IcpMail *base, unsigned long long seq, unsigned long long key
 
 constexpr double kIcpArmedRowLimitMs = 2.0;
 
+// The part of one ICPMANUAL / point-to-plane iteration that runs on the host (icp_registration_manual.cpp:165-176) from the 32 sums
+// of the iteration ([1..6] B, [7..27] the upper triangle of H): Hessian.determinant() == 0 -> the pose stays; else
+// delta_x = Hessian.inverse() * B, translation += delta[0:3], rotation_matrix_ *= exp(delta[3:6]) — Eigen's own f32 operation order
+// (gn_math.h; the checker's copy is pinned against the reference's vendored Eigen).  Every rank of a sharded ScanMatch runs it on the
+// same reduced sums and arrives at the same bits: no broadcast.
+void icp_host_step(const double *o, float R[9], float t[3]) {
+  float H[36], B[6];
+  int k = 7;
+  for (int a = 0; a < 6; a++) B[a] = (float)o[1 + a];
+  for (int a = 0; a < 6; a++)
+    for (int b = a; b < 6; b++) { H[a * 6 + b] = H[b * 6 + a] = (float)o[k]; k++; }
+  float d[6];
+  if (gm::solve6f_eigen(H, B, d) == 0.0f) return;  // :165
+  t[0] += d[0]; t[1] += d[1]; t[2] += d[2];
+  float dR[9];
+  so3_exp(d + 3, dR);
+  gm::mul3f_eigen(R, dR, R);
+}
+
 int icp_match_manual(lsa_icp *h, const float4 *d_src, size_t n, const float predict[16], float result[16]) {
   lsa_context *ctx = h->ctx;
   float T[16];
@@ -688,7 +717,7 @@ int icp_match_manual(lsa_icp *h, const float4 *d_src, size_t n, const float pred
   const bool plane = h->mode == LSA_ICP_MODE_PLANE;
   // armed passes: iteration 0 is launched with its parameters; from then on the kernel of iteration k + 1 is enqueued while k
   // runs and takes its pose by mail
-  bool armed = !h->no_armed && g <= kHostRows && h->max_iter > 1;
+  bool armed = !h->no_armed && icp_host_rows(h, g) && h->max_iter > 1;   // (not with an exchange step: every iteration ends in a collective)
   if (armed && (rc = icp_mail_ensure(h))) return rc;
   armed = armed && h->mail;
   const float gate = plane ? h->max_corr * h->max_corr : h->max_corr;
@@ -747,19 +776,7 @@ int icp_match_manual(lsa_icp *h, const float4 *d_src, size_t n, const float pred
     const double *o = h->h_out.p;
     h->searches_per_iter.push_back((uint32_t)o[30]);
     h->n_searches += (uint64_t)o[30]; h->n_queries += (uint64_t)o[29];
-    float H[36], B[6];
-    int k = 7;
-    for (int a = 0; a < 6; a++) B[a] = (float)o[1 + a];
-    for (int a = 0; a < 6; a++)
-      for (int b = a; b < 6; b++) { H[a * 6 + b] = H[b * 6 + a] = (float)o[k]; k++; }
-    // Hessian.determinant() == 0 -> continue; delta_x = Hessian.inverse() * B; rotation_matrix_ *= exp(delta) (:165-173): Eigen's
-    // own f32 operation order (gn_math.h; the checker's copy is pinned against the reference's vendored Eigen)
-    float d[6];
-    if (gm::solve6f_eigen(H, B, d) == 0.0f) continue;  // :165
-    t[0] += d[0]; t[1] += d[1]; t[2] += d[2];
-    float dR[9];
-    so3_exp(d + 3, dR);
-    gm::mul3f_eigen(R, dR, R);
+    icp_host_step(o, R, t);
   }
   for (int r = 0; r < 3; r++) {
     for (int c = 0; c < 3; c++) T[c * 4 + r] = R[r * 3 + c];
@@ -934,6 +951,45 @@ extern "C" int lsa_icp_create(lsa_icp **out, lsa_context *ctx, float max_corresp
   return LSA_OK;
 }
 
+extern "C" int lsa_icp_set_allreduce(lsa_icp *h, lsa_allreduce_fn fn, void *user) {
+  if (!h) return LSA_ERR_INVALID;
+  h->allreduce = fn;
+  h->allreduce_user = user;
+  return LSA_OK;
+}
+
+// The host driver of ICPMANUAL / the point-to-plane extension with a caller-supplied evaluator of the per-iteration sums (what
+// lsa_gn_solve is for NDT): the multi-process path without a GPU — tests/test_dist_cpu.py evaluates each rank's shard with the CPU
+// oracle and sums over gloo.  eval fills out32 as the pass kernels do ([1..6] B, [7..27] H upper triangle row by row, [28] pairs),
+// already summed over the ranks, for the pose T (column-major 4x4).
+extern "C" int lsa_icp_gn_solve(lsa_icp_eval_fn eval, void *user, int max_iter, const float predict_pose[16], float result_pose[16]) {
+  if (!eval || !predict_pose || !result_pose || max_iter < 0) return LSA_ERR_INVALID;
+  float T[16];
+  memcpy(T, predict_pose, sizeof(T));
+  float R[9], t[3];
+  for (int r = 0; r < 3; r++) {
+    for (int c = 0; c < 3; c++) R[r * 3 + c] = T[c * 4 + r];
+    t[r] = T[12 + r];
+  }
+  for (int it = 0; it < max_iter; it++) {
+    double o[32];
+    for (int c = 0; c < 32; c++) o[c] = 0.0;
+    for (int r = 0; r < 3; r++) {
+      for (int c = 0; c < 3; c++) T[c * 4 + r] = R[r * 3 + c];
+      T[12 + r] = t[r];
+    }
+    int rc = eval(user, T, o);
+    if (rc) return LSA_ERR_COLLECTIVE;
+    icp_host_step(o, R, t);
+  }
+  for (int r = 0; r < 3; r++) {
+    for (int c = 0; c < 3; c++) T[c * 4 + r] = R[r * 3 + c];
+    T[12 + r] = t[r];
+  }
+  memcpy(result_pose, T, sizeof(T));
+  return LSA_OK;
+}
+
 extern "C" int lsa_icp_set_criteria(lsa_icp *h, float euclid_eps, float trans_eps) {
   if (!h) return LSA_ERR_INVALID;
   h->euclid_eps = euclid_eps; h->trans_eps = trans_eps;
@@ -1039,7 +1095,7 @@ extern "C" int lsa_icp_get_fitness_score(lsa_icp *h, float *score) {
   if (rc) return rc;
   if (!h->has_target || !h->has_result) return lsa_fail(h->ctx, LSA_ERR_NO_TARGET, "GetFitnessScore before SetInputTarget + ScanMatch");
   double v = 0;
-  if ((rc = nn_fitness(h->ctx, h->grid, h->d_last_src, h->n_last_src, h->last_T, INFINITY, &v))) return rc;
+  if ((rc = nn_fitness(h->ctx, h->grid, h->d_last_src, h->n_last_src, h->last_T, INFINITY, &v, h->allreduce, h->allreduce_user))) return rc;
   *score = (float)v;  // icp_registration.cpp:60-63: float GetFitnessScore() { return icp_ptr_->getFitnessScore(); }
   return LSA_OK;
 }

@@ -22,17 +22,25 @@
 // (live + dead) pass 60 % of the capacity.  The NDT pass probes a dense table over a WINDOW of level-N cells that contains
 // the map's bounding box with a margin; cells outside the bounding box are empty in the reference too, so the window's
 // extent is not observable.  A valid voxel outside the window raises a flag that the front end reads before its next
-// ScanMatch (behind the frame filter's wait, which orders it after this update's kernels) and re-fits the window.
+// ScanMatch and re-fits the window.
+//
+// Layout (round 4).  ONE cache line per level-F cell (64 B: key, 4 sums, count word, output point) and one 128-byte line per
+// level-N cell (key, 10 sums, count word, state), so that everything a kernel needs of a cell comes with one request and the
+// NS + 1 atomics of a (tile, cell) contribution are ONE wave-instruction's adjacent lanes into one line.  The count word's high
+// half counts the contributions of the running update: the returning add that carries a tile's count tells the tile whether it
+// is the cell's first toucher — it then lists the cell as dirty — with no flag array and no exchange of its own.  Dirty cells are
+// listed per TILE (a region of the list per workgroup of the producing kernel, its length in a per-region word): no counter that
+// every workgroup appends to; the consuming kernel scans the region lengths (a few hundred words) and deals the entries out
+// evenly.  What the three launches of a key-frame cost before (23 + 22 + 14 us, profiles/r03_*) and after: DESIGN.md 6d.
 #ifndef LSA_LOCAL_MAP_H_
 #define LSA_LOCAL_MAP_H_
 
 #include "voxel_index.h"
 
 struct LmStatus {
-  unsigned n_dirty_f, n_dirty_n;      // dirty lists being built
   unsigned keys_f, keys_n;            // keys in the tables (live + dead)
   int live_f, live_n;                 // cells with a positive count
-  unsigned overflow;                  // a probe sequence ran out of slots: the tables must be rebuilt larger
+  unsigned overflow;                  // 1: a probe sequence ran out of slots (rebuild larger); 2: coordinates beyond +-2^20 cells
   unsigned window_miss;               // a valid voxel lies outside the dense window
   unsigned done;                      // workgroups of k_lm_ndt_dirty that have finished (the last one publishes the status)
   unsigned pad;
@@ -40,24 +48,42 @@ struct LmStatus {
   int bmin[3], bmax[3];               // k_lm_bounds: cell bounds of the valid voxels
 };
 
-struct LmHash {
-  DevBuf<unsigned long long> keys;    // packed absolute cell (21 bits per axis); ~0 = empty
-  DevBuf<int32_t> cnt;
-  DevBuf<long long> acc;              // [cap][ns]
-  DevBuf<unsigned> flag;              // 1 = in the dirty list
-  DevBuf<unsigned> dirty;             // slots
-  unsigned cap = 0;                   // power of two
-  int ns = 0;
-  void release() { keys.release(); cnt.release(); acc.release(); flag.release(); dirty.release(); cap = 0; }
+// count word of a cell: bits 0..31 the point count (never negative at any instant: points leave only after they came),
+// bits 32..62 the contributions received in the running update (0 = clean), bit 63 (level F) "has an output point in level N"
+constexpr unsigned long long kLmTouch = 1ull << 32;
+constexpr unsigned long long kLmHasOut = 1ull << 63;
+
+struct alignas(64) LmCellF {
+  unsigned long long key;             // packed absolute cell (21 bits per axis), 0 = empty
+  long long sum[4];
+  unsigned long long cnt;
+  float4 out;                         // the cell's current output point (valid with kLmHasOut)
+};
+struct alignas(128) LmCellN {
+  unsigned long long key;
+  long long sum[10];
+  unsigned long long cnt;
+  int32_t state, alive;               // record state (0 / 1 / -1); cell counted in live_n
+  unsigned long long spare[3];
+};
+static_assert(sizeof(LmCellF) == 64 && sizeof(LmCellN) == 128, "one line per cell");
+
+// a dirty list: `regions` regions of `region_cap` slots + one overflow region behind them; len[r] = entries of region r,
+// written (also when 0) by the workgroup that owns the region in the producing launch
+struct LmDirty {
+  DevBuf<unsigned> slot;
+  DevBuf<unsigned> len;
+  unsigned regions = 0, region_cap = 0, over_cap = 0;
+  void release() { slot.release(); len.release(); regions = region_cap = over_cap = 0; }
 };
 
 struct LocalMap {
   lsa_context *ctx = nullptr;
-  LmHash f, n;
-  DevBuf<float4> out;                 // level F: the cell's current output point
-  DevBuf<int32_t> has_out;            // level F: 1 if `out` is in level N
+  DevBuf<LmCellF> f;
+  DevBuf<LmCellN> n;
+  unsigned cap_f = 0, cap_n = 0;      // powers of two
+  LmDirty dirty_f, dirty_n;
   DevBuf<double> rec;                 // level N: [cap][10] voxel records, indexed by hash slot
-  DevBuf<int32_t> state, alive;       // level N: record state (0 / 1 / -1), cell counted in live_n
   DevBuf<float4> dense;               // dense probe table over the window
   int wmin[3] = {0, 0, 0}, wdim[3] = {0, 0, 0};
   bool window_set = false;
@@ -73,17 +99,15 @@ struct LocalMap {
   long long dense_max_cells = 16ll << 20;
   unsigned long long rebuilds = 0, refits = 0, updates = 0;
   void release() {
-    f.release(); n.release(); out.release(); has_out.release(); rec.release(); state.release(); alive.release(); dense.release();
+    f.release(); n.release(); dirty_f.release(); dirty_n.release(); rec.release(); dense.release();
     d_status.release(); h_status.release();
+    cap_f = cap_n = 0;
     valid = false; window_set = false;
   }
 };
 
 // scales / leaves / mode; capacities are chosen here (and grown by lm_rebuild when a table fills up)
 int lm_configure(LocalMap &lm, lsa_context *ctx, const float leaf_f[3], float leaf_n, int pcl, unsigned long long scale_n);
-// One range of the local-map buffer (a slot of transformed points, NaN padded) added to (sign +1) or subtracted from
-// (sign -1) the persistent sums.  Enqueue only.
-int lm_points(LocalMap &lm, const float4 *d_pts, size_t n, int sign);
 // The steady-state key-frame in ONE launch: the slot's old contents (the evicted key-frame's transformed points; skipped if
 // !evict) leave the sums while the new key-frame's cloud d_raw is transformed (row-major 3x4, f32, PCL's order) into the slot
 // and enters them; a cell both clouds touch receives its net change once.  Enqueue only.
@@ -91,8 +115,8 @@ int lm_points(LocalMap &lm, const float4 *d_pts, size_t n, int sign);
 // front_end.cpp:304-306).
 int lm_swap(LocalMap &lm, float4 *d_slot, size_t slot_cap, bool evict, const float4 *d_raw, size_t n_raw, const float T_rowmajor12[12],
             float4 *d_keep = nullptr, bool force_w_one = false);
-// After the adds / subtracts of an update: move the touched level-F cells' changes into level N, re-finalise the touched
-// level-N cells, publish the status.  Enqueue only; the owner reads lm.h_status once later stream work has completed.
+// After lm_swap: move the touched level-F cells' changes into level N, re-finalise the touched level-N cells, publish the
+// status.  Enqueue only; the owner reads lm.h_status once later stream work has completed.
 int lm_finish(LocalMap &lm);
 // Everything from scratch from `nranges` ranges of the local-map buffer (first key-frame, the switch to the filtered map,
 // a table that filled up, a re-laid-out buffer): clears, re-adds, finalises every cell, fits the window.  Waits for the stream.

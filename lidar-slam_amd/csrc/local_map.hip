@@ -2,18 +2,20 @@
 // (FrontEnd::UpdateWithNewFrame, front_end.cpp:348-424) and for the design.
 //
 // Kernels (all HBM / atomic bound streaming work, nothing GEMM shaped):
-//   k_lm_points<NS, MODE>   one 512-point tile per workgroup: the tile's points are pre-aggregated per cell in an LDS table
-//                           (consecutive lidar returns share cells), then each distinct cell finds or claims its slot in the
-//                           global table (64-bit CAS on the key) and receives NS + 1 atomics; level F (NS 4, PCL's cell rule)
+//   k_lm_points<NS, MODE, SWAP>  one tile of points per workgroup (a swap tile: 512 of the evicted key-frame's and 512 of the new
+//                           one's): pre-aggregated per cell in an LDS table (consecutive lidar returns share cells), then each
+//                           distinct cell finds or claims its line in the global table (64-bit CAS on the key) and receives its
+//                           NS sums and its count as ONE wave-instruction's adjacent lanes into that line — a returning add:
+//                           the lane that carried the count learns from the old value whether its tile is the cell's first
+//                           toucher and lists the cell in the TILE's region of the dirty list.  Level F (NS 4, PCL's cell rule)
 //                           or, while the map is unfiltered, level N directly (NS 10, the reference VoxelGrid's cell rule).
-//                           Bytes per point: 16 read; per distinct (tile, cell): 8 (key) + 8 NS + 4 + 4 of atomic traffic.
-//   k_lm_filter_dirty       one lane per touched F cell: new output point from the sums (vi_filter_mean: the VoxelFilter's own
-//                           arithmetic), old point out of / new point into level N (one set of atomics when both lie in the
-//                           same N cell, which is the rule).
+//                           Bytes per point: 16 read (+ 16 written for the new key-frame's); per distinct (tile, cell): one line.
+//   k_lm_filter_dirty       one workgroup per tile region of the dirty list, up to four touched F cells per lane: new
+//                           output point from the sums (vi_filter_mean: the VoxelFilter's own arithmetic), old point out of / new
+//                           point into level N, summed per N cell in LDS first.
 //   k_lm_ndt_dirty          one lane per touched N cell: the voxel record (ndt_cell_record: the full build's own function) and
-//                           the dense probe table entry.
-//                           the last workgroup to finish publishes the status block into host-mapped memory and resets the
-//                           dirty counters.
+//                           the dense probe table entry; the last workgroup to finish publishes the status block into host-mapped
+//                           memory.
 #include "local_map.h"
 
 #include <chrono>
@@ -22,11 +24,15 @@
 
 namespace {
 constexpr int kBlock = 256;
-constexpr int kTile = 512;          // points per workgroup tile
-constexpr int kLdsProbes = 8;
+constexpr int kTile = 512;          // points per workgroup tile (per cloud)
+constexpr int kLdsProbes = 16;
 constexpr int kGlobalProbes = 512;
-constexpr unsigned long long kEmpty = ~0ull;
-constexpr int kCoordOff = 1 << 20;  // 21 bits per axis
+constexpr unsigned long long kEmpty = 0ull;   // a zero-filled table is empty
+constexpr int kCoordOff = 1 << 20;  // 21 bits per axis; the cell (-2^20, -2^20, -2^20) would pack to 0 and is out of range
+constexpr unsigned kMaxRegions = 4096;   // regions of a dirty list one consumer launch can scan (its prefix lives in LDS)
+constexpr unsigned kMaxTiles = kMaxRegions - 16;   // tiles of one k_lm_points launch: k_lm_filter_dirty adds its overflow workgroups' regions
+constexpr unsigned kFdRegion = 512;      // level-N region of a k_lm_filter_dirty workgroup
+constexpr unsigned kTouchMask = 0x7fffffffu;
 
 __host__ __device__ inline unsigned long long lm_pack(int i, int j, int k) {
   return (unsigned long long)(unsigned)(i + kCoordOff) | ((unsigned long long)(unsigned)(j + kCoordOff) << 21) | ((unsigned long long)(unsigned)(k + kCoordOff) << 42);
@@ -37,7 +43,8 @@ __host__ __device__ inline void lm_unpack(unsigned long long key, int ijk[3]) {
   ijk[2] = (int)((key >> 42) & 0x1fffffull) - kCoordOff;
 }
 __device__ __forceinline__ bool lm_in_range(const int ijk[3]) {
-  return (unsigned)(ijk[0] + kCoordOff) < (1u << 21) && (unsigned)(ijk[1] + kCoordOff) < (1u << 21) && (unsigned)(ijk[2] + kCoordOff) < (1u << 21);
+  return (unsigned)(ijk[0] + kCoordOff - 1) < (1u << 21) - 1u && (unsigned)(ijk[1] + kCoordOff - 1) < (1u << 21) - 1u &&
+         (unsigned)(ijk[2] + kCoordOff - 1) < (1u << 21) - 1u;
 }
 __device__ __forceinline__ unsigned lm_hash(unsigned long long key, unsigned cap) {
   return (unsigned)((key * 0x9E3779B97F4A7C15ull) >> 32) & (cap - 1u);
@@ -45,8 +52,7 @@ __device__ __forceinline__ unsigned lm_hash(unsigned long long key, unsigned cap
 
 // Probe sequence of a cell in a GLOBAL table: cells are hashed by 4 x 4 x 2 BLOCK, and a block's 32 cells occupy the 32
 // consecutive slots behind the block's hash (a collision moves a cell on by whole groups of 32).  Neighbouring cells — which
-// consecutive lidar returns, and the members of one NDT voxel, are — so land in neighbouring rows of the sums: their atomics
-// share cache lines instead of each pulling a line of its own from a 70 MB table.
+// consecutive lidar returns, and the members of one NDT voxel, are — so land in neighbouring lines of the table.
 __device__ __forceinline__ unsigned lm_probe0(unsigned long long key, unsigned cap) {
   int ijk[3];
   lm_unpack(key, ijk);
@@ -68,24 +74,32 @@ __device__ __forceinline__ void lm_cell_abs(const float4 &p, const float leaf[3]
   }
 }
 
-struct HashView {
-  unsigned long long *keys;
-  int32_t *cnt;
-  long long *acc;
-  unsigned *flag, *dirty;
+// a table seen as lines of STRIDE 64-bit words: word 0 the key, words 1..NS the sums, word NS + 1 the count word
+template <int NS>
+struct TableView {
+  static constexpr unsigned kStride = NS == 4 ? 8u : 16u;
+  unsigned long long *w;
   unsigned cap;
+  __device__ __forceinline__ unsigned long long *line(unsigned slot) const { return w + (size_t)slot * kStride; }
+};
+
+struct DirtyView {
+  unsigned *slot, *len;      // len[0]: entries of the overflow region slot[0 .. over_cap); len[1 + r]: entries of region r
+  unsigned regions, region_cap, over_cap;
+  __device__ __forceinline__ unsigned *region(unsigned r) const { return slot + over_cap + (size_t)r * region_cap; }
 };
 
 // Slot of `key` in the global table, claiming one if it is new.  Keys never change once written, so a plain (possibly stale,
 // the eight L2s are not coherent with each other) read can only err towards "empty", which the CAS then settles.
-__device__ __forceinline__ int lm_find_insert(const HashView &H, unsigned long long key, unsigned *n_keys, unsigned *overflow) {
+template <int NS>
+__device__ __forceinline__ int lm_find_insert(const TableView<NS> &H, unsigned long long key, unsigned *n_new, unsigned *overflow) {
   unsigned h = lm_probe0(key, H.cap);
   for (int probe = 0; probe < kGlobalProbes; probe++) {
-    unsigned long long k = H.keys[h];
+    unsigned long long k = *H.line(h);
     if (k == key) return (int)h;
     if (k == kEmpty) {
-      unsigned long long old = atomicCAS(H.keys + h, kEmpty, key);
-      if (old == kEmpty) { atomicAdd(n_keys, 1u); return (int)h; }
+      unsigned long long old = atomicCAS(H.line(h), kEmpty, key);
+      if (old == kEmpty) { atomicAdd(n_new, 1u); return (int)h; }
       if (old == key) return (int)h;
     }
     h = (h + kProbeStep) & (H.cap - 1u);
@@ -94,11 +108,13 @@ __device__ __forceinline__ int lm_find_insert(const HashView &H, unsigned long l
   return -1;
 }
 
-__device__ __forceinline__ void lm_mark_dirty(const HashView &H, int slot, unsigned *n_dirty) {
-  if (atomicExch(H.flag + slot, 1u) == 0u) H.dirty[atomicAdd(n_dirty, 1u)] = (unsigned)slot;   // (each slot at most once: the list cannot overflow)
+// a cell that bypassed a workgroup's LDS table (table full), or that no longer fits the workgroup's region: the overflow region
+__device__ __forceinline__ void lm_dirty_overflow(const DirtyView &D, unsigned g, unsigned *overflow) {
+  const unsigned i = atomicAdd(D.len, 1u);
+  if (i < D.over_cap) D.slot[i] = g; else atomicOr(overflow, 1u);
 }
 
-// slot of `key` in the tile's LDS table (inserting it), or -1 when no slot is free within kLdsProbes steps
+// slot of `key` in the workgroup's LDS table (inserting it), or -1 when no slot is free within kLdsProbes steps
 template <int CAP>
 __device__ __forceinline__ int lm_lds_insert(unsigned long long *keys, unsigned long long key) {
   unsigned h = lm_hash(key, CAP);
@@ -114,10 +130,67 @@ __device__ __forceinline__ int lm_lds_insert(unsigned long long *keys, unsigned 
   return -1;
 }
 
+// The flush of a workgroup's LDS table (`CAP` slots: keys / counts / sums) into the global table H, and the cells it is the
+// first toucher of into `won` (LDS; *n_won entries on return, behind a barrier).  Every step issues ALL of a lane's memory
+// operations before it looks at the first result — a lane owns up to CAP / 256 cells, and taken one after the other their
+// round trips to the memory side (~2 us each for a returning atomic) were most of the kernel:
+//   step 0: the used LDS slots are listed (LDS only);
+//   step 1: every listed cell finds (or claims) its line: the first probe of all of a lane's cells is loaded together;
+//   step 2: the NS sums of a cell leave as adjacent lanes of plain (non-returning) adds into its line — nobody waits for them —
+//           and the count word takes count + 2^32 by a RETURNING add, all of a lane's issued together: the old value's high half
+//           says whether the cell was clean, i.e. whether this workgroup is its first toucher and lists it as dirty.
+template <int NS, int CAP>
+__device__ __forceinline__ void lm_flush(const TableView<NS> &H, const unsigned long long *keys, const int *counts, const unsigned long long (*sums)[NS],
+                                         int *used, int *gslot, unsigned *won, int *n_used, unsigned *n_won, unsigned *n_new_keys, unsigned *overflow) {
+  constexpr int kPer = CAP / kBlock;
+  for (int k = threadIdx.x; k < CAP; k += kBlock)
+    if (keys[k] != kEmpty) used[atomicAdd(n_used, 1)] = k;
+  __syncthreads();
+  const int nu = *n_used;
+  {
+    unsigned long long key[kPer], first[kPer];
+    unsigned h0[kPer];
+#pragma unroll
+    for (int m = 0; m < kPer; m++) {
+      const int u = threadIdx.x + m * kBlock;
+      key[m] = u < nu ? keys[used[u]] : kEmpty;
+      h0[m] = u < nu ? lm_probe0(key[m], H.cap) : 0u;
+    }
+#pragma unroll
+    for (int m = 0; m < kPer; m++) first[m] = *H.line(h0[m]);   // (idle lanes read line 0: harmless)
+#pragma unroll
+    for (int m = 0; m < kPer; m++) {
+      const int u = threadIdx.x + m * kBlock;
+      if (u < nu) gslot[u] = first[m] == key[m] ? (int)h0[m] : lm_find_insert<NS>(H, key[m], n_new_keys, overflow);
+    }
+  }
+  __syncthreads();
+  for (int e = threadIdx.x; e < nu * NS; e += kBlock) {
+    const int u = e / NS, j = e - u * NS;
+    const int g = gslot[u];
+    if (g >= 0) atomicAdd(H.line((unsigned)g) + 1 + j, sums[used[u]][j]);
+  }
+  {
+    unsigned long long old[kPer];
+#pragma unroll
+    for (int m = 0; m < kPer; m++) {
+      const int u = threadIdx.x + m * kBlock;
+      const int g = u < nu ? gslot[u] : -1;
+      old[m] = g >= 0 ? atomicAdd(H.line((unsigned)g) + 1 + NS, (unsigned long long)(long long)counts[used[u]] + kLmTouch) : ~0ull;
+    }
+#pragma unroll
+    for (int m = 0; m < kPer; m++) {
+      const int u = threadIdx.x + m * kBlock;
+      if (u < nu && gslot[u] >= 0 && ((unsigned)(old[m] >> 32) & kTouchMask) == 0u) won[atomicAdd(n_won, 1u)] = (unsigned)gslot[u];
+    }
+  }
+  __syncthreads();
+}
+
 struct PointsArgs {
   float leaf[3], inv[3];
   FixScales fs;
-  int sign;          // +1 add, -1 subtract (the points of `pts`)
+  int sign;          // +1 add, -1 subtract (the points of `pts`; plain launches)
   int to_level_n;    // which counters of the status block this table uses
   // swap (k_lm_points with SWAP): `pts` is a slot of the local-map buffer whose old contents leave the sums (if evict) while
   // the key-frame cloud `raw` (n_raw points, rigid transform T, f32 like pcl::transformPointCloud) is written into it and enters
@@ -129,17 +202,20 @@ struct PointsArgs {
   int force_w_one;
 };
 
+template <int NS, bool SWAP>
+struct PointsCap { static constexpr int value = SWAP ? (NS == 4 ? 1024 : 512) : (NS == 4 ? 512 : 256); };
+
 template <int NS, int MODE, bool SWAP>
-__global__ __launch_bounds__(kBlock) void k_lm_points(float4 *__restrict__ pts, size_t n, PointsArgs A, HashView H, LmStatus *__restrict__ st) {
-  constexpr int kLdsCap = SWAP ? 512 : 256;   // a swap tile carries two clouds' points
+__global__ __launch_bounds__(kBlock) void k_lm_points(float4 *__restrict__ pts, size_t n, PointsArgs A, TableView<NS> H, DirtyView D, LmStatus *__restrict__ st) {
+  constexpr int kLdsCap = PointsCap<NS, SWAP>::value;   // a swap tile carries two clouds' points; == D.region_cap
   __shared__ unsigned long long keys[kLdsCap];
   __shared__ int counts[kLdsCap];
   __shared__ unsigned long long sums[kLdsCap][NS];
   __shared__ int gslot[kLdsCap];
   __shared__ int used[kLdsCap];
-  __shared__ unsigned won[kLdsCap];     // global slots this tile was the first to mark dirty
+  __shared__ unsigned won[kLdsCap];     // global slots this tile was the first to touch
   __shared__ int n_used;
-  __shared__ unsigned n_won, n_new_keys, dirty_base;
+  __shared__ unsigned n_won, n_new_keys;
   if (threadIdx.x == 0) { n_used = 0; n_won = 0u; n_new_keys = 0u; }
   for (int k = threadIdx.x; k < kLdsCap; k += kBlock) {
     keys[k] = kEmpty;
@@ -148,8 +224,6 @@ __global__ __launch_bounds__(kBlock) void k_lm_points(float4 *__restrict__ pts, 
     for (int j = 0; j < NS; j++) sums[k][j] = 0ull;
   }
   __syncthreads();
-  unsigned *n_keys = A.to_level_n ? &st->keys_n : &st->keys_f;
-  unsigned *n_dirty = A.to_level_n ? &st->n_dirty_n : &st->n_dirty_f;
   const size_t base = (size_t)blockIdx.x * kTile;
   // One pass (plain) or two (swap: first the slot's old points with sign -1, then the new key-frame's with sign +1, written
   // into the slot on the way); both passes aggregate into the same LDS table, so a cell both clouds touch is flushed once
@@ -208,46 +282,72 @@ __global__ __launch_bounds__(kBlock) void k_lm_points(float4 *__restrict__ pts, 
         for (int j = 0; j < NS; j++) atomicAdd(&sums[slot][j], (v[j] ^ sgn) - sgn);
         atomicAdd(&counts[slot], sign);
       } else {  // the tile's table is full (a tile of an already sparse cloud): straight to the global table
-        int g = lm_find_insert(H, key, n_keys, &st->overflow);
+        int g = lm_find_insert<NS>(H, key, &n_new_keys, &st->overflow);
         if (g >= 0) {
-          unsigned long long *a = (unsigned long long *)(H.acc + (size_t)g * NS);
+          unsigned long long *a = H.line((unsigned)g) + 1;
 #pragma unroll
           for (int j = 0; j < NS; j++) atomicAdd(a + j, (v[j] ^ sgn) - sgn);
-          atomicAdd(H.cnt + g, sign);
-          lm_mark_dirty(H, g, n_dirty);
+          const unsigned long long old = atomicAdd(a + NS, (unsigned long long)(long long)sign + kLmTouch);
+          if (((unsigned)(old >> 32) & kTouchMask) == 0u) lm_dirty_overflow(D, (unsigned)g, &st->overflow);
         }
       }
     }
     if (SWAP) __syncthreads();   // (the slot's old points are read by the lanes that overwrite them: no hazard; this keeps the passes apart in LDS only)
   }
   __syncthreads();
-  // flush, step 1: every used LDS slot finds (or claims) its global slot.  The dirty list and the key counter are single
-  // words that every tile of the launch appends to (~40 k cells per cloud): appended cell by cell, those same-address atomics
-  // WERE the kernel (41-61 us for a 131 k-point key-frame); a tile now reserves its share with one atomic each.
-  for (int k = threadIdx.x; k < kLdsCap; k += kBlock) {
-    if (keys[k] == kEmpty) continue;
-    int g = lm_find_insert(H, keys[k], &n_new_keys, &st->overflow);
-    if (g < 0) continue;
-    int u = atomicAdd(&n_used, 1);
-    used[u] = k;
-    gslot[u] = g;
-    if (atomicExch(H.flag + g, 1u) == 0u) won[atomicAdd(&n_won, 1u)] = (unsigned)g;
-  }
-  __syncthreads();
+  lm_flush<NS, kLdsCap>(H, keys, counts, sums, used, gslot, won, &n_used, &n_won, &n_new_keys, &st->overflow);
+  // the tile's region of the dirty list (every region's length is written, the empty ones' too: the consumer does not clear)
+  unsigned *reg = D.region(blockIdx.x);
+  for (unsigned e = threadIdx.x; e < n_won; e += kBlock) reg[e] = won[e];
   if (threadIdx.x == 0) {
-    dirty_base = n_won ? atomicAdd(n_dirty, n_won) : 0u;
-    if (n_new_keys) atomicAdd(n_keys, n_new_keys);
+    D.len[1 + blockIdx.x] = n_won;
+    if (n_new_keys) atomicAdd(A.to_level_n ? &st->keys_n : &st->keys_f, n_new_keys);
+  }
+}
+
+// Scan of a dirty list's region lengths by one workgroup: pre[q] = entries in front of region q (q = 0 the overflow region,
+// q = 1 + r region r), pre[R + 1] = the total.  R + 1 <= kMaxRegions + 1.  The lengths are read in ONE coalesced sweep (a lane's
+// loads are independent: one round trip), then scanned in LDS.
+__device__ __forceinline__ unsigned lm_scan_regions(const DirtyView &D, unsigned *pre, unsigned *wave_sums) {
+  const unsigned R1 = D.regions + 1u;
+  for (unsigned q = threadIdx.x; q < R1; q += kBlock) {
+    const unsigned c = D.len[q];
+    const unsigned room = q == 0u ? D.over_cap : D.region_cap;
+    pre[q] = c < room ? c : room;
   }
   __syncthreads();
-  for (unsigned e = threadIdx.x; e < n_won; e += kBlock) H.dirty[dirty_base + e] = won[e];
-  // step 2: one lane per (cell, term): the NS + 1 atomics of a cell leave from adjacent lanes into one or two lines
-  const int total = n_used * (NS + 1);
-  for (int e = threadIdx.x; e < total; e += kBlock) {
-    int u = e / (NS + 1), j = e - u * (NS + 1);
-    int slot = used[u], g = gslot[u];
-    if (j < NS) atomicAdd((unsigned long long *)(H.acc + (size_t)g * NS) + j, sums[slot][j]);
-    else atomicAdd(H.cnt + g, counts[slot]);
+  const unsigned per = (R1 + kBlock - 1u) / kBlock;   // consecutive lengths per lane
+  const unsigned q0 = threadIdx.x * per;
+  unsigned local = 0u;
+  for (unsigned k = 0; k < per; k++)
+    if (q0 + k < R1) local += pre[q0 + k];
+  unsigned incl = local;
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    unsigned t = __shfl_up(incl, off, 64);
+    if ((int)(threadIdx.x & 63) >= off) incl += t;
   }
+  if ((threadIdx.x & 63) == 63) wave_sums[threadIdx.x >> 6] = incl;
+  __syncthreads();
+  unsigned run = incl - local;
+  for (unsigned w = 0; w < (threadIdx.x >> 6); w++) run += wave_sums[w];
+  for (unsigned k = 0; k < per; k++) {
+    const unsigned q = q0 + k;
+    if (q < R1) { const unsigned c = pre[q]; pre[q] = run; run += c; }
+  }
+  if (threadIdx.x == kBlock - 1) pre[R1] = run;
+  __syncthreads();
+  return pre[R1];
+}
+// entry i of the concatenated list
+__device__ __forceinline__ unsigned lm_dirty_entry(const DirtyView &D, const unsigned *pre, unsigned i) {
+  unsigned lo = 0u, hi = D.regions + 1u;   // largest q with pre[q] <= i (lengths may be 0: pre is non-decreasing)
+  while (hi - lo > 1u) {
+    const unsigned mid = (lo + hi) >> 1;
+    if (pre[mid] <= i) lo = mid; else hi = mid;
+  }
+  const unsigned off = i - pre[lo];
+  return lo == 0u ? D.slot[off] : D.region(lo - 1u)[off];
 }
 
 struct FilterDirtyArgs {
@@ -256,13 +356,15 @@ struct FilterDirtyArgs {
   FixScales fs_f, fs_n;
 };
 
-// one lane per touched level-F cell.  Consecutive entries of the dirty list are spatial neighbours (cells enter it in the order
-// the scan first touches them), so the 256 cells of a chunk fall into a few dozen level-N cells: their changes are summed per N
-// cell in an LDS table first and leave the workgroup as ONE set of atomics per N cell (cell by cell, ~80 k x 10 atomics landed on
-// ~6 k x 10 words: 30 us).
-constexpr int kFdCap = 128;   // LDS slots (N cells) per chunk of 256 F cells; what does not fit goes straight to memory
-__global__ __launch_bounds__(kBlock) void k_lm_filter_dirty(HashView F, float4 *__restrict__ out, int32_t *__restrict__ has_out, HashView N, FilterDirtyArgs A,
-                                                            LmStatus *__restrict__ st) {
+// One workgroup per TILE region of the level-F dirty list (plus a few that share the overflow region), up to kFdPer touched cells
+// per lane, everything a lane needs of ALL its cells requested before the first is looked at: the region's length and the entries
+// in one round trip (the entries are read whatever the length says), the cells' lines in the next.  A tile's cells are spatial
+// neighbours (in the order the scan first touches them), so the workgroup's cells fall into a few dozen level-N cells: their
+// changes are summed per N cell in an LDS table first and leave the workgroup as one line's worth of atomics per N cell.
+constexpr int kFdCap = 256;    // LDS slots (N cells) of a workgroup; what does not fit goes straight to memory
+constexpr int kFdPer = 4;      // cells per lane and step: a swap tile's region holds up to 1024
+constexpr unsigned kFdOverWg = 8;   // workgroups that share the overflow region (usually empty)
+__global__ __launch_bounds__(kBlock) void k_lm_filter_dirty(TableView<4> F, DirtyView DF, TableView<10> N, DirtyView DN, FilterDirtyArgs A, LmStatus *__restrict__ st) {
   __shared__ unsigned long long keys[kFdCap];
   __shared__ int counts[kFdCap];
   __shared__ unsigned long long sums[kFdCap][10];
@@ -270,10 +372,16 @@ __global__ __launch_bounds__(kBlock) void k_lm_filter_dirty(HashView F, float4 *
   __shared__ int used[kFdCap];
   __shared__ unsigned won[kFdCap];
   __shared__ int n_used;
-  __shared__ unsigned n_won, n_new_keys, dirty_base;
-  const unsigned nd = st->n_dirty_f;
+  __shared__ unsigned n_won, n_new_keys;
+  const bool over = blockIdx.x >= DF.regions;
+  const unsigned *list = over ? DF.slot : DF.region(blockIdx.x);
+  const unsigned room = over ? DF.over_cap : DF.region_cap;
+  unsigned nd = over ? DF.len[0] : DF.len[1 + blockIdx.x];
+  nd = nd < room ? nd : room;
+  const unsigned step = kBlock * kFdPer;
+  unsigned fill = 0u;   // entries of this workgroup's level-N region so far (uniform)
   int d_live = 0;
-  for (unsigned chunk = blockIdx.x; chunk * kBlock < nd; chunk += gridDim.x) {
+  for (unsigned base = over ? (blockIdx.x - DF.regions) * step : 0u; base < nd; base += over ? kFdOverWg * step : step) {
     if (threadIdx.x == 0) { n_used = 0; n_won = 0u; n_new_keys = 0u; }
     for (int k = threadIdx.x; k < kFdCap; k += kBlock) {
       keys[k] = kEmpty;
@@ -282,86 +390,94 @@ __global__ __launch_bounds__(kBlock) void k_lm_filter_dirty(HashView F, float4 *
       for (int j = 0; j < 10; j++) sums[k][j] = 0ull;
     }
     __syncthreads();
-    const unsigned t = chunk * kBlock + threadIdx.x;
-    if (t < nd) {
-      const unsigned s = F.dirty[t];
-      F.flag[s] = 0u;
-      const int cnt = F.cnt[s];
-      const bool had = has_out[s] != 0, has = cnt > 0;
-      const float4 old = out[s];
+    unsigned s[kFdPer];
+    bool live[kFdPer];
+    ulonglong2 q0[kFdPer], q1[kFdPer], q2[kFdPer];
+    float4 oldp[kFdPer];
+#pragma unroll
+    for (int m = 0; m < kFdPer; m++) {
+      const unsigned t = base + (unsigned)m * kBlock + threadIdx.x;
+      live[m] = t < nd;
+      s[m] = live[m] ? list[t] : 0u;
+    }
+#pragma unroll
+    for (int m = 0; m < kFdPer; m++) {
+      // the cell's line: key | 4 sums | count word | output point  (idle lanes read line 0: harmless)
+      const ulonglong2 *ln = reinterpret_cast<const ulonglong2 *>(F.line(s[m]));
+      q0[m] = ln[0]; q1[m] = ln[1]; q2[m] = ln[2];
+      oldp[m] = reinterpret_cast<const float4 *>(F.line(s[m]))[3];
+    }
+#pragma unroll
+    for (int m = 0; m < kFdPer; m++) {
+      if (!live[m]) continue;
+      const float4 old = oldp[m];
+      const long long a[4] = {(long long)q0[m].y, (long long)q1[m].x, (long long)q1[m].y, (long long)q2[m].x};
+      const unsigned long long cw = q2[m].y;
+      const int cnt = (int)(unsigned)cw;
+      const bool had = (cw & kLmHasOut) != 0ull, has = cnt > 0;
       float4 nw = make_float4(0.f, 0.f, 0.f, 0.f);
       if (has) {
         int ijk[3];
-        lm_unpack(F.keys[s], ijk);
+        lm_unpack(q0[m].x, ijk);
         double o[3];
         lsa_abs_origin(ijk, A.leaf_f, o);
-        const long long a[4] = {F.acc[(size_t)s * 4], F.acc[(size_t)s * 4 + 1], F.acc[(size_t)s * 4 + 2], F.acc[(size_t)s * 4 + 3]};
         nw = vi_filter_mean(a, cnt, o, A.fs_f);
       }
       d_live += (int)has - (int)had;
       const bool same = had && has && __float_as_uint(old.x) == __float_as_uint(nw.x) && __float_as_uint(old.y) == __float_as_uint(nw.y) &&
                         __float_as_uint(old.z) == __float_as_uint(nw.z) && __float_as_uint(old.w) == __float_as_uint(nw.w);
-      if (!same) {  // the old output point leaves level N, the new one enters it
-        out[s] = nw;
-        has_out[s] = has ? 1 : 0;
+      // the count word back to "clean" (no contributions of a running update), with the output point's presence
+      F.line(s[m])[5] = (unsigned long long)(unsigned)cnt | (has ? kLmHasOut : 0ull);
+      if (same) continue;
+      // the old output point leaves level N, the new one enters it
+      reinterpret_cast<float4 *>(F.line(s[m]))[3] = nw;
 #pragma unroll
-        for (int side = 0; side < 2; side++) {
-          if (side == 0 ? !had : !has) continue;
-          const float4 p = side == 0 ? old : nw;
-          const int sign = side == 0 ? -1 : +1;
-          const unsigned long long sgn = sign < 0 ? ~0ull : 0ull;
-          int c[3];
-          lm_cell_abs<1>(p, A.leaf_n, A.inv_n, c);
-          if (!lm_in_range(c)) { atomicOr(&st->overflow, 2u); continue; }
-          double o[3];
-          lsa_abs_origin(c, A.leaf_n, o);
-          unsigned long long v[10];
-          vi_point_terms<10>(o, A.fs_n, p, v);
-          const unsigned long long key = lm_pack(c[0], c[1], c[2]);
-          int slot = lm_lds_insert<kFdCap>(keys, key);
-          if (slot >= 0) {
+      for (int side = 0; side < 2; side++) {
+        if (side == 0 ? !had : !has) continue;
+        const float4 p = side == 0 ? old : nw;
+        const int sign = side == 0 ? -1 : +1;
+        const unsigned long long sgn = sign < 0 ? ~0ull : 0ull;
+        int c[3];
+        lm_cell_abs<1>(p, A.leaf_n, A.inv_n, c);
+        if (!lm_in_range(c)) { atomicOr(&st->overflow, 2u); continue; }
+        double o[3];
+        lsa_abs_origin(c, A.leaf_n, o);
+        unsigned long long v[10];
+        vi_point_terms<10>(o, A.fs_n, p, v);
+        const unsigned long long key = lm_pack(c[0], c[1], c[2]);
+        int slot = lm_lds_insert<kFdCap>(keys, key);
+        if (slot >= 0) {
 #pragma unroll
-            for (int j = 0; j < 10; j++) atomicAdd(&sums[slot][j], (v[j] ^ sgn) - sgn);
-            atomicAdd(&counts[slot], sign);
-          } else {
-            int g = lm_find_insert(N, key, &st->keys_n, &st->overflow);
-            if (g >= 0) {
-              unsigned long long *a = (unsigned long long *)(N.acc + (size_t)g * 10);
+          for (int j = 0; j < 10; j++) atomicAdd(&sums[slot][j], (v[j] ^ sgn) - sgn);
+          atomicAdd(&counts[slot], sign);
+        } else {
+          int g = lm_find_insert<10>(N, key, &n_new_keys, &st->overflow);
+          if (g >= 0) {
+            unsigned long long *a2 = N.line((unsigned)g) + 1;
 #pragma unroll
-              for (int j = 0; j < 10; j++) atomicAdd(a + j, (v[j] ^ sgn) - sgn);
-              atomicAdd(N.cnt + g, sign);
-              lm_mark_dirty(N, g, &st->n_dirty_n);
-            }
+            for (int j = 0; j < 10; j++) atomicAdd(a2 + j, (v[j] ^ sgn) - sgn);
+            const unsigned long long oldw = atomicAdd(a2 + 10, (unsigned long long)(long long)sign + kLmTouch);
+            if (((unsigned)(oldw >> 32) & kTouchMask) == 0u) lm_dirty_overflow(DN, (unsigned)g, &st->overflow);
           }
         }
       }
     }
     __syncthreads();
-    for (int k = threadIdx.x; k < kFdCap; k += kBlock) {
-      if (keys[k] == kEmpty) continue;
-      int g = lm_find_insert(N, keys[k], &n_new_keys, &st->overflow);
-      if (g < 0) continue;
-      int u = atomicAdd(&n_used, 1);
-      used[u] = k;
-      gslot[u] = g;
-      if (atomicExch(N.flag + g, 1u) == 0u) won[atomicAdd(&n_won, 1u)] = (unsigned)g;
-    }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-      dirty_base = n_won ? atomicAdd(&st->n_dirty_n, n_won) : 0u;
-      if (n_new_keys) atomicAdd(&st->keys_n, n_new_keys);
-    }
-    __syncthreads();
-    for (unsigned e = threadIdx.x; e < n_won; e += kBlock) N.dirty[dirty_base + e] = won[e];
-    const int total = n_used * 11;
-    for (int e = threadIdx.x; e < total; e += kBlock) {
-      int u = e / 11, j = e - u * 11;
-      int slot = used[u], g = gslot[u];
-      if (j < 10) atomicAdd((unsigned long long *)(N.acc + (size_t)g * 10) + j, sums[slot][j]);
-      else atomicAdd(N.cnt + g, counts[slot]);
+    lm_flush<10, kFdCap>(N, keys, counts, sums, used, gslot, won, &n_used, &n_won, &n_new_keys, &st->overflow);
+    // the cells this step was the first toucher of: into the workgroup's region while it has room, the rest into the overflow region
+    {
+      unsigned *reg = DN.region(blockIdx.x);
+      const unsigned nw_ = n_won;
+      for (unsigned e = threadIdx.x; e < nw_; e += kBlock) {
+        if (fill + e < DN.region_cap) reg[fill + e] = won[e];
+        else lm_dirty_overflow(DN, won[e], &st->overflow);
+      }
+      fill = fill + nw_ < DN.region_cap ? fill + nw_ : DN.region_cap;
+      if (threadIdx.x == 0 && n_new_keys) atomicAdd(&st->keys_n, n_new_keys);
     }
     __syncthreads();
   }
+  if (threadIdx.x == 0) DN.len[1 + blockIdx.x] = fill;
   // one atomic per wave for the live-cell counter
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) d_live += __shfl_down(d_live, off, 64);
@@ -377,33 +493,46 @@ struct NdtDirtyArgs {
 };
 
 // one lane per touched level-N cell: voxel record + dense table entry
-__global__ __launch_bounds__(kBlock) void k_lm_ndt_dirty(HashView N, double *__restrict__ rec, int32_t *__restrict__ state, int32_t *__restrict__ alive,
-                                                         float4 *__restrict__ dense, NdtDirtyArgs A, LmStatus *__restrict__ st, LmStatus *__restrict__ host_mirror,
-                                                         unsigned long long epoch) {
-  const unsigned nd = __hip_atomic_load(&st->n_dirty_n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+__global__ __launch_bounds__(kBlock) void k_lm_ndt_dirty(TableView<10> N, DirtyView DN, unsigned *__restrict__ f_over_len, double *__restrict__ rec, float4 *__restrict__ dense,
+                                                         NdtDirtyArgs A, LmStatus *__restrict__ st, LmStatus *__restrict__ host_mirror, unsigned long long epoch) {
+  __shared__ unsigned pre[kMaxRegions + 2];
+  __shared__ unsigned wave_sums[kBlock / 64];
+  const unsigned nd = lm_scan_regions(DN, pre, wave_sums);
+  // workgroups that have a chunk (workgroup 0 always): the others leave without a word
+  const unsigned chunks = (nd + kBlock - 1u) / kBlock;
+  const unsigned active = chunks < gridDim.x ? (chunks ? chunks : 1u) : gridDim.x;
+  if (blockIdx.x >= active) return;
   int d_live = 0;
-  for (unsigned t = blockIdx.x * blockDim.x + threadIdx.x; t < nd; t += gridDim.x * blockDim.x) {
-    const unsigned s = N.dirty[t];
-    N.flag[s] = 0u;
-    const int cnt = N.cnt[s];
+  for (unsigned t = blockIdx.x * kBlock + threadIdx.x; t < nd; t += active * kBlock) {
+    const unsigned s = lm_dirty_entry(DN, pre, t);
+    const ulonglong2 *ln = reinterpret_cast<const ulonglong2 *>(N.line(s));
+    ulonglong2 q[7];
+#pragma unroll
+    for (int k = 0; k < 7; k++) q[k] = ln[k];
+    const unsigned long long key = q[0].x, cw = q[5].y;
+    const long long a[10] = {(long long)q[0].y, (long long)q[1].x, (long long)q[1].y, (long long)q[2].x, (long long)q[2].y,
+                             (long long)q[3].x, (long long)q[3].y, (long long)q[4].x, (long long)q[4].y, (long long)q[5].x};
+    const int cnt = (int)(unsigned)cw;
+    const int was = (int)(q[6].x >> 32);   // {state, alive} packed in one word: state low, alive high
     int ijk[3];
-    lm_unpack(N.keys[s], ijk);
+    lm_unpack(key, ijk);
     double *R = rec + (size_t)s * 10;
     int stt = 0;
     if (cnt > 0) {
       double o[3];
       lsa_abs_origin(ijk, A.leaf, o);
-      long long a[10];
-#pragma unroll
-      for (int j = 0; j < 10; j++) a[j] = N.acc[(size_t)s * 10 + j];
       stt = ndt_cell_record(a, cnt, o, A.fs, A.pcl, R);
     } else {
 #pragma unroll
       for (int j = 0; j < 10; j++) R[j] = 0.0;
     }
-    state[s] = stt;
-    const int was = alive[s], is = cnt > 0 ? 1 : 0;
-    alive[s] = is;
+    const int is = cnt > 0 ? 1 : 0;
+    // count word back to clean; state and alive
+    ulonglong2 tail;
+    tail.x = (unsigned long long)(unsigned)stt | ((unsigned long long)(unsigned)is << 32);
+    tail.y = 0ull;
+    N.line(s)[11] = (unsigned long long)(unsigned)cnt;
+    reinterpret_cast<ulonglong2 *>(N.line(s))[6] = tail;
     d_live += is - was;
     if (A.have_window) {
       const int i = ijk[0] - A.wmin[0], j = ijk[1] - A.wmin[1], k = ijk[2] - A.wmin[2];
@@ -419,28 +548,28 @@ __global__ __launch_bounds__(kBlock) void k_lm_ndt_dirty(HashView N, double *__r
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) d_live += __shfl_down(d_live, off, 64);
   if ((threadIdx.x & 63) == 0 && d_live != 0) atomicAdd(&st->live_n, d_live);
-  // The LAST workgroup to finish publishes the status block to the host and resets the dirty counters (this was a launch of
-  // its own: ~4 us of kernel + a dispatch gap per key-frame).  Every word of the block is only ever changed by device-scope
-  // atomics, which are performed at the memory side, so no cache write-back is involved: each wave drains its own
-  // outstanding operations (s_waitcnt), the workgroup meets, one lane counts it done; the workgroup that finds itself last
-  // reads the words with device-scope loads.
+  // The LAST active workgroup to finish publishes the status block to the host and resets the overflow regions' lengths.  Every
+  // word of the block is only ever changed by device-scope atomics, which are performed at the memory side, so no cache
+  // write-back is involved: each wave drains its own outstanding operations (s_waitcnt), the workgroup meets, one lane counts
+  // it done; the workgroup that finds itself last reads the words with device-scope loads.
   __builtin_amdgcn_s_waitcnt(0);
   __syncthreads();
   __shared__ unsigned s_last;
-  if (threadIdx.x == 0) s_last = atomicAdd(&st->done, 1u) == gridDim.x - 1u ? 1u : 0u;
+  if (threadIdx.x == 0) s_last = atomicAdd(&st->done, 1u) == active - 1u ? 1u : 0u;
   __syncthreads();
   if (s_last && threadIdx.x < 64) {
-    // one lane per 32-bit word of the block in front of the epoch, all loads in ONE instruction (read one after the other
-    // by a single lane, six dependent trips to the memory side cost the kernel 11 us)
+    // one lane per 32-bit word of the block in front of the epoch, all loads in ONE instruction
     constexpr int kW = (int)(offsetof(LmStatus, epoch) / 4);
-    constexpr int kNdF = (int)(offsetof(LmStatus, n_dirty_f) / 4), kNdN = (int)(offsetof(LmStatus, n_dirty_n) / 4), kDone = (int)(offsetof(LmStatus, done) / 4);
+    constexpr int kDone = (int)(offsetof(LmStatus, done) / 4);
     const int lane = (int)threadIdx.x;
     unsigned *sw = reinterpret_cast<unsigned *>(st), *hw = reinterpret_cast<unsigned *>(host_mirror);
-    const bool reset = lane == kNdF || lane == kNdN || lane == kDone;
+    const bool reset = lane == kDone;
     unsigned v = 0u;
     if (lane < kW && !reset) v = __hip_atomic_load(sw + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (lane < kW) __hip_atomic_store(hw + lane, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     if (reset) __hip_atomic_store(sw + lane, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (lane == 62) __hip_atomic_store(DN.len, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (lane == 63 && f_over_len) __hip_atomic_store(f_over_len, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     // the epoch word last, behind the completion of the others (a drain of the wave's stores: a RELEASE at system scope
     // would write back the whole L2 — the records and table entries this kernel has just written — for nothing)
     __builtin_amdgcn_s_waitcnt(0);
@@ -449,13 +578,12 @@ __global__ __launch_bounds__(kBlock) void k_lm_ndt_dirty(HashView N, double *__r
 }
 
 // bounds of the valid voxels (window re-fit)
-__global__ __launch_bounds__(kBlock) void k_lm_bounds(const unsigned long long *__restrict__ keys, const int32_t *__restrict__ state, unsigned cap,
-                                                      LmStatus *__restrict__ st) {
+__global__ __launch_bounds__(kBlock) void k_lm_bounds(const LmCellN *__restrict__ cells, unsigned cap, LmStatus *__restrict__ st) {
   int mn[3] = {INT_MAX, INT_MAX, INT_MAX}, mx[3] = {INT_MIN, INT_MIN, INT_MIN};
   for (unsigned s = blockIdx.x * blockDim.x + threadIdx.x; s < cap; s += gridDim.x * blockDim.x) {
-    if (keys[s] == kEmpty || state[s] != 1) continue;
+    if (cells[s].key == kEmpty || cells[s].state != 1) continue;
     int ijk[3];
-    lm_unpack(keys[s], ijk);
+    lm_unpack(cells[s].key, ijk);
     for (int a = 0; a < 3; a++) { mn[a] = min(mn[a], ijk[a]); mx[a] = max(mx[a], ijk[a]); }
   }
   for (int a = 0; a < 3; a++) {
@@ -468,12 +596,12 @@ __global__ __launch_bounds__(kBlock) void k_lm_bounds(const unsigned long long *
   }
 }
 
-__global__ __launch_bounds__(kBlock) void k_lm_dense_fill(const unsigned long long *__restrict__ keys, const int32_t *__restrict__ state, const double *__restrict__ rec,
-                                                          unsigned cap, NdtDirtyArgs A, float4 *__restrict__ dense) {
+__global__ __launch_bounds__(kBlock) void k_lm_dense_fill(const LmCellN *__restrict__ cells, const double *__restrict__ rec, unsigned cap, NdtDirtyArgs A,
+                                                          float4 *__restrict__ dense) {
   unsigned s = blockIdx.x * blockDim.x + threadIdx.x;
-  if (s >= cap || keys[s] == kEmpty || state[s] != 1) return;
+  if (s >= cap || cells[s].key == kEmpty || cells[s].state != 1) return;
   int ijk[3];
-  lm_unpack(keys[s], ijk);
+  lm_unpack(cells[s].key, ijk);
   const int i = ijk[0] - A.wmin[0], j = ijk[1] - A.wmin[1], k = ijk[2] - A.wmin[2];
   if ((unsigned)i >= (unsigned)A.wdim[0] || (unsigned)j >= (unsigned)A.wdim[1] || (unsigned)k >= (unsigned)A.wdim[2]) return;
   dense[(size_t)i + (size_t)j * A.wdim[0] + (size_t)k * A.wdim[0] * A.wdim[1]] = ndt_dense_entry(rec + (size_t)s * 10, ijk, A.leaf, (int)s);
@@ -481,7 +609,7 @@ __global__ __launch_bounds__(kBlock) void k_lm_dense_fill(const unsigned long lo
 
 // verification (tests): every occupied cell of a FULL table build must be in level N with the same state and the same ten
 // doubles, bit for bit; out[0] cells compared, [1] mismatches
-__global__ __launch_bounds__(kBlock) void k_lm_verify(HashView N, const double *__restrict__ rec, const int32_t *__restrict__ state, const int32_t *__restrict__ full_cor,
+__global__ __launch_bounds__(kBlock) void k_lm_verify(const LmCellN *__restrict__ cells, unsigned cap, const double *__restrict__ rec, const int32_t *__restrict__ full_cor,
                                                       const double *__restrict__ full_rec, const int32_t *__restrict__ full_state, size_t V, CellMap m,
                                                       unsigned long long *__restrict__ out) {
   size_t r = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -489,46 +617,46 @@ __global__ __launch_bounds__(kBlock) void k_lm_verify(HashView N, const double *
   int ijk[3];
   lsa_cell_unravel(m, full_cor[r], ijk);
   const unsigned long long key = lm_pack(ijk[0], ijk[1], ijk[2]);
-  unsigned h = lm_probe0(key, N.cap);
+  unsigned h = lm_probe0(key, cap);
   int slot = -1;
   for (int probe = 0; probe < kGlobalProbes; probe++) {
-    unsigned long long k = N.keys[h];
+    unsigned long long k = cells[h].key;
     if (k == key) { slot = (int)h; break; }
     if (k == kEmpty) break;
-    h = (h + kProbeStep) & (N.cap - 1u);
+    h = (h + kProbeStep) & (cap - 1u);
   }
-  bool same = slot >= 0 && N.cnt[slot] > 0 && state[slot] == full_state[r];
+  bool same = slot >= 0 && (int)(unsigned)cells[slot].cnt > 0 && (cells[slot].cnt >> 32) == 0ull && cells[slot].state == full_state[r];
   if (same)
     for (int j = 0; j < 10; j++)
       same = same && __double_as_longlong(rec[(size_t)slot * 10 + j]) == __double_as_longlong(full_rec[r * 10 + j]);
   atomicAdd(out, 1ull);
   if (!same) atomicAdd(out + 1, 1ull);
 }
-__global__ __launch_bounds__(kBlock) void k_lm_count(const int32_t *__restrict__ alive, const int32_t *__restrict__ state, unsigned cap, unsigned long long *__restrict__ out) {
+__global__ __launch_bounds__(kBlock) void k_lm_count(const LmCellN *__restrict__ cells, unsigned cap, unsigned long long *__restrict__ out) {
   unsigned s = blockIdx.x * blockDim.x + threadIdx.x;
   if (s >= cap) return;
-  if (alive[s]) atomicAdd(out + 2, 1ull);
-  if (alive[s] && state[s] == 1) atomicAdd(out + 3, 1ull);
+  if (cells[s].alive) atomicAdd(out + 2, 1ull);
+  if (cells[s].alive && cells[s].state == 1) atomicAdd(out + 3, 1ull);
 }
 
-HashView view(LmHash &h) { return HashView{h.keys.p, h.cnt.p, h.acc.p, h.flag.p, h.dirty.p, h.cap}; }
+TableView<4> view_f(LocalMap &lm) { return TableView<4>{reinterpret_cast<unsigned long long *>(lm.f.p), lm.cap_f}; }
+TableView<10> view_n(LocalMap &lm) { return TableView<10>{reinterpret_cast<unsigned long long *>(lm.n.p), lm.cap_n}; }
+DirtyView view(const LmDirty &d) { return DirtyView{d.slot.p, d.len.p, d.regions, d.region_cap, d.over_cap}; }
 
-int hash_alloc(lsa_context *ctx, LmHash &h, unsigned cap, int ns) {
+// geometry of a dirty list for the next producing launch; (re)allocates when it does not fit.  The overflow region's length
+// (len[0]) is zero between updates: the consumer's last workgroup resets it.
+int dirty_shape(lsa_context *ctx, LmDirty &d, unsigned regions, unsigned region_cap, unsigned over_cap) {
   int rc;
-  if (cap == h.cap && ns == h.ns) return LSA_OK;
-  h.release();
-  if ((rc = h.keys.reserve(ctx, cap)) || (rc = h.cnt.reserve(ctx, cap)) || (rc = h.acc.reserve(ctx, (size_t)cap * ns)) || (rc = h.flag.reserve(ctx, cap)) ||
-      (rc = h.dirty.reserve(ctx, cap)))
-    return rc;
-  h.cap = cap; h.ns = ns;
-  return LSA_OK;
-}
-
-int hash_clear(lsa_context *ctx, LmHash &h) {
-  LSA_HIP(ctx, hipMemsetAsync(h.keys.p, 0xFF, (size_t)h.cap * sizeof(unsigned long long), ctx->stream));
-  LSA_HIP(ctx, hipMemsetAsync(h.cnt.p, 0, (size_t)h.cap * sizeof(int32_t), ctx->stream));
-  LSA_HIP(ctx, hipMemsetAsync(h.acc.p, 0, (size_t)h.cap * h.ns * sizeof(long long), ctx->stream));
-  LSA_HIP(ctx, hipMemsetAsync(h.flag.p, 0, (size_t)h.cap * sizeof(unsigned), ctx->stream));
+  const size_t need = (size_t)over_cap + (size_t)regions * region_cap;
+  const bool fresh = need > d.slot.cap || (size_t)regions + 1 > d.len.cap || over_cap != d.over_cap;
+  if (fresh) {
+    // (nothing is in flight that reads the old buffers: a list is reshaped between updates only, behind lm_check / a rebuild's wait)
+    LSA_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (need > d.slot.cap) { d.slot.release(); if ((rc = d.slot.reserve(ctx, need, 1.25))) return rc; }
+    if ((size_t)regions + 1 > d.len.cap) { d.len.release(); if ((rc = d.len.reserve(ctx, (size_t)kMaxRegions + 1))) return rc; }
+    LSA_HIP(ctx, hipMemsetAsync(d.len.p, 0, d.len.cap * sizeof(unsigned), ctx->stream));
+  }
+  d.regions = regions; d.region_cap = region_cap; d.over_cap = over_cap;
   return LSA_OK;
 }
 
@@ -541,23 +669,48 @@ NdtDirtyArgs ndt_args(const LocalMap &lm, bool with_window) {
   return A;
 }
 
-unsigned dirty_grid(const lsa_context *ctx) { return (unsigned)ctx->num_cus * 2u; }   // grid-stride over a count only the device knows
-
 int alloc_level_n(LocalMap &lm, unsigned cap) {
   lsa_context *ctx = lm.ctx;
   int rc;
-  if ((rc = hash_alloc(ctx, lm.n, cap, 10))) return rc;
-  if (lm.rec.cap != (size_t)cap * 10) { lm.rec.release(); lm.state.release(); lm.alive.release(); }
-  if ((rc = lm.rec.reserve(ctx, (size_t)cap * 10)) || (rc = lm.state.reserve(ctx, cap)) || (rc = lm.alive.reserve(ctx, cap))) return rc;
+  if (cap != lm.cap_n) { lm.n.release(); lm.rec.release(); }
+  if ((rc = lm.n.reserve(ctx, cap)) || (rc = lm.rec.reserve(ctx, (size_t)cap * 10))) return rc;
+  lm.cap_n = cap;
   return LSA_OK;
 }
 
 int alloc_level_f(LocalMap &lm, unsigned cap) {
   lsa_context *ctx = lm.ctx;
   int rc;
-  if ((rc = hash_alloc(ctx, lm.f, cap, 4))) return rc;
-  if (lm.out.cap != cap) { lm.out.release(); lm.has_out.release(); }
-  if ((rc = lm.out.reserve(ctx, cap)) || (rc = lm.has_out.reserve(ctx, cap))) return rc;
+  if (cap != lm.cap_f) lm.f.release();
+  if ((rc = lm.f.reserve(ctx, cap))) return rc;
+  lm.cap_f = cap;
+  return LSA_OK;
+}
+
+// one launch of k_lm_points over `n` points (plain: sign +-1) with the dirty list shaped for its tiles; at most kMaxTiles tiles
+int lm_points(LocalMap &lm, const float4 *d_pts, size_t n, int sign) {
+  lsa_context *ctx = lm.ctx;
+  if (n == 0) return LSA_OK;
+  PointsArgs A;
+  A.sign = sign;
+  A.evict = 0; A.raw = nullptr; A.n_raw = 0; A.keep = nullptr; A.force_w_one = 0;
+  for (int k = 0; k < 12; k++) A.T[k] = 0.f;
+  const unsigned g = lsa_div_up(n, kTile);
+  int rc;
+  if (lm.filtered) {
+    for (int a = 0; a < 3; a++) { A.leaf[a] = lm.leaf_f[a]; A.inv[a] = 1.0f / lm.leaf_f[a]; }
+    A.fs = lm.fs_f;
+    A.to_level_n = 0;
+    if ((rc = dirty_shape(ctx, lm.dirty_f, g, PointsCap<4, false>::value, lm.cap_f))) return rc;
+    hipLaunchKernelGGL((k_lm_points<4, 0, false>), dim3(g), dim3(kBlock), 0, ctx->stream, const_cast<float4 *>(d_pts), n, A, view_f(lm), view(lm.dirty_f), lm.d_status.p);
+  } else {
+    for (int a = 0; a < 3; a++) { A.leaf[a] = lm.leaf_n; A.inv[a] = 1.0f / lm.leaf_n; }
+    A.fs = lm.fs_n;
+    A.to_level_n = 1;
+    if ((rc = dirty_shape(ctx, lm.dirty_n, g, PointsCap<10, false>::value, lm.cap_n))) return rc;
+    hipLaunchKernelGGL((k_lm_points<10, 1, false>), dim3(g), dim3(kBlock), 0, ctx->stream, const_cast<float4 *>(d_pts), n, A, view_n(lm), view(lm.dirty_n), lm.d_status.p);
+  }
+  LSA_HIP(ctx, hipGetLastError());
   return LSA_OK;
 }
 }  // namespace
@@ -574,30 +727,7 @@ int lm_configure(LocalMap &lm, lsa_context *ctx, const float leaf_f[3], float le
   lm.valid = false;
   int rc;
   if ((rc = lm.d_status.reserve(ctx, 1)) || (rc = lm.h_status.reserve(ctx, 1))) return rc;
-  if (!lm.n.cap && (rc = alloc_level_n(lm, 1u << 17))) return rc;
-  return LSA_OK;
-}
-
-int lm_points(LocalMap &lm, const float4 *d_pts, size_t n, int sign) {
-  lsa_context *ctx = lm.ctx;
-  if (n == 0) return LSA_OK;
-  PointsArgs A;
-  A.sign = sign;
-  A.evict = 0; A.raw = nullptr; A.n_raw = 0; A.keep = nullptr; A.force_w_one = 0;
-  for (int k = 0; k < 12; k++) A.T[k] = 0.f;
-  const unsigned g = lsa_div_up(n, kTile);
-  if (lm.filtered) {
-    for (int a = 0; a < 3; a++) { A.leaf[a] = lm.leaf_f[a]; A.inv[a] = 1.0f / lm.leaf_f[a]; }
-    A.fs = lm.fs_f;
-    A.to_level_n = 0;
-    hipLaunchKernelGGL((k_lm_points<4, 0, false>), dim3(g), dim3(kBlock), 0, ctx->stream, const_cast<float4 *>(d_pts), n, A, view(lm.f), lm.d_status.p);
-  } else {
-    for (int a = 0; a < 3; a++) { A.leaf[a] = lm.leaf_n; A.inv[a] = 1.0f / lm.leaf_n; }
-    A.fs = lm.fs_n;
-    A.to_level_n = 1;
-    hipLaunchKernelGGL((k_lm_points<10, 1, false>), dim3(g), dim3(kBlock), 0, ctx->stream, const_cast<float4 *>(d_pts), n, A, view(lm.n), lm.d_status.p);
-  }
-  LSA_HIP(ctx, hipGetLastError());
+  if (!lm.cap_n && (rc = alloc_level_n(lm, 1u << 17))) return rc;
   return LSA_OK;
 }
 
@@ -612,16 +742,20 @@ int lm_swap(LocalMap &lm, float4 *d_slot, size_t slot_cap, bool evict, const flo
   for (int k = 0; k < 12; k++) A.T[k] = T_rowmajor12[k];
   A.keep = d_keep; A.force_w_one = force_w_one ? 1 : 0;
   const unsigned g = lsa_div_up(slot_cap, kTile);
+  if (g > kMaxTiles) return lsa_fail(ctx, LSA_ERR_CAPACITY, "incremental local map: a key-frame of %zu points exceeds %u tiles", slot_cap, kMaxTiles);
+  int rc;
   if (lm.filtered) {
     for (int a = 0; a < 3; a++) { A.leaf[a] = lm.leaf_f[a]; A.inv[a] = 1.0f / lm.leaf_f[a]; }
     A.fs = lm.fs_f;
     A.to_level_n = 0;
-    hipLaunchKernelGGL((k_lm_points<4, 0, true>), dim3(g), dim3(kBlock), 0, ctx->stream, d_slot, slot_cap, A, view(lm.f), lm.d_status.p);
+    if ((rc = dirty_shape(ctx, lm.dirty_f, g, PointsCap<4, true>::value, lm.cap_f))) return rc;
+    hipLaunchKernelGGL((k_lm_points<4, 0, true>), dim3(g), dim3(kBlock), 0, ctx->stream, d_slot, slot_cap, A, view_f(lm), view(lm.dirty_f), lm.d_status.p);
   } else {
     for (int a = 0; a < 3; a++) { A.leaf[a] = lm.leaf_n; A.inv[a] = 1.0f / lm.leaf_n; }
     A.fs = lm.fs_n;
     A.to_level_n = 1;
-    hipLaunchKernelGGL((k_lm_points<10, 1, true>), dim3(g), dim3(kBlock), 0, ctx->stream, d_slot, slot_cap, A, view(lm.n), lm.d_status.p);
+    if ((rc = dirty_shape(ctx, lm.dirty_n, g, PointsCap<10, true>::value, lm.cap_n))) return rc;
+    hipLaunchKernelGGL((k_lm_points<10, 1, true>), dim3(g), dim3(kBlock), 0, ctx->stream, d_slot, slot_cap, A, view_n(lm), view(lm.dirty_n), lm.d_status.p);
   }
   LSA_HIP(ctx, hipGetLastError());
   return LSA_OK;
@@ -629,17 +763,21 @@ int lm_swap(LocalMap &lm, float4 *d_slot, size_t slot_cap, bool evict, const flo
 
 int lm_finish(LocalMap &lm) {
   lsa_context *ctx = lm.ctx;
+  int rc;
   if (lm.filtered) {
     FilterDirtyArgs A;
     for (int a = 0; a < 3; a++) { A.leaf_f[a] = lm.leaf_f[a]; A.leaf_n[a] = lm.leaf_n; A.inv_n[a] = 1.0f / lm.leaf_n; }
     A.fs_f = lm.fs_f; A.fs_n = lm.fs_n;
-    hipLaunchKernelGGL(k_lm_filter_dirty, dim3(dirty_grid(ctx)), dim3(kBlock), 0, ctx->stream, view(lm.f), lm.out.p, lm.has_out.p, view(lm.n), A, lm.d_status.p);
+    // one workgroup per tile region + a few for the overflow region; each owns a region of the level-N dirty list
+    const unsigned g = lm.dirty_f.regions + kFdOverWg;
+    if ((rc = dirty_shape(ctx, lm.dirty_n, g, kFdRegion, lm.cap_n))) return rc;
+    hipLaunchKernelGGL(k_lm_filter_dirty, dim3(g), dim3(kBlock), 0, ctx->stream, view_f(lm), view(lm.dirty_f), view_n(lm), view(lm.dirty_n), A, lm.d_status.p);
   }
   lm.epoch++;
-  // (a small grid: every workgroup ends with one same-address atomic — ~20 ns each at the memory side, 512 of them were 11 us —
-  // and a key-frame touches ~6 k level-N cells, one per lane of 24 workgroups)
-  hipLaunchKernelGGL(k_lm_ndt_dirty, dim3(64), dim3(kBlock), 0, ctx->stream, view(lm.n), lm.rec.p, lm.state.p, lm.alive.p, lm.dense.p, ndt_args(lm, true),
-                     lm.d_status.p, lm.h_status.p, lm.epoch);
+  // (a small grid: a key-frame touches ~6 k level-N cells, one per lane of 24 workgroups, and every ACTIVE workgroup ends with one
+  // same-address atomic — ~20 ns each at the memory side)
+  hipLaunchKernelGGL(k_lm_ndt_dirty, dim3(64), dim3(kBlock), 0, ctx->stream, view_n(lm), view(lm.dirty_n), lm.filtered ? lm.dirty_f.len.p : nullptr, lm.rec.p,
+                     lm.dense.p, ndt_args(lm, true), lm.d_status.p, lm.h_status.p, lm.epoch);
   LSA_HIP(ctx, hipGetLastError());
   lm.pending = true;
   lm.updates++;
@@ -653,7 +791,7 @@ int lm_refit_window(LocalMap &lm) {
   memset(&init, 0, sizeof(init));
   for (int a = 0; a < 3; a++) { init.bmin[a] = INT_MAX; init.bmax[a] = INT_MIN; }
   LSA_HIP(ctx, hipMemcpyAsync((char *)lm.d_status.p + offsetof(LmStatus, bmin), init.bmin, 6 * sizeof(int), hipMemcpyHostToDevice, ctx->stream));
-  hipLaunchKernelGGL(k_lm_bounds, dim3(lsa_div_up(lm.n.cap, kBlock * 4)), dim3(kBlock), 0, ctx->stream, lm.n.keys.p, lm.state.p, lm.n.cap, lm.d_status.p);
+  hipLaunchKernelGGL(k_lm_bounds, dim3(lsa_div_up(lm.cap_n, kBlock * 4)), dim3(kBlock), 0, ctx->stream, lm.n.p, lm.cap_n, lm.d_status.p);
   LmStatus got;
   LSA_HIP(ctx, hipMemcpyAsync(&got, lm.d_status.p, sizeof(got), hipMemcpyDeviceToHost, ctx->stream));
   LSA_HIP(ctx, hipStreamSynchronize(ctx->stream));
@@ -677,7 +815,7 @@ int lm_refit_window(LocalMap &lm) {
   for (int a = 0; a < 3; a++) { lm.wmin[a] = mn[a]; lm.wdim[a] = dm[a]; }
   lm.window_set = true;
   LSA_HIP(ctx, hipMemsetAsync(lm.dense.p, 0xFF, cells * sizeof(float4), ctx->stream));
-  hipLaunchKernelGGL(k_lm_dense_fill, dim3(lsa_div_up(lm.n.cap, kBlock)), dim3(kBlock), 0, ctx->stream, lm.n.keys.p, lm.state.p, lm.rec.p, lm.n.cap, ndt_args(lm, true), lm.dense.p);
+  hipLaunchKernelGGL(k_lm_dense_fill, dim3(lsa_div_up(lm.cap_n, kBlock)), dim3(kBlock), 0, ctx->stream, lm.n.p, lm.rec.p, lm.cap_n, ndt_args(lm, true), lm.dense.p);
   // the flag is consumed
   const unsigned zero = 0;
   LSA_HIP(ctx, hipMemcpyAsync((char *)lm.d_status.p + offsetof(LmStatus, window_miss), &zero, sizeof(zero), hipMemcpyHostToDevice, ctx->stream));
@@ -692,27 +830,30 @@ int lm_rebuild(LocalMap &lm, const float4 *const *d_ranges, const size_t *n_rang
   int rc;
   lm.valid = false;
   lm.filtered = filtered;
-  unsigned cap_f = lm.f.cap ? lm.f.cap : (1u << 20), cap_n = lm.n.cap ? lm.n.cap : (1u << 17);
+  unsigned cap_f = lm.cap_f ? lm.cap_f : (1u << 20), cap_n = lm.cap_n ? lm.cap_n : (1u << 17);
   for (int attempt = 0; attempt < 8; attempt++) {
     if ((rc = alloc_level_n(lm, cap_n))) return rc;
     if (filtered && (rc = alloc_level_f(lm, cap_f))) return rc;
-    if ((rc = hash_clear(ctx, lm.n))) return rc;
-    LSA_HIP(ctx, hipMemsetAsync(lm.state.p, 0, (size_t)lm.n.cap * sizeof(int32_t), ctx->stream));
-    LSA_HIP(ctx, hipMemsetAsync(lm.alive.p, 0, (size_t)lm.n.cap * sizeof(int32_t), ctx->stream));
-    if (filtered) {
-      if ((rc = hash_clear(ctx, lm.f))) return rc;
-      LSA_HIP(ctx, hipMemsetAsync(lm.has_out.p, 0, (size_t)lm.f.cap * sizeof(int32_t), ctx->stream));
-    }
+    LSA_HIP(ctx, hipMemsetAsync(lm.n.p, 0, (size_t)lm.cap_n * sizeof(LmCellN), ctx->stream));
+    if (filtered) LSA_HIP(ctx, hipMemsetAsync(lm.f.p, 0, (size_t)lm.cap_f * sizeof(LmCellF), ctx->stream));
     LSA_HIP(ctx, hipMemsetAsync(lm.d_status.p, 0, sizeof(LmStatus), ctx->stream));
-    for (int r = 0; r < nranges; r++)
-      if ((rc = lm_points(lm, d_ranges[r], n_ranges[r], +1))) return rc;
-    // every cell is in the dirty lists: finalise them all (no window yet: the table is filled by the re-fit below)
+    if (lm.dirty_f.len.p) LSA_HIP(ctx, hipMemsetAsync(lm.dirty_f.len.p, 0, sizeof(unsigned), ctx->stream));
+    if (lm.dirty_n.len.p) LSA_HIP(ctx, hipMemsetAsync(lm.dirty_n.len.p, 0, sizeof(unsigned), ctx->stream));
+    // every cell ends up in the dirty lists: finalise them all (no window yet: the table is filled by the re-fit below), in rounds
+    // of at most kMaxTiles tiles — a round's dirty list has one region per tile
     lm.window_set = false;
-    if ((rc = lm_finish(lm))) return rc;
+    for (int r = 0; r < nranges; r++) {
+      const size_t round = (size_t)kMaxTiles * kTile;
+      for (size_t at = 0; at < n_ranges[r]; at += round) {
+        const size_t m = n_ranges[r] - at < round ? n_ranges[r] - at : round;
+        if ((rc = lm_points(lm, d_ranges[r] + at, m, +1))) return rc;
+        if ((rc = lm_finish(lm))) return rc;
+      }
+    }
     LSA_HIP(ctx, hipStreamSynchronize(ctx->stream));
     const LmStatus &s = *lm.h_status.p;
     if (s.overflow & 2u) return lsa_fail(ctx, LSA_ERR_RANGE, "incremental local map: a point lies beyond +-2^20 cells");
-    const bool grow_f = filtered && (s.overflow || s.keys_f > lm.f.cap / 4), grow_n = s.overflow || s.keys_n > lm.n.cap / 4;
+    const bool grow_f = filtered && (s.overflow || s.keys_f > lm.cap_f / 4), grow_n = s.overflow || s.keys_n > lm.cap_n / 4;
     if (!grow_f && !grow_n) break;
     if (attempt == 7 || (grow_f && cap_f >= (1u << 26)) || (grow_n && cap_n >= (1u << 24)))
       return lsa_fail(ctx, LSA_ERR_CAPACITY, "incremental local map: %u / %u cells do not fit the tables", s.keys_f, s.keys_n);
@@ -731,7 +872,7 @@ int lm_check(LocalMap &lm) {
   const LmStatus &s = *lm.h_status.p;
   if (__atomic_load_n(&lm.h_status.p->epoch, __ATOMIC_ACQUIRE) != lm.epoch) {
     // The update is still running (a batch of Updates filters on another stream, so nothing has ordered the host behind it):
-    // its last kernel writes the epoch, ~60 us after the key-frame.  Past any plausible run time: ask the runtime.
+    // its last kernel writes the epoch, ~40 us after the key-frame.  Past any plausible run time: ask the runtime.
     const auto t0 = std::chrono::steady_clock::now();
     while (__atomic_load_n(&lm.h_status.p->epoch, __ATOMIC_ACQUIRE) != lm.epoch) {
       __builtin_ia32_pause();
@@ -740,7 +881,7 @@ int lm_check(LocalMap &lm) {
   }
   lm.pending = false;
   if (s.overflow) return 2;
-  if ((lm.filtered && s.keys_f > (lm.f.cap / 10) * 6) || s.keys_n > (lm.n.cap / 10) * 6) return 2;
+  if ((lm.filtered && s.keys_f > (lm.cap_f / 10) * 6) || s.keys_n > (lm.cap_n / 10) * 6) return 2;
   if (s.window_miss) return 1;
   return 0;
 }
@@ -751,8 +892,8 @@ int lm_verify(LocalMap &lm, const int32_t *full_cell_of_rank, const double *full
   unsigned long long *d_out = nullptr;
   LSA_HIP(ctx, hipMalloc((void **)&d_out, 4 * sizeof(unsigned long long)));
   (void)hipMemsetAsync(d_out, 0, 4 * sizeof(unsigned long long), ctx->stream);
-  if (V) hipLaunchKernelGGL(k_lm_verify, dim3(lsa_div_up(V, kBlock)), dim3(kBlock), 0, ctx->stream, view(lm.n), lm.rec.p, lm.state.p, full_cell_of_rank, full_rec, full_state, V, map, d_out);
-  hipLaunchKernelGGL(k_lm_count, dim3(lsa_div_up(lm.n.cap, kBlock)), dim3(kBlock), 0, ctx->stream, lm.alive.p, lm.state.p, lm.n.cap, d_out);
+  if (V) hipLaunchKernelGGL(k_lm_verify, dim3(lsa_div_up(V, kBlock)), dim3(kBlock), 0, ctx->stream, lm.n.p, lm.cap_n, lm.rec.p, full_cell_of_rank, full_rec, full_state, V, map, d_out);
+  hipLaunchKernelGGL(k_lm_count, dim3(lsa_div_up(lm.cap_n, kBlock)), dim3(kBlock), 0, ctx->stream, lm.n.p, lm.cap_n, d_out);
   hipError_t e = hipMemcpyAsync(out, d_out, 4 * sizeof(unsigned long long), hipMemcpyDeviceToHost, ctx->stream);
   if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
   (void)hipFree(d_out);

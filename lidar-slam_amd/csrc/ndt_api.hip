@@ -77,6 +77,7 @@ struct ArmedPosted {
   unsigned long long seq;
   unsigned g;
   bool kept;
+  bool deferred = false;   // taken long after it was posted, by design: its post -> first look interval says nothing about the host
   std::chrono::steady_clock::time_point at0, at1;
 };
 int armed_post(lsa_ndt *h, const PassParams &P, ArmedPosted *ap) {
@@ -97,6 +98,8 @@ int armed_post(lsa_ndt *h, const PassParams &P, ArmedPosted *ap) {
   static const bool no_keep = getenv("LSA_NO_KEEP") != nullptr;   // A/B switch for measurements (scratch: ab_match.py)
   ap->kept = !no_keep && h->keep_match == h->match_id && h->keep_n == h->n_source;
   ap->at0 = std::chrono::steady_clock::now();
+  // host-stall detector: inside a ScanMatch the kernel of this pass has been waiting since the previous pass's rows were taken
+  if (h->at_have_last) lsa_host_gap_note_us(std::chrono::duration<double, std::micro>(ap->at0 - h->at_last_rows).count());
   ndt_mail_post(reinterpret_cast<PassMail *>(h->mail), &P, seq, false, h->d_source, h->n_source, g, ap->kept);
   ap->at1 = std::chrono::steady_clock::now();
   h->armed_seq = seq + 1;
@@ -119,10 +122,14 @@ int armed_take(lsa_ndt *h, const ArmedPosted &ap, double out32[32], bool *redo) 
   const unsigned g = ap.g;
   volatile unsigned long long *gave_up = reinterpret_cast<volatile unsigned long long *>(h->h_gave_up.p);
   const double *rows = ndt_armed_rows(h, seq);
+  // host-stall detector: the way from the mail to the first look at the rows (the launch of the next pass's kernel, ~3 us) ...
+  if (!ap.deferred) lsa_host_gap_note_us(std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - ap.at0).count());
   bool ok = !h->no_row_polling && ndt_reduce_partials_host(rows, g, ndt_armed_row_key(seq), kArmedRowLimitMs, out32, gave_up, seq);
   {
     const double w = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - ap.at1).count();
     if (w > h->rows_wait_max_us) h->rows_wait_max_us = w;
+    const double gp = lsa_host_gap_take_us(true);   // ... and every interval between two looks
+    if (gp > h->host_gap_max_us) h->host_gap_max_us = gp;
   }
   if (!ok) {
     // rows missing.  Either a workgroup of the kernel ran out of patience before the mail came (this thread was held up;
@@ -170,7 +177,7 @@ int collect_pending(lsa_ndt *h) {
   lsa_ndt::Pending pd = h->pending;
   h->pending.on = false;
   ArmedPosted ap;
-  ap.seq = pd.seq; ap.g = pd.g; ap.kept = true; ap.at0 = ap.at1 = pd.posted;
+  ap.seq = pd.seq; ap.g = pd.g; ap.kept = true; ap.deferred = true; ap.at0 = ap.at1 = pd.posted;
   double out32[32];
   bool redo = false;
   const bool have_last = h->at_have_last;
@@ -219,8 +226,15 @@ int run_pass(lsa_ndt *h, const float T[16], const double p[6], int kind, double 
   int rc;
   if (h->armed_scope && kind == 0 && h->mail && ndt_pass_host_reduce(h, 0)) {
     ArmedPosted ap;
+    // The previous ScanMatch's deferred final pass is normally taken BEHIND this pass's mail (its kernel ran in front of this
+    // pass's, its rows are being delivered while this one starts).  If its kernel is known to have left before its mail came, the
+    // pass will be redone the ordinary way — whose rows go to the shared row half 0 and whose stream wait would sit in front of a
+    // pass already posted: redo it first, then post.
+    {
+      volatile unsigned long long *gave_up = h->h_gave_up.p ? reinterpret_cast<volatile unsigned long long *>(h->h_gave_up.p) : nullptr;
+      if (h->pending.on && gave_up && *gave_up == h->pending.seq && (rc = collect_pending(h))) return rc;
+    }
     if ((rc = armed_post(h, P, &ap))) return rc;
-    // the previous ScanMatch's deferred final pass: its kernel ran in front of this pass's, its rows are (being) delivered
     if (h->pending.on && (rc = collect_pending(h))) return rc;
     bool redo = false;
     if ((rc = armed_take(h, ap, out32, &redo))) return rc;
@@ -241,6 +255,8 @@ int run_pass(lsa_ndt *h, const float T[16], const double p[6], int kind, double 
     {
       const double w = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - rt0).count();
       if (w > h->rows_wait_max_us) h->rows_wait_max_us = w;
+      const double gp = lsa_host_gap_take_us(true);
+      if (gp > h->host_gap_max_us) h->host_gap_max_us = gp;
     }
     if (!ok) {
       LSA_HIP(ctx, hipStreamSynchronize(ctx->stream));
@@ -520,7 +536,7 @@ extern "C" int lsa_ndt_get_fitness_score(lsa_ndt *h, float *score) {
   if (h->mode == LSA_NDT_MODE_PCL) {  // pcl::Registration::getFitnessScore over the target POINTS (ndt_registration.cpp:63-66)
     if (!h->nn.built && (rc = nn_grid_build(h->ctx, h->nn, h->d_target_pts, h->n_target, h->resolution, "GetFitnessScore"))) return rc;
     double v = 0;
-    if ((rc = nn_fitness(h->ctx, h->nn, h->d_source, h->n_source, h->last_T, INFINITY, &v))) return rc;
+    if ((rc = nn_fitness(h->ctx, h->nn, h->d_source, h->n_source, h->last_T, INFINITY, &v, h->allreduce, h->allreduce_user))) return rc;
     *score = (float)v;
     return LSA_OK;
   }
@@ -552,8 +568,9 @@ extern "C" int lsa_ndt_armed_stats(lsa_ndt *h, lsa_ndt_armed_stats_t *out, int r
     out->parked = (h->armed_outstanding && h->ctx->unpark_arg == h) ? 1 : 0;
     out->pad = 0;
     out->deferred = h->deferred_passes;
+    out->host_gap_max_us = h->host_gap_max_us;
   }
-  if (reset) { h->armed_passes = h->armed_cancels = h->armed_fallbacks = h->armed_late = h->rows_late = h->armed_gave_up_seen = h->armed_expired = h->deferred_passes = 0; h->rows_wait_max_us = 0; }
+  if (reset) { h->armed_passes = h->armed_cancels = h->armed_fallbacks = h->armed_late = h->rows_late = h->armed_gave_up_seen = h->armed_expired = h->deferred_passes = 0; h->rows_wait_max_us = 0; h->host_gap_max_us = 0; }
   return LSA_OK;
 }
 

@@ -395,25 +395,62 @@ int ndt_enqueue_pass_host(lsa_ndt *h, const PassParams &P, int kind, unsigned *g
 // return false (the caller then waits for the stream the ordinary way and calls again).
 // One check-worded row out of host-mapped memory, taken as it ARRIVES: accepted once its check word matches (the kernel
 // may still be running, nothing waits for the stream).  false: the row did not show up within limit_ms.
+namespace {
+thread_local unsigned long long t_gap_max_tsc = 0;
+thread_local double t_gap_max_noted_us = 0.0;
+// ticks of the time-stamp counter per microsecond, measured once (200 us against the steady clock)
+double tsc_per_us() {
+  static const double r = [] {
+    const auto t0 = std::chrono::steady_clock::now();
+    const unsigned long long c0 = __builtin_ia32_rdtsc();
+    while (std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count() < 200.0) __builtin_ia32_pause();
+    const unsigned long long c1 = __builtin_ia32_rdtsc();
+    const double us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
+    return (double)(c1 - c0) / us;
+  }();
+  return r;
+}
+}  // namespace
+
+double lsa_host_gap_take_us(bool reset) {
+  double us = t_gap_max_tsc ? (double)t_gap_max_tsc / tsc_per_us() : 0.0;
+  if (t_gap_max_noted_us > us) us = t_gap_max_noted_us;
+  if (reset) { t_gap_max_tsc = 0; t_gap_max_noted_us = 0.0; }
+  return us;
+}
+void lsa_host_gap_note_us(double us) {
+  if (us > t_gap_max_noted_us) t_gap_max_noted_us = us;
+}
+
 bool ndt_fetch_row_host(const double *row, unsigned long long key, double limit_ms, unsigned long long out32[32], const volatile unsigned long long *abort_word,
                         unsigned long long abort_value) {
   const volatile unsigned long long *wr = reinterpret_cast<const volatile unsigned long long *>(row);
   std::chrono::steady_clock::time_point t0;
   bool timing = false;
   unsigned spins = 0;
+  unsigned long long last = __builtin_ia32_rdtsc(), gap = 0;
   for (;;) {
     unsigned long long w[32], x = 0ull;
     for (int col = 0; col < 32; col++) w[col] = wr[col];
     for (int col = 0; col < 31; col++) x ^= lsa_row_mix(w[col], col);
+    const unsigned long long now = __builtin_ia32_rdtsc();   // host-stall detector (ndt_pass.h): the longest interval between two looks
+    if (now - last > gap) gap = now - last;
+    last = now;
     if ((x ^ key) == w[31]) {
       memcpy(out32, w, sizeof(w));
       out32[31] = 0ull;
+      if (gap > t_gap_max_tsc) t_gap_max_tsc = gap;
       return true;
     }
     if ((++spins & 63u) == 0u) {
-      if (abort_word && *abort_word == abort_value) return false;   // the producer has said that it will not deliver
-      if (!timing) { t0 = std::chrono::steady_clock::now(); timing = true; }
-      else if (std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count() > limit_ms) return false;
+      bool out = false;
+      if (abort_word && *abort_word == abort_value) out = true;   // the producer has said that it will not deliver
+      else if (!timing) { t0 = std::chrono::steady_clock::now(); timing = true; }
+      else if (std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count() > limit_ms) out = true;
+      if (out) {
+        if (gap > t_gap_max_tsc) t_gap_max_tsc = gap;
+        return false;
+      }
     }
     __builtin_ia32_pause();
   }

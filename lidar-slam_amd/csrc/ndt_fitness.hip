@@ -290,19 +290,31 @@ int ndt_fitness(lsa_ndt *h, float *score) {
   }
   FitnessState *f = h->fitness;
   size_t n = h->n_source;
-  if (n == 0 || !h->d_source || f->nleaves == 0) {
+  if (!h->allreduce && (n == 0 || !h->d_source || f->nleaves == 0)) {
     *score = FLT_MAX;  // the reference returns DBL_MAX when no point qualifies (:964)
     return LSA_OK;
+  }
+  if ((rc = h->h_out.reserve(ctx, kOutDoubles))) return rc;
+  if (n == 0 || !h->d_source || f->nleaves == 0) {   // an empty shard of a sharded source still takes part in the collective
+    LSA_HIP(ctx, hipMemsetAsync(f->small.p, 0, 2 * sizeof(double), ctx->stream));
+    n = 0;
   }
   T12s Tm;
   for (int r = 0; r < 3; r++)
     for (int c = 0; c < 4; c++) Tm.v[r * 4 + c] = h->last_T[c * 4 + r];
   unsigned nb = lsa_div_up(n * kFitLanes, kBlock);
   if ((rc = f->partials.reserve(ctx, (size_t)nb * 2 + 2, 1.25))) return rc;
-  hipLaunchKernelGGL(k_fitness, dim3(nb), dim3(kBlock), 0, ctx->stream, h->d_source, n, Tm, f->leaves.p, f->nleaves, h->vi.map, h->words.p,
-                     h->rec.p, f->partials.p);
-  hipLaunchKernelGGL(k_fitness_final, dim3(1), dim3(kBlock), 0, ctx->stream, f->partials.p, (int)nb, f->small.p);
+  if (n) {
+    hipLaunchKernelGGL(k_fitness, dim3(nb), dim3(kBlock), 0, ctx->stream, h->d_source, n, Tm, f->leaves.p, f->nleaves, h->vi.map, h->words.p,
+                       h->rec.p, f->partials.p);
+    hipLaunchKernelGGL(k_fitness_final, dim3(1), dim3(kBlock), 0, ctx->stream, f->partials.p, (int)nb, f->small.p);
+  }
   LSA_HIP(ctx, hipGetLastError());
+  if (h->allreduce) {
+    // source sharded over the ranks ("one extra all-reduce of 2 scalars for fitness"): {sum of distances, points}
+    int crc = h->allreduce(h->allreduce_user, f->small.p, 2, (void *)ctx->stream);
+    if (crc) return lsa_fail(ctx, LSA_ERR_COLLECTIVE, "GetFitnessScore: all-reduce callback returned %d", crc);
+  }
   LSA_HIP(ctx, hipMemcpyAsync(h->h_out.p, f->small.p, 2 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
   LSA_HIP(ctx, hipStreamSynchronize(ctx->stream));
   double sum = h->h_out.p[0], cnt = h->h_out.p[1];

@@ -112,6 +112,7 @@ struct lsa_ndt {
   // ordinary host-reduced passes), armed kernels seen to have given up, and the longest time any pass's rows took
   unsigned long long armed_late = 0, rows_late = 0, armed_gave_up_seen = 0, armed_expired = 0;
   double rows_wait_max_us = 0;
+  double host_gap_max_us = 0;   // lsa_host_gap_take_us, folded in after every wait for rows
 
   // deferred final pass of a ScanMatch inside a batch (ndt_api.hip: collect_pending)
   struct Pending {

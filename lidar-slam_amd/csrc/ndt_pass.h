@@ -33,5 +33,11 @@ bool ndt_fetch_row_host(const double *row, unsigned long long key, double limit_
                         const volatile unsigned long long *abort_word = nullptr, unsigned long long abort_value = 0);
 bool ndt_reduce_partials_host(const double *partials, unsigned nb, unsigned long long key, double limit_ms, double out32[32],
                               const volatile unsigned long long *abort_word = nullptr, unsigned long long abort_value = 0);
+// Host-stall detector.  The row spin loop reads the time-stamp counter every iteration and keeps, per calling thread, the longest
+// interval between two consecutive looks; the armed paths add the interval from posting a pass to the first look.  An interval of a
+// millisecond means the OS held the thread up (a look takes well under a microsecond): what tells a late or redone armed pass that is
+// the box's doing from one that is the library's.  Returns the maximum since the last reset, in microseconds.
+double lsa_host_gap_take_us(bool reset);
+void lsa_host_gap_note_us(double us);
 
 #endif

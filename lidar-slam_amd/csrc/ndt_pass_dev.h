@@ -160,7 +160,7 @@ constexpr int kRedLanes = 128;    // the transpose runs in two rounds of 128 lan
 struct TilePoint {
   float tx, ty, tz;  // transformed point
   int cell0;         // linear index of the box's low corner
-  int nxyz;          // box extent packed nx | ny << 8 | nz << 16 (0 = point contributes nothing)
+  int nxyz;          // per axis one byte, x | y << 8 | z << 16: box extent (bits 0-1) and cells clipped off in front (bits 2-3); 0 = point contributes nothing
   float rx, ry, rz;  // transformed point relative to the low corner of the box's first cell (f32; dense-table pre-filter)
 };
 
@@ -319,12 +319,18 @@ __device__ __forceinline__ double ndt_pass_body(const float4 *__restrict__ src, 
           h = (int)floorf(lsa_fdiv(lsa_fadd(t, r), r)) - mb; l = (int)floorf(lsa_fdiv(lsa_fsub(t, r), r)) - mb;
         }
         h = min(h, dmax);
+        const int l0 = l;                  // the cube's first cell on this axis BEFORE it is clipped to the table's box
         l = max(l, 0);
         const int na = min(h - l + 1, 3);  // with radius == leaf the box is at most 3 cells wide per axis
         const bool ok = ppl < kTilePts && i < n && part4 < 3 && (__float_as_uint(t) & 0x7f800000u) != 0x7f800000u && na > 0;
-        unsigned w = ok ? (((unsigned)na << (8 * a)) | (1u << (24 + a))) : 0u;  // extent of this axis + "axis fine" bit
+        // extent of this axis (2 bits) + how many cells the clip cut off in front (2 bits: <= 2 where any cell is left) + "axis fine" bit
+        unsigned w = ok ? ((((unsigned)na) | ((unsigned)(l - l0) << 2)) << (8 * a)) | (1u << (24 + a)) : 0u;
         int lin = ok ? l * stride : 0;
-        const float rr = t - (float)(l + mb) * r;  // relative to the low corner of the box's first cell (dense pre-filter)
+        // Relative to the low corner of the UNCLIPPED cube's first cell (dense pre-filter): the f32 distances of the pre-filter —
+        // and with them which borderline candidates take a slot of the pair queue, i.e. which lane adds which pair — must not depend
+        // on where the table's box happens to end (a full build's bounding box and the incremental map's window differ there; the
+        // same cell measured from two different corners rounds differently once in ~10^7 candidates).
+        const float rr = t - (float)(l0 + mb) * r;
         // quad_perm broadcasts of lane 1 (0x55) and lane 2 (0xaa) of each quad
         w += (unsigned)__builtin_amdgcn_mov_dpp((int)w, 0x55, 0xf, 0xf, true) + (unsigned)__builtin_amdgcn_mov_dpp((int)w, 0xaa, 0xf, 0xf, true);
         lin += __builtin_amdgcn_mov_dpp(lin, 0x55, 0xf, 0xf, true) + __builtin_amdgcn_mov_dpp(lin, 0xaa, 0xf, 0xf, true);
@@ -372,11 +378,15 @@ __device__ __forceinline__ double ndt_pass_body(const float4 *__restrict__ src, 
         const unsigned lut = lut_v >> (16 * j);
         const int pl = lut & 0x3f, dy = (lut >> 8) & 3, dz = (lut >> 10) & 3;
         const bool live = (lut >> 15) & 1;
-        int nxyz = tp[pbase + pl].nxyz;
-        bool in_box = live && dy < ((nxyz >> 8) & 0xff) && dz < (nxyz >> 16);
+        // (dy, dz) — and i below — count from the UNCLIPPED cube's first cell: which lane probes which row, and in which step a
+        // cell's survivors enter the queue, must not depend on where the table's box ends either (the queue order decides which
+        // lane adds which pair, i.e. the last bits of every sum).  The row is loaded from the clipped box.
+        int nxyz = tp[pbase + pl].nxyz;   // per axis: extent | cells clipped off in front << 2
+        const int iy = dy - ((nxyz >> 10) & 3), iz = dz - ((nxyz >> 18) & 3);   // the row's place inside the clipped box
+        bool in_box = live && (unsigned)iy < (unsigned)((nxyz >> 8) & 3) && (unsigned)iz < (unsigned)((nxyz >> 16) & 3);
         r_pl[j] = pl;
-        r_nx[j] = in_box ? (nxyz & 0xff) : 0;
-        r_cell[j] = in_box ? tp[pbase + pl].cell0 + __mul24(dy, dimx) + ((dz & 1) ? dimxy : 0) + ((dz & 2) ? 2 * dimxy : 0) : 0;
+        r_nx[j] = in_box ? (nxyz & 0xf) : 0;
+        r_cell[j] = in_box ? tp[pbase + pl].cell0 + __mul24(iy, dimx) + ((iz & 1) ? dimxy : 0) + ((iz & 2) ? 2 * dimxy : 0) : 0;
         r_y[j] = tp[pbase + pl].ry - (float)dy * P.res;
         r_z[j] = tp[pbase + pl].rz - (float)dz * P.res;
       }
@@ -395,10 +405,12 @@ __device__ __forceinline__ double ndt_pass_body(const float4 *__restrict__ src, 
         const float4 ev[3] = {e0[j], e1[j], e2[j]};
 #pragma unroll
         for (int i = 0; i < 3; i++) {
-          float dx = (rx - (float)i * P.res) - ev[i].x, dy = r_y[j] - ev[i].y, dz = r_z[j] - ev[i].z;
+          const int ii = i - (r_nx[j] >> 2);   // cell i of the unclipped cube = entry ii of the loaded (clipped) row
+          const float4 en = ii == 0 ? ev[0] : (ii == 1 ? ev[1] : ev[2]);
+          float dx = (rx - (float)i * P.res) - en.x, dy = r_y[j] - en.y, dz = r_z[j] - en.z;
           float d2 = dx * dx + dy * dy + dz * dz;
-          int rank = __float_as_int(ev[i].w);  // -1: unoccupied, too few points or rejected eigenvalues (VoxelGrid.cpp:465)
-          bool ok = i < r_nx[j] && rank >= 0 && d2 <= P.r2f_pre;
+          int rank = __float_as_int(en.w);  // -1: unoccupied, too few points or rejected eigenvalues (VoxelGrid.cpp:465)
+          bool ok = (unsigned)ii < (unsigned)(r_nx[j] & 3) && rank >= 0 && d2 <= P.r2f_pre;
           const unsigned long long m = __ballot(ok);
           const unsigned below = __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
           if (ok) queue[total + below] = ((unsigned)(pbase + r_pl[j])) | ((unsigned)rank << 6);  // point slot incl. its buffer half
@@ -425,9 +437,9 @@ __device__ __forceinline__ double ndt_pass_body(const float4 *__restrict__ src, 
         int o = q - pl * kRowsPerPoint;
         int dz = o / 3, dy = o - dz * 3;
         int nxyz = tp[pbase + pl].nxyz;
-        bool in_box = q < kRowProbes && dy < ((nxyz >> 8) & 0xff) && dz < (nxyz >> 16);
+        bool in_box = q < kRowProbes && dy < ((nxyz >> 8) & 3) && dz < ((nxyz >> 16) & 3);
         r_pl[j] = pl;
-        r_nx[j] = in_box ? (nxyz & 0xff) : 0;
+        r_nx[j] = in_box ? (nxyz & 3) : 0;
         r_cell[j] = in_box ? tp[pbase + pl].cell0 + dy * dimx + dz * dimxy : 0;
       }
       // all word loads first so the L2 round trips overlap; the second word is needed only when the row straddles a

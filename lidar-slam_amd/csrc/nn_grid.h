@@ -44,7 +44,9 @@ int nn_grid_build(lsa_context *ctx, NNGrid &g, const float4 *d_pts, size_t n, fl
 // pcl::Registration::getFitnessScore(max_range) (PCL 1.7 registration/impl/registration.hpp): mean over the source points,
 // transformed by the f32 column-major T, of the SQUARED f32 distance to the nearest point of the grid; pairs with
 // d2 > max_range are dropped; DBL_MAX (std::numeric_limits<double>::max()) when no pair is left.
-int nn_fitness(lsa_context *ctx, NNGrid &g, const float4 *d_src, size_t n, const float T[16], float max_range, double *out);
+// allreduce (optional): the source is one rank's shard; {sum, count} are summed over the ranks before the division
+int nn_fitness(lsa_context *ctx, NNGrid &g, const float4 *d_src, size_t n, const float T[16], float max_range, double *out, lsa_allreduce_fn allreduce = nullptr,
+               void *allreduce_user = nullptr);
 inline NNView nn_view(const NNGrid &g) { return NNView{g.vi.map, g.vi.bits.p, g.vi.prefix.p, g.start.p, g.sorted.p, g.cell, (unsigned)g.n_sorted, g.use_dense ? g.dense.p : nullptr}; }
 
 #endif

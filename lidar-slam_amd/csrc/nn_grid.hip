@@ -95,23 +95,37 @@ __global__ __launch_bounds__(kBlock) void k_nn_fitness(const float4 *__restrict_
 }
 }  // namespace
 
-int nn_fitness(lsa_context *ctx, NNGrid &g, const float4 *d_src, size_t n, const float T[16], float max_range, double *out) {
+int nn_fitness(lsa_context *ctx, NNGrid &g, const float4 *d_src, size_t n, const float T[16], float max_range, double *out, lsa_allreduce_fn allreduce,
+               void *allreduce_user) {
   if (!g.built) return lsa_fail(ctx, LSA_ERR_NO_TARGET, "fitness: no neighbour grid");
   *out = 1.7976931348623157e308;
-  if (!n) return LSA_OK;
+  if (!n && !allreduce) return LSA_OK;   // (a rank with an empty shard still takes part in the collective)
   unsigned nb = (unsigned)std::min<size_t>(lsa_div_up(n * kFitSub, kBlock), (size_t)ctx->num_cus * 8);
   int rc;
-  if ((rc = g.fit_partials.reserve(ctx, (size_t)nb * 2, 1.0))) return rc;
-  if ((rc = g.fit_host.reserve(ctx, (size_t)nb * 2))) return rc;
+  if ((rc = g.fit_partials.reserve(ctx, (size_t)(nb ? nb : 1) * 2, 1.0))) return rc;
+  if ((rc = g.fit_host.reserve(ctx, (size_t)(nb ? nb : 1) * 2))) return rc;
   T12 t;
   for (int r = 0; r < 3; r++)
     for (int c = 0; c < 4; c++) t.v[r * 4 + c] = T[c * 4 + r];
-  hipLaunchKernelGGL(k_nn_fitness, dim3(nb), dim3(kBlock), 0, ctx->stream, d_src, n, t, max_range, nn_view(g), g.fit_partials.p);
-  LSA_HIP(ctx, hipGetLastError());
-  LSA_HIP(ctx, hipMemcpyAsync(g.fit_host.p, g.fit_partials.p, (size_t)nb * 2 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
-  LSA_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  if (n) {
+    hipLaunchKernelGGL(k_nn_fitness, dim3(nb), dim3(kBlock), 0, ctx->stream, d_src, n, t, max_range, nn_view(g), g.fit_partials.p);
+    LSA_HIP(ctx, hipGetLastError());
+    LSA_HIP(ctx, hipMemcpyAsync(g.fit_host.p, g.fit_partials.p, (size_t)nb * 2 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    LSA_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  }
   double sum = 0.0, cnt = 0.0;
-  for (unsigned b = 0; b < nb; b++) { sum += g.fit_host.p[2 * b]; cnt += g.fit_host.p[2 * b + 1]; }  // fixed order
+  for (unsigned b = 0; b < nb && n; b++) { sum += g.fit_host.p[2 * b]; cnt += g.fit_host.p[2 * b + 1]; }  // fixed order
+  if (allreduce) {
+    // source sharded over the ranks ("one extra all-reduce of 2 scalars for fitness"): {sum, count} of this shard
+    // go back to the device, are summed over the ranks in place and come back
+    g.fit_host.p[0] = sum; g.fit_host.p[1] = cnt;
+    LSA_HIP(ctx, hipMemcpyAsync(g.fit_partials.p, g.fit_host.p, 2 * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    int crc = allreduce(allreduce_user, g.fit_partials.p, 2, (void *)ctx->stream);
+    if (crc) return lsa_fail(ctx, LSA_ERR_COLLECTIVE, "fitness: all-reduce callback returned %d", crc);
+    LSA_HIP(ctx, hipMemcpyAsync(g.fit_host.p, g.fit_partials.p, 2 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    LSA_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    sum = g.fit_host.p[0]; cnt = g.fit_host.p[1];
+  }
   if (cnt > 0) *out = sum / cnt;
   return LSA_OK;
 }

@@ -121,6 +121,12 @@ extern "C" int lsa_ndt_set_allreduce_rccl(lsa_ndt *ndt, lsa_rccl_comm *comm) {
   return lsa_ndt_set_allreduce(ndt, rccl_allreduce_cb, comm);
 }
 
+extern "C" int lsa_icp_set_allreduce_rccl(lsa_icp *icp, lsa_rccl_comm *comm) {
+  if (!icp) return LSA_ERR_INVALID;
+  if (!comm) return lsa_icp_set_allreduce(icp, nullptr, nullptr);
+  return lsa_icp_set_allreduce(icp, rccl_allreduce_cb, comm);
+}
+
 // in-place sum of n doubles in device memory over the communicator, on the context's stream (no host sync): the same
 // call the NDT passes make, exposed for self-tests and for reducing other per-rank blocks (ICP's 32 doubles)
 extern "C" int lsa_rccl_allreduce_f64(lsa_rccl_comm *c, void *d_buf, size_t n) {

@@ -17,6 +17,8 @@
 
 #include "ndt_internal.h"
 
+#include <climits>
+
 namespace {
 constexpr int kBlock = 256;
 constexpr float kCell = 2.0f;
@@ -72,8 +74,12 @@ int ndt_source_order(lsa_ndt *h, const float4 *d_src, size_t n, const float4 **d
   *d_use = d_src;
   h->source_sorted = false;
   constexpr size_t kSortMinPoints = 262144;
-  if (h->source_sort_mode == 0 || n < kSortMinPoints || n > 0xfffffff0ull) return LSA_OK;
+  // (hipcub's segment-free radix sort takes an int count: clouds beyond INT_MAX points are walked as they come)
+  if (h->source_sort_mode == 0 || n < kSortMinPoints || n > (size_t)INT_MAX) return LSA_OK;
   int rc;
+  // A deferred final pass of the previous ScanMatch (ndt_api.hip) may still have to be REDONE on the host's say-so, on the cloud it
+  // was posted for — which may be the sorted copy this call is about to overwrite: take its rows first.
+  if ((rc = ndt_collect_deferred(h))) return rc;
   lsa_ctx_unpark(ctx);   // kernels are about to go onto the stream: nothing may be parked on it
   if ((rc = h->sort_small.reserve(ctx, 4))) return rc;
   if (h->source_sort_mode == 1) {

@@ -221,7 +221,13 @@ int lsa_voxel_filter_apply_device_async_here(lsa_voxel_filter *f, const float *d
 
 // internal (pipeline.cpp): a device buffer of n points owned by this handle (grow-only)
 float *lsa_voxel_filter_pipe_buffer(lsa_voxel_filter *f, size_t n) {
-  if (!f || f->d_pipe.reserve(f->ctx, n ? n : 1, 1.1)) return nullptr;
+  if (!f) return nullptr;
+  // This is the first thing lsa_pipeline_scan_match does, BEFORE any call that enters the filter's context: a worker thread driving
+  // a context on GPU n > 0 still has device 0 current, and a buffer allocated now would land there (the filter of every third scan
+  // would write it, the NDT pass read it, from another device).  Select the context's device — nothing else of lsa_enter: a kernel
+  // parked on the context's stream has no business being released by an allocation.
+  if ((n ? n : 1) > f->d_pipe.cap && hipSetDevice(f->ctx->device) != hipSuccess) return nullptr;
+  if (f->d_pipe.reserve(f->ctx, n ? n : 1, 1.1)) return nullptr;
   return (float *)f->d_pipe.p;
 }
 

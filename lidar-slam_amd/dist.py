@@ -87,6 +87,11 @@ class NativeRccl:
         from . import capi
         self.ctx.check(capi.lib().lsa_ndt_set_allreduce_rccl(ndt.h, self.h))
 
+    def attach_icp(self, icp):
+        """the same exchange step for an ICP handle (lsa_icp_set_allreduce_rccl): one all-reduce per iteration"""
+        from . import capi
+        self.ctx.check(capi.lib().lsa_icp_set_allreduce_rccl(icp.h, self.h))
+
     def comm_count(self):
         """ncclCommCount of the communicator."""
         import ctypes as C

@@ -144,6 +144,13 @@ class FrontEndHip:
         self.ctx.check(capi.lib().lsa_front_end_map_counters(self.h, out))
         return dict(full_builds=out[0], updates=out[1], rebuilds=out[2], refits=out[3], adopted=out[4], switched_off=out[5])
 
+    def armed_stats(self, reset=False):
+        """lsa_ndt_armed_stats of the front end's own registration handle (every outcome of an armed pass other than the plain one)."""
+        L = capi.lib()
+        st = capi.NdtArmedStats()
+        self.ctx.check(L.lsa_ndt_armed_stats(L.lsa_front_end_registration(self.h), C.byref(st), 1 if reset else 0))
+        return st.as_dict()
+
     def map_verify(self):
         """Full build on scratch handles against the incremental map, bit by bit (lsa_front_end_map_verify)."""
         out = (C.c_uint64 * 6)()

@@ -292,6 +292,22 @@ class ICPRegistrationHip(RegistrationInterface):
         self.ctx.check(capi.lib().lsa_icp_get_fitness_score(self.h, C.byref(v)))
         return v.value
 
+    def set_allreduce(self, fn):
+        """Multi-GPU: fn(device_ptr:int, n_doubles:int, stream:int) -> int (0 ok) sums the iteration's 32-double block over the ranks
+        in place (one all-reduce per iteration; each rank's ScanMatch gets its shard of the source).  None clears it."""
+        if fn is None:
+            self._cb = capi.ALLREDUCE_FN(0)
+        else:
+            def _tramp(user, buf, n, stream):
+                try:
+                    return int(fn(buf, n, stream) or 0)
+                except Exception:  # never let an exception cross the C ABI
+                    import traceback
+                    traceback.print_exc()
+                    return 1
+            self._cb = capi.ALLREDUCE_FN(_tramp)
+        self.ctx.check(capi.lib().lsa_icp_set_allreduce(self.h, self._cb, None))
+
     def close(self):
         if self.h and self.ctx.h:
             capi.lib().lsa_icp_destroy(self.h)
@@ -350,6 +366,28 @@ def pack_out32(score, g, H, pairs, npoints):
     out[28] = pairs
     out[29] = npoints
     return out
+
+
+def icp_gn_solve(eval_fn, max_iter, predict_pose):
+    """lsa_icp_gn_solve with a Python evaluator eval_fn(T column-major 16 f32) -> out32 (the iteration's sums, already summed over the
+    ranks): the host step of ICPMANUAL without a device."""
+    def _tramp(user, T, out):
+        try:
+            o = np.asarray(eval_fn(np.ctypeslib.as_array(T, shape=(16,)).copy()), dtype=np.float64)
+            for k in range(32):
+                out[k] = o[k]
+            return 0
+        except Exception:
+            import traceback
+            traceback.print_exc()
+            return 1
+    cb = capi.ICP_EVAL_FN(_tramp)
+    guess = capi.colmajor(predict_pose)
+    out = np.zeros(16, dtype=np.float32)
+    rc = capi.lib().lsa_icp_gn_solve(cb, None, int(max_iter), capi.fptr(guess), capi.fptr(out))
+    if rc:
+        raise capi.LsaError(rc, "lsa_icp_gn_solve failed")
+    return capi.from_colmajor(out)
 
 
 def gn_solve(eval_fn, res, step_size, trans_eps, max_iter, outlier_ratio, predict_pose, mode=0):

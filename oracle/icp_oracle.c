@@ -150,6 +150,49 @@ int orc_icp_manual(const void *tgt, size_t nt, size_t tstride, const void *src, 
   return 0;
 }
 
+/* One ICPRegistrationManual iteration's sums over `src` at pose T (column-major): out32[1..6] = -J^T e, [7..27] the upper triangle of
+ * J^T J row by row, [28] correspondences, [29] finite source points — the layout of csrc/icp.hip's workgroup rows, accumulated in f64 as
+ * the kernels do.  What a rank of a sharded ScanMatch contributes to the exchange step (tests/test_dist_cpu.py evaluates each rank's
+ * shard with this and sums over gloo).  J and e are formed in f32 exactly as orc_icp_manual forms them (:132-159). */
+int orc_icp_sums(const void *tgt, size_t nt, size_t tstride, const void *src, size_t ns, size_t sstride, float max_correspond_dis,
+                 const float T[16], double out32[32]) {
+  float R[9];
+  for (int r = 0; r < 3; r++) for (int c = 0; c < 3; c++) R[r * 3 + c] = T[c * 4 + r];
+  for (int k = 0; k < 32; k++) out32[k] = 0.0;
+  float cell = sqrtf(max_correspond_dis);
+  if (!(cell > 0.05f)) cell = 0.05f;
+  nn_grid *g = nt ? nn_build(tgt, nt, tstride, cell) : NULL;
+  for (size_t i = 0; i < ns; i++) {
+    const float *p = P(src, sstride, i);
+    if (!isfinite(p[0]) || !isfinite(p[1]) || !isfinite(p[2])) continue;
+    out32[29] += 1.0;
+    float q[3];
+    orc_transform_point(T, p, q);
+    float sqd;
+    int id = g ? nn_query(g, q, max_correspond_dis, &sqd) : -1;
+    if (id < 0) continue;
+    const float *c = P(tgt, tstride, (size_t)id);
+    float e[3] = {q[0] - c[0], q[1] - c[1], q[2] - c[2]};
+    float H1[36], B1[6];
+    memset(H1, 0, sizeof(H1)); memset(B1, 0, sizeof(B1));
+    orc_icp_acc(R, p, e, H1, B1);   /* this point's J^T J and -J^T e (f32 J; every product of two f32 is exact in f64) */
+    float J[3][6];
+    memset(J, 0, sizeof(J));
+    J[0][0] = J[1][1] = J[2][2] = 1.0f;
+    const float hat[9] = {0.0f, -p[2], p[1], p[2], 0.0f, -p[0], -p[1], p[0], 0.0f};
+    for (int r = 0; r < 3; r++)
+      for (int cc = 0; cc < 3; cc++) J[r][3 + cc] = (-R[r * 3]) * hat[cc] + ((-R[r * 3 + 1]) * hat[3 + cc] + (-R[r * 3 + 2]) * hat[6 + cc]);
+    int k = 7;
+    for (int a = 0; a < 6; a++) {
+      out32[1 + a] += -((double)J[0][a] * (double)e[0] + (double)J[1][a] * (double)e[1] + (double)J[2][a] * (double)e[2]);
+      for (int b = a; b < 6; b++) { out32[k] += (double)J[0][a] * J[0][b] + (double)J[1][a] * J[1][b] + (double)J[2][a] * J[2][b]; k++; }
+    }
+    out32[28] += 1.0;
+  }
+  nn_free(g);
+  return 0;
+}
+
 /* ======================================================================================================================
  * Point-to-plane ICP — a BUILD EXTENSION, not reference code: BASELINE.json configs[2] asks for "point-to-plane ICP" but
  * both ICP plugins of the reference are point-to-point (SURVEY.md 8a note).  It reuses the ICPRegistrationManual skeleton

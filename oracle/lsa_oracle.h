@@ -151,6 +151,9 @@ int orc_box_filter(const void *pts, size_t n, size_t stride, size_t w_off, const
                    float *out_xyzi, size_t cap, size_t *n_out);
 
 /* ---- ICP (S/models/registration/icp_registration_manual.cpp:125-178) --- */
+/* one iteration's sums of ICPRegistrationManual over a (shard of the) source at pose T: the exchange step's payload (icp_oracle.c) */
+int orc_icp_sums(const void *tgt, size_t nt, size_t tstride, const void *src, size_t ns, size_t sstride, float max_correspond_dis,
+                 const float T[16], double out32[32]);
 int orc_icp_manual(const void *tgt, size_t nt, size_t tstride, const void *src, size_t ns, size_t sstride,
                    float max_correspond_dis, int max_iter, const float guess[16], float out_pose[16]);
 

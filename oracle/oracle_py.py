@@ -124,6 +124,8 @@ class Oracle:
         L.orc_voxel_filter.restype = i
         L.orc_icp_manual.argtypes = [vp, sz, sz, vp, sz, sz, f, i, PF, PF]
         L.orc_icp_manual.restype = i
+        L.orc_icp_sums.argtypes = [vp, sz, sz, vp, sz, sz, f, PF, PD]
+        L.orc_icp_sums.restype = i
         L.orc_ndt_set_mode.argtypes = [vp, i]
         L.orc_icp_plane.argtypes = [vp, sz, sz, vp, sz, sz, f, i, f, PF, PF, PD]
         L.orc_icp_plane.restype = i
@@ -379,6 +381,18 @@ def icp_manual(tgt8, src8, guess, max_correspond_dis=2.0, max_iter=30):
     o.L.orc_icp_manual(tgt8.ctypes.data, tgt8.shape[0], POINT_STRIDE, src8.ctypes.data, src8.shape[0], POINT_STRIDE,
                        max_correspond_dis, max_iter, _fp(_colmajor(guess)), _fp(out))
     return out.reshape(4, 4).T.copy()
+
+
+def icp_sums(tgt8, src8, T_colmajor16, max_correspond_dis=2.0):
+    """One ICPRegistrationManual iteration's 32 sums over (a shard of) the source at pose T (column-major 16 floats): the payload
+    of the exchange step (orc_icp_sums)."""
+    o = Oracle()
+    tgt8 = np.ascontiguousarray(tgt8, dtype=np.float32)
+    src8 = np.ascontiguousarray(src8, dtype=np.float32)
+    T = np.ascontiguousarray(T_colmajor16, dtype=np.float32).reshape(16)
+    out = np.zeros(32)
+    o.L.orc_icp_sums(tgt8.ctypes.data, tgt8.shape[0], POINT_STRIDE, src8.ctypes.data, src8.shape[0], POINT_STRIDE, max_correspond_dis, _fp(T), _dp(out))
+    return out
 
 
 def fitness_pcl(tgt8, src8, T, max_range=float("inf")):

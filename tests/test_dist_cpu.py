@@ -97,6 +97,60 @@ def test_sharded_registration_two_ranks_gloo(scan_pair, oracle, tmp_path):
     assert abs(float(r0["tp"]) - st_ref["trans_probability"]) <= 1e-9 * abs(st_ref["trans_probability"])
 
 
+def _icp_worker(rank, world, port, tgt, src, guess, out_dir):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import conftest  # noqa: F401
+    import torch.distributed as dist
+    import oracle_py
+    from lidar_slam_amd import dist as lsa_dist
+    from lidar_slam_amd import registration
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    lo, hi = lsa_dist.shard_bounds(src.shape[0], rank, world)
+    shard = src[lo:hi]
+    n_calls = [0]
+
+    def evaluator(T16):
+        n_calls[0] += 1
+        return lsa_dist.allreduce_out32_cpu(oracle_py.icp_sums(tgt, shard, T16, 2.0))   # ONE collective per iteration
+
+    T = registration.icp_gn_solve(evaluator, 12, guess)
+    np.savez(os.path.join(out_dir, "icp_rank%d.npz" % rank), T=T, calls=n_calls[0])
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_sharded_icp_two_ranks_gloo(scan_pair, oracle, tmp_path):
+    """ICP over the exchange step ("ICP shards identically"): the source sharded over two ranks, the target replicated,
+    the iteration's 32 sums all-reduced over gloo, the product's host step (lsa_icp_gn_solve: the code icp.hip runs between two
+    iterations) on every rank.  Without a GPU the per-shard sums come from the oracle; under test are the sharding, the wiring and
+    that both ranks take the identical step."""
+    import torch.multiprocessing as mp
+    import oracle_py
+    from lidar_slam_amd import registration, synth
+
+    s0, s1, _, _ = scan_pair
+    tgt = synth.to_xyzi32(s0[::3])
+    filt, _ = oracle.voxel_filter(synth.to_xyzi32(s1), 0.5)
+    src = synth.to_xyzi32(filt)
+    guess = synth.pose_matrix(0.8, 0.03, 0.0, 0.0, 0.0, 0.015).astype(np.float32)
+    # one process, the whole cloud, through the same driver
+    T_one = registration.icp_gn_solve(lambda T16: oracle_py.icp_sums(tgt, src, T16, 2.0), 12, guess)
+    # ... which is ICPRegistrationManual up to the f64 accumulation of H and B (the reference sums in f32)
+    T_ref = oracle_py.icp_manual(tgt, src, guess, 2.0, 12)
+    assert np.max(np.abs(T_one - T_ref)) <= 2e-4
+    port = _free_port()
+    mp.spawn(_icp_worker, args=(2, port, tgt, src, guess, str(tmp_path)), nprocs=2, join=True)
+    r0, r1 = np.load(tmp_path / "icp_rank0.npz"), np.load(tmp_path / "icp_rank1.npz")
+    assert np.array_equal(r0["T"], r1["T"])                        # every rank took the identical steps: no broadcast needed
+    assert int(r0["calls"]) == int(r1["calls"]) == 12              # one collective per iteration
+    assert np.max(np.abs(r0["T"] - T_one)) <= 1e-6                 # only the grouping of the f64 sums differs
+
+
 def test_shard_pays_break_even():
     """The shard-or-not rule every rank evaluates (dist.shard_pays): KITTI-sized filtered scans stay unsharded, cfg5-sized
     sources are sharded; the break-even shrinks with the rank count and the rule is monotone in the point count."""

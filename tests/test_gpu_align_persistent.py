@@ -270,7 +270,15 @@ def test_armed_kernel_carried_between_scan_matches(ctx, cfg2):
     for d_s, guess in zip(cfg2["d_src"][:3], cfg2["guesses"][:3]):
         n.ScanMatch(d_s, guess)
     tl = n.armed_timing()
-    assert tl["passes"] >= 3 and 0.0 < tl["dev_body_us"] < 1000.0 and 0.0 <= tl["dev_wait_us"] < 1000.0 and 0.0 < tl["post_to_rows_us"] < 5000.0, tl
-    print("armed pass timeline (us per pass):", {k: round(v, 2) for k, v in tl.items()})
+    # the armed kernel's BODY is the unarmed kernel's code behind a wait: its device-side stamp is held against the same pass run as
+    # an ordinary launch, timed between HIP events in this very test (a 10x regression of the body cannot hide behind a wall-clock
+    # bound that has to survive a busy box); the waits depend on the host and only get the generous bounds
+    plain.set_source(cfg2["d_src"][0])
+    p0 = np.zeros(6)
+    capi.lib().lsa_matrix_to_pose(capi.fptr(capi.colmajor(cfg2["guesses"][0])), capi.dptr(p0))
+    _, iso_ms = plain.derivatives_timed(cfg2["guesses"][0], p0, kind=0, repeat=100)
+    print("armed pass timeline (us per pass):", {k: round(v, 2) for k, v in tl.items()}, "; the same pass as an ordinary launch: %.2f us" % (iso_ms * 1e3))
+    assert tl["passes"] >= 3 and 0.0 < tl["dev_body_us"] < 3.0 * iso_ms * 1e3, (tl, iso_ms)
+    assert 0.0 <= tl["dev_wait_us"] < 1000.0 and 0.0 < tl["post_to_rows_us"] < 5000.0, tl
     plain.close()
     n.close()

@@ -24,11 +24,26 @@ from lidar_slam_amd import workloads as wl
 pytestmark = pytest.mark.gpu
 
 
+ROW_LIMIT_US = 2500.0    # the library's own bound on an armed pass's rows (ndt_api.hip: kArmedRowLimitMs = 2 ms) + slack
+HOST_STALL_US = 1000.0   # an interval this long between two looks of the calling thread at its rows is the OS, not the library
+
+
 def _quiet(s, allow=2):
     """The outcomes that cost time (late rows, passes redone the ordinary way, kernels seen giving up) are COUNTED, never silent;
-    what these tests were written against showed as dozens per run (one per batch, 123 per 22 k scans).  A host thread held up
-    for milliseconds on a busy box can cost the odd one with every result still identical: up to `allow` pass."""
-    return s["late"] + s["rows_late"] + s["fallbacks"] + s["gave_up_seen"] <= allow
+    what these tests were written against showed as dozens per run (one per batch, 123 per 22 k scans).  NONE is accepted unless the
+    library's host-stall detector (armed_stats: host_gap_max_us = the longest interval between two consecutive looks of the calling
+    thread at the rows it waited for, or between two passes of one ScanMatch) shows that the OS held the thread up for a millisecond
+    or more — then up to `allow` pass, every result still identical.  Both numbers are printed."""
+    n = s["late"] + s["rows_late"] + s["fallbacks"] + s["gave_up_seen"]
+    stalled = s["host_gap_max_us"] >= HOST_STALL_US
+    if n or stalled:
+        print("armed outcomes other than the plain one: %d; host gap max %.1f us (%s)" % (n, s["host_gap_max_us"], "thread held up" if stalled else "no stall seen"))
+    return n == 0 or (stalled and n <= allow)
+
+
+def _rows_in_time(s):
+    """no wait for rows beyond the library's own limit — unless the detector saw the thread itself held up that long"""
+    return s["rows_wait_max_us"] < ROW_LIMIT_US or s["host_gap_max_us"] >= HOST_STALL_US
 
 
 def _armed_all(s, total):
@@ -167,9 +182,10 @@ def test_batch_idle_then_standalone_scan_matches(rig, carry):
     ts = np.array(ts) * 1e6
     print("carry %s: ScanMatch min / median / p90 / max = %.1f / %.1f / %.1f / %.1f us; %s" % (carry, ts.min(), np.median(ts), np.percentile(ts, 90), ts.max(), s))
     assert _quiet(s), s
-    assert s["rows_wait_max_us"] < 25000.0, s
+    assert _rows_in_time(s), s
     assert _armed_all(s, sum(ref[i % 9][1] for i in range(50))), s
-    # only the kernel the last batch left parked (opt-in) had expired (plus, on a box that holds this thread up, the odd one)
+    # only the kernel the last batch left parked (opt-in) had expired (with the carry on, Python's own time between two calls counts
+    # against the parked kernel's 300 us: a collection or a held-up thread there costs the odd one more; without it, none can)
     assert (1 if carry else 0) <= s["expired"] <= (3 if carry else 0), s
     assert np.percentile(ts, 90) < 1000.0 and ts.max() < 5000.0, ts
     n.close()
@@ -195,8 +211,9 @@ def test_patience_as_short_as_the_host_gap(rig):
         dt = time.perf_counter() - t0
         s = n.armed_stats()
         print("patience %4.1f us: %.1f us per ScanMatch, %s" % (patience, dt / 36 * 1e6, s))
-        assert s["late"] + s["rows_late"] <= 1, s          # no row limit was sat out (but for a thread held up by the box)
-        assert s["rows_wait_max_us"] < 25000.0, s
+        # no row limit was sat out: a workgroup that leaves says so and the wait ends at once (a thread the box holds up shows in the detector)
+        assert s["late"] + s["rows_late"] == 0 or (s["host_gap_max_us"] >= HOST_STALL_US and s["late"] + s["rows_late"] <= 1), s
+        assert _rows_in_time(s), s
         assert dt / 36 < 2e-3, (patience, dt)
         for key in seen:
             seen[key] += s[key]

@@ -483,6 +483,58 @@ def test_concurrent_pipelines_on_one_gpu(scene):
     alone.close()
 
 
+def test_pipeline_from_a_fresh_thread_uses_the_contexts_device(scene):
+    """lsa_pipeline_scan_match allocates its third filtered-cloud buffer before any call has entered the filter's context; a worker
+    thread that has never touched HIP has device 0 current, whatever device the context lives on.  The batch is driven from a fresh
+    thread — on the LAST visible device too when the box has more than one (a buffer on the wrong device faults or gives other poses;
+    a one-GPU box only runs the device-0 leg) — and must return the poses of the calling thread's run."""
+    import ctypes as C
+    import threading
+    import torch
+    poses = synth.trajectory(4)
+    scans = [synth.gen_scan(scene, poses[i], seed=960 + i, beams=32, az_steps=900) for i in range(4)]
+    P0i = np.linalg.inv(poses[0])
+    tgt = synth.to_xyzi32(np.concatenate([synth.transform_points(P0i @ poses[i], scans[i]) for i in range(2)], 0))
+    guesses = np.ascontiguousarray(np.stack([capi.colmajor((P0i @ poses[max(0, i - 1)]).astype(np.float32)) for i in range(4)]).astype(np.float32))
+    L = capi.lib()
+    L.lsa_pipeline_scan_match.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t), C.POINTER(C.c_float),
+                                          C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_float), C.POINTER(capi.NdtStats), C.POINTER(C.c_size_t)]
+    idx = [i % 4 for i in range(12)]
+
+    def batch(dev, in_thread):
+        with torch.cuda.device(dev):
+            d_scans = [torch.from_numpy(np.ascontiguousarray(s)).to("cuda:%d" % dev) for s in scans]
+            bufs = [torch.empty((max(t.shape[0] for t in d_scans), 4), dtype=torch.float32, device="cuda:%d" % dev) for _ in range(2)]
+            torch.cuda.synchronize(dev)
+        ctx, ctx_f = capi.Context(dev), capi.Context(dev)
+        ndt = registration.NDTRegistrationHip(ctx)
+        ndt.SetInputTarget(tgt)
+        ff = cloud_filter.VoxelFilterHip(ctx_f, 0.5, 0.5, 0.5)
+        n = len(idx)
+        ptrs = (C.c_void_p * n)(*[d_scans[k].data_ptr() for k in idx])
+        nn = (C.c_size_t * n)(*[d_scans[k].shape[0] for k in idx])
+        pred = np.ascontiguousarray(guesses[idx])
+        out = np.zeros((n, 16), dtype=np.float32)
+        st, nf = (capi.NdtStats * n)(), (C.c_size_t * n)()
+        res = {}
+
+        def run():
+            res["rc"] = L.lsa_pipeline_scan_match(ff.h, ndt.h, n, ptrs, nn, capi.fptr(pred), bufs[0].data_ptr(), bufs[1].data_ptr(), 0, 1, capi.fptr(out), st, nf)
+        if in_thread:
+            t = threading.Thread(target=run)   # a thread that has made no HIP call: its current device is 0
+            t.start(); t.join()
+        else:
+            run()
+        assert res["rc"] == 0, L.lsa_last_error(ctx_f.h)
+        ndt.close(); ff.close(); ctx_f.close(); ctx.close()
+        return out.copy(), [int(v) for v in nf]
+    ref, ref_n = batch(0, False)
+    devs = [0] + ([torch.cuda.device_count() - 1] if torch.cuda.device_count() > 1 else [])
+    for dev in devs:
+        got, got_n = batch(dev, True)
+        assert got_n == ref_n and np.array_equal(got, ref), dev
+
+
 def test_bitmap_probe_path_matches_dense_table_path(oracle, scan_pair):
     """Targets whose cell box is too large for the dense probe table fall back to the bitmap probe; forced here on a small
     target: both structures must select the same (point, voxel) pairs and give the same sums and the same ScanMatch."""
