@@ -486,6 +486,10 @@ int lsa_front_end_update(lsa_front_end *fe, const void *cloud, size_t n, size_t 
  * (FrontEnd keeps the key-frame's cloud as well: front_end.cpp:375): leave the buffer unchanged until the next call on this handle
  * has returned (or the device has been synchronised). */
 int lsa_front_end_update_device(lsa_front_end *fe, const float *d_xyzw, size_t n, float pose_out[16], lsa_front_end_stats *stats);
+/* diagnostics: with out == NULL, enable != 0 makes the three kernels of every following incremental map update note the device's
+ * 100 MHz wall clock at their phase boundaries (8 values per workgroup); with out != NULL the 3 x *per_kernel values are copied out
+ * (kernel k's workgroup w at out[k * *per_kernel + 8 w ...]) and cleared.  profiles/scripts/lm_stamps.py prints them. */
+int lsa_front_end_map_stamps(lsa_front_end *fe, int enable, uint64_t *out, size_t cap, size_t *per_kernel);
 /* `count` Updates in one call — a recorded drive being replayed, or a sensor queue that has backed up: the loop
  * front_end_flow.cpp:18-36 runs over its cloud_data_buff_ (while (HasData()) { ValidData(); UpdateLaserOdometry(); }).  The
  * frame filter of scan k + 1 runs on a second stream while scan k is registered and the local map updated (it needs no pose);

@@ -137,7 +137,12 @@ struct lsa_front_end {
   // one), in a batch the tail of the deferred final pass and the release of the parked kernel.  The registration's stream is ordered
   // behind the update by an event before anything on it reads the table (fe_map_join); what the update reads — the caller's scan, the
   // slot's old points — is complete by then as far as the HOST knows (the frame filter that read the scan has been waited for).
+  // Inside a BATCH (lsa_front_end_update_batch_device) the update stays on the registration's stream: the next scan's frame filter
+  // already runs on a stream of its own there, nothing is left to put beside the update, and a cross-stream event in front of the
+  // next ScanMatch's first (pre-launched) kernel costs ~10 us per key-frame (measured: the kernel starts 11.7 us after the update's
+  // last kernel ends, against 0 on one stream).
   lsa_context *ctx_m = nullptr;
+  bool in_batch = false;
   hipEvent_t ev_map = nullptr, ev_in = nullptr;
   bool map_inflight = false;   // an update has been enqueued on ctx_m's stream that the registration's stream is not yet ordered behind
   DevBuf<float4> d_in_alt;     // lsa_front_end_update (host clouds): the upload alternates between two buffers (see there)
@@ -165,7 +170,8 @@ namespace {
 // not in age order, with NaN padding behind each: the 0.3 m filter and the voxel table sum in exact fixed point, so their
 // results do not depend on the order of the points (and they skip non-finite ones).
 // which stream the local-map buffer is written on: the map's own while the incremental map is in use, the registration's otherwise
-hipStream_t fe_map_stream(lsa_front_end *fe) { return (fe->incremental && !fe->lm_off) ? fe->ctx_m->stream : fe->ctx->stream; }
+lsa_context *fe_map_ctx(lsa_front_end *fe) { return (fe->incremental && !fe->lm_off && !fe->in_batch) ? fe->ctx_m : fe->ctx; }
+hipStream_t fe_map_stream(lsa_front_end *fe) { return fe_map_ctx(fe)->stream; }
 
 // order the registration's stream behind the map update in flight (before anything on it reads the table, the map buffer or a
 // key-frame's cloud); the host itself learns of the update's end from the status block (lm_check)
@@ -272,9 +278,16 @@ int fe_rebuild_map(lsa_front_end *fe, KeyFrame *added, bool evicted, const float
   // the steady state of the incremental map: ONE launch takes the caller's cloud, keeps the key-frame's copy of it, writes its
   // transformed points into the slot and swaps it for the evicted key-frame in the persistent sums
   const bool steady = fe->incremental && !fe->lm_off && !relayout && fe->lm.valid && want_filtered == fe->lm.filtered;
+  const bool own_stream = fe_map_ctx(fe) == fe->ctx_m;
   if (fe->incremental && !fe->lm_off) {
+    // an update still in flight on the OTHER stream (the caller alternates between single Updates and batches) comes first
+    if (!own_stream && (rc = fe_map_join(fe))) return rc;
+    fe->lm.ctx = fe_map_ctx(fe);
+  }
+  if (own_stream) {
     // the map's stream behind whatever the registration's stream still holds (the caller's own producer of this scan, if it has
-    // not been waited for by a frame filter; normally nothing: the event is complete when it is recorded)
+    // not been waited for by a frame filter; an update a batch left on the registration's stream; normally nothing: the event is
+    // complete when it is recorded)
     lsa_ctx_unpark(ctx);   // (a kernel parked on the registration's stream — a caller who opted into the carry — would hold the event back)
     LSA_HIP(ctx, hipEventRecord(fe->ev_in, ctx->stream));
     LSA_HIP(ctx, hipStreamWaitEvent(fe->ctx_m->stream, fe->ev_in, 0));
@@ -295,7 +308,7 @@ int fe_rebuild_map(lsa_front_end *fe, KeyFrame *added, bool evicted, const float
     if (fe->map_filter) lsa_voxel_filter_set_scale_floor(fe->map_filter, s);
     ndt_set_scale_floor(fe->ndt, s);
     fe->lm.valid = false;
-    if (fe->incremental && !fe->lm_off && (rc = lm_configure(fe->lm, fe->ctx_m, fe->cfg.map_leaf, fe->cfg.ndt_res, /*pcl*/ 0, s))) return rc;
+    if (fe->incremental && !fe->lm_off && (rc = lm_configure(fe->lm, fe_map_ctx(fe), fe->cfg.map_leaf, fe->cfg.ndt_res, /*pcl*/ 0, s))) return rc;
   }
   LSA_HIP(ctx, hipGetLastError());
   fe->map_points = sum;
@@ -315,8 +328,10 @@ int fe_rebuild_map(lsa_front_end *fe, KeyFrame *added, bool evicted, const float
     for (int c = 0; c < 4; c++) T[r * 4 + c] = added->pose[c * 4 + r];
   if ((rc = lm_swap(fe->lm, slot, fe->slot_cap, evicted, d_cloud, added->n, T, added->pts.p, reset_w))) return rc;
   if ((rc = lm_finish(fe->lm))) return rc;
-  LSA_HIP(ctx, hipEventRecord(fe->ev_map, fe->ctx_m->stream));
-  fe->map_inflight = true;
+  if (own_stream) {
+    LSA_HIP(ctx, hipEventRecord(fe->ev_map, fe->ctx_m->stream));
+    fe->map_inflight = true;
+  }
   if (!want_filtered) fe->target_points = sum;   // (filtered: the live-cell count arrives with the update's status)
   if (!fe->lm_adopted) return fe_lm_adopt(fe);
   ndt_touch_external(fe->ndt, fe->target_points);
@@ -453,10 +468,11 @@ int fe_update_batch(lsa_front_end *fe, size_t count, const float *const *d_scans
   if ((rc = lsa_voxel_filter_apply_device_async_here(ff, d_scans[0], n_points[0], (float *)fe->d_batch[0].p))) return lsa_fail(ctx, rc, "%s", lsa_last_error(fe->ctx_b));
   const bool carry_user = ndt_carry_scope(fe->ndt, true);
   const bool defer_user = ndt_defer_scope(fe->ndt, true);
+  fe->in_batch = true;
   struct Restore {
-    lsa_ndt *h; bool prev, prev_defer;
-    ~Restore() { (void)ndt_collect_deferred(h); (void)ndt_defer_scope(h, prev_defer); (void)ndt_carry_scope(h, prev); if (!prev) ndt_release_parked(h); }
-  } restore{fe->ndt, carry_user, defer_user};
+    lsa_front_end *fe; lsa_ndt *h; bool prev, prev_defer;
+    ~Restore() { fe->in_batch = false; (void)ndt_collect_deferred(h); (void)ndt_defer_scope(h, prev_defer); (void)ndt_carry_scope(h, prev); if (!prev) ndt_release_parked(h); }
+  } restore{fe, fe->ndt, carry_user, defer_user};
   lsa_front_end_stats local;
   for (size_t k = 0; k < count; k++) {
     size_t m = 0;
@@ -621,6 +637,17 @@ extern "C" int lsa_front_end_map_verify(lsa_front_end *fe, uint64_t out[6]) {
   if (sf) lsa_voxel_filter_destroy(sf);
   tmp.release();
   return rc;
+}
+
+// diagnostics (profiles/scripts/lm_stamps.py): phase stamps of the local-map update's three kernels
+extern "C" int lsa_front_end_map_stamps(lsa_front_end *fe, int enable, uint64_t *out, size_t cap, size_t *per_kernel) {
+  if (!fe) return LSA_ERR_INVALID;
+  LSA_HIP(fe->ctx, lsa_enter(fe->ctx));
+  if (!fe->lm.ctx) return lsa_fail(fe->ctx, LSA_ERR_INVALID, "lsa_front_end_map_stamps: the incremental map is not configured yet");
+  int rc;
+  if ((rc = fe_map_drain(fe))) return rc;
+  if (out) return lm_stamps_fetch(fe->lm, (unsigned long long *)out, cap, per_kernel);
+  return lm_stamps_enable(fe->lm, enable != 0);
 }
 
 extern "C" int lsa_front_end_map_counters(lsa_front_end *fe, uint64_t out[6]) {

@@ -89,6 +89,7 @@ struct LocalMap {
   bool window_set = false;
   DevBuf<LmStatus> d_status;
   PinnedBuf<LmStatus> h_status;
+  DevBuf<unsigned long long> stamps;  // diagnostics (lm_stamps_enable): 3 kernels x kMaxRegions workgroups x 8 clock values
   FixScales fs_f{}, fs_n{};
   float leaf_f[3] = {0.3f, 0.3f, 0.3f}, leaf_n = 1.0f;
   int pcl = 0;
@@ -100,7 +101,7 @@ struct LocalMap {
   unsigned long long rebuilds = 0, refits = 0, updates = 0;
   void release() {
     f.release(); n.release(); dirty_f.release(); dirty_n.release(); rec.release(); dense.release();
-    d_status.release(); h_status.release();
+    d_status.release(); h_status.release(); stamps.release();
     cap_f = cap_n = 0;
     valid = false; window_set = false;
   }
@@ -126,6 +127,11 @@ int lm_refit_window(LocalMap &lm);
 // Look at the status of the last update (the caller guarantees its kernels have completed): 0 fine, 1 window re-fit needed,
 // 2 rebuild needed (tables filling up / overflow)
 int lm_check(LocalMap &lm);
+
+// diagnostics: the three kernels of the updates that follow note the 100 MHz wall clock at their phase boundaries (8 values per
+// workgroup: local_map.hip lm_stamp); fetch copies the 3 x *per_kernel values out and clears them
+int lm_stamps_enable(LocalMap &lm, bool on);
+int lm_stamps_fetch(LocalMap &lm, unsigned long long *out, size_t cap, size_t *per_kernel);
 
 // tests: compare level N with a full table build of the same window (its occupied cells, records and states).
 // out[0] cells of the full table compared, [1] cells that differ in any bit, [2] live cells of level N, [3] valid voxels of level N

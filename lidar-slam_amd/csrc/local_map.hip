@@ -2,7 +2,7 @@
 // (FrontEnd::UpdateWithNewFrame, front_end.cpp:348-424) and for the design.
 //
 // Kernels (all HBM / atomic bound streaming work, nothing GEMM shaped):
-//   k_lm_points<NS, MODE, SWAP>  one tile of points per workgroup (a swap tile: 512 of the evicted key-frame's and 512 of the new
+//   k_lm_points<NS, MODE, SWAP>  one tile of points per workgroup (a swap tile: 256 of the evicted key-frame's and 256 of the new
 //                           one's): pre-aggregated per cell in an LDS table (consecutive lidar returns share cells), then each
 //                           distinct cell finds or claims its line in the global table (64-bit CAS on the key) and receives its
 //                           NS sums and its count as ONE wave-instruction's adjacent lanes into that line — a returning add:
@@ -24,7 +24,8 @@
 
 namespace {
 constexpr int kBlock = 256;
-constexpr int kTile = 512;          // points per workgroup tile (per cloud)
+constexpr int kTile = 256;          // points per workgroup tile (per cloud): one point of each cloud per lane — the tile's work is a dependent chain
+                                    // (load -> cell -> LDS table -> line -> atomics), shorter tiles on more workgroups overlap more of it
 constexpr int kLdsProbes = 16;
 constexpr int kGlobalProbes = 512;
 constexpr unsigned long long kEmpty = 0ull;   // a zero-filled table is empty
@@ -82,6 +83,11 @@ struct TableView {
   unsigned cap;
   __device__ __forceinline__ unsigned long long *line(unsigned slot) const { return w + (size_t)slot * kStride; }
 };
+
+// diagnostics (lsa_front_end_map_stamps): thread 0 of a workgroup notes the 100 MHz wall clock at phase boundaries, 8 per workgroup
+__device__ __forceinline__ void lm_stamp(unsigned long long *stamps, int k) {
+  if (stamps && threadIdx.x == 0) stamps[(size_t)blockIdx.x * 8 + k] = wall_clock64();
+}
 
 struct DirtyView {
   unsigned *slot, *len;      // len[0]: entries of the overflow region slot[0 .. over_cap); len[1 + r]: entries of region r
@@ -141,7 +147,8 @@ __device__ __forceinline__ int lm_lds_insert(unsigned long long *keys, unsigned 
 //           says whether the cell was clean, i.e. whether this workgroup is its first toucher and lists it as dirty.
 template <int NS, int CAP>
 __device__ __forceinline__ void lm_flush(const TableView<NS> &H, const unsigned long long *keys, const int *counts, const unsigned long long (*sums)[NS],
-                                         int *used, int *gslot, unsigned *won, int *n_used, unsigned *n_won, unsigned *n_new_keys, unsigned *overflow) {
+                                         int *used, int *gslot, unsigned *won, int *n_used, unsigned *n_won, unsigned *n_new_keys, unsigned *overflow,
+                                         unsigned long long *stamps = nullptr) {
   constexpr int kPer = CAP / kBlock;
   for (int k = threadIdx.x; k < CAP; k += kBlock)
     if (keys[k] != kEmpty) used[atomicAdd(n_used, 1)] = k;
@@ -165,6 +172,7 @@ __device__ __forceinline__ void lm_flush(const TableView<NS> &H, const unsigned 
     }
   }
   __syncthreads();
+  lm_stamp(stamps, 3);
   for (int e = threadIdx.x; e < nu * NS; e += kBlock) {
     const int u = e / NS, j = e - u * NS;
     const int g = gslot[u];
@@ -185,6 +193,7 @@ __device__ __forceinline__ void lm_flush(const TableView<NS> &H, const unsigned 
     }
   }
   __syncthreads();
+  lm_stamp(stamps, 4);
 }
 
 struct PointsArgs {
@@ -203,11 +212,13 @@ struct PointsArgs {
 };
 
 template <int NS, bool SWAP>
-struct PointsCap { static constexpr int value = SWAP ? (NS == 4 ? 1024 : 512) : (NS == 4 ? 512 : 256); };
+struct PointsCap { static constexpr int value = SWAP ? (NS == 4 ? 512 : 256) : 256; };
 
 template <int NS, int MODE, bool SWAP>
-__global__ __launch_bounds__(kBlock) void k_lm_points(float4 *__restrict__ pts, size_t n, PointsArgs A, TableView<NS> H, DirtyView D, LmStatus *__restrict__ st) {
+__global__ __launch_bounds__(kBlock) void k_lm_points(float4 *__restrict__ pts, size_t n, PointsArgs A, TableView<NS> H, DirtyView D, LmStatus *__restrict__ st,
+                                                      unsigned long long *stamps) {
   constexpr int kLdsCap = PointsCap<NS, SWAP>::value;   // a swap tile carries two clouds' points; == D.region_cap
+  lm_stamp(stamps, 0);
   __shared__ unsigned long long keys[kLdsCap];
   __shared__ int counts[kLdsCap];
   __shared__ unsigned long long sums[kLdsCap][NS];
@@ -240,6 +251,7 @@ __global__ __launch_bounds__(kBlock) void k_lm_points(float4 *__restrict__ pts, 
       pv_all[0][k] = (i < n) ? pts[i] : make_float4(NAN, NAN, NAN, 0.f);
     }
   }
+  lm_stamp(stamps, 1);
 #pragma unroll
   for (int pass = 0; pass < (SWAP ? 2 : 1); pass++) {
     const bool old_pass = SWAP && pass == 0;
@@ -295,7 +307,8 @@ __global__ __launch_bounds__(kBlock) void k_lm_points(float4 *__restrict__ pts, 
     if (SWAP) __syncthreads();   // (the slot's old points are read by the lanes that overwrite them: no hazard; this keeps the passes apart in LDS only)
   }
   __syncthreads();
-  lm_flush<NS, kLdsCap>(H, keys, counts, sums, used, gslot, won, &n_used, &n_won, &n_new_keys, &st->overflow);
+  lm_stamp(stamps, 2);
+  lm_flush<NS, kLdsCap>(H, keys, counts, sums, used, gslot, won, &n_used, &n_won, &n_new_keys, &st->overflow, stamps);
   // the tile's region of the dirty list (every region's length is written, the empty ones' too: the consumer does not clear)
   unsigned *reg = D.region(blockIdx.x);
   for (unsigned e = threadIdx.x; e < n_won; e += kBlock) reg[e] = won[e];
@@ -303,6 +316,7 @@ __global__ __launch_bounds__(kBlock) void k_lm_points(float4 *__restrict__ pts, 
     D.len[1 + blockIdx.x] = n_won;
     if (n_new_keys) atomicAdd(A.to_level_n ? &st->keys_n : &st->keys_f, n_new_keys);
   }
+  lm_stamp(stamps, 5);
 }
 
 // Scan of a dirty list's region lengths by one workgroup: pre[q] = entries in front of region q (q = 0 the overflow region,
@@ -362,9 +376,11 @@ struct FilterDirtyArgs {
 // neighbours (in the order the scan first touches them), so the workgroup's cells fall into a few dozen level-N cells: their
 // changes are summed per N cell in an LDS table first and leave the workgroup as one line's worth of atomics per N cell.
 constexpr int kFdCap = 256;    // LDS slots (N cells) of a workgroup; what does not fit goes straight to memory
-constexpr int kFdPer = 4;      // cells per lane and step: a swap tile's region holds up to 1024
+constexpr int kFdPer = 2;      // cells per lane and step: a swap tile's region holds up to 512
 constexpr unsigned kFdOverWg = 8;   // workgroups that share the overflow region (usually empty)
-__global__ __launch_bounds__(kBlock) void k_lm_filter_dirty(TableView<4> F, DirtyView DF, TableView<10> N, DirtyView DN, FilterDirtyArgs A, LmStatus *__restrict__ st) {
+__global__ __launch_bounds__(kBlock) void k_lm_filter_dirty(TableView<4> F, DirtyView DF, TableView<10> N, DirtyView DN, FilterDirtyArgs A, LmStatus *__restrict__ st,
+                                                            unsigned long long *stamps) {
+  lm_stamp(stamps, 0);
   __shared__ unsigned long long keys[kFdCap];
   __shared__ int counts[kFdCap];
   __shared__ unsigned long long sums[kFdCap][10];
@@ -407,6 +423,7 @@ __global__ __launch_bounds__(kBlock) void k_lm_filter_dirty(TableView<4> F, Dirt
       q0[m] = ln[0]; q1[m] = ln[1]; q2[m] = ln[2];
       oldp[m] = reinterpret_cast<const float4 *>(F.line(s[m]))[3];
     }
+    if (base == 0u || over) lm_stamp(stamps, 1);
 #pragma unroll
     for (int m = 0; m < kFdPer; m++) {
       if (!live[m]) continue;
@@ -463,7 +480,8 @@ __global__ __launch_bounds__(kBlock) void k_lm_filter_dirty(TableView<4> F, Dirt
       }
     }
     __syncthreads();
-    lm_flush<10, kFdCap>(N, keys, counts, sums, used, gslot, won, &n_used, &n_won, &n_new_keys, &st->overflow);
+    lm_stamp(stamps, 2);
+    lm_flush<10, kFdCap>(N, keys, counts, sums, used, gslot, won, &n_used, &n_won, &n_new_keys, &st->overflow, stamps);
     // the cells this step was the first toucher of: into the workgroup's region while it has room, the rest into the overflow region
     {
       unsigned *reg = DN.region(blockIdx.x);
@@ -478,6 +496,7 @@ __global__ __launch_bounds__(kBlock) void k_lm_filter_dirty(TableView<4> F, Dirt
     __syncthreads();
   }
   if (threadIdx.x == 0) DN.len[1 + blockIdx.x] = fill;
+  lm_stamp(stamps, 5);
   // one atomic per wave for the live-cell counter
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) d_live += __shfl_down(d_live, off, 64);
@@ -494,10 +513,13 @@ struct NdtDirtyArgs {
 
 // one lane per touched level-N cell: voxel record + dense table entry
 __global__ __launch_bounds__(kBlock) void k_lm_ndt_dirty(TableView<10> N, DirtyView DN, unsigned *__restrict__ f_over_len, double *__restrict__ rec, float4 *__restrict__ dense,
-                                                         NdtDirtyArgs A, LmStatus *__restrict__ st, LmStatus *__restrict__ host_mirror, unsigned long long epoch) {
+                                                         NdtDirtyArgs A, LmStatus *__restrict__ st, LmStatus *__restrict__ host_mirror, unsigned long long epoch,
+                                                         unsigned long long *stamps) {
+  lm_stamp(stamps, 0);
   __shared__ unsigned pre[kMaxRegions + 2];
   __shared__ unsigned wave_sums[kBlock / 64];
   const unsigned nd = lm_scan_regions(DN, pre, wave_sums);
+  lm_stamp(stamps, 1);
   // workgroups that have a chunk (workgroup 0 always): the others leave without a word
   const unsigned chunks = (nd + kBlock - 1u) / kBlock;
   const unsigned active = chunks < gridDim.x ? (chunks ? chunks : 1u) : gridDim.x;
@@ -516,12 +538,14 @@ __global__ __launch_bounds__(kBlock) void k_lm_ndt_dirty(TableView<10> N, DirtyV
     const int was = (int)(q[6].x >> 32);   // {state, alive} packed in one word: state low, alive high
     int ijk[3];
     lm_unpack(key, ijk);
+    lm_stamp(stamps, 2);
     double *R = rec + (size_t)s * 10;
     int stt = 0;
     if (cnt > 0) {
       double o[3];
       lsa_abs_origin(ijk, A.leaf, o);
       stt = ndt_cell_record(a, cnt, o, A.fs, A.pcl, R);
+      lm_stamp(stamps, 3);
     } else {
 #pragma unroll
       for (int j = 0; j < 10; j++) R[j] = 0.0;
@@ -554,9 +578,11 @@ __global__ __launch_bounds__(kBlock) void k_lm_ndt_dirty(TableView<10> N, DirtyV
   // it done; the workgroup that finds itself last reads the words with device-scope loads.
   __builtin_amdgcn_s_waitcnt(0);
   __syncthreads();
+  lm_stamp(stamps, 4);
   __shared__ unsigned s_last;
   if (threadIdx.x == 0) s_last = atomicAdd(&st->done, 1u) == active - 1u ? 1u : 0u;
   __syncthreads();
+  lm_stamp(stamps, 5);
   if (s_last && threadIdx.x < 64) {
     // one lane per 32-bit word of the block in front of the epoch, all loads in ONE instruction
     constexpr int kW = (int)(offsetof(LmStatus, epoch) / 4);
@@ -574,6 +600,7 @@ __global__ __launch_bounds__(kBlock) void k_lm_ndt_dirty(TableView<10> N, DirtyV
     // would write back the whole L2 — the records and table entries this kernel has just written — for nothing)
     __builtin_amdgcn_s_waitcnt(0);
     if (lane == 0) __hip_atomic_store(&host_mirror->epoch, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    lm_stamp(stamps, 6);
   }
 }
 
@@ -660,6 +687,9 @@ int dirty_shape(lsa_context *ctx, LmDirty &d, unsigned regions, unsigned region_
   return LSA_OK;
 }
 
+// diagnostics: where kernel `which` (0 points, 1 filter_dirty, 2 ndt_dirty) of the NEXT update notes its phase boundaries; null unless enabled
+unsigned long long *lm_stamps(LocalMap &lm, int which) { return lm.stamps.p ? lm.stamps.p + (size_t)which * kMaxRegions * 8 : nullptr; }
+
 NdtDirtyArgs ndt_args(const LocalMap &lm, bool with_window) {
   NdtDirtyArgs A;
   for (int a = 0; a < 3; a++) { A.leaf[a] = lm.leaf_n; A.wmin[a] = lm.wmin[a]; A.wdim[a] = lm.wdim[a]; }
@@ -702,13 +732,13 @@ int lm_points(LocalMap &lm, const float4 *d_pts, size_t n, int sign) {
     A.fs = lm.fs_f;
     A.to_level_n = 0;
     if ((rc = dirty_shape(ctx, lm.dirty_f, g, PointsCap<4, false>::value, lm.cap_f))) return rc;
-    hipLaunchKernelGGL((k_lm_points<4, 0, false>), dim3(g), dim3(kBlock), 0, ctx->stream, const_cast<float4 *>(d_pts), n, A, view_f(lm), view(lm.dirty_f), lm.d_status.p);
+    hipLaunchKernelGGL((k_lm_points<4, 0, false>), dim3(g), dim3(kBlock), 0, ctx->stream, const_cast<float4 *>(d_pts), n, A, view_f(lm), view(lm.dirty_f), lm.d_status.p, (unsigned long long *)nullptr);
   } else {
     for (int a = 0; a < 3; a++) { A.leaf[a] = lm.leaf_n; A.inv[a] = 1.0f / lm.leaf_n; }
     A.fs = lm.fs_n;
     A.to_level_n = 1;
     if ((rc = dirty_shape(ctx, lm.dirty_n, g, PointsCap<10, false>::value, lm.cap_n))) return rc;
-    hipLaunchKernelGGL((k_lm_points<10, 1, false>), dim3(g), dim3(kBlock), 0, ctx->stream, const_cast<float4 *>(d_pts), n, A, view_n(lm), view(lm.dirty_n), lm.d_status.p);
+    hipLaunchKernelGGL((k_lm_points<10, 1, false>), dim3(g), dim3(kBlock), 0, ctx->stream, const_cast<float4 *>(d_pts), n, A, view_n(lm), view(lm.dirty_n), lm.d_status.p, (unsigned long long *)nullptr);
   }
   LSA_HIP(ctx, hipGetLastError());
   return LSA_OK;
@@ -749,13 +779,13 @@ int lm_swap(LocalMap &lm, float4 *d_slot, size_t slot_cap, bool evict, const flo
     A.fs = lm.fs_f;
     A.to_level_n = 0;
     if ((rc = dirty_shape(ctx, lm.dirty_f, g, PointsCap<4, true>::value, lm.cap_f))) return rc;
-    hipLaunchKernelGGL((k_lm_points<4, 0, true>), dim3(g), dim3(kBlock), 0, ctx->stream, d_slot, slot_cap, A, view_f(lm), view(lm.dirty_f), lm.d_status.p);
+    hipLaunchKernelGGL((k_lm_points<4, 0, true>), dim3(g), dim3(kBlock), 0, ctx->stream, d_slot, slot_cap, A, view_f(lm), view(lm.dirty_f), lm.d_status.p, lm_stamps(lm, 0));
   } else {
     for (int a = 0; a < 3; a++) { A.leaf[a] = lm.leaf_n; A.inv[a] = 1.0f / lm.leaf_n; }
     A.fs = lm.fs_n;
     A.to_level_n = 1;
     if ((rc = dirty_shape(ctx, lm.dirty_n, g, PointsCap<10, true>::value, lm.cap_n))) return rc;
-    hipLaunchKernelGGL((k_lm_points<10, 1, true>), dim3(g), dim3(kBlock), 0, ctx->stream, d_slot, slot_cap, A, view_n(lm), view(lm.dirty_n), lm.d_status.p);
+    hipLaunchKernelGGL((k_lm_points<10, 1, true>), dim3(g), dim3(kBlock), 0, ctx->stream, d_slot, slot_cap, A, view_n(lm), view(lm.dirty_n), lm.d_status.p, lm_stamps(lm, 0));
   }
   LSA_HIP(ctx, hipGetLastError());
   return LSA_OK;
@@ -771,13 +801,13 @@ int lm_finish(LocalMap &lm) {
     // one workgroup per tile region + a few for the overflow region; each owns a region of the level-N dirty list
     const unsigned g = lm.dirty_f.regions + kFdOverWg;
     if ((rc = dirty_shape(ctx, lm.dirty_n, g, kFdRegion, lm.cap_n))) return rc;
-    hipLaunchKernelGGL(k_lm_filter_dirty, dim3(g), dim3(kBlock), 0, ctx->stream, view_f(lm), view(lm.dirty_f), view_n(lm), view(lm.dirty_n), A, lm.d_status.p);
+    hipLaunchKernelGGL(k_lm_filter_dirty, dim3(g), dim3(kBlock), 0, ctx->stream, view_f(lm), view(lm.dirty_f), view_n(lm), view(lm.dirty_n), A, lm.d_status.p, lm_stamps(lm, 1));
   }
   lm.epoch++;
   // (a small grid: a key-frame touches ~6 k level-N cells, one per lane of 24 workgroups, and every ACTIVE workgroup ends with one
   // same-address atomic — ~20 ns each at the memory side)
   hipLaunchKernelGGL(k_lm_ndt_dirty, dim3(64), dim3(kBlock), 0, ctx->stream, view_n(lm), view(lm.dirty_n), lm.filtered ? lm.dirty_f.len.p : nullptr, lm.rec.p,
-                     lm.dense.p, ndt_args(lm, true), lm.d_status.p, lm.h_status.p, lm.epoch);
+                     lm.dense.p, ndt_args(lm, true), lm.d_status.p, lm.h_status.p, lm.epoch, lm_stamps(lm, 2));
   LSA_HIP(ctx, hipGetLastError());
   lm.pending = true;
   lm.updates++;
@@ -864,6 +894,24 @@ int lm_rebuild(LocalMap &lm, const float4 *const *d_ranges, const size_t *n_rang
   lm.pending = false;
   lm.valid = true;
   lm.rebuilds++;
+  return LSA_OK;
+}
+
+int lm_stamps_enable(LocalMap &lm, bool on) {
+  if (!on) { lm.stamps.release(); return LSA_OK; }
+  int rc = lm.stamps.reserve(lm.ctx, (size_t)3 * kMaxRegions * 8);
+  if (rc) return rc;
+  LSA_HIP(lm.ctx, hipMemsetAsync(lm.stamps.p, 0, (size_t)3 * kMaxRegions * 8 * sizeof(unsigned long long), lm.ctx->stream));
+  return LSA_OK;
+}
+int lm_stamps_fetch(LocalMap &lm, unsigned long long *out, size_t cap, size_t *per_kernel) {
+  if (per_kernel) *per_kernel = (size_t)kMaxRegions * 8;
+  if (!lm.stamps.p) return LSA_ERR_INVALID;
+  size_t n = (size_t)3 * kMaxRegions * 8;
+  if (n > cap) n = cap;
+  LSA_HIP(lm.ctx, hipMemcpyAsync(out, lm.stamps.p, n * sizeof(unsigned long long), hipMemcpyDeviceToHost, lm.ctx->stream));
+  LSA_HIP(lm.ctx, hipStreamSynchronize(lm.ctx->stream));
+  LSA_HIP(lm.ctx, hipMemsetAsync(lm.stamps.p, 0, (size_t)3 * kMaxRegions * 8 * sizeof(unsigned long long), lm.ctx->stream));
   return LSA_OK;
 }
 

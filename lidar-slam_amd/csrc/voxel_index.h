@@ -31,6 +31,8 @@ struct FixScales {
   double s1, inv_s1;  // first moments  (metres)
   double s2, inv_s2;  // second moments (metres^2)
   double sw, inv_sw;  // intensity / static weight
+  int fast_round;     // every scaled term stays below 2^51: round-to-nearest-even by adding 1.5 * 2^52 (vi_round_ll), same bits as rint
+  int pad;
 };
 
 enum { VI_OK = 0, VI_CAPACITY = 1, VI_RANGE = 2, VI_EMPTY = 3, VI_SPEC_MISS = 4 };

@@ -52,6 +52,9 @@ __host__ __device__ inline FixScales vi_make_scales(double n, double leaf_max, u
   fs.s1 = ldexp(1.0, k1); fs.inv_s1 = ldexp(1.0, -k1);
   fs.s2 = ldexp(1.0, k2); fs.inv_s2 = ldexp(1.0, -k2);
   fs.sw = ldexp(1.0, kw); fs.inv_sw = ldexp(1.0, -kw);
+  // |d| < 2^bits_d, |d d| < 2^(2 bits_d), |w| < 2^10: below 2^51 the terms can be rounded with the magic-number add
+  fs.fast_round = (bits_d + k1 <= 50 && 2 * bits_d + k2 <= 50 && 10 + kw <= 50) ? 1 : 0;
+  fs.pad = 0;
   if (n_cap) *n_cap = (bits_n >= 62) ? ~0ull : ((1ull << bits_n) - 1ull);
   return fs;
 }
@@ -97,22 +100,36 @@ __device__ __forceinline__ void lsa_cell_origin(const CellMap &m, int cell, doub
 }
 
 // fixed-point terms of one point against its cell's low corner `o`: first moments (3), [second moments (6)], intensity
+// x rounded to the nearest integer, ties to even, as a 64-bit integer (what __double2ll_rn gives).  FAST (|x| < 2^51, which the
+// scales guarantee when FixScales::fast_round is set): x + 1.5 * 2^52 lands in [2^52, 2^53), where doubles are the integers, so the
+// add itself rounds x to the nearest-even integer and the sum's low mantissa bits are that integer in offset form: one f64 add and
+// one 64-bit integer subtraction instead of rint + the ~10-instruction f64 -> i64 sequence (gfx950 has no f64 -> i64 conversion), on a
+// path that runs once per point and term (4 or 10 per point in every voxel-index build and in the incremental local map).
+__device__ __forceinline__ unsigned long long vi_round_ll(double x, bool fast) {
+#pragma clang fp contract(off)
+  if (fast) {
+    const double magic = 6755399441055744.0;   // 1.5 * 2^52
+    return (unsigned long long)(__double_as_longlong(x + magic) - __double_as_longlong(magic));
+  }
+  return (unsigned long long)__double2ll_rn(x);
+}
 template <int NS>
 __device__ __forceinline__ void vi_point_terms(const double o[3], const FixScales &fs, const float4 &p, unsigned long long v[NS]) {
 #pragma clang fp contract(off)
+  const bool fast = fs.fast_round != 0;
   double dx = (double)p.x - o[0], dy = (double)p.y - o[1], dz = (double)p.z - o[2];
-  v[0] = (unsigned long long)__double2ll_rn(dx * fs.s1);
-  v[1] = (unsigned long long)__double2ll_rn(dy * fs.s1);
-  v[2] = (unsigned long long)__double2ll_rn(dz * fs.s1);
+  v[0] = vi_round_ll(dx * fs.s1, fast);
+  v[1] = vi_round_ll(dy * fs.s1, fast);
+  v[2] = vi_round_ll(dz * fs.s1, fast);
   if (NS == 10) {
-    v[3] = (unsigned long long)__double2ll_rn(dx * dx * fs.s2);
-    v[4] = (unsigned long long)__double2ll_rn(dx * dy * fs.s2);
-    v[5] = (unsigned long long)__double2ll_rn(dx * dz * fs.s2);
-    v[6] = (unsigned long long)__double2ll_rn(dy * dy * fs.s2);
-    v[7] = (unsigned long long)__double2ll_rn(dy * dz * fs.s2);
-    v[8] = (unsigned long long)__double2ll_rn(dz * dz * fs.s2);
+    v[3] = vi_round_ll(dx * dx * fs.s2, fast);
+    v[4] = vi_round_ll(dx * dy * fs.s2, fast);
+    v[5] = vi_round_ll(dx * dz * fs.s2, fast);
+    v[6] = vi_round_ll(dy * dy * fs.s2, fast);
+    v[7] = vi_round_ll(dy * dz * fs.s2, fast);
+    v[8] = vi_round_ll(dz * dz * fs.s2, fast);
   }
-  v[NS - 1] = (unsigned long long)__double2ll_rn((double)p.w * fs.sw);
+  v[NS - 1] = vi_round_ll((double)p.w * fs.sw, fast);
 }
 
 // the VoxelFilter's output point of a cell: the f32 mean of x, y, z and the intensity from the cell's four sums
