@@ -91,6 +91,9 @@ def main():
     ap.add_argument("--no-large", action="store_true", help="skip the cfg5-sized roofline probe of the pass kernel")
     ap.add_argument("--streams", type=int, default=4, help="extra key `concurrent_streams`: S independent scan streams on ONE GPU (0: skip)")
     args = ap.parse_args()
+    if os.environ.get("LSA_BENCH_DUMP_AFTER"):   # diagnostics: where every thread stands if the run is still going after N seconds
+        import faulthandler
+        faulthandler.dump_traceback_later(int(os.environ["LSA_BENCH_DUMP_AFTER"]), exit=False)
 
     # stdout carries exactly ONE line, the JSON result: RCCL prints a version banner on stdout when its first communicator
     # comes up, gloo a "[Gloo] Rank ..." line, so everything any library writes to fd 1 is sent to stderr instead and the
@@ -294,12 +297,13 @@ def main():
         for i in range(max(0, len(idx) - ns), len(idx)):   # the last visit of every test scan
             results[idx[i]] = (capi.from_colmajor(out[i]), st[i].as_dict(), int(nf[i]))
 
-    def sync_all():
+    def sync_all(local=False):
         # through the library first: lsa_context_synchronize releases anything a handle has left parked on the context's stream
         # before it waits (a bare device-wide wait would sit out a parked kernel's patience)
+        # local: this rank only — the sections only rank 0 runs must not enter a collective the other ranks never reach
         ctx.synchronize(); ctx_f.synchronize()
         torch.cuda.synchronize()
-        if dist_mode:
+        if dist_mode and not local:
             dist.barrier()
             torch.cuda.synchronize()
 
@@ -357,7 +361,7 @@ def main():
         set_mode(False)
         k = 0
         reps = 50
-        sync_all()
+        sync_all(local=True)
 
         def per_call(fn):
             """min / median / max of `reps` synchronous calls (each returns with its result on the host): one outlier — a page
@@ -373,7 +377,7 @@ def main():
         f = f.contiguous()
         ndt.ScanMatch(f, guesses[k])
         _, split["align_ms"], split["align_ms_spread"] = per_call(lambda: ndt.ScanMatch(f, guesses[k]))
-        sync_all()
+        sync_all(local=True)
         split["armed_after_split"] = ndt.armed_stats()
         # PCIe-inclusive rate through the host-pointer boundary (what a PCL caller sees): pack 32-B PointXYZI -> 16 B,
         # H2D, filter, D2H, H2D, align.  Reported for DESIGN.md; it is never the headline `value`.
@@ -732,6 +736,7 @@ def main():
     progress("sharded cfg5 / cfg4")
     cfg5_sharded = None
     cfg4_sharded = None
+    cfg3_sharded = None
     exchange_info = None
     if dist_mode and world > 1 and not args.no_large:
         tgt5 = wl.submap_2m(poses, scans)
@@ -793,6 +798,44 @@ def main():
         src4, g4 = wl.cfg4_source(poses)
         cfg4_sharded = sharded(src4, g4, "cfg4 (BASELINE.json configs[3]): raw ~132 k-point scan sharded over the ranks, 2 M-point target replicated, one all-reduce per pass")
         del d_t5
+
+        def sharded_icp(src_np, guess, mode, label):
+            """BASELINE.json configs[2] over the exchange step: the source sharded over the ranks against the replicated local map,
+            one all-reduce of the iteration's 32-double block (B, H, pairs) per iteration, GetFitnessScore's 2-double sum at the end."""
+            lo, hi = lsa_dist.shard_bounds(int(src_np.shape[0]), rank, world)
+            d_sh = torch.from_numpy(np.ascontiguousarray(src_np[lo:hi])).to(dev)
+            ic = registration.ICPRegistrationHip(ctx, 2.0, 30, mode=mode)
+            ic.SetInputTarget(d_map_f.contiguous())
+            if exchange["native"] is not None:
+                exchange["native"].attach_icp(ic)
+            else:
+                ic.set_allreduce(exchange["cb"])
+            ic.ScanMatch(d_sh, guess)
+            sync_all()
+            t0 = time.perf_counter()
+            _, T_ic = ic.ScanMatch(d_sh, guess)
+            sync_all()
+            t_al = torch.tensor([time.perf_counter() - t0], dtype=torch.float64)
+            dist.all_reduce(t_al, op=dist.ReduceOp.MAX)
+            st_ic = dict(ic.last_stats)
+            fit = float(ic.GetFitnessScore())
+            Tt = torch.from_numpy(np.ascontiguousarray(T_ic, dtype=np.float32).copy())
+            same = [torch.zeros_like(Tt) for _ in range(world)]
+            dist.all_gather(same, Tt)
+            identical = all(torch.equal(x, same[0]) for x in same)     # every rank took the same solve from the summed block
+            ic.close()
+            if rank != 0:
+                return None
+            al = float(t_al.item())
+            return {"workload": label, "ranks": world, "source_points": int(src_np.shape[0]), "source_points_per_rank": int(hi - lo),
+                    "align_ms": round(al * 1e3, 3), "iterations": int(st_ic["iterations"]), "us_per_iteration": round(al * 1e6 / max(1, int(st_ic["iterations"])), 1),
+                    "correspondences": int(st_ic["correspondences"]), "fitness": fit, "poses_identical_across_ranks": bool(identical)}
+
+        cfg3_sharded = {"plane": sharded_icp(src4, g4, capi.ICP_MODE_PLANE, "cfg3 (BASELINE.json configs[2]) at raw-scan size: point-to-plane ICP, ~132 k-point scan sharded over the ranks, local map replicated, one all-reduce per iteration"),
+                        "icpmanual": sharded_icp(src4, g4, 0, "ICPMANUAL (the reference's plugin), same sharding")}
+        if rank != 0:
+            cfg3_sharded = None
+        del src4
 
     # ---- capacity of one GPU beyond a single sensor stream: S independent scan streams (own contexts / HIP streams / filter /
     # registration handles / voxel table each, one host thread per stream in lsa_pipeline_scan_match) share the GPU.  A
@@ -1036,6 +1079,7 @@ def main():
             "kitti_shaped": kitti_key,
             "cfg5_sharded": cfg5_sharded,
             "cfg4_sharded": cfg4_sharded,
+            "cfg3_sharded": cfg3_sharded,
             "exchange": exchange_info,
             "multi_gpu_alt": alt,
             "concurrent_streams": concurrent,

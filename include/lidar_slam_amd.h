@@ -81,6 +81,10 @@ typedef struct lsa_voxel_filter lsa_voxel_filter;
 /* VoxelFilter::VoxelFilter(float leaf_size_x, y, z)  (voxel_filter.cpp:20-22) */
 int lsa_voxel_filter_create(lsa_voxel_filter **out, lsa_context *ctx, float leaf_x, float leaf_y, float leaf_z);
 void lsa_voxel_filter_destroy(lsa_voxel_filter *f);
+/* Optional, no reference counterpart (PCL allocates per call): allocate now what filtering clouds of up to max_points needs,
+ * so that the first Filter calls neither allocate nor have to grow the occupancy bitmap; async_too also starts the helper
+ * thread of lsa_voxel_filter_apply_device_async.  Changes no result. */
+int lsa_voxel_filter_reserve(lsa_voxel_filter *f, size_t max_points, int async_too);
 
 /* Filter(input_cloud_ptr, filtered_cloud_ptr): host AoS in, host AoS out.
  * out may alias in (viewer.cpp:207 calls Filter with in == out); out_cap in points (n is always
@@ -474,8 +478,14 @@ typedef struct {
   lsa_ndt_stats ndt;          /* of this scan's ScanMatch (zero for the first frame) */
 } lsa_front_end_stats;
 
+/* FrontEnd::FrontEnd() + InitWithConfig (front_end.cpp:30-86).  Also allocates the session's device buffers for scans of up to
+ * 160,000 points (lsa_front_end_reserve; environment LSA_FE_RESERVE_POINTS = another size, 0 = allocate on the way as scans come). */
 int lsa_front_end_create(lsa_front_end **out, lsa_context *ctx, const lsa_front_end_config *cfg);
 void lsa_front_end_destroy(lsa_front_end *fe);
+/* Allocate now what Update would otherwise allocate under the first scans of a session (key-frame clouds of a whole window, the
+ * local-map buffer and tables, filter and registration buffers, the batch entry point's stream and helper thread): ~300 MB at
+ * 160 k points.  Larger scans still work (buffers grow); no result depends on it. */
+int lsa_front_end_reserve(lsa_front_end *fe, size_t max_scan_points);
 /* FrontEnd::SetInitPose */
 int lsa_front_end_set_init_pose(lsa_front_end *fe, const float pose[16]);
 /* FrontEnd::Update(cloud_data, cloud_pose): one scan in, its pose (map <- lidar, column-major) out */

@@ -163,6 +163,8 @@ bool ndt_defer_scope(lsa_ndt *h, bool on);
 int ndt_collect_deferred(lsa_ndt *h);
 int lsa_voxel_filter_apply_device_async_here(lsa_voxel_filter *f, const float *d_in_xyzw, size_t n, float *d_out_xyzw);   // voxel_filter.hip
 
+static int fe_batch_context(lsa_front_end *fe);
+
 namespace {
 // The local map buffer is `local_frame_num` slots of slot_cap points; a key-frame's transformed cloud lives in its slot
 // until the frame leaves the window (its pose never changes), so a new key-frame costs ONE transform launch — into the
@@ -448,10 +450,7 @@ int fe_update_batch(lsa_front_end *fe, size_t count, const float *const *d_scans
       if ((rc = fe_update_device(fe, (const float4 *)d_scans[k], n_points[k], poses_out + 16 * k, stats ? stats + k : nullptr))) return rc;
     return LSA_OK;
   }
-  if (!fe->ctx_b) {
-    if ((rc = lsa_context_create(&fe->ctx_b, ctx->device, nullptr))) return lsa_fail(ctx, rc, "lsa_front_end_update_batch_device: second context: %s", lsa_last_global_error());
-    if ((rc = lsa_voxel_filter_create(&fe->frame_filter_b, fe->ctx_b, fe->cfg.frame_leaf[0], fe->cfg.frame_leaf[1], fe->cfg.frame_leaf[2]))) return rc;
-  }
+  if ((rc = fe_batch_context(fe))) return rc;
   size_t n_max = 1;
   for (size_t k = 0; k < count; k++) n_max = std::max(n_max, n_points[k]);
   // before the reserves (they may free a buffer): neither stream may still read the old ones
@@ -513,7 +512,61 @@ extern "C" int lsa_front_end_create(lsa_front_end **out, lsa_context *ctx, const
     rc = lsa_fail(ctx, LSA_ERR_HIP, "lsa_front_end_create: hipEventCreate failed");
   if (rc) { lsa_front_end_destroy(fe); return rc; }
   identity16(fe->init_pose); identity16(fe->last_pose); identity16(fe->predict_pose); identity16(fe->step_pose); identity16(fe->last_kf_pose);
+  // buffers for scans of a 64-beam sensor (<= 160 k points per revolution) are allocated here rather than under the first scans
+  // (lsa_front_end_reserve; LSA_FE_RESERVE_POINTS=0 switches it off, another value sizes it; larger scans still just grow them)
+  const size_t reserve_points = getenv("LSA_FE_RESERVE_POINTS") ? (size_t)atoll(getenv("LSA_FE_RESERVE_POINTS")) : (size_t)160000;
+  if ((rc = lsa_front_end_reserve(fe, reserve_points))) { lsa_front_end_destroy(fe); return rc; }
   *out = fe;
+  return LSA_OK;
+}
+
+// the second context (stream) and frame filter of lsa_front_end_update_batch_device
+static int fe_batch_context(lsa_front_end *fe) {
+  if (fe->ctx_b) return LSA_OK;
+  int rc;
+  if ((rc = lsa_context_create(&fe->ctx_b, fe->ctx->device, nullptr))) return lsa_fail(fe->ctx, rc, "lsa_front_end_update_batch_device: second context: %s", lsa_last_global_error());
+  return lsa_voxel_filter_create(&fe->frame_filter_b, fe->ctx_b, fe->cfg.frame_leaf[0], fe->cfg.frame_leaf[1], fe->cfg.frame_leaf[2]);
+}
+
+int lsa_voxel_filter_reserve(lsa_voxel_filter *f, size_t max_points, int async_too);   // voxel_filter.hip
+
+// Allocate now everything Update would otherwise allocate on its way through the first scans of a session: the frame filters'
+// index buffers and bitmaps, the filtered-cloud buffers, the key-frame clouds of a whole window, the local-map buffer, the
+// incremental map's tables / dirty lists / dense window, the registration's mailbox and row buffers, the batch entry point's second
+// stream and helper thread.  Measured on the 30-scan drive of bench.py: scan 0 costs 450 us, scan 1 340 us and the tenth key-frame
+// 590 us of which ~150 us each are allocation calls, and every key-frame of the first window pays a 10 us hipMalloc.  None of this
+// changes a result: buffers are sized, not laid out (the slot size and the fixed-point scales still come from the first scan).
+extern "C" int lsa_front_end_reserve(lsa_front_end *fe, size_t max_scan_points) {
+  if (!fe) return LSA_ERR_INVALID;
+  lsa_context *ctx = fe->ctx;
+  LSA_HIP(ctx, lsa_enter(ctx));
+  if (max_scan_points == 0) return LSA_OK;
+  const size_t n = max_scan_points;
+  int rc;
+  if (fe->cfg.use_frame_filter) {
+    if ((rc = lsa_voxel_filter_reserve(fe->frame_filter, n, 0))) return rc;
+    if ((rc = fe->d_filtered.reserve(ctx, n, 1.25))) return rc;
+    if ((rc = fe_batch_context(fe))) return rc;
+    if ((rc = lsa_voxel_filter_reserve(fe->frame_filter_b, n, 1))) return lsa_fail(ctx, rc, "%s", lsa_last_error(fe->ctx_b));
+    if (fe->d_batch[0].cap < n) {
+      LSA_HIP(ctx, hipStreamSynchronize(ctx->stream));
+      LSA_HIP(ctx, hipStreamSynchronize(fe->ctx_b->stream));
+      for (int b = 0; b < 3; b++)
+        if ((rc = fe->d_batch[b].reserve(ctx, n, 1.25))) return rc;
+    }
+  }
+  // key-frame clouds: one per slot of the window (an evicted key-frame's object and buffer are reused from then on)
+  while (fe->frames.size() + fe->pool.size() < (size_t)fe->cfg.local_frame_num) {
+    KeyFrame *kf = new KeyFrame();
+    if ((rc = kf->pts.reserve(ctx, n, 1.1))) { delete kf; return rc; }
+    fe->pool.push_back(kf);
+  }
+  if (!fe->d_map.p && (rc = fe->d_map.reserve(ctx, (n + n / 8 + 1) * (size_t)fe->cfg.local_frame_num))) return rc;
+  if (fe->incremental && !fe->lm_off && (rc = lm_reserve(fe->lm, fe->ctx_m, fe->cfg.use_map_filter != 0))) return rc;
+  if ((rc = ndt_reserve(fe->ndt))) return rc;
+  LSA_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  LSA_HIP(ctx, hipStreamSynchronize(fe->ctx_m->stream));
+  LSA_HIP(ctx, hipStreamSynchronize(fe->ctx_b ? fe->ctx_b->stream : ctx->stream));
   return LSA_OK;
 }
 

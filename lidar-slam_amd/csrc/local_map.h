@@ -109,6 +109,8 @@ struct LocalMap {
 
 // scales / leaves / mode; capacities are chosen here (and grown by lm_rebuild when a table fills up)
 int lm_configure(LocalMap &lm, lsa_context *ctx, const float leaf_f[3], float leaf_n, int pcl, unsigned long long scale_n);
+// optional: allocate now, at the default capacities, what a session otherwise allocates on the way (local_map.hip)
+int lm_reserve(LocalMap &lm, lsa_context *ctx, bool with_level_f);
 // The steady-state key-frame in ONE launch: the slot's old contents (the evicted key-frame's transformed points; skipped if
 // !evict) leave the sums while the new key-frame's cloud d_raw is transformed (row-major 3x4, f32, PCL's order) into the slot
 // and enters them; a cell both clouds touch receives its net change once.  Enqueue only.

@@ -761,6 +761,22 @@ int lm_configure(LocalMap &lm, lsa_context *ctx, const float leaf_f[3], float le
   return LSA_OK;
 }
 
+// Everything a session with the default capacities allocates on the way — the status blocks at the first key-frame, level N, its
+// records and dirty list, the dense window at the first re-fit, level F and its dirty list at the switch to the filtered map (the
+// tenth key-frame) — allocated now instead: ~120 MB.  Tables that turn out too small are still grown by lm_rebuild.
+int lm_reserve(LocalMap &lm, lsa_context *ctx, bool with_level_f) {
+  lm.ctx = ctx;
+  int rc;
+  if ((rc = lm.d_status.reserve(ctx, 1)) || (rc = lm.h_status.reserve(ctx, 1))) return rc;
+  if (!lm.cap_n && (rc = alloc_level_n(lm, 1u << 17))) return rc;
+  if (with_level_f && !lm.cap_f && (rc = alloc_level_f(lm, 1u << 20))) return rc;
+  // the dirty lists at the largest shape a launch may ask for (kMaxRegions regions of 512 entries + the overflow region)
+  if ((rc = dirty_shape(ctx, lm.dirty_n, kMaxRegions, 512, lm.cap_n))) return rc;
+  if (with_level_f && (rc = dirty_shape(ctx, lm.dirty_f, kMaxRegions, 512, lm.cap_f))) return rc;
+  if (!lm.dense.p && (rc = lm.dense.reserve(ctx, (size_t)2 << 20))) return rc;
+  return LSA_OK;
+}
+
 int lm_swap(LocalMap &lm, float4 *d_slot, size_t slot_cap, bool evict, const float4 *d_raw, size_t n_raw, const float T_rowmajor12[12],
             float4 *d_keep, bool force_w_one) {
   lsa_context *ctx = lm.ctx;

@@ -51,6 +51,9 @@ int lsa_fail(lsa_context *ctx, int code, const char *fmt, ...);
                       "%s failed: %s (%s:%d)", #call, hipGetErrorString(e__), __FILE__, __LINE__); \
   } while (0)
 
+// diagnostics (LSA_ALLOC_TRACE=1): one line on stderr per device / pinned allocation, so that a loop that should not allocate shows that it does not
+void lsa_alloc_trace(const char *kind, size_t bytes, const char *who);
+
 // grow-only device allocation
 template <typename T>
 struct DevBuf {
@@ -61,6 +64,7 @@ struct DevBuf {
     size_t want = (size_t)((double)n * headroom);
     if (want < n) want = n;
     if (p) { (void)hipFree(p); p = nullptr; cap = 0; }
+    lsa_alloc_trace("device", want * sizeof(T), __PRETTY_FUNCTION__);
     hipError_t e = hipMalloc((void **)&p, want * sizeof(T));
     if (e != hipSuccess) return lsa_fail(ctx, LSA_ERR_HIP, "hipMalloc(%zu B) failed: %s", want * sizeof(T), hipGetErrorString(e));
     cap = want;
@@ -80,6 +84,7 @@ struct PinnedBuf {
     if (n <= cap) return LSA_OK;
     if (p) { (void)hipHostFree(p); p = nullptr; cap = 0; }
     size_t want = n + n / 4;
+    lsa_alloc_trace("pinned", want * sizeof(T), __PRETTY_FUNCTION__);
     hipError_t e = hipHostMalloc((void **)&p, want * sizeof(T), hipHostMallocMapped | hipHostMallocCoherent);
     if (e != hipSuccess) return lsa_fail(ctx, LSA_ERR_HIP, "hipHostMalloc(%zu B) failed: %s", want * sizeof(T), hipGetErrorString(e));
     // The runtime recycles pinned memory WITH its contents.  Several of these buffers receive check-worded rows that the

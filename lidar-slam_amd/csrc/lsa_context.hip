@@ -20,6 +20,11 @@ void lsa_set_global_error(const char *fmt, ...) {
   g_global_err = buf;
 }
 
+void lsa_alloc_trace(const char *kind, size_t bytes, const char *who) {
+  static const bool on = getenv("LSA_ALLOC_TRACE") && atoi(getenv("LSA_ALLOC_TRACE")) != 0;
+  if (on) fprintf(stderr, "[lsa alloc] %s %zu B  %s\n", kind, bytes, who);
+}
+
 int lsa_fail(lsa_context *ctx, int code, const char *fmt, ...) {
   char buf[768];
   va_list ap;

@@ -624,6 +624,14 @@ int ndt_collect_deferred(lsa_ndt *h) { return collect_pending(h); }
 // internal: release a kernel this handle has left parked (the batch is over and nobody is known to follow)
 void ndt_release_parked(lsa_ndt *h) { armed_cancel(h); }
 
+// what the first ScanMatch on a handle otherwise sets up on the way (the mailbox of the armed passes, their host-mapped row
+// buffer, the result block): ~250 us of allocation calls the owner of a handle can pay when it creates it
+int ndt_reserve(lsa_ndt *h) {
+  int rc = mail_ensure(h);
+  if (rc) return rc;
+  return ndt_reserve_armed(h);
+}
+
 extern "C" int lsa_ndt_armed_timing(lsa_ndt *h, double out[6], int reset) {
   if (!h) return LSA_ERR_INVALID;
   if (out) {

@@ -188,7 +188,8 @@ void ndt_mail_post(PassMail *mail_base, const PassParams *P, unsigned long long 
 
 // enqueue the kernel of pass `seq` with `grid` workgroups (>= the grid the pass will turn out to need: the mail names the
 // number that share the tiles, the others leave); it waits at most patience_us for its mail
-int ndt_launch_armed(lsa_ndt *h, const PassParams &P, unsigned long long seq, unsigned grid, double patience_us) {
+// the host-mapped row buffer, the give-up word and the kept first-tile points of the armed passes (sized once, never moved)
+int ndt_reserve_armed(lsa_ndt *h) {
   lsa_context *ctx = h->ctx;
   int rc;
   if ((rc = h->h_partials.reserve(ctx, kHostRowsDoubles))) return rc;
@@ -198,6 +199,13 @@ int ndt_launch_armed(lsa_ndt *h, const PassParams &P, unsigned long long seq, un
   }
   // first-tile points kept from pass to pass (k_ndt_pass_armed): sized once for the largest armed grid, never moved
   if (!h->src_keep.p && (rc = h->src_keep.reserve(ctx, (size_t)kHostReduceMaxBlocks * kWaves * kTilePts))) return rc;
+  return h->h_out.reserve(ctx, kOutDoubles);
+}
+
+int ndt_launch_armed(lsa_ndt *h, const PassParams &P, unsigned long long seq, unsigned grid, double patience_us) {
+  lsa_context *ctx = h->ctx;
+  int rc;
+  if ((rc = ndt_reserve_armed(h))) return rc;
   const PassMail *mail = reinterpret_cast<const PassMail *>(h->mail) + (seq & 1ull);   // the slot of this sequence number's parity
   double *rows = ndt_armed_rows(h, seq);                                                   // ... and its half of the row buffer
   const unsigned long long ticks = (unsigned long long)(patience_us * 100.0);
@@ -307,6 +315,8 @@ unsigned ndt_pass_grid(const lsa_ndt *h, size_t n, int kind) {
   size_t blocks = (n + kWaves * kTilePts - 1) / (kWaves * kTilePts);  // one tile per wave until the chip is full, then grid-stride
   size_t cap = (size_t)h->ctx->num_cus * pass_waves(kind);  // the resident set: every workgroup runs at once
   if (blocks > cap) blocks = cap;
+  static const size_t forced = getenv("LSA_PASS_GRID_CAP") ? (size_t)atoi(getenv("LSA_PASS_GRID_CAP")) : 0;   // experiments: fewer, longer-running workgroups
+  if (forced && blocks > forced) blocks = forced;
   if (blocks < 1) blocks = 1;
   return (unsigned)blocks;
 }

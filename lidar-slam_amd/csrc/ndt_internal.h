@@ -150,6 +150,7 @@ inline const float4 *ndt_dense(const lsa_ndt *h) { return h->dense_ext ? h->dens
 // adopt / leave an external table (ndt_grid.hip); window = {min_b, dim} in cells of the handle's resolution
 int ndt_adopt_external(lsa_ndt *h, const double *rec, const float4 *dense, const int min_b[3], const int dim[3], size_t n_target,
                        int (*materialize)(void *), void *user);
+int ndt_reserve(lsa_ndt *h);   // ndt_api.hip: set up now what the first ScanMatch would allocate
 void ndt_touch_external(lsa_ndt *h, size_t n_target);   // the owner changed the table's contents in place
 int ndt_materialize(lsa_ndt *h);                         // no-op unless the table is external
 int ndt_source_order(lsa_ndt *h, const float4 *d_src, size_t n, const float4 **d_use);   // source_sort.hip

@@ -27,6 +27,7 @@ int ndt_enqueue_pass_host(lsa_ndt *h, const PassParams &P, int kind, unsigned *g
 struct PassMail;
 void ndt_mail_post(PassMail *mail, const PassParams *P, unsigned long long seq, bool cancel, const void *d_src, size_t n, unsigned vgrid, bool kept = false);
 int ndt_launch_armed(lsa_ndt *h, const PassParams &P, unsigned long long seq, unsigned grid, double patience_us);
+int ndt_reserve_armed(lsa_ndt *h);
 unsigned long long ndt_armed_row_key(unsigned long long seq);
 double *ndt_armed_rows(lsa_ndt *h, unsigned long long seq);
 bool ndt_fetch_row_host(const double *row, unsigned long long key, double limit_ms, unsigned long long out32[32],

@@ -283,6 +283,22 @@ extern "C" int lsa_voxel_filter_create(lsa_voxel_filter **out, lsa_context *ctx,
   return LSA_OK;
 }
 
+// Allocate ahead what filtering clouds of up to max_points will need (index buffers, a bitmap of 2^20 words = 33 M cells: a
+// 250 m x 250 m x 60 m box at a 0.5 m leaf with the speculative margin), and start the helper thread of the asynchronous entry
+// point if `async_too`: after this a Filter call over such a cloud allocates nothing and finds the bitmap large enough on its
+// first build.  Optional — every call sizes what it needs — and without effect on any result.
+extern "C" int lsa_voxel_filter_reserve(lsa_voxel_filter *f, size_t max_points, int async_too) {
+  if (!f) return LSA_ERR_INVALID;
+  LSA_HIP(f->ctx, lsa_enter(f->ctx));
+  int rc = vi_prepare(f->ctx, f->vi, max_points ? max_points : 1, 4, (size_t)1 << 20);
+  if (rc) return rc;
+  if (async_too && !f->worker_started) {
+    f->worker = std::thread(filter_worker, f);
+    f->worker_started = true;
+  }
+  return LSA_OK;
+}
+
 extern "C" void lsa_voxel_filter_destroy(lsa_voxel_filter *f) {
   if (!f) return;
   if (getenv("LSA_FILTER_STATS")) fprintf(stderr, "voxel filter: %llu sync calls, %llu speculative misses, %llu capacity growths, W_cap %zu, last W %zu dims %d %d %d\n", f->n_calls, f->n_miss, f->n_cap, f->vi.W_cap, f->vi.W, f->vi.map.dim[0], f->vi.map.dim[1], f->vi.map.dim[2]);

@@ -112,6 +112,9 @@ struct VoxelIndex {
 // build may reuse the previous build's grid definition (defined with a margin) and skip the two bounding-box launches;
 // k_mark flags any finite point that falls outside (spec_miss) and the caller then rebuilds exactly.
 int vi_enqueue(lsa_context *ctx, VoxelIndex &vi, const float4 *d_pts, size_t n, int mode, const float leaf[3], int ns, bool allow_spec = false);
+// Allocate now what a build over up to `n` points with `ns` sums per cell will need, with a bitmap of at least w_min words
+// (vi_enqueue calls this itself; a caller that knows its sizes calls it ahead so that no build allocates).
+int vi_prepare(lsa_context *ctx, VoxelIndex &vi, size_t n, int ns, size_t w_min);
 // Enqueue the D2H copy of the grid definition + result count, record the completion event (call after the caller's own
 // finalize kernel).  vi_wait() blocks on that event only and refreshes vi.map / vi.fs / vi.W / vi.nocc.
 // Returns VI_* in *status.  On VI_CAPACITY the caller calls vi_grow() and re-enqueues.

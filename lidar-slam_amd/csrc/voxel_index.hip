@@ -560,10 +560,12 @@ inline unsigned stream_grid(lsa_context *ctx, size_t n) {
 
 }  // namespace
 
-int vi_enqueue(lsa_context *ctx, VoxelIndex &vi, const float4 *d_pts, size_t n, int mode, const float leaf[3], int ns, bool allow_spec) {
+// every buffer a build over `n` points with `ns` sums per cell needs, and a bitmap of at least w_min words (0: whatever is there,
+// 4096 words on first use — the device reports VI_CAPACITY with the bounding box and vi_grow() sizes it)
+int vi_prepare(lsa_context *ctx, VoxelIndex &vi, size_t n, int ns, size_t w_min) {
   int rc;
   unsigned nb = stream_grid(ctx, n);
-  if ((rc = vi.scratch.reserve(ctx, (size_t)nb * 8 + 8))) return rc;
+  if ((rc = vi.scratch.reserve(ctx, (size_t)nb * 8 + 8, 1.25))) return rc;
   if ((rc = vi.dparams.reserve(ctx, 1))) return rc;
   if ((rc = vi.h_params.reserve(ctx, 2))) return rc;
   if (!vi.ev_done) LSA_HIP(ctx, hipEventCreateWithFlags(&vi.ev_done, hipEventDisableTiming | hipEventReleaseToSystem));
@@ -574,19 +576,29 @@ int vi_enqueue(lsa_context *ctx, VoxelIndex &vi, const float4 *d_pts, size_t n, 
   if ((rc = vi.cnt.reserve(ctx, n + 1, 1.25))) return rc;
   if ((rc = vi.acc.reserve(ctx, (n + 1) * (size_t)ns, 1.25))) return rc;
   if (vi.cnt.cap != old_cnt || vi.acc.cap != old_acc || vi.cell_of_rank.cap != old_cor || vi.acc_ns != ns) vi.clean = false;
-  if (vi.W_cap == 0) {  // first use: a small bitmap; the device reports VI_CAPACITY with the bbox and vi_grow() sizes it
-    vi.W_cap = 4096;
-    if ((rc = vi.bits.reserve(ctx, vi.W_cap))) return rc;
-    if ((rc = vi.prefix.reserve(ctx, vi.W_cap))) return rc;
-    if ((rc = vi.scan_state.reserve(ctx, vi.W_cap / kScanTile + 2))) return rc;
+  if (vi.W_cap == 0 && w_min < 4096) w_min = 4096;
+  if (vi.W_cap < w_min) {
+    w_min = (w_min + kScanTile - 1) / kScanTile * kScanTile;  // whole scan tiles: k_scan reads / writes 16-byte vectors
+    if (vi.bits.p) LSA_HIP(ctx, hipStreamSynchronize(ctx->stream));   // (the reserves free the old bitmap)
+    if ((rc = vi.bits.reserve(ctx, w_min))) return rc;
+    if ((rc = vi.prefix.reserve(ctx, w_min))) return rc;
+    if ((rc = vi.scan_state.reserve(ctx, w_min / kScanTile + 2))) return rc;
     LSA_HIP(ctx, hipMemsetAsync(vi.scan_state.p, 0, vi.scan_state.cap * sizeof(unsigned long long), ctx->stream));
     vi.scan_epoch = 0;
+    vi.W_cap = w_min;
     vi.clean = false;
   }
   if (!vi.tickets.p) {
     if ((rc = vi.tickets.reserve(ctx, 2))) return rc;
     LSA_HIP(ctx, hipMemsetAsync(vi.tickets.p, 0, 2 * sizeof(unsigned), ctx->stream));
   }
+  return LSA_OK;
+}
+
+int vi_enqueue(lsa_context *ctx, VoxelIndex &vi, const float4 *d_pts, size_t n, int mode, const float leaf[3], int ns, bool allow_spec) {
+  int rc;
+  unsigned nb = stream_grid(ctx, n);
+  if ((rc = vi_prepare(ctx, vi, n, ns, 0))) return rc;
   if (++vi.scan_epoch >= (1u << 30)) {  // epoch wrap: invalidate every state word the old way
     LSA_HIP(ctx, hipMemsetAsync(vi.scan_state.p, 0, vi.scan_state.cap * sizeof(unsigned long long), ctx->stream));
     vi.scan_epoch = 1;
@@ -604,9 +616,11 @@ int vi_enqueue(lsa_context *ctx, VoxelIndex &vi, const float4 *d_pts, size_t n, 
   for (int a = 0; a < 3; a++) req.leaf[a] = leaf[a];
   req.W_cap = vi.W_cap;
   req.scale_n_min = vi.scale_n_min;
-  // only for small inputs: there the two bounding-box launches are ~10 of ~50 us; on a 2 M-point map they are noise, the
-  // extent moves with the vehicle, and a miss costs a whole second build
-  req.expand = (allow_spec && mode == 0 && n < kSmallInput) ? 1 : 0;
+  // (round 4: for large inputs too.  At 2 M points the two bounding-box launches are 16 of ~100 us — a full read of the cloud —
+  // and a map assembled from a sliding window of key-frames keeps its extent from one build to the next: the box is defined with
+  // a 10 % margin, the window moves ~2 m per key-frame, so a miss — detected by k_mark, answered with one exact rebuild — comes
+  // about once in a dozen builds.)
+  req.expand = (allow_spec && mode == 0) ? 1 : 0;
   // reuse the previous build's grid definition (still in vi.dparams on the device) when it is known to be good for
   // this request: same rule set and leaf, scales valid for n, bitmap capacity unchanged
   const bool spec = req.expand && vi.spec_valid && vi.spec_mode == mode && vi.spec_leaf[0] == leaf[0] && vi.spec_leaf[1] == leaf[1] &&

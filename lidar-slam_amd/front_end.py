@@ -68,12 +68,17 @@ class FrontEndHip:
         L.lsa_front_end_set_incremental.argtypes = [C.c_void_p, C.c_int]
         L.lsa_front_end_map_counters.argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]
         L.lsa_front_end_map_verify.argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]
+        L.lsa_front_end_reserve.argtypes = [C.c_void_p, C.c_size_t]
         self.ctx = ctx
         self.cfg = config or default_config()
         h = C.c_void_p()
         ctx.check(L.lsa_front_end_create(C.byref(h), ctx.h, C.byref(self.cfg)))
         self.h = h
         self._last_st, self._last_dict = None, None
+
+    def reserve(self, max_scan_points):
+        """lsa_front_end_reserve: allocate now what Update would allocate under the first scans (create already does it for 160 k points)."""
+        self.ctx.check(capi.lib().lsa_front_end_reserve(self.h, int(max_scan_points)))
 
     def SetInitPose(self, init_pose):  # noqa: N802
         p = capi.colmajor(init_pose)

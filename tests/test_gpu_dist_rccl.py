@@ -1,6 +1,6 @@
 """GPU: the multi-GPU exchange step through REAL RCCL (backend "nccl"), on the one GPU a test box has: a process group of
-size 1.  The sum over one rank is the identity, so ScanMatch with the all-reduce callback installed must reproduce the
-single-GPU result bit for bit — what this exercises is everything a world of 8 also needs: RCCL initialisation, the
+size 1.  The sum over one rank is the identity, so ScanMatch (NDT, ICPMANUAL, point-to-plane ICP) and GetFitnessScore with
+the all-reduce installed must reproduce the single-GPU result bit for bit — what this exercises is everything a world of 8 also needs: RCCL initialisation, the
 zero-copy alias of the library's 32-double device buffer as a torch tensor, and the ordering of kernel -> collective ->
 copy on one HIP stream.  (The world-2 sharding arithmetic is covered on CPU by tests/test_dist_cpu.py over gloo.)"""
 import os
@@ -53,6 +53,33 @@ native.close()
 assert np.array_equal(T_single, T_native) and st_native["passes"] == st_single["passes"] and st_native["score"] == st_single["score"]
 assert np.array_equal(T_single, T_rccl), (T_single, T_rccl)
 assert st_single["passes"] == st_rccl["passes"] and st_single["score"] == st_rccl["score"]
+# fitness (GetFitnessScore: a 2-double sum) and the ICP plugins (one 32-double block per iteration) over the same exchange step
+fit_single = ndt.GetFitnessScore()
+native = lsa_dist.NativeRccl(ctx, 0, 1)
+native.attach(ndt)
+_, T_n2 = ndt.ScanMatch(d_s[lo:hi], guess)
+fit_native = ndt.GetFitnessScore()
+capi.lib().lsa_ndt_set_allreduce_rccl(ndt.h, None)
+assert np.array_equal(T_n2, T_single) and fit_native == fit_single, (fit_native, fit_single)
+for mode in (0, capi.ICP_MODE_PLANE):
+    icp = registration.ICPRegistrationHip(ctx, 2.0, 30, mode=mode)
+    icp.SetInputTarget(d_t)
+    _, Ti = icp.ScanMatch(d_s, guess)
+    st_i = dict(icp.last_stats); fit_i = icp.GetFitnessScore()
+    icp.set_allreduce(lsa_dist.make_rccl_allreduce())          # torch.distributed's RCCL group through the callback
+    _, Tc = icp.ScanMatch(d_s[lo:hi], guess)
+    st_c = dict(icp.last_stats); fit_c = icp.GetFitnessScore()
+    icp.set_allreduce(None)
+    native.attach_icp(icp)                                      # the library's own ncclAllReduce on the handle's stream
+    _, Tn = icp.ScanMatch(d_s[lo:hi], guess)
+    st_n = dict(icp.last_stats); fit_n = icp.GetFitnessScore()
+    capi.lib().lsa_icp_set_allreduce_rccl(icp.h, None)
+    assert st_i["iterations"] > 1
+    assert np.array_equal(Ti, Tc) and np.array_equal(Ti, Tn), (mode, Ti, Tc, Tn)
+    assert st_i == st_c == st_n, (mode, st_i, st_c, st_n)
+    assert fit_i == fit_c == fit_n, (mode, fit_i, fit_c, fit_n)
+    icp.close()
+native.close()
 ndt.close(); ctx.close()
 dist.destroy_process_group()
 print("RCCL_PATH_OK", st_rccl["passes"])
