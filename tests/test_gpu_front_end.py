@@ -269,6 +269,45 @@ def test_update_batch_equals_single_updates(scene):
     fe_b.close(); fe_s.close(); ctx_b.close(); ctx_s.close()
 
 
+def test_reserve_changes_no_result(scene, monkeypatch):
+    """lsa_front_end_reserve (what lsa_front_end_create calls for 160 k-point scans) only moves allocations ahead of the drive: a front end
+    created with the reservation switched off (LSA_FE_RESERVE_POINTS=0: every buffer allocated under the scan that first needs it,
+    bitmaps grown after a capacity report), one reserved far too small (the buffers grow under the drive) and the default one give
+    the same poses, statistics and map, bit for bit — scan by scan and as one run."""
+    import torch
+    N = 30
+    poses = synth.trajectory(N, step=1.1)
+    scans = [synth.gen_scan(scene, poses[i], seed=2300 + i, beams=32, az_steps=900) for i in range(N)]
+    d = [torch.from_numpy(np.ascontiguousarray(s)).cuda() for s in scans]
+    torch.cuda.synchronize()
+    cfg = front_end.default_config()
+    cfg.local_frame_num = 12
+    runs = {}
+    for name, env in (("default", None), ("off", "0"), ("small", "500")):
+        if env is None:
+            monkeypatch.delenv("LSA_FE_RESERVE_POINTS", raising=False)
+        else:
+            monkeypatch.setenv("LSA_FE_RESERVE_POINTS", env)
+        ctx = capi.Context(0)
+        fe = front_end.FrontEndHip(ctx, cfg)
+        T_all, st_all = [], []
+        for i in range(N // 2):
+            _, T = fe.Update(d[i])
+            T_all.append(T); st_all.append(_flat(fe.last_stats))
+        Ts, sts = fe.UpdateBatch(d[N // 2:])
+        T_all += list(Ts); st_all += [_flat(x) for x in sts]
+        runs[name] = (np.stack(T_all), st_all, fe.map_verify(), fe.map_counters())
+        fe.close(); ctx.close()
+    monkeypatch.delenv("LSA_FE_RESERVE_POINTS", raising=False)
+    ref = runs["default"]
+    assert sum(1 for x in ref[1] if x) == N and ref[2]["mismatches"] == 0
+    for name in ("off", "small"):
+        got = runs[name]
+        assert np.array_equal(got[0], ref[0]), name
+        assert got[1] == ref[1], name
+        assert got[2] == ref[2] and got[3] == ref[3], (name, got[2], ref[2], got[3], ref[3])
+
+
 def test_update_batch_full_rebuild_and_no_frame_filter(scene):
     """The same equality with the incremental local map switched off (every key-frame rebuilds filter output and voxel table on the
     registration's stream, between two ScanMatches of the run) and, separately, without a frame filter (nothing to overlap: the run
