@@ -85,6 +85,10 @@ void lsa_voxel_filter_destroy(lsa_voxel_filter *f);
  * so that the first Filter calls neither allocate nor have to grow the occupancy bitmap; async_too also starts the helper
  * thread of lsa_voxel_filter_apply_device_async.  Changes no result. */
 int lsa_voxel_filter_reserve(lsa_voxel_filter *f, size_t max_points, int async_too);
+/* Diagnostics: out[0] synchronous builds, [1] builds repeated because a point fell outside the reused cell box, [2] bitmap growths,
+ * [3] host clouds whose rows the device pulled over the link itself while they were being packed (lsa_voxel_filter_apply, from the
+ * second scan of a stream on; environment LSA_FILTER_PULL=0 selects the copy-command path). */
+int lsa_voxel_filter_counters(lsa_voxel_filter *f, uint64_t out[4]);
 
 /* Filter(input_cloud_ptr, filtered_cloud_ptr): host AoS in, host AoS out.
  * out may alias in (viewer.cpp:207 calls Filter with in == out); out_cap in points (n is always

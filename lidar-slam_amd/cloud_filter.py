@@ -59,6 +59,14 @@ class VoxelFilterHip(CloudFilterInterface):
             self.ctx.check(rc)
         return True, (buf[: n_out.value] if own else buf[: n_out.value].copy())
 
+    def counters(self):
+        """lsa_voxel_filter_counters: builds, speculative misses, bitmap growths, host clouds pulled by the device."""
+        out = (C.c_uint64 * 4)()
+        L = capi.lib()
+        L.lsa_voxel_filter_counters.argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]
+        self.ctx.check(L.lsa_voxel_filter_counters(self.h, out))
+        return dict(builds=out[0], misses=out[1], growths=out[2], pulled=out[3])
+
     def filter_device(self, d_in, d_out=None):
         """Device path: d_in a CUDA float32 tensor (n, 4) {x,y,z,intensity}; returns a view of d_out[:m]."""
         import torch

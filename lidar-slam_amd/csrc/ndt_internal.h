@@ -64,6 +64,8 @@ struct lsa_ndt {
   const float4 *d_source = nullptr;
   size_t n_source = 0;
   PinnedBuf<float> h_stage;
+  hipEvent_t ev_upload = nullptr;   // behind the kernel that took the last host cloud out of h_stage (upload_points)
+  bool upload_pending = false;
 
   // per-pass buffers
   DevBuf<double> partials;      // [grid][kOutDoubles]

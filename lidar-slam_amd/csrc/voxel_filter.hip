@@ -8,6 +8,8 @@
 // the points once per streaming pass (bbox, mark, accumulate: 3 x 16*N + 2 x 4*N cell ids).
 #include "voxel_index_dev.h"
 
+#include <immintrin.h>
+
 #include <atomic>
 #include <chrono>
 #include <condition_variable>
@@ -44,6 +46,22 @@ struct lsa_voxel_filter {
   unsigned long long n_miss = 0, n_calls = 0, n_cap = 0;
   hipStream_t stream2 = nullptr;   // second copy queue of the host path (two SDMA queues move 2 MB in ~50 us, one in ~73)
   hipEvent_t ev2 = nullptr;
+  // job kind 4 (the pulled host path, lsa_voxel_filter_apply): both threads claim chunks of the caller's cloud from u_next, pack them
+  // into h_stage and publish ready[chunk] = pull_seq; the mark kernel (already enqueued) takes each chunk over the link as it appears
+  PinnedBuf<unsigned> h_ready;
+  // a second packer (packing 131 k rows is ~70 us of one core's memory bandwidth; the link needs 44): same claim loop, own thread.
+  // p2_state: 0 idle, 1 posted, 3 packing, 2 done, -1 shut down
+  std::thread packer2;
+  std::atomic<int> p2_state{0};
+  bool packer2_started = false;
+  std::atomic<unsigned> u_next{0};
+  unsigned u_chunks = 0, pull_seq = 0;
+  bool no_pull = getenv("LSA_FILTER_PULL") ? atoi(getenv("LSA_FILTER_PULL")) == 0 : false;
+  unsigned long long n_pulled = 0;
+  // LSA_FILTER_STATS: where a pulled call spends its time (sums of microseconds) and how many chunks the caller's thread packed itself
+  bool stats_on = getenv("LSA_FILTER_STATS") != nullptr;
+  double st_enqueue = 0, st_pack = 0, st_join = 0, st_wait = 0, st_unpack = 0;
+  unsigned long long st_main_chunks = 0, st_withdrawn = 0;
 };
 
 namespace {
@@ -74,7 +92,12 @@ __global__ __launch_bounds__(kBlock) void k_filter_finalize(long long *__restric
   bits[cell >> 5] = 0u;
 }
 
-int filter_device(lsa_voxel_filter *f, const float4 *d_in, size_t n, float4 *d_out, size_t *n_out) {
+void filter_pull_join(lsa_voxel_filter *f);
+
+// pull (host path only): the first attempt's mark kernel takes the rows out of pinned memory while both threads are still packing
+// them (filter_pull_join: this thread packs too, then waits for the helper); d_in is where the kernel leaves them, so a rebuild
+// after a speculative miss finds them resident
+int filter_device(lsa_voxel_filter *f, const float4 *d_in, size_t n, float4 *d_out, size_t *n_out, const PullSource *pull = nullptr) {
   lsa_context *ctx = f->ctx;
   *n_out = 0;
   if (n == 0) return LSA_OK;
@@ -84,13 +107,23 @@ int filter_device(lsa_voxel_filter *f, const float4 *d_in, size_t n, float4 *d_o
   int rc, status = VI_OK;
   f->n_calls++;
   for (int attempt = 0; attempt < 3; attempt++) {
-    if ((rc = vi_enqueue(ctx, vi, d_in, n, /*mode PCL*/ 0, f->leaf, 4, /*allow_spec*/ true))) return rc;
-    hipLaunchKernelGGL(k_filter_finalize, dim3(lsa_div_up(n, kBlock)), dim3(kBlock), 0, ctx->stream, vi.acc.p, vi.cnt.p, vi.cell_of_rank.p, vi.dparams.p,
-                       d_out, vi.h_params.p, vi.bits.p);
-    LSA_HIP(ctx, hipGetLastError());
-    if ((rc = vi_mark_done(ctx, vi))) return rc;
+    const bool pulling = pull && attempt == 0;
+    const auto tq0 = std::chrono::steady_clock::now();
+    rc = vi_enqueue(ctx, vi, d_in, n, /*mode PCL*/ 0, f->leaf, 4, /*allow_spec*/ true, pulling ? pull : nullptr);
+    if (!rc) {
+      hipLaunchKernelGGL(k_filter_finalize, dim3(lsa_div_up(n, kBlock)), dim3(kBlock), 0, ctx->stream, vi.acc.p, vi.cnt.p, vi.cell_of_rank.p, vi.dparams.p,
+                         d_out, vi.h_params.p, vi.bits.p);
+      if (hipGetLastError() != hipSuccess) rc = lsa_fail(ctx, LSA_ERR_HIP, "voxel filter: launch failed");
+    }
+    if (!rc) rc = vi_mark_done(ctx, vi);
+    if (pulling && f->stats_on) f->st_enqueue += std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - tq0).count();
+    if (pulling) filter_pull_join(f);   // (also behind a failed enqueue: the helper thread is packing the caller's cloud and must be done before this returns)
+    if (rc) return rc;
+    const auto tw0 = std::chrono::steady_clock::now();
     if ((rc = vi_wait(ctx, vi, &status))) return rc;
+    if (pulling && f->stats_on) f->st_wait += std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - tw0).count();
     vi.clean = (status == VI_OK || status == VI_SPEC_MISS);  // the finalize kernel zeroed what this build touched
+    if (status == VI_SPEC_MISS && vi.last_pull_timeout) return lsa_fail(ctx, LSA_ERR_HIP, "voxel filter: the device waited in vain for the packed rows of the host cloud");
     if (status == VI_SPEC_MISS) { f->n_miss++; continue; }  // a point fell outside the reused cell box: rebuild from the bounding box
     if (status != VI_CAPACITY) break;
     f->n_cap++;
@@ -122,6 +155,42 @@ int filter_enqueue(lsa_voxel_filter *f, const float4 *d_in, size_t n, float4 *d_
 }  // namespace
 
 namespace {
+constexpr unsigned kPullChunkShift = 13;   // 8 192 rows = 128 KB per chunk: ~4 us of packing, ~3 us on the link
+// claim chunks until none is left: pack, then publish (rows before the flag; the kernel acquires the flag at system scope)
+unsigned filter_pack_chunks(lsa_voxel_filter *f) {
+  const size_t chunk = (size_t)1 << kPullChunkShift;
+  for (unsigned done = 0;; done++) {
+    const unsigned c = f->u_next.fetch_add(1, std::memory_order_relaxed);
+    if (c >= f->u_chunks) return done;
+    const size_t at = (size_t)c * chunk, m = f->u_n - at < chunk ? f->u_n - at : chunk;
+    lsa_pack_xyzw((const char *)f->u_pts + at * f->u_stride, m, f->u_stride, f->u_w_off, f->h_stage.p + 4 * at);
+    _mm_sfence();
+    __atomic_store_n(f->h_ready.p + (size_t)c * kPullFlagStride, f->pull_seq, __ATOMIC_RELEASE);
+  }
+}
+
+// the second packer's thread: spins for 200 us after a job (scans come back to back in a loop), then sleeps in short naps — it never
+// touches HIP, the context or anything but the claim counter, the caller's rows, the staging buffer and the flags
+void filter_packer2(lsa_voxel_filter *f) {
+  for (;;) {
+    auto t0 = std::chrono::steady_clock::now();
+    int st;
+    for (unsigned spin = 0;; spin++) {
+      st = f->p2_state.load(std::memory_order_acquire);
+      if (st == 1 || st == -1) break;
+      __builtin_ia32_pause();
+      if ((spin & 1023u) == 1023u && std::chrono::steady_clock::now() - t0 > std::chrono::microseconds(200)) {
+        std::this_thread::sleep_for(std::chrono::microseconds(50));
+      }
+    }
+    if (st == -1) return;
+    int expect = 1;
+    if (!f->p2_state.compare_exchange_strong(expect, 3, std::memory_order_acq_rel)) continue;   // withdrawn meanwhile
+    (void)filter_pack_chunks(f);
+    f->p2_state.store(2, std::memory_order_release);
+  }
+}
+
 void filter_worker(lsa_voxel_filter *f) {
   (void)hipSetDevice(f->ctx->device);
   for (;;) {
@@ -149,6 +218,16 @@ void filter_worker(lsa_voxel_filter *f) {
       // caller's next wait on the device ~11 us of bookkeeping) while the caller's thread drives the last registration
       f->job_hip = hipStreamSynchronize(f->ctx->stream);
       f->job_rc = f->job_hip == hipSuccess ? LSA_OK : LSA_ERR_HIP;
+      f->job_state.store(2, std::memory_order_release);
+      continue;
+    }
+    if (f->job_kind == 4) {
+      // claimed, not just seen: the caller withdraws a job the helper has not picked up by the time every chunk is packed (a helper
+      // that was asleep needs ~50 us to wake — longer than the whole cloud takes to pack)
+      int expect = 1;
+      if (!f->job_state.compare_exchange_strong(expect, 3, std::memory_order_acq_rel)) continue;
+      (void)filter_pack_chunks(f);
+      f->job_rc = LSA_OK;
       f->job_state.store(2, std::memory_order_release);
       continue;
     }
@@ -187,6 +266,34 @@ void filter_post_job(lsa_voxel_filter *f, int kind) {
     f->job_state.store(1, std::memory_order_release);
   }
   f->cv.notify_one();
+}
+}  // namespace
+
+namespace {
+void filter_pull_join(lsa_voxel_filter *f) {
+  const auto t0 = std::chrono::steady_clock::now();
+  const unsigned mine = filter_pack_chunks(f);
+  const auto t1 = std::chrono::steady_clock::now();
+  bool withdrawn = false;
+  for (;;) {   // every chunk is claimed; the helper may still be packing its last one — or may never have woken up
+    int st = f->job_state.load(std::memory_order_acquire);
+    if (st == 2) { f->job_state.store(0, std::memory_order_release); break; }
+    if (st == 1 && f->job_state.compare_exchange_strong(st, 0, std::memory_order_acq_rel)) { withdrawn = true; break; }   // withdrawn before it was claimed
+    __builtin_ia32_pause();
+  }
+  for (;;) {   // the same for the second packer
+    int st = f->p2_state.load(std::memory_order_acquire);
+    if (st == 0) break;
+    if (st == 2) { f->p2_state.store(0, std::memory_order_release); break; }
+    if (st == 1 && f->p2_state.compare_exchange_strong(st, 0, std::memory_order_acq_rel)) break;
+    __builtin_ia32_pause();
+  }
+  if (f->stats_on) {
+    f->st_pack += std::chrono::duration<double, std::micro>(t1 - t0).count();
+    f->st_join += std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t1).count();
+    f->st_main_chunks += mine;
+    f->st_withdrawn += withdrawn ? 1 : 0;
+  }
 }
 }  // namespace
 
@@ -299,9 +406,22 @@ extern "C" int lsa_voxel_filter_reserve(lsa_voxel_filter *f, size_t max_points, 
   return LSA_OK;
 }
 
+// diagnostics: out[0] synchronous builds, [1] speculative misses (built twice), [2] bitmap growths, [3] host clouds whose rows the
+// mark kernel pulled over the link itself (lsa_voxel_filter_apply's steady state)
+extern "C" int lsa_voxel_filter_counters(lsa_voxel_filter *f, uint64_t out[4]) {
+  if (!f || !out) return LSA_ERR_INVALID;
+  out[0] = f->n_calls; out[1] = f->n_miss; out[2] = f->n_cap; out[3] = f->n_pulled;
+  return LSA_OK;
+}
+
 extern "C" void lsa_voxel_filter_destroy(lsa_voxel_filter *f) {
   if (!f) return;
   if (getenv("LSA_FILTER_STATS")) fprintf(stderr, "voxel filter: %llu sync calls, %llu speculative misses, %llu capacity growths, W_cap %zu, last W %zu dims %d %d %d\n", f->n_calls, f->n_miss, f->n_cap, f->vi.W_cap, f->vi.W, f->vi.map.dim[0], f->vi.map.dim[1], f->vi.map.dim[2]);
+  if (f->stats_on && f->n_pulled) {
+    const double k = 1.0 / (double)f->n_pulled;
+    fprintf(stderr, "voxel filter: %llu pulled host clouds: enqueue %.1f us, this thread packing %.1f us (%.1f chunks), waiting for the helper %.1f us (withdrawn %llu), waiting for the build %.1f us\n",
+            f->n_pulled, f->st_enqueue * k, f->st_pack * k, (double)f->st_main_chunks * k, f->st_join * k, f->st_withdrawn, f->st_wait * k);
+  }
   if (f->worker_started) {
     {
       std::lock_guard<std::mutex> lk(f->mu);
@@ -310,10 +430,14 @@ extern "C" void lsa_voxel_filter_destroy(lsa_voxel_filter *f) {
     f->cv.notify_one();
     f->worker.join();
   }
+  if (f->packer2_started) {
+    f->p2_state.store(-1, std::memory_order_release);
+    f->packer2.join();
+  }
   (void)lsa_enter(f->ctx);
   (void)hipStreamSynchronize(f->ctx->stream);
   if (f->stream2) { (void)hipStreamSynchronize(f->stream2); (void)hipStreamDestroy(f->stream2); (void)hipEventDestroy(f->ev2); }
-  f->vi.release(); f->d_in.release(); f->d_out.release(); f->d_pipe.release(); f->h_stage.release();
+  f->vi.release(); f->d_in.release(); f->d_out.release(); f->d_pipe.release(); f->h_stage.release(); f->h_ready.release();
   delete f;
 }
 
@@ -347,7 +471,33 @@ extern "C" int lsa_voxel_filter_apply(lsa_voxel_filter *f, const void *in_pts, s
   // ~35 us on one copy queue.  Large clouds are therefore split in two: the helper thread packs the second half and sends
   // it down a second copy queue while this thread does the same with the first half (measured: the data is resident
   // after ~85 us instead of ~100: the two packers share the memory system and the runtime's locks).
-  if (n >= 65536 && !f->pending) {
+  bool pulled = false;
+  PullSource pull;
+  if (n >= 65536 && !f->pending && !f->no_pull && vi_spec_ready(f->vi, n, 0, f->leaf)) {
+    // The steady state of a scan stream (the previous scan left a grid definition this one fits): nothing is copied by a copy
+    // command.  The helper thread starts packing at once, this thread enqueues the build — whose first kernel pulls the rows as
+    // they are published — and then packs too (filter_device -> filter_pull_join).
+    const size_t chunk = (size_t)1 << kPullChunkShift;
+    f->u_chunks = (unsigned)((n + chunk - 1) / chunk);
+    if ((rc = f->h_ready.reserve(ctx, (size_t)f->u_chunks * kPullFlagStride))) return rc;
+    if (++f->pull_seq == 0) f->pull_seq = 1;   // (the flags start zeroed and are never reset: a sequence number per call)
+    f->u_pts = in_pts; f->u_stride = in_stride; f->u_w_off = in_w_off; f->u_off = 0; f->u_n = n;
+    f->u_next.store(0, std::memory_order_relaxed);
+    pull.h_rows = reinterpret_cast<const float4 *>(f->h_stage.p);
+    pull.d_copy = f->d_in.p;
+    pull.ready = f->h_ready.p;
+    pull.seq = f->pull_seq;
+    pull.chunk_shift = kPullChunkShift;
+    pull.patience_ticks = 200000000ull;   // 2 s
+    filter_post_job(f, 4);
+    if (!f->packer2_started) {
+      f->packer2 = std::thread(filter_packer2, f);
+      f->packer2_started = true;
+    }
+    f->p2_state.store(1, std::memory_order_release);
+    pulled = true;
+    f->n_pulled++;
+  } else if (n >= 65536 && !f->pending) {
     if (!f->stream2) {
       LSA_HIP(ctx, hipStreamCreateWithFlags(&f->stream2, hipStreamNonBlocking));
       LSA_HIP(ctx, hipEventCreateWithFlags(&f->ev2, hipEventDisableTiming));
@@ -375,7 +525,9 @@ extern "C" int lsa_voxel_filter_apply(lsa_voxel_filter *f, const void *in_pts, s
   // command and a second wait (13 us).  The staging buffer is free by then — its uploads were ordered in front of the kernels —
   // and visible to the host once the build's completion event has been waited for (vi_wait); a build that ends in the range
   // error writes nothing, so the packed input the pass-through below reads is still there.
-  rc = filter_device(f, f->d_in.p, n, reinterpret_cast<float4 *>(f->h_stage.p), &V);
+  // (pulled: the staging buffer is input and output at once here too — an attempt's finalize kernel runs behind its mark kernel,
+  // i.e. behind the last read of the packed rows, and a rebuild after a miss reads the rows from d_in, where the pull left them)
+  rc = filter_device(f, f->d_in.p, n, reinterpret_cast<float4 *>(f->h_stage.p), &V, pulled ? &pull : nullptr);
   if (rc == LSA_ERR_RANGE) {
     // PCL: warns and sets output = *input_
     if (out_pts != in_pts) {

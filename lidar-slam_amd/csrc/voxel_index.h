@@ -65,6 +65,16 @@ struct KnownParams {
   FixScales fs;
 };
 
+// rows the host is still packing into device-visible pinned memory when the build is enqueued (k_mark<.., PULL>, voxel_index.hip)
+constexpr unsigned kPullFlagStride = 16;   // ready flags are 16 words (one 64-byte line) apart
+struct PullSource {
+  const float4 *h_rows;               // the pinned rows (device-visible address)
+  float4 *d_copy;                     // where the kernel leaves them in device memory (k_accum reads them there)
+  const unsigned *ready;              // [chunks * kPullFlagStride], device-visible: ready[c * kPullFlagStride] == seq once chunk c's rows are packed
+  unsigned seq, chunk_shift;          // a chunk is 1 << chunk_shift rows
+  unsigned long long patience_ticks;  // 100 MHz ticks a tile waits for its chunk before it flags the build (spec_miss = 2)
+};
+
 struct VoxelIndex {
   DevBuf<uint32_t> bits, prefix;
   DevBuf<unsigned long long> scan_state;  // decoupled look-back states, one per 2048-word tile
@@ -85,7 +95,7 @@ struct VoxelIndex {
   // rebuild are quantised exactly like the persistent sums of the incremental local map (local_map.hip)
   unsigned long long scale_n_min = 0;
   // speculative reuse of the previous grid definition (VoxelFilter only, see vi_enqueue)
-  bool spec_valid = false, last_allow_spec = false, last_was_spec = false;
+  bool spec_valid = false, last_allow_spec = false, last_was_spec = false, last_pull_timeout = false;
   int spec_mode = 0;
   float spec_leaf[3] = {0, 0, 0};
   unsigned long long spec_n_cap = 0;
@@ -111,7 +121,12 @@ struct VoxelIndex {
 // k*dx*dy) and values do not depend on where the cell box starts or how large it is, only on floor(x * inv_leaf) — so a
 // build may reuse the previous build's grid definition (defined with a margin) and skip the two bounding-box launches;
 // k_mark flags any finite point that falls outside (spec_miss) and the caller then rebuilds exactly.
-int vi_enqueue(lsa_context *ctx, VoxelIndex &vi, const float4 *d_pts, size_t n, int mode, const float leaf[3], int ns, bool allow_spec = false);
+// pull (optional, only when vi_spec_ready() holds): k_mark reads the rows from pull->h_rows as the host delivers them and copies
+// them to pull->d_copy == d_pts on the way.
+int vi_enqueue(lsa_context *ctx, VoxelIndex &vi, const float4 *d_pts, size_t n, int mode, const float leaf[3], int ns, bool allow_spec = false,
+               const PullSource *pull = nullptr);
+// will the next vi_enqueue(.., allow_spec = true) over n points reuse the grid definition the device holds?
+bool vi_spec_ready(const VoxelIndex &vi, size_t n, int mode, const float leaf[3]);
 // Allocate now what a build over up to `n` points with `ns` sums per cell will need, with a bitmap of at least w_min words
 // (vi_enqueue calls this itself; a caller that knows its sizes calls it ahead so that no build allocates).
 int vi_prepare(lsa_context *ctx, VoxelIndex &vi, size_t n, int ns, size_t w_min);

@@ -196,7 +196,7 @@ __global__ __launch_bounds__(kBlock) void k_bbox_final_params(const float *__res
 // Tile geometry: points per workgroup TILE and LDS slots CAP (power of two, = TILE / 2).  Big tiles de-duplicate best
 // (2 M-point maps); a KITTI scan (131 k points) cut into 2048-point tiles is only 64 workgroups on a 256-CU chip and each
 // kernel is a latency chain, so small inputs use 512-point tiles: four times the workgroups, a quarter of the chain.
-constexpr int kTileBig = 2048, kTileSmall = 512;
+constexpr int kTileBig = 2048, kTileSmall = 512, kTilePull = 1024;   // (pull: four 16-byte link reads per lane in flight, 128 workgroups per 131 k-point scan: 48 GB/s measured)
 constexpr size_t kSmallInput = 512 * 1024;  // points; below this the small tile is used
 
 __device__ __forceinline__ unsigned lds_hash(int cell) { return ((unsigned)cell * 2654435761u) >> 22; }  // top 10 bits
@@ -221,12 +221,32 @@ __device__ __forceinline__ int lds_insert(int *keys, int cell) {
   return -1;
 }
 
-template <int TILE>
+// PULL (host clouds, lsa_voxel_filter_apply): the rows are not resident yet when this kernel starts.  The host packs them into
+// device-visible pinned memory chunk by chunk and sets ready[chunk] = seq behind each; a tile waits for its chunk, reads its rows
+// over the link itself (no copy command: four 0.5 MB copies cost 73 us on one queue against 44 us for the bytes), leaves them in
+// device memory for k_accum and marks them in the same pass — the transfer runs under the packing and the mark under the transfer.
+// Only with a known grid definition (kp.valid: the speculative box of the previous scan), so nothing has to see all rows first.
+template <int TILE, bool PULL>
 __global__ __launch_bounds__(kBlock) void k_mark(const float4 *__restrict__ pts, size_t n, DevParams *__restrict__ dp, KnownParams kp,
-                                                 uint32_t *__restrict__ bits, int32_t *__restrict__ cell_idx) {
+                                                 uint32_t *__restrict__ bits, int32_t *__restrict__ cell_idx, PullSource pull) {
   constexpr int kTile = TILE, kHashCap = TILE / 2;
   if (!kp.valid && dp->status != VI_OK) return;
   const CellMap m = kp.valid ? kp.map : dp->map;
+  __shared__ int pull_ok;
+  if (PULL && threadIdx.x == 0) {
+    const size_t first = (size_t)blockIdx.x * kTile, last = (first + kTile < n ? first + kTile : n) - 1;
+    const unsigned long long t0 = wall_clock64();
+    int ok = 1;
+    // (a flag per 64-byte line, a look about once a microsecond: every look is a read over the link that snoops the line out of the
+    // packing core's cache, and 128 workgroups looking at one shared line every 0.1 us made that core's flag stores — hence its
+    // packing — five times slower)
+    for (size_t c = first >> pull.chunk_shift; ok && c <= (last >> pull.chunk_shift); c++)
+      while (__hip_atomic_load(pull.ready + c * kPullFlagStride, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) != pull.seq) {
+        if (wall_clock64() - t0 > pull.patience_ticks) { ok = 0; break; }
+        __builtin_amdgcn_s_sleep(32);
+      }
+    pull_ok = ok;
+  }
   // the table is keyed by bitmap WORD (32 x-adjacent cells) and holds the OR of the tile's bits in it: the memory-side
   // atomics of the flush serialise on a shared word, and x-neighbours in one word are the common case (measured at 2 M
   // points / 0.3 m: 269 distinct cells but 107 distinct words per tile; one atomic per cell made the flush 42 of 56 us)
@@ -235,12 +255,30 @@ __global__ __launch_bounds__(kBlock) void k_mark(const float4 *__restrict__ pts,
   for (int k = threadIdx.x; k < kHashCap; k += kBlock) { keys[k] = -1; vals[k] = 0u; }
   __syncthreads();
   size_t base = (size_t)blockIdx.x * kTile;
+  if (PULL) {
+    if (!pull_ok) {   // the host never delivered (it is gone, or held up for seconds): flag the build, touch nothing else
+      for (int k = 0; k < kTile / kBlock; k++) {
+        size_t i = base + (size_t)k * kBlock + threadIdx.x;
+        if (i < n) cell_idx[i] = -1;
+      }
+      if (threadIdx.x == 0) atomicMax(&dp->spec_miss, 2);
+      return;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");   // (every wave: its loads of the rows come behind the flag thread 0 saw)
+  }
   // all 8 loads of a lane are issued before the first use: one HBM latency per tile instead of eight
   float4 pv[kTile / kBlock];
 #pragma unroll
   for (int k = 0; k < kTile / kBlock; k++) {
     size_t i = base + (size_t)k * kBlock + threadIdx.x;
-    pv[k] = (i < n) ? pts[i] : make_float4(NAN, NAN, NAN, 0.f);
+    pv[k] = (i < n) ? (PULL ? pull.h_rows[i] : pts[i]) : make_float4(NAN, NAN, NAN, 0.f);
+  }
+  if (PULL) {
+#pragma unroll
+    for (int k = 0; k < kTile / kBlock; k++) {
+      size_t i = base + (size_t)k * kBlock + threadIdx.x;
+      if (i < n) pull.d_copy[i] = pv[k];
+    }
   }
 #pragma unroll
   for (int k = 0; k < kTile / kBlock; k++) {
@@ -252,7 +290,7 @@ __global__ __launch_bounds__(kBlock) void k_mark(const float4 *__restrict__ pts,
       int ijk[3];
       lsa_cell_ijk(m, p.x, p.y, p.z, ijk);
       cell = lsa_cell_linear(m, ijk);
-      if (cell < 0) dp->spec_miss = 1;  // only possible when the grid definition was reused from an earlier build
+      if (cell < 0) atomicMax(&dp->spec_miss, 1);  // only possible when the grid definition was reused from an earlier build (rare; never hides a 2)
     }
     cell_idx[i] = cell;
     if (cell >= 0) {
@@ -595,7 +633,12 @@ int vi_prepare(lsa_context *ctx, VoxelIndex &vi, size_t n, int ns, size_t w_min)
   return LSA_OK;
 }
 
-int vi_enqueue(lsa_context *ctx, VoxelIndex &vi, const float4 *d_pts, size_t n, int mode, const float leaf[3], int ns, bool allow_spec) {
+bool vi_spec_ready(const VoxelIndex &vi, size_t n, int mode, const float leaf[3]) {
+  return mode == 0 && vi.spec_valid && vi.spec_mode == mode && vi.spec_leaf[0] == leaf[0] && vi.spec_leaf[1] == leaf[1] && vi.spec_leaf[2] == leaf[2] &&
+         (unsigned long long)n <= vi.spec_n_cap && vi.spec_W_cap == vi.W_cap && vi.W_cap != 0;
+}
+
+int vi_enqueue(lsa_context *ctx, VoxelIndex &vi, const float4 *d_pts, size_t n, int mode, const float leaf[3], int ns, bool allow_spec, const PullSource *pull) {
   int rc;
   unsigned nb = stream_grid(ctx, n);
   if ((rc = vi_prepare(ctx, vi, n, ns, 0))) return rc;
@@ -644,8 +687,13 @@ int vi_enqueue(lsa_context *ctx, VoxelIndex &vi, const float4 *d_pts, size_t n, 
     kp.W = (unsigned long long)vi.W;
     kp.nsb = (unsigned)((vi.W + kScanTile - 1) / kScanTile);
   }
-  if (small) hipLaunchKernelGGL(k_mark<kTileSmall>, dim3(lsa_div_up(n, kTileSmall)), dim3(kBlock), 0, ctx->stream, d_pts, n, dp, kp, vi.bits.p, vi.cell_idx.p);
-  else hipLaunchKernelGGL(k_mark<kTileBig>, dim3(lsa_div_up(n, kTileBig)), dim3(kBlock), 0, ctx->stream, d_pts, n, dp, kp, vi.bits.p, vi.cell_idx.p);
+  PullSource no_pull;
+  memset(&no_pull, 0, sizeof(no_pull));
+  if (pull) {
+    if (!spec) return lsa_fail(ctx, LSA_ERR_INVALID, "vi_enqueue: rows can only be pulled into a known grid definition (vi_spec_ready)");
+    hipLaunchKernelGGL((k_mark<kTilePull, true>), dim3(lsa_div_up(n, kTilePull)), dim3(kBlock), 0, ctx->stream, d_pts, n, dp, kp, vi.bits.p, vi.cell_idx.p, *pull);
+  } else if (small) hipLaunchKernelGGL((k_mark<kTileSmall, false>), dim3(lsa_div_up(n, kTileSmall)), dim3(kBlock), 0, ctx->stream, d_pts, n, dp, kp, vi.bits.p, vi.cell_idx.p, no_pull);
+  else hipLaunchKernelGGL((k_mark<kTileBig, false>), dim3(lsa_div_up(n, kTileBig)), dim3(kBlock), 0, ctx->stream, d_pts, n, dp, kp, vi.bits.p, vi.cell_idx.p, no_pull);
   hipLaunchKernelGGL(k_scan, dim3(nsb_cap), dim3(kBlock), 0, ctx->stream, vi.bits.p, vi.dparams.p, kp, vi.scan_state.p, vi.tickets.p + 1, vi.scan_epoch,
                      vi.prefix.p, vi.cell_of_rank.p);
   unsigned g = lsa_div_up(n, small ? kTileSmall : kTileBig);
@@ -681,6 +729,7 @@ int vi_wait(lsa_context *ctx, VoxelIndex &vi, int *status) {
   vi.spec_n_cap = p.n_cap;
   vi.spec_W_cap = vi.W_cap;
   if (p.spec_miss) *status = VI_SPEC_MISS;
+  vi.last_pull_timeout = p.spec_miss == 2;
   return LSA_OK;
 }
 

@@ -370,6 +370,43 @@ def test_voxel_filter_speculative_grid_reuse(oracle, scan_pair):
     ctx.close()
 
 
+def test_host_filter_pulled_rows_equal_copied_rows(scene, monkeypatch):
+    """lsa_voxel_filter_apply on full-size host clouds: from the second scan of a stream on, the mark kernel pulls the packed rows out of
+    pinned memory itself while both host threads are still packing them (chunk flags, no copy command).  The same history through a
+    handle with the pull switched off (LSA_FILTER_PULL=0: packed halves sent by copy commands): every output bit for bit the same —
+    including a scan shifted out of the reused cell box (detected by the pulling kernel, rebuilt exactly from the rows it left in
+    device memory), an xyz-only cloud (12-byte rows, no intensity), and a short cloud in between (below the pull threshold)."""
+    scans = [synth.gen_scan(scene, synth.pose_matrix(float(k), 0.1 * k, 0.0, 0.0, 0.0, 0.01 * k), seed=4100 + k) for k in range(5)]
+    assert all(sc.shape[0] >= 65536 for sc in scans)
+    history = [scans[0], scans[1], scans[2], scans[3] + np.float32([60.0, -25.0, 2.0, 0.0]), scans[4] + np.float32([60.0, -25.0, 2.0, 0.0]),
+               scans[1][:3000], scans[2], scans[0]]
+    outs = {}
+    for name, env in (("pull", None), ("copy", "0")):
+        if env is None:
+            monkeypatch.delenv("LSA_FILTER_PULL", raising=False)
+        else:
+            monkeypatch.setenv("LSA_FILTER_PULL", env)
+        ctx = capi.Context(0)
+        f = cloud_filter.VoxelFilterHip(ctx, 0.5, 0.5, 0.5)
+        res = []
+        for pts in history:
+            _, out = f.Filter(synth.to_xyzi32(pts))
+            res.append(out.copy())
+        # an xyz-only cloud (12-byte rows, no intensity column): same path, other packing
+        xyz = np.ascontiguousarray(scans[0][:, :3])
+        _, out3 = f.Filter(xyz)
+        res.append(out3.copy())
+        outs[name] = (res, f.counters())
+        f.close(); ctx.close()
+    monkeypatch.delenv("LSA_FILTER_PULL", raising=False)
+    (rp, cp), (rc, cc) = outs["pull"], outs["copy"]
+    assert cp["pulled"] >= 4 and cc["pulled"] == 0, (cp, cc)
+    assert cp["misses"] >= 1 and cp["misses"] == cc["misses"], (cp, cc)
+    for k, (a, b) in enumerate(zip(rp, rc)):
+        assert a.shape == b.shape and np.array_equal(a.view(np.uint32), b.view(np.uint32)), k
+    assert rp[0].shape[0] > 5000
+
+
 def test_pipeline_batch_equals_sequential_calls(oracle, scene):
     """lsa_pipeline_scan_match (filter of scan k+1 under the registration of scan k, inside the library) returns exactly
     what Filter + ScanMatch called scan by scan return."""
