@@ -47,11 +47,27 @@ size_t lsa_upload_chunk() {
   return c < 1024 ? 1024 : c;
 }
 
+// Small clouds (a filtered scan: 7-25 k rows, 120-400 KB) are taken out of the pinned staging buffer by a KERNEL, not by a copy command:
+// the bytes need ~4 us on the link either way, but a copy between two kernels of one stream is a change of engine on both sides (queue ->
+// SDMA -> queue: two cross-engine dependencies) and the runtime's copy path costs the host more than a launch.  Measured on the
+// host-pointer ScanMatch of a 7.7 k-point source: 91-98 -> 68 us per call (profiles/r04_host_boundary_ab.log).
+constexpr size_t kPullRowsMax = 65536;
+__global__ __launch_bounds__(256) void k_pull_rows(const float4 *__restrict__ h_rows, float4 *__restrict__ d_rows, size_t n) {
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i < n) d_rows[i] = h_rows[i];
+}
+
 int lsa_upload_xyzw(lsa_context *ctx, const void *pts, size_t n, size_t stride, size_t w_off, float *h_stage, float4 *d_dst) {
   // an intensity offset that does not fit the row would read the next point (or past the buffer): (n,3) xyz rows have
   // no intensity and must say so with w_off == SIZE_MAX
   if (n && (stride < 12 || (w_off != SIZE_MAX && w_off + 4 > stride)))
     return lsa_fail(ctx, LSA_ERR_INVALID, "point rows of %zu bytes cannot hold xyz + an intensity at offset %zu (pass SIZE_MAX for clouds without one)", stride, w_off);
+  if (n && n <= kPullRowsMax) {
+    lsa_pack_xyzw(pts, n, stride, w_off, h_stage);
+    hipLaunchKernelGGL(k_pull_rows, dim3(lsa_div_up(n, 256)), dim3(256), 0, ctx->stream, reinterpret_cast<const float4 *>(h_stage), d_dst, n);
+    LSA_HIP(ctx, hipGetLastError());
+    return LSA_OK;
+  }
   const size_t kChunk = lsa_upload_chunk();
   for (size_t off = 0; off < n; off += kChunk) {
     const size_t m = n - off < kChunk ? n - off : kChunk;

@@ -13,14 +13,7 @@ int lsa_gn_solve_defer(lsa_pass_eval_fn eval, int (*defer)(void *, const float[1
 
 namespace {
 
-constexpr size_t kPullRowsMax = 65536;
-// small clouds (a filtered scan: 7-25 k rows, 120-400 KB): the rows are taken out of the pinned staging buffer by a kernel, not by a copy
-// command — the bytes need ~4 us either way, but a copy between two kernels of one stream is a change of engine on both sides
-// (queue -> SDMA -> queue: two cross-engine dependencies) and the runtime's copy path costs the host more than a launch
-__global__ __launch_bounds__(256) void k_pull_rows(const float4 *__restrict__ h_rows, float4 *__restrict__ d_rows, size_t n) {
-  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
-  if (i < n) d_rows[i] = h_rows[i];
-}
+constexpr size_t kPullRowsMax = 65536;   // lsa_upload_xyzw takes clouds up to this size out of the staging buffer with one kernel
 
 int upload_points(lsa_ndt *h, const void *pts, size_t n, size_t stride, size_t w_off, DevBuf<float4> &dst) {
   lsa_context *ctx = h->ctx;
@@ -36,13 +29,9 @@ int upload_points(lsa_ndt *h, const void *pts, size_t n, size_t stride, size_t w
   h->upload_pending = false;
   if ((rc = h->h_stage.reserve(ctx, n * 4))) return rc;
   if ((rc = dst.reserve(ctx, n, 1.25))) return rc;
-  if (n == 0 || n > kPullRowsMax) return lsa_upload_xyzw(ctx, pts, n, stride, w_off, h->h_stage.p, dst.p);
-  if (stride < 12 || (w_off != SIZE_MAX && w_off + 4 > stride))
-    return lsa_fail(ctx, LSA_ERR_INVALID, "point rows of %zu bytes cannot hold xyz + an intensity at offset %zu (pass SIZE_MAX for clouds without one)", stride, w_off);
+  if ((rc = lsa_upload_xyzw(ctx, pts, n, stride, w_off, h->h_stage.p, dst.p))) return rc;
+  if (n == 0 || n > kPullRowsMax) return LSA_OK;
   if (!h->ev_upload) LSA_HIP(ctx, hipEventCreateWithFlags(&h->ev_upload, hipEventDisableTiming));
-  lsa_pack_xyzw(pts, n, stride, w_off, h->h_stage.p);
-  hipLaunchKernelGGL(k_pull_rows, dim3(lsa_div_up(n, 256)), dim3(256), 0, ctx->stream, reinterpret_cast<const float4 *>(h->h_stage.p), dst.p, n);
-  LSA_HIP(ctx, hipGetLastError());
   LSA_HIP(ctx, hipEventRecord(h->ev_upload, ctx->stream));
   h->upload_pending = true;
   return LSA_OK;
