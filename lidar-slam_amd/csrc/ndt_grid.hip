@@ -134,6 +134,22 @@ int ndt_materialize(lsa_ndt *h) {
   return h->rec_ext ? lsa_fail(h->ctx, LSA_ERR_INVALID, "the owner of the external NDT table did not materialise it") : LSA_OK;
 }
 
+namespace {
+// hipMemsetAsync costs the host 6-14 us per call on this runtime (it picks a fill kernel, splits unaligned sizes in two launches); a
+// plain launch costs 4-5.  n16 = number of 16-byte units.
+__global__ __launch_bounds__(256) void k_fill16(uint4 *__restrict__ p, size_t n16, unsigned v) {
+  const uint4 q = make_uint4(v, v, v, v);
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n16; i += (size_t)gridDim.x * 256) p[i] = q;
+}
+void fill16(lsa_context *ctx, void *p, size_t bytes, unsigned v) {   // bytes rounded up to 16: every buffer filled here has the room (DevBuf headroom / +2 pad)
+  const size_t n16 = (bytes + 15) / 16;
+  if (!n16) return;
+  size_t g = (n16 + 255) / 256;
+  if (g > 2048) g = 2048;
+  hipLaunchKernelGGL(k_fill16, dim3((unsigned)g), dim3(256), 0, ctx->stream, reinterpret_cast<uint4 *>(p), n16, v);
+}
+}  // namespace
+
 int ndt_build_grid(lsa_ndt *h, const float4 *d_pts, size_t n) {
   lsa_context *ctx = h->ctx;
   VoxelIndex &vi = h->vi;
@@ -141,9 +157,9 @@ int ndt_build_grid(lsa_ndt *h, const float4 *d_pts, size_t n) {
   h->rec_ext = nullptr; h->dense_ext = nullptr;   // an ordinary table from here on
   int rc, status = VI_OK;
   const float leaf[3] = {h->resolution, h->resolution, h->resolution};
+  vi.mirror_at_scan = true;   // the definition and the occupied-cell count reach the host behind k_scan (no copy command, k_accum still running)
   for (int attempt = 0; attempt < 2; attempt++) {
     if ((rc = vi_enqueue(ctx, vi, d_pts, n, /*mode NDT*/ 1, leaf, 10))) return rc;
-    if ((rc = vi_fetch(ctx, vi))) return rc;
     if ((rc = vi_wait(ctx, vi, &status))) return rc;
     if (status != VI_CAPACITY) break;
     if ((rc = vi_grow(ctx, vi))) return rc;
@@ -153,11 +169,11 @@ int ndt_build_grid(lsa_ndt *h, const float4 *d_pts, size_t n) {
   size_t V = vi.nocc;
   if ((rc = h->rec.reserve(ctx, V * kRecDoubles + kRecDoubles, 1.25))) return rc;
   if ((rc = h->state.reserve(ctx, V + 1, 1.25))) return rc;
-  if ((rc = h->vbits.reserve(ctx, vi.W, 1.25))) return rc;
+  if ((rc = h->vbits.reserve(ctx, vi.W + 4, 1.25))) return rc;
   if ((rc = h->words.reserve(ctx, vi.W, 1.25))) return rc;
   if ((rc = h->d_small.reserve(ctx, 64))) return rc;
   if ((rc = h->counts.reserve(ctx, V + 1, 1.25))) return rc;
-  LSA_HIP(ctx, hipMemsetAsync(h->vbits.p, 0, vi.W * sizeof(uint32_t), ctx->stream));
+  fill16(ctx, h->vbits.p, vi.W * sizeof(uint32_t), 0u);
   hipLaunchKernelGGL(k_ndt_finalize, dim3(lsa_div_up(V, kBlock)), dim3(kBlock), 0, ctx->stream, vi.acc.p, vi.cnt.p, vi.cell_of_rank.p, V, vi.map, vi.fs,
                      h->rec.p, h->state.p, h->counts.p, h->vbits.p, h->mode == LSA_NDT_MODE_PCL ? 1 : 0);
   hipLaunchKernelGGL(k_pack_words, dim3(lsa_div_up(vi.W, kBlock)), dim3(kBlock), 0, ctx->stream, vi.bits.p, h->vbits.p, vi.prefix.p, vi.W, h->words.p);
@@ -167,7 +183,7 @@ int ndt_build_grid(lsa_ndt *h, const float4 *d_pts, size_t n) {
   if (h->use_dense) {
     size_t nc = (size_t)vi.map.ncells + 2;  // a row load reads 3 entries from any in-box cell
     if ((rc = h->dense.reserve(ctx, nc, 1.1))) return rc;
-    LSA_HIP(ctx, hipMemsetAsync(h->dense.p, 0xFF, nc * sizeof(float4), ctx->stream));
+    fill16(ctx, h->dense.p, nc * sizeof(float4), 0xFFFFFFFFu);
     hipLaunchKernelGGL(k_dense_fill, dim3(lsa_div_up(V, kBlock)), dim3(kBlock), 0, ctx->stream, h->rec.p, h->state.p, vi.cell_of_rank.p, V, vi.map, h->dense.p);
   }
   LSA_HIP(ctx, hipGetLastError());

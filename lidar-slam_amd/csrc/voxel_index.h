@@ -90,6 +90,9 @@ struct VoxelIndex {
   size_t acc_rows = 0;    // rows of acc / cnt known to be zero ("clean") on entry
   int acc_ns = 0;
   bool clean = false;     // bits[0..W_cap), acc, cnt are all zero
+  // the owner sizes buffers of its own by the definition / the occupied-cell count: k_scan mirrors them to h_params and vi_enqueue records
+  // ev_done behind it, so vi_wait() (without vi_fetch / vi_mark_done) returns while k_accum still runs
+  bool mirror_at_scan = false;
   // floor of the point count the fixed-point scales are derived from: 0 = from the cloud at hand (default).  The front end
   // sets it to the capacity of its local map so that the scales are a constant of the session, and the sums of a full
   // rebuild are quantised exactly like the persistent sums of the incremental local map (local_map.hip)

@@ -327,7 +327,10 @@ __device__ __forceinline__ unsigned long long scan_word(unsigned epoch, unsigned
 
 __global__ __launch_bounds__(kBlock) void k_scan(const uint32_t *__restrict__ bits, DevParams *__restrict__ dp, KnownParams kp,
                                                  unsigned long long *__restrict__ state, unsigned *__restrict__ ticket, unsigned epoch,
-                                                 uint32_t *__restrict__ prefix, int32_t *__restrict__ cell_of_rank) {
+                                                 uint32_t *__restrict__ prefix, int32_t *__restrict__ cell_of_rank, DevParams *__restrict__ host_mirror) {
+  // host_mirror (optional, host-mapped pinned memory): the grid definition + occupied-cell count + status as soon as they exist, i.e.
+  // behind this kernel — the caller that has to size its own buffers by them (the NDT table) waits for THIS kernel's event while the
+  // sums are still being accumulated, instead of for a copy command behind everything
   __shared__ unsigned s_tile, s_excl;
   __shared__ unsigned wt[kBlock / 64], wr[kBlock / 64];
   // Small bitmaps (a lidar scan at 0.5 m: ~24 tiles) do not go through the look-back at all: the chain of tile-to-tile
@@ -351,7 +354,10 @@ __global__ __launch_bounds__(kBlock) void k_scan(const uint32_t *__restrict__ bi
     __syncthreads();
   }
   const unsigned tile = redundant ? blockIdx.x : s_tile;
-  if ((!kp.valid && dp->status != VI_OK) || tile >= nsb) return;
+  if ((!kp.valid && dp->status != VI_OK) || tile >= nsb) {
+    if (host_mirror && !kp.valid && dp->status != VI_OK && blockIdx.x == 0 && threadIdx.x == 0) *host_mirror = *dp;   // (no tile runs: the status goes out here)
+    return;
+  }
   const size_t W = kp.valid ? (size_t)kp.W : (size_t)dp->W;
   unsigned front = 0;  // redundant path: this thread's share of the popcount of words [0, tile * kScanTile)
   if (redundant) {
@@ -413,7 +419,10 @@ __global__ __launch_bounds__(kBlock) void k_scan(const uint32_t *__restrict__ bi
 #pragma unroll
       for (int w = 0; w < kBlock / 64; w++) excl += wr[w];
       s_excl = excl;
-      if (tile == nsb - 1) dp->V = excl + agg;  // #occupied cells
+      if (tile == nsb - 1) {
+        dp->V = excl + agg;  // #occupied cells
+        if (host_mirror) { DevParams t = *dp; t.V = excl + agg; *host_mirror = t; }
+      }
     }
   } else if (wave == 0) {
     if (lane == 0) __hip_atomic_store(state + tile, scan_word(epoch, tile == 0 ? kFlagPrefix : kFlagAgg, agg), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -442,7 +451,10 @@ __global__ __launch_bounds__(kBlock) void k_scan(const uint32_t *__restrict__ bi
     if (lane == 0) {
       if (tile != 0) __hip_atomic_store(state + tile, scan_word(epoch, kFlagPrefix, excl + agg), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       s_excl = excl;
-      if (tile == nsb - 1) dp->V = excl + agg;  // #occupied cells
+      if (tile == nsb - 1) {
+        dp->V = excl + agg;  // #occupied cells
+        if (host_mirror) { DevParams t = *dp; t.V = excl + agg; *host_mirror = t; }
+      }
     }
   }
   __syncthreads();
@@ -695,7 +707,8 @@ int vi_enqueue(lsa_context *ctx, VoxelIndex &vi, const float4 *d_pts, size_t n, 
   } else if (small) hipLaunchKernelGGL((k_mark<kTileSmall, false>), dim3(lsa_div_up(n, kTileSmall)), dim3(kBlock), 0, ctx->stream, d_pts, n, dp, kp, vi.bits.p, vi.cell_idx.p, no_pull);
   else hipLaunchKernelGGL((k_mark<kTileBig, false>), dim3(lsa_div_up(n, kTileBig)), dim3(kBlock), 0, ctx->stream, d_pts, n, dp, kp, vi.bits.p, vi.cell_idx.p, no_pull);
   hipLaunchKernelGGL(k_scan, dim3(nsb_cap), dim3(kBlock), 0, ctx->stream, vi.bits.p, vi.dparams.p, kp, vi.scan_state.p, vi.tickets.p + 1, vi.scan_epoch,
-                     vi.prefix.p, vi.cell_of_rank.p);
+                     vi.prefix.p, vi.cell_of_rank.p, vi.mirror_at_scan ? vi.h_params.p : (DevParams *)nullptr);
+  if (vi.mirror_at_scan) LSA_HIP(ctx, hipEventRecord(vi.ev_done, ctx->stream));   // vi_wait() returns behind the scan; the accumulation is still running then
   unsigned g = lsa_div_up(n, small ? kTileSmall : kTileBig);
 #define LSA_LAUNCH_ACCUM(NS_, TILE_) hipLaunchKernelGGL((k_accum<NS_, TILE_>), dim3(g), dim3(kBlock), 0, ctx->stream, d_pts, vi.cell_idx.p, n, dp, kp, vi.bits.p, vi.prefix.p, vi.acc.p, vi.cnt.p)
   if (ns == 4) { if (small) LSA_LAUNCH_ACCUM(4, kTileSmall); else LSA_LAUNCH_ACCUM(4, kTileBig); }
