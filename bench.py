@@ -413,7 +413,7 @@ def main():
         alg_bytes = M * (16.0 + 4.0 * 27.0 + 48.0 * kbar)
         achieved = alg_bytes / (ms * 1e-3) / 1e9
         traffic = None
-        for tname in ("r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json"):   # PMC passes of this command, see profiles/README.md
+        for tname in ("r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json"):   # PMC passes of this command, see profiles/README.md
             tpath = os.path.join(ROOT, "profiles", tname)
             if os.path.exists(tpath):
                 try:
@@ -434,7 +434,7 @@ def main():
         # what rocprofv3's kernel trace of the same command says for that kernel (committed summary under profiles/; the traced run
         # is slower on the host side — the tracer sits in every API call — so its kernels wait longer for their mail than here)
         rocprof_avg = None
-        for pname in ("r03_final_bench_kernel_stats.csv", "r03_a_bench_kernel_stats.csv"):
+        for pname in ("r04_final_bench_kernel_stats.csv", "r03_final_bench_kernel_stats.csv", "r03_a_bench_kernel_stats.csv"):
             ppath = os.path.join(ROOT, "profiles", pname)
             if os.path.exists(ppath):
                 try:

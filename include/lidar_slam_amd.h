@@ -240,6 +240,9 @@ typedef struct {
   double host_gap_max_us; /* host-stall detector: the longest interval between two consecutive looks of the calling thread at the rows
                            * it was waiting for (a look takes < 1 us), or from posting a pass to the first look.  >= 1000 means the OS
                            * held the thread up for longer than that: late / redone passes beside such a value are the box's doing */
+  double row_wait_max_us; /* longest wait for ONE workgroup row (first look -> taken or given up): the quantity the 2 ms / 20 ms limits
+                           * bound.  rows_wait_max_us above is a whole pass — its rows taken one after the other as they arrive — and
+                           * exceeds a limit, with nothing late, when the DEVICE delivers slowly (another process on the GPU, a clock change) */
 } lsa_ndt_armed_stats_t;
 int lsa_ndt_armed_stats(lsa_ndt *ndt, lsa_ndt_armed_stats_t *out, int reset);
 /* diagnostics / tests: how long an armed kernel waits for its mail before it leaves by itself (default 300 us; [1, 1e5]) */

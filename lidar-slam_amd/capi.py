@@ -38,12 +38,12 @@ class NdtArmedStats(C.Structure):
     """lsa_ndt_armed_stats_t"""
     _fields_ = [("passes", C.c_uint64), ("cancels", C.c_uint64), ("fallbacks", C.c_uint64), ("late", C.c_uint64), ("rows_late", C.c_uint64),
                 ("gave_up_seen", C.c_uint64), ("expired", C.c_uint64), ("rows_wait_max_us", C.c_double), ("parked", C.c_int32), ("pad", C.c_int32),
-                ("deferred", C.c_uint64), ("host_gap_max_us", C.c_double)]
+                ("deferred", C.c_uint64), ("host_gap_max_us", C.c_double), ("row_wait_max_us", C.c_double)]
 
     def as_dict(self):
         return dict(passes=self.passes, cancels=self.cancels, fallbacks=self.fallbacks, late=self.late, rows_late=self.rows_late,
                     gave_up_seen=self.gave_up_seen, expired=self.expired, rows_wait_max_us=round(self.rows_wait_max_us, 2), parked=self.parked,
-                    deferred=self.deferred, host_gap_max_us=round(self.host_gap_max_us, 2))
+                    deferred=self.deferred, host_gap_max_us=round(self.host_gap_max_us, 2), row_wait_max_us=round(self.row_wait_max_us, 2))
 
 
 class NdtStats(C.Structure):

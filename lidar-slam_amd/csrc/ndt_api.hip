@@ -144,6 +144,8 @@ int armed_take(lsa_ndt *h, const ArmedPosted &ap, double out32[32], bool *redo) 
     if (w > h->rows_wait_max_us) h->rows_wait_max_us = w;
     const double gp = lsa_host_gap_take_us(true);   // ... and every interval between two looks
     if (gp > h->host_gap_max_us) h->host_gap_max_us = gp;
+    const double rw = lsa_row_wait_take_us(true);
+    if (rw > h->row_wait_max_us) h->row_wait_max_us = rw;
   }
   if (!ok) {
     // rows missing.  Either a workgroup of the kernel ran out of patience before the mail came (this thread was held up;
@@ -271,6 +273,8 @@ int run_pass(lsa_ndt *h, const float T[16], const double p[6], int kind, double 
       if (w > h->rows_wait_max_us) h->rows_wait_max_us = w;
       const double gp = lsa_host_gap_take_us(true);
       if (gp > h->host_gap_max_us) h->host_gap_max_us = gp;
+      const double rw = lsa_row_wait_take_us(true);
+      if (rw > h->row_wait_max_us) h->row_wait_max_us = rw;
     }
     if (!ok) {
       LSA_HIP(ctx, hipStreamSynchronize(ctx->stream));
@@ -584,8 +588,9 @@ extern "C" int lsa_ndt_armed_stats(lsa_ndt *h, lsa_ndt_armed_stats_t *out, int r
     out->pad = 0;
     out->deferred = h->deferred_passes;
     out->host_gap_max_us = h->host_gap_max_us;
+    out->row_wait_max_us = h->row_wait_max_us;
   }
-  if (reset) { h->armed_passes = h->armed_cancels = h->armed_fallbacks = h->armed_late = h->rows_late = h->armed_gave_up_seen = h->armed_expired = h->deferred_passes = 0; h->rows_wait_max_us = 0; h->host_gap_max_us = 0; }
+  if (reset) { h->armed_passes = h->armed_cancels = h->armed_fallbacks = h->armed_late = h->rows_late = h->armed_gave_up_seen = h->armed_expired = h->deferred_passes = 0; h->rows_wait_max_us = 0; h->host_gap_max_us = 0; h->row_wait_max_us = 0; }
   return LSA_OK;
 }
 

@@ -408,6 +408,7 @@ int ndt_enqueue_pass_host(lsa_ndt *h, const PassParams &P, int kind, unsigned *g
 namespace {
 thread_local unsigned long long t_gap_max_tsc = 0;
 thread_local double t_gap_max_noted_us = 0.0;
+thread_local unsigned long long t_row_max_tsc = 0;   // the longest wait for ONE row (first look -> accepted / given up): what limit_ms bounds
 // ticks of the time-stamp counter per microsecond, measured once (200 us against the steady clock)
 double tsc_per_us() {
   static const double r = [] {
@@ -428,6 +429,11 @@ double lsa_host_gap_take_us(bool reset) {
   if (reset) { t_gap_max_tsc = 0; t_gap_max_noted_us = 0.0; }
   return us;
 }
+double lsa_row_wait_take_us(bool reset) {
+  const double us = t_row_max_tsc ? (double)t_row_max_tsc / tsc_per_us() : 0.0;
+  if (reset) t_row_max_tsc = 0;
+  return us;
+}
 void lsa_host_gap_note_us(double us) {
   if (us > t_gap_max_noted_us) t_gap_max_noted_us = us;
 }
@@ -439,6 +445,7 @@ bool ndt_fetch_row_host(const double *row, unsigned long long key, double limit_
   bool timing = false;
   unsigned spins = 0;
   unsigned long long last = __builtin_ia32_rdtsc(), gap = 0;
+  const unsigned long long first = last;
   for (;;) {
     unsigned long long w[32], x = 0ull;
     for (int col = 0; col < 32; col++) w[col] = wr[col];
@@ -450,6 +457,7 @@ bool ndt_fetch_row_host(const double *row, unsigned long long key, double limit_
       memcpy(out32, w, sizeof(w));
       out32[31] = 0ull;
       if (gap > t_gap_max_tsc) t_gap_max_tsc = gap;
+      if (now - first > t_row_max_tsc) t_row_max_tsc = now - first;
       return true;
     }
     if ((++spins & 63u) == 0u) {
@@ -459,6 +467,7 @@ bool ndt_fetch_row_host(const double *row, unsigned long long key, double limit_
       else if (std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count() > limit_ms) out = true;
       if (out) {
         if (gap > t_gap_max_tsc) t_gap_max_tsc = gap;
+        if (now - first > t_row_max_tsc) t_row_max_tsc = now - first;
         return false;
       }
     }

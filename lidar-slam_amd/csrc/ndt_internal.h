@@ -115,6 +115,7 @@ struct lsa_ndt {
   unsigned long long armed_late = 0, rows_late = 0, armed_gave_up_seen = 0, armed_expired = 0;
   double rows_wait_max_us = 0;
   double host_gap_max_us = 0;   // lsa_host_gap_take_us, folded in after every wait for rows
+  double row_wait_max_us = 0;   // lsa_row_wait_take_us, likewise: the longest wait for ONE row
 
   // deferred final pass of a ScanMatch inside a batch (ndt_api.hip: collect_pending)
   struct Pending {

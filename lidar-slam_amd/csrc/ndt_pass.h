@@ -39,6 +39,9 @@ bool ndt_reduce_partials_host(const double *partials, unsigned nb, unsigned long
 // millisecond means the OS held the thread up (a look takes well under a microsecond): what tells a late or redone armed pass that is
 // the box's doing from one that is the library's.  Returns the maximum since the last reset, in microseconds.
 double lsa_host_gap_take_us(bool reset);
+// the longest wait for a single row since the last reset (first look -> accepted or given up), microseconds: the quantity the per-row
+// limits bound.  A pass's rows_wait_max_us is the sum over its rows as they trickle in and may exceed the limit when the DEVICE is slow.
+double lsa_row_wait_take_us(bool reset);
 void lsa_host_gap_note_us(double us);
 
 #endif

@@ -52,6 +52,8 @@ struct lsa_voxel_filter {
   // a second packer (packing 131 k rows is ~70 us of one core's memory bandwidth; the link needs 44): same claim loop, own thread.
   // p2_state: 0 idle, 1 posted, 3 packing, 2 done, -1 shut down
   std::thread packer2;
+  std::mutex mu2;
+  std::condition_variable cv2;
   std::atomic<int> p2_state{0};
   bool packer2_started = false;
   std::atomic<unsigned> u_next{0};
@@ -179,9 +181,12 @@ void filter_packer2(lsa_voxel_filter *f) {
       st = f->p2_state.load(std::memory_order_acquire);
       if (st == 1 || st == -1) break;
       __builtin_ia32_pause();
-      if ((spin & 1023u) == 1023u && std::chrono::steady_clock::now() - t0 > std::chrono::microseconds(200)) {
-        std::this_thread::sleep_for(std::chrono::microseconds(50));
-      }
+      if ((spin & 1023u) == 1023u && std::chrono::steady_clock::now() - t0 > std::chrono::microseconds(200)) break;
+    }
+    if (st != 1 && st != -1) {   // nothing for 200 us: sleep until the next job is posted (an idle handle costs no CPU)
+      std::unique_lock<std::mutex> lk(f->mu2);
+      f->cv2.wait(lk, [&] { int s = f->p2_state.load(std::memory_order_acquire); return s == 1 || s == -1; });
+      st = f->p2_state.load(std::memory_order_acquire);
     }
     if (st == -1) return;
     int expect = 1;
@@ -431,7 +436,11 @@ extern "C" void lsa_voxel_filter_destroy(lsa_voxel_filter *f) {
     f->worker.join();
   }
   if (f->packer2_started) {
-    f->p2_state.store(-1, std::memory_order_release);
+    {
+      std::lock_guard<std::mutex> lk(f->mu2);
+      f->p2_state.store(-1, std::memory_order_release);
+    }
+    f->cv2.notify_one();
     f->packer2.join();
   }
   (void)lsa_enter(f->ctx);
@@ -494,7 +503,11 @@ extern "C" int lsa_voxel_filter_apply(lsa_voxel_filter *f, const void *in_pts, s
       f->packer2 = std::thread(filter_packer2, f);
       f->packer2_started = true;
     }
-    f->p2_state.store(1, std::memory_order_release);
+    {
+      std::lock_guard<std::mutex> lk(f->mu2);
+      f->p2_state.store(1, std::memory_order_release);
+    }
+    f->cv2.notify_one();
     pulled = true;
     f->n_pulled++;
   } else if (n >= 65536 && !f->pending) {
