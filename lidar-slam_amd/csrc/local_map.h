@@ -96,6 +96,7 @@ struct LocalMap {
   bool filtered = false;              // level F in use (>= 10 key-frames and a local-map filter configured)
   bool valid = false;                 // the persistent sums are those of the current window
   bool pending = false;               // an update has been enqueued whose status the owner has not looked at yet
+  bool n_zero = false, f_zero = false; // the level's table is known to be all zero (fresh from lm_reserve): the next rebuild need not clear it
   unsigned long long epoch = 0;
   long long dense_max_cells = 16ll << 20;
   unsigned long long rebuilds = 0, refits = 0, updates = 0;

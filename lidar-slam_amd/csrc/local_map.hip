@@ -604,8 +604,19 @@ __global__ __launch_bounds__(kBlock) void k_lm_ndt_dirty(TableView<10> N, DirtyV
   }
 }
 
-// bounds of the valid voxels (window re-fit)
-__global__ __launch_bounds__(kBlock) void k_lm_bounds(const LmCellN *__restrict__ cells, unsigned cap, LmStatus *__restrict__ st) {
+// window re-fit, first launch: the sentinels the bounds are reduced into (a kernel, not a copy command: the runtime's copy path costs the host more)
+__global__ void k_lm_bounds_init(LmStatus *__restrict__ st) {
+  if (threadIdx.x < 3) { st->bmin[threadIdx.x] = INT_MAX; st->bmax[threadIdx.x] = INT_MIN; }
+}
+// 16-byte fill (the dense window's "no voxel" entries are all-ones)
+__global__ __launch_bounds__(kBlock) void k_lm_fill16(uint4 *__restrict__ p, size_t n16, unsigned v) {
+  const uint4 q = make_uint4(v, v, v, v);
+  for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < n16; i += (size_t)gridDim.x * kBlock) p[i] = q;
+}
+
+// bounds of the valid voxels (window re-fit); the LAST workgroup to finish hands them to the host through the host-mapped status block
+// (no copy command; the host waits for the stream once)
+__global__ __launch_bounds__(kBlock) void k_lm_bounds(const LmCellN *__restrict__ cells, unsigned cap, LmStatus *__restrict__ st, LmStatus *__restrict__ host_mirror) {
   int mn[3] = {INT_MAX, INT_MAX, INT_MAX}, mx[3] = {INT_MIN, INT_MIN, INT_MIN};
   for (unsigned s = blockIdx.x * blockDim.x + threadIdx.x; s < cap; s += gridDim.x * blockDim.x) {
     if (cells[s].key == kEmpty || cells[s].state != 1) continue;
@@ -621,11 +632,26 @@ __global__ __launch_bounds__(kBlock) void k_lm_bounds(const LmCellN *__restrict_
       if (mx[a] != INT_MIN) atomicMax(&st->bmax[a], mx[a]);
     }
   }
+  // every wave drains its own atomics (the fence waits for the wave's outstanding memory operations), then the workgroup counts itself done
+  __threadfence();
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const unsigned t = atomicAdd(&st->pad, 1u);
+    if (t == gridDim.x - 1) {
+      st->pad = 0u;
+      for (int a = 0; a < 3; a++) {
+        const int lo = __hip_atomic_load(&st->bmin[a], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), hi = __hip_atomic_load(&st->bmax[a], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(&host_mirror->bmin[a], lo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        __hip_atomic_store(&host_mirror->bmax[a], hi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      }
+    }
+  }
 }
 
 __global__ __launch_bounds__(kBlock) void k_lm_dense_fill(const LmCellN *__restrict__ cells, const double *__restrict__ rec, unsigned cap, NdtDirtyArgs A,
-                                                          float4 *__restrict__ dense) {
+                                                          float4 *__restrict__ dense, LmStatus *__restrict__ st) {
   unsigned s = blockIdx.x * blockDim.x + threadIdx.x;
+  if (s == 0) st->window_miss = 0u;   // the flag that asked for this re-fit is consumed
   if (s >= cap || cells[s].key == kEmpty || cells[s].state != 1) return;
   int ijk[3];
   lm_unpack(cells[s].key, ijk);
@@ -702,7 +728,7 @@ NdtDirtyArgs ndt_args(const LocalMap &lm, bool with_window) {
 int alloc_level_n(LocalMap &lm, unsigned cap) {
   lsa_context *ctx = lm.ctx;
   int rc;
-  if (cap != lm.cap_n) { lm.n.release(); lm.rec.release(); }
+  if (cap != lm.cap_n) { lm.n.release(); lm.rec.release(); lm.n_zero = false; }
   if ((rc = lm.n.reserve(ctx, cap)) || (rc = lm.rec.reserve(ctx, (size_t)cap * 10))) return rc;
   lm.cap_n = cap;
   return LSA_OK;
@@ -711,7 +737,7 @@ int alloc_level_n(LocalMap &lm, unsigned cap) {
 int alloc_level_f(LocalMap &lm, unsigned cap) {
   lsa_context *ctx = lm.ctx;
   int rc;
-  if (cap != lm.cap_f) lm.f.release();
+  if (cap != lm.cap_f) { lm.f.release(); lm.f_zero = false; }
   if ((rc = lm.f.reserve(ctx, cap))) return rc;
   lm.cap_f = cap;
   return LSA_OK;
@@ -768,8 +794,16 @@ int lm_reserve(LocalMap &lm, lsa_context *ctx, bool with_level_f) {
   lm.ctx = ctx;
   int rc;
   if ((rc = lm.d_status.reserve(ctx, 1)) || (rc = lm.h_status.reserve(ctx, 1))) return rc;
-  if (!lm.cap_n && (rc = alloc_level_n(lm, 1u << 17))) return rc;
-  if (with_level_f && !lm.cap_f && (rc = alloc_level_f(lm, 1u << 20))) return rc;
+  if (!lm.cap_n) {
+    if ((rc = alloc_level_n(lm, 1u << 17))) return rc;
+    LSA_HIP(ctx, hipMemsetAsync(lm.n.p, 0, (size_t)lm.cap_n * sizeof(LmCellN), ctx->stream));
+    lm.n_zero = true;
+  }
+  if (with_level_f && !lm.cap_f) {
+    if ((rc = alloc_level_f(lm, 1u << 20))) return rc;
+    LSA_HIP(ctx, hipMemsetAsync(lm.f.p, 0, (size_t)lm.cap_f * sizeof(LmCellF), ctx->stream));
+    lm.f_zero = true;
+  }
   // the dirty lists at the largest shape a launch may ask for (kMaxRegions regions of 512 entries + the overflow region)
   if ((rc = dirty_shape(ctx, lm.dirty_n, kMaxRegions, 512, lm.cap_n))) return rc;
   if (with_level_f && (rc = dirty_shape(ctx, lm.dirty_f, kMaxRegions, 512, lm.cap_f))) return rc;
@@ -833,14 +867,12 @@ int lm_finish(LocalMap &lm) {
 int lm_refit_window(LocalMap &lm) {
   lsa_context *ctx = lm.ctx;
   // bounds of the valid voxels
-  LmStatus init;
-  memset(&init, 0, sizeof(init));
-  for (int a = 0; a < 3; a++) { init.bmin[a] = INT_MAX; init.bmax[a] = INT_MIN; }
-  LSA_HIP(ctx, hipMemcpyAsync((char *)lm.d_status.p + offsetof(LmStatus, bmin), init.bmin, 6 * sizeof(int), hipMemcpyHostToDevice, ctx->stream));
-  hipLaunchKernelGGL(k_lm_bounds, dim3(lsa_div_up(lm.cap_n, kBlock * 4)), dim3(kBlock), 0, ctx->stream, lm.n.p, lm.cap_n, lm.d_status.p);
-  LmStatus got;
-  LSA_HIP(ctx, hipMemcpyAsync(&got, lm.d_status.p, sizeof(got), hipMemcpyDeviceToHost, ctx->stream));
+  hipLaunchKernelGGL(k_lm_bounds_init, dim3(1), dim3(64), 0, ctx->stream, lm.d_status.p);
+  // (one cell per thread: 16 MB of table lines at the default capacity, ~5 us over 512 workgroups; 128 workgroups of 4 cells per thread took 17)
+  hipLaunchKernelGGL(k_lm_bounds, dim3(lsa_div_up(lm.cap_n, kBlock)), dim3(kBlock), 0, ctx->stream, lm.n.p, lm.cap_n, lm.d_status.p, lm.h_status.p);
+  LSA_HIP(ctx, hipGetLastError());
   LSA_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  LmStatus got = *lm.h_status.p;   // (bmin / bmax: written by the kernel's last workgroup)
   int mn[3], dm[3];
   // margin: 24 m of travel horizontally (a dozen key-frames at the 2 m default), 8 m vertically, in cells
   const int mxy = (int)ceilf(24.0f / lm.leaf_n), mz = (int)ceilf(8.0f / lm.leaf_n);
@@ -860,12 +892,15 @@ int lm_refit_window(LocalMap &lm) {
   }
   for (int a = 0; a < 3; a++) { lm.wmin[a] = mn[a]; lm.wdim[a] = dm[a]; }
   lm.window_set = true;
-  LSA_HIP(ctx, hipMemsetAsync(lm.dense.p, 0xFF, cells * sizeof(float4), ctx->stream));
-  hipLaunchKernelGGL(k_lm_dense_fill, dim3(lsa_div_up(lm.cap_n, kBlock)), dim3(kBlock), 0, ctx->stream, lm.n.p, lm.rec.p, lm.cap_n, ndt_args(lm, true), lm.dense.p);
-  // the flag is consumed
-  const unsigned zero = 0;
-  LSA_HIP(ctx, hipMemcpyAsync((char *)lm.d_status.p + offsetof(LmStatus, window_miss), &zero, sizeof(zero), hipMemcpyHostToDevice, ctx->stream));
-  LSA_HIP(ctx, hipStreamSynchronize(ctx->stream));   // (`zero` and `init` are stack variables)
+  {
+    size_t g = (cells + kBlock - 1) / kBlock;
+    if (g > 2048) g = 2048;
+    hipLaunchKernelGGL(k_lm_fill16, dim3((unsigned)g), dim3(kBlock), 0, ctx->stream, reinterpret_cast<uint4 *>(lm.dense.p), cells, 0xFFFFFFFFu);
+  }
+  hipLaunchKernelGGL(k_lm_dense_fill, dim3(lsa_div_up(lm.cap_n, kBlock)), dim3(kBlock), 0, ctx->stream, lm.n.p, lm.rec.p, lm.cap_n, ndt_args(lm, true), lm.dense.p, lm.d_status.p);
+  LSA_HIP(ctx, hipGetLastError());
+  // (the table is read next on the REGISTRATION's stream, which is not necessarily this one: the re-fit ends with a wait)
+  LSA_HIP(ctx, hipStreamSynchronize(ctx->stream));
   lm.h_status.p->window_miss = 0;
   lm.refits++;
   return LSA_OK;
@@ -880,8 +915,11 @@ int lm_rebuild(LocalMap &lm, const float4 *const *d_ranges, const size_t *n_rang
   for (int attempt = 0; attempt < 8; attempt++) {
     if ((rc = alloc_level_n(lm, cap_n))) return rc;
     if (filtered && (rc = alloc_level_f(lm, cap_f))) return rc;
-    LSA_HIP(ctx, hipMemsetAsync(lm.n.p, 0, (size_t)lm.cap_n * sizeof(LmCellN), ctx->stream));
-    if (filtered) LSA_HIP(ctx, hipMemsetAsync(lm.f.p, 0, (size_t)lm.cap_f * sizeof(LmCellF), ctx->stream));
+    // (tables fresh from lm_reserve are zero already: the first build of a session — and the first filtered one — skip the 16 / 64 MB fill)
+    if (!lm.n_zero) LSA_HIP(ctx, hipMemsetAsync(lm.n.p, 0, (size_t)lm.cap_n * sizeof(LmCellN), ctx->stream));
+    if (filtered && !lm.f_zero) LSA_HIP(ctx, hipMemsetAsync(lm.f.p, 0, (size_t)lm.cap_f * sizeof(LmCellF), ctx->stream));
+    lm.n_zero = false;
+    if (filtered) lm.f_zero = false;
     LSA_HIP(ctx, hipMemsetAsync(lm.d_status.p, 0, sizeof(LmStatus), ctx->stream));
     if (lm.dirty_f.len.p) LSA_HIP(ctx, hipMemsetAsync(lm.dirty_f.len.p, 0, sizeof(unsigned), ctx->stream));
     if (lm.dirty_n.len.p) LSA_HIP(ctx, hipMemsetAsync(lm.dirty_n.len.p, 0, sizeof(unsigned), ctx->stream));

@@ -404,6 +404,14 @@ extern "C" int lsa_voxel_filter_reserve(lsa_voxel_filter *f, size_t max_points, 
   LSA_HIP(f->ctx, lsa_enter(f->ctx));
   int rc = vi_prepare(f->ctx, f->vi, max_points ? max_points : 1, 4, (size_t)1 << 20);
   if (rc) return rc;
+  if (!f->vi.clean) {   // the bitmap and the accumulator rows are cleared here instead of under the first Filter call
+    VoxelIndex &vi = f->vi;
+    LSA_HIP(f->ctx, hipMemsetAsync(vi.bits.p, 0, vi.W_cap * sizeof(uint32_t), f->ctx->stream));
+    LSA_HIP(f->ctx, hipMemsetAsync(vi.acc.p, 0, vi.acc.cap * sizeof(long long), f->ctx->stream));
+    LSA_HIP(f->ctx, hipMemsetAsync(vi.cnt.p, 0, vi.cnt.cap * sizeof(int32_t), f->ctx->stream));
+    vi.acc_ns = 4;
+    vi.clean = true;
+  }
   if (async_too && !f->worker_started) {
     f->worker = std::thread(filter_worker, f);
     f->worker_started = true;
