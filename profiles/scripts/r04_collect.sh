@@ -54,3 +54,7 @@ for grp in "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum" "SQ_INSTS_VALU S
   python3 $R/profiles/scripts/pmc_summarize.py $f k_ndt_pass >> $R/gpurun_out/${tag}_cfg5_pass_pmc.csv
 done
 cat $R/gpurun_out/${tag}_cfg5_pass_pmc.csv
+echo "[r04_collect] big filter" >&2
+bash $R/profiles/scripts/r03_big_filter_pmc.sh ${tag} > $R/gpurun_out/${tag}_big_filter_collect.log 2>&1 || echo "big filter collection failed" >&2
+echo "[r04_collect] front-end loop trace" >&2
+bash $R/profiles/scripts/fe_loop_trace.sh ${tag} > $R/gpurun_out/${tag}_fe_loop_collect.log 2>&1 || echo "front-end loop trace failed" >&2
