@@ -408,9 +408,8 @@ int ndt_enqueue_pass_host(lsa_ndt *h, const PassParams &P, int kind, unsigned *g
 namespace {
 thread_local unsigned long long t_gap_max_tsc = 0;
 thread_local double t_gap_max_noted_us = 0.0;
-thread_local unsigned long long t_row_max_tsc = 0;
+thread_local unsigned long long t_row_max_tsc = 0;   // the longest wait for ONE row (first look -> accepted / given up): what limit_ms bounds
 thread_local unsigned long long t_last_tsc = 0;      // the last time stamp taken while rows were being taken (0: none since the last reset)
-thread_local unsigned t_fast_rows = 0;   // the longest wait for ONE row (first look -> accepted / given up): what limit_ms bounds
 // ticks of the time-stamp counter per microsecond, measured once (200 us against the steady clock)
 double tsc_per_us() {
   static const double r = [] {
@@ -441,13 +440,27 @@ void lsa_host_gap_note_us(double us) {
   t_last_tsc = __builtin_ia32_rdtsc();   // (called where a wait for rows begins: the first checkpoint measures from here)
 }
 
-bool ndt_fetch_row_host(const double *row, unsigned long long key, double limit_ms, unsigned long long out32[32], const volatile unsigned long long *abort_word,
-                        unsigned long long abort_value) {
+namespace {
+// the detector's state while ONE caller takes rows: kept on the caller's stack and folded into the thread's maxima once, at the end
+// (a thread-local access per row is a call into the dynamic linker's TLS lookup in a shared library: 135 of them per pass)
+struct RowClock {
+  unsigned long long last = 0;      // the last time stamp taken (0: none yet)
+  unsigned long long gap_max = 0;   // longest interval between two stamps
+  unsigned long long row_max = 0;   // longest wait for one row
+  unsigned fast_rows = 0;
+};
+void row_clock_fold(const RowClock &c) {
+  if (c.gap_max > t_gap_max_tsc) t_gap_max_tsc = c.gap_max;
+  if (c.row_max > t_row_max_tsc) t_row_max_tsc = c.row_max;
+  t_last_tsc = c.last;
+}
+
+// Host-stall detector (ndt_pass.h).  A row that is already there — 130 of a pass's 135, normally — costs NO time-stamp read of its
+// own: two per row were measured as +0.3..0.4 us per pass (+3..5 % on the pipeline); such rows are covered by a checkpoint every 16th
+// of them (last stamp -> now: pure host time, since none of them was waited for).  A row that has to be waited for is timed look by look.
+inline bool fetch_row(const double *row, unsigned long long key, double limit_ms, unsigned long long out32[32], const volatile unsigned long long *abort_word,
+                      unsigned long long abort_value, RowClock &c) {
   const volatile unsigned long long *wr = reinterpret_cast<const volatile unsigned long long *>(row);
-  // Host-stall detector (ndt_pass.h).  A row that is already there — 130 of a pass's 135, normally — costs NO time-stamp read of its
-  // own: two per row were measured as +0.3..0.4 us per pass (+3 % on the pipeline, more with several streams per GPU); such rows
-  // are covered by a checkpoint every 16th of them (t_last_tsc -> now: pure host time, since none of them was waited for).  A row
-  // that has to be waited for is timed look by look.
   {
     unsigned long long w[32], x = 0ull;
     for (int col = 0; col < 32; col++) w[col] = wr[col];
@@ -455,10 +468,10 @@ bool ndt_fetch_row_host(const double *row, unsigned long long key, double limit_
     if ((x ^ key) == w[31]) {
       memcpy(out32, w, sizeof(w));
       out32[31] = 0ull;
-      if ((++t_fast_rows & 15u) == 0u) {
+      if ((++c.fast_rows & 15u) == 0u) {
         const unsigned long long now = __builtin_ia32_rdtsc();
-        if (t_last_tsc && now - t_last_tsc > t_gap_max_tsc) t_gap_max_tsc = now - t_last_tsc;
-        t_last_tsc = now;
+        if (c.last && now - c.last > c.gap_max) c.gap_max = now - c.last;
+        c.last = now;
       }
       return true;
     }
@@ -466,8 +479,8 @@ bool ndt_fetch_row_host(const double *row, unsigned long long key, double limit_
   std::chrono::steady_clock::time_point t0;
   bool timing = false;
   unsigned spins = 0;
-  unsigned long long last = __builtin_ia32_rdtsc(), gap = 0;
-  if (t_last_tsc && last - t_last_tsc > gap) gap = last - t_last_tsc;
+  unsigned long long last = __builtin_ia32_rdtsc();
+  if (c.last && last - c.last > c.gap_max) c.gap_max = last - c.last;
   const unsigned long long first = last;
   for (;;) {
     __builtin_ia32_pause();
@@ -475,33 +488,42 @@ bool ndt_fetch_row_host(const double *row, unsigned long long key, double limit_
     for (int col = 0; col < 32; col++) w[col] = wr[col];
     for (int col = 0; col < 31; col++) x ^= lsa_row_mix(w[col], col);
     const unsigned long long now = __builtin_ia32_rdtsc();   // the longest interval between two looks
-    if (now - last > gap) gap = now - last;
+    if (now - last > c.gap_max) c.gap_max = now - last;
     last = now;
-    if ((x ^ key) == w[31]) {
-      memcpy(out32, w, sizeof(w));
-      out32[31] = 0ull;
-      if (gap > t_gap_max_tsc) t_gap_max_tsc = gap;
-      if (now - first > t_row_max_tsc) t_row_max_tsc = now - first;
-      t_last_tsc = now;
-      return true;
-    }
-    if ((++spins & 63u) == 0u) {
-      bool out = false;
+    const bool match = (x ^ key) == w[31];
+    bool out = false;
+    if (!match && (++spins & 63u) == 0u) {
       if (abort_word && *abort_word == abort_value) out = true;   // the producer has said that it will not deliver
       else if (!timing) { t0 = std::chrono::steady_clock::now(); timing = true; }
       else if (std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count() > limit_ms) out = true;
-      if (out) {
-        if (gap > t_gap_max_tsc) t_gap_max_tsc = gap;
-        if (now - first > t_row_max_tsc) t_row_max_tsc = now - first;
-        t_last_tsc = now;
-        return false;
+    }
+    if (match || out) {
+      if (now - first > c.row_max) c.row_max = now - first;
+      c.last = now;
+      if (match) {
+        memcpy(out32, w, sizeof(w));
+        out32[31] = 0ull;
       }
+      return match;
     }
   }
+}
+}  // namespace
+
+bool ndt_fetch_row_host(const double *row, unsigned long long key, double limit_ms, unsigned long long out32[32], const volatile unsigned long long *abort_word,
+                        unsigned long long abort_value) {
+  RowClock c;
+  c.last = t_last_tsc;
+  const bool ok = fetch_row(row, key, limit_ms, out32, abort_word, abort_value, c);
+  row_clock_fold(c);
+  return ok;
 }
 
 bool ndt_reduce_partials_host(const double *partials, unsigned nb, unsigned long long key, double limit_ms, double out32[32],
                               const volatile unsigned long long *abort_word, unsigned long long abort_value) {
+  RowClock clk;
+  clk.last = t_last_tsc;
+  struct Fold { RowClock &c; ~Fold() { row_clock_fold(c); } } fold{clk};
   double sm[32][32];
   for (int rl = 0; rl < 32; rl++)
     for (int col = 0; col < 32; col++) sm[rl][col] = 0.0;
@@ -510,7 +532,7 @@ bool ndt_reduce_partials_host(const double *partials, unsigned nb, unsigned long
     double v[32];
     if (key) {
       unsigned long long w[32];
-      if (!ndt_fetch_row_host(row, key, limit_ms, w, abort_word, abort_value)) return false;  // the limit applies per row: a stalled kernel stalls at its first missing one
+      if (!fetch_row(row, key, limit_ms, w, abort_word, abort_value, clk)) return false;  // the limit applies per row: a stalled kernel stalls at its first missing one
       memcpy(v, w, sizeof(v));
     } else {
       memcpy(v, row, sizeof(v));
