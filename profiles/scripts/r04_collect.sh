@@ -58,3 +58,7 @@ echo "[r04_collect] big filter" >&2
 bash $R/profiles/scripts/r03_big_filter_pmc.sh ${tag} > $R/gpurun_out/${tag}_big_filter_collect.log 2>&1 || echo "big filter collection failed" >&2
 echo "[r04_collect] front-end loop trace" >&2
 bash $R/profiles/scripts/fe_loop_trace.sh ${tag} > $R/gpurun_out/${tag}_fe_loop_collect.log 2>&1 || echo "front-end loop trace failed" >&2
+echo "[r04_collect] headline-only trace" >&2
+rm -rf /tmp/htrace
+rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/htrace -- python3 $R/bench.py --steps 2000 --warmup 20 --ramp-seconds 0.5 --no-cpu-baseline --no-large --streams 0 --no-extra > $R/gpurun_out/${tag}_headline_traced_run.json 2> $R/gpurun_out/${tag}_headline_trace.err
+cp $(find /tmp/htrace -name "*kernel_stats.csv" | head -1) $R/gpurun_out/${tag}_headline_kernel_stats.csv
