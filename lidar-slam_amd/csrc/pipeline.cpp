@@ -5,6 +5,9 @@
 // stage.  Results are exactly those of the sequential calls: every scan is filtered once and registered once.
 #include "lsa_common.h"
 
+#include <chrono>
+#include <vector>
+
 bool ndt_carry_scope(lsa_ndt *h, bool on);   // ndt_api.hip
 void ndt_release_parked(lsa_ndt *h);
 void ndt_prearm(lsa_ndt *h);
@@ -44,9 +47,24 @@ extern "C" int lsa_pipeline_scan_match(lsa_voxel_filter *frame_filter, lsa_ndt *
     lsa_ndt *h; bool prev, prev_defer;
     ~Restore() { (void)ndt_collect_deferred(h); (void)ndt_defer_scope(h, prev_defer); (void)ndt_carry_scope(h, prev); if (!prev) ndt_release_parked(h); }
   } restore{ndt, carry_user, defer_user};
+  // diagnostics (LSA_PIPE_TRACE=1, batches of <= 64 scans): when each scan's filter was there and its ScanMatch returned, on stderr
+  static const bool trace = getenv("LSA_PIPE_TRACE") != nullptr;
+  const auto tr0 = std::chrono::steady_clock::now();
+  std::vector<double> tr;
+  auto stamp = [&] { if (trace && count <= 64) tr.push_back(std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - tr0).count()); };
+  struct Dump {
+    std::vector<double> &t;
+    ~Dump() {
+      if (t.empty()) return;
+      fprintf(stderr, "[lsa pipe] us since the call began (filter there / ScanMatch back):");
+      for (size_t i = 0; i + 1 < t.size(); i += 2) fprintf(stderr, " %.0f/%.0f", t[i], t[i + 1]);
+      fprintf(stderr, "\n");
+    }
+  } dump{tr};
   for (size_t k = 0; k < count; k++) {
     size_t m = 0;
     if ((rc = lsa_voxel_filter_wait(frame_filter, &m))) return rc;
+    stamp();
     if (k + 1 < count && (rc = lsa_voxel_filter_apply_device_async(frame_filter, d_scans_xyzw[k + 1], n_points[k + 1], buf[(k + 1) % nbuf]))) return rc;
     // multi-GPU: this rank's contiguous shard of the filtered source; the all-reduce callback installed on
     // the NDT handle sums the per-rank normal equations
@@ -56,6 +74,7 @@ extern "C" int lsa_pipeline_scan_match(lsa_voxel_filter *frame_filter, lsa_ndt *
     }
     size_t lo = (m * (size_t)rank) / (size_t)world, hi = (m * (size_t)(rank + 1)) / (size_t)world;
     rc = lsa_ndt_scan_match_device(ndt, buf[k % nbuf] + 4 * lo, hi - lo, predict_poses + 16 * k, result_poses + 16 * k, stats ? stats + k : nullptr);
+    stamp();
     if (k + 1 == count) lsa_voxel_filter_retire_end(frame_filter);
     if (rc) {  // leave no filter in flight behind an error
       if (k + 1 < count) { size_t dummy; (void)lsa_voxel_filter_wait(frame_filter, &dummy); }
