@@ -395,14 +395,15 @@ extern "C" int lsa_voxel_filter_create(lsa_voxel_filter **out, lsa_context *ctx,
   return LSA_OK;
 }
 
-// Allocate ahead what filtering clouds of up to max_points will need (index buffers, a bitmap of 2^20 words = 33 M cells: a
-// 250 m x 250 m x 60 m box at a 0.5 m leaf with the speculative margin), and start the helper thread of the asynchronous entry
+// Allocate ahead what filtering clouds of up to max_points will need (index buffers, a bitmap of 2^17 words = 4.2 M cells: a
+// 200 m x 200 m x 25 m box at a 0.5 m leaf with the speculative margin; the scan kernel's grid covers the capacity, so a much
+// larger one costs every build: 2^20 words made k_scan 9.3 instead of 7.2 us; a larger box still grows it once), and start the helper thread of the asynchronous entry
 // point if `async_too`: after this a Filter call over such a cloud allocates nothing and finds the bitmap large enough on its
 // first build.  Optional — every call sizes what it needs — and without effect on any result.
 extern "C" int lsa_voxel_filter_reserve(lsa_voxel_filter *f, size_t max_points, int async_too) {
   if (!f) return LSA_ERR_INVALID;
   LSA_HIP(f->ctx, lsa_enter(f->ctx));
-  int rc = vi_prepare(f->ctx, f->vi, max_points ? max_points : 1, 4, (size_t)1 << 20);
+  int rc = vi_prepare(f->ctx, f->vi, max_points ? max_points : 1, 4, (size_t)1 << 17);
   if (rc) return rc;
   if (!f->vi.clean) {   // the bitmap and the accumulator rows are cleared here instead of under the first Filter call
     VoxelIndex &vi = f->vi;
