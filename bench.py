@@ -169,7 +169,7 @@ def main():
     dev = torch.device("cuda", dev_index)
     # one non-default stream shared by torch (uploads, RCCL collectives) and the library (kernels, copies):
     # everything the hot path does is ordered on it, no cross-stream events needed
-    tstream = torch.cuda.Stream(device=dev)
+    tstream = torch.cuda.Stream(device=dev, priority=int(os.environ["LSA_STREAM_PRIORITY"])) if os.environ.get("LSA_STREAM_PRIORITY") else torch.cuda.Stream(device=dev)
     torch.cuda.set_stream(tstream)
     ctx = capi.Context(dev_index, tstream.cuda_stream)
 

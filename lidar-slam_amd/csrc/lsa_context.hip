@@ -130,7 +130,10 @@ extern "C" int lsa_context_create(lsa_context **out, int device, void *hip_strea
     ctx->stream = (hipStream_t)hip_stream;
     ctx->own_stream = false;
   } else {
-    e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
+    // LSA_STREAM_PRIORITY (experiments): the HIP priority of the streams this library creates itself (-1 = high on this runtime)
+    static const char *prio_env = getenv("LSA_STREAM_PRIORITY");
+    if (prio_env) e = hipStreamCreateWithPriority(&ctx->stream, hipStreamNonBlocking, atoi(prio_env));
+    else e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
     if (e != hipSuccess) { lsa_set_global_error("hipStreamCreate: %s", hipGetErrorString(e)); delete ctx; return LSA_ERR_HIP; }
     ctx->own_stream = true;
   }
