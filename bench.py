@@ -930,7 +930,25 @@ def main():
             torch.cuda.synchronize()
             front_end_loop = front_end_drive(lsa_fe, ctx, d_all, poses)
             front_end_loop["note"] = "device-resident FrontEnd::Update loop incl. key-frame work (local map of <= 20 key-frames, 0.3 m map filter, voxel table)"
-            del d_all
+            # the same drive from HOST clouds (PointXYZI rows of 32 bytes, what front_end.cpp's caller holds): lsa_front_end_update, one
+            # call per scan — the PCIe-inclusive figure of the whole FrontEnd::Update drop-in (never `value`)
+            h_all = [synth.to_xyzi32(sc) for sc in scans]
+            t_h = []
+            for _rep in range(4):
+                fe_h = lsa_fe.FrontEndHip(ctx)
+                fe_h.SetInitPose(poses[0].astype(np.float32))
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for hc in h_all:
+                    _, T_h = fe_h.Update(hc)
+                torch.cuda.synchronize()
+                t_h.append((time.perf_counter() - t0) * 1e3 / len(h_all))
+                ffc = fe_h.frame_filter_counters()
+                fe_h.close()
+            front_end_loop["host_clouds"] = {"value": round(1e3 / float(np.median(t_h[1:])), 1), "unit": "scans/s", "ms_per_scan": round(float(np.median(t_h[1:])), 4),
+                                             "ms_per_scan_spread": spread(t_h[1:]), "scans_pulled_by_the_device": int(ffc["pulled"]), "of": len(h_all),
+                                             "what": "lsa_front_end_update on 32-byte PointXYZI host rows, one call per scan (median of 3 drives behind one untimed): pack + PCIe inside"}
+            del d_all, h_all
 
     # ---- BASELINE.json configs[2]: point-to-plane ICP (the second RegistrationInterface plugin, lsa_icp_* in its point-to-plane
     # mode; 30 iterations, max correspondence distance 2 m, normals from the target's 1 m voxels) on the same scans against the

@@ -519,6 +519,8 @@ int lsa_front_end_update_batch_device(lsa_front_end *fe, size_t count, const flo
                                       lsa_front_end_stats *stats);
 /* the NDT handle the front end owns (for GetFitnessScore / introspection); do not destroy it */
 lsa_ndt *lsa_front_end_registration(lsa_front_end *fe);
+/* ... and its frame filter (NULL without one): diagnostics (lsa_voxel_filter_counters: how many host scans the device pulled itself) */
+lsa_voxel_filter *lsa_front_end_frame_filter(lsa_front_end *fe);
 /* Incremental local map (default ON; 0 or the environment variable LSA_FE_INCREMENTAL=0 selects the full rebuild).
  * UpdateWithNewFrame (front_end.cpp:348-424) rebuilds filter output and voxel table from all <= 20 key-frames on every
  * key-frame; with the incremental map the per-cell sums of both levels are persistent exact integers, a key-frame adds its own

@@ -162,6 +162,8 @@ void ndt_prearm(lsa_ndt *h);
 bool ndt_defer_scope(lsa_ndt *h, bool on);
 int ndt_collect_deferred(lsa_ndt *h);
 int lsa_voxel_filter_apply_device_async_here(lsa_voxel_filter *f, const float *d_in_xyzw, size_t n, float *d_out_xyzw);   // voxel_filter.hip
+int lsa_voxel_filter_apply_host_to_device(lsa_voxel_filter *f, const void *in_pts, size_t n, size_t in_stride, size_t in_w_off, float *d_rows, float *d_out,
+                                          size_t *n_out, int *pulled);
 
 static int fe_batch_context(lsa_front_end *fe);
 
@@ -621,19 +623,40 @@ extern "C" int lsa_front_end_update(lsa_front_end *fe, const void *cloud, size_t
   lsa_context *ctx = fe->ctx;
   LSA_HIP(ctx, lsa_enter(ctx));
   int rc;
-  LSA_HIP(ctx, hipStreamSynchronize(ctx->stream));  // before the reserves: they may free a buffer an earlier copy still reads
   // The upload alternates between two device buffers: a key-frame's map update reads the scan on the map's own stream after this
   // call has returned, and it is the NEXT call that sees that update complete (fe_lm_settle) — the one after it may overwrite.
   DevBuf<float4> &din = fe->in_alt ? fe->d_in_alt : fe->d_in;
   fe->in_alt = !fe->in_alt;
-  if (n > din.cap && (rc = fe_map_drain(fe))) return rc;   // (growing frees the old buffer)
-  if ((rc = fe->h_stage.reserve(ctx, (n ? n : 1) * 4))) return rc;
+  if (n > din.cap || (n ? n : 1) * 4 > fe->h_stage.cap) {   // before the reserves: they free a buffer an earlier copy / update may still read
+    LSA_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if ((rc = fe_map_drain(fe))) return rc;
+  }
   if ((rc = din.reserve(ctx, n ? n : 1, 1.25))) return rc;
+  // From the second scan on the frame filter's first kernel PULLS the packed rows out of pinned memory while three threads are still
+  // packing them (voxel_filter.hip: the host-pointer Filter's path), leaves the raw cloud in `din` and the filtered one in
+  // d_filtered: no copy command, the transfer under the packing, the mark under the transfer (238 -> ~150 us per Update of a
+  // 131 k-point host scan).
+  if (fe->cfg.use_frame_filter && n) {
+    if ((rc = fe->d_filtered.reserve(ctx, n, 1.25))) return rc;
+    size_t V = 0;
+    int pulled = 0;
+    rc = lsa_voxel_filter_apply_host_to_device(fe->frame_filter, cloud, n, stride, w_off, (float *)din.p, (float *)fe->d_filtered.p, &V, &pulled);
+    if (pulled) {
+      if (rc && rc != LSA_ERR_RANGE) return rc;
+      lsa_front_end_stats local;
+      if (rc == LSA_ERR_RANGE) return fe_update_filtered(fe, din.p, n, din.p, n, pose_out, stats ? stats : &local, false);   // PCL passes the input through
+      return fe_update_filtered(fe, din.p, n, fe->d_filtered.p, V, pose_out, stats ? stats : &local, false);
+    }
+    if (rc) return rc;
+  }
+  LSA_HIP(ctx, hipStreamSynchronize(ctx->stream));  // (the staging buffer may still feed an earlier copy)
+  if ((rc = fe->h_stage.reserve(ctx, (n ? n : 1) * 4))) return rc;
   if ((rc = lsa_upload_xyzw(ctx, cloud, n, stride, w_off, fe->h_stage.p, din.p))) return rc;
   return fe_update_device(fe, din.p, n, pose_out, stats);
 }
 
 extern "C" lsa_ndt *lsa_front_end_registration(lsa_front_end *fe) { return fe ? fe->ndt : nullptr; }
+extern "C" lsa_voxel_filter *lsa_front_end_frame_filter(lsa_front_end *fe) { return fe ? fe->frame_filter : nullptr; }
 
 extern "C" int lsa_front_end_set_incremental(lsa_front_end *fe, int on) {
   if (!fe) return LSA_ERR_INVALID;

@@ -467,6 +467,64 @@ extern "C" int lsa_voxel_filter_apply_device(lsa_voxel_filter *f, const float *d
   return filter_device(f, (const float4 *)d_in_xyzw, n, (float4 *)d_out_xyzw, n_out);
 }
 
+namespace {
+// The steady state of a stream of host scans (the previous scan left a grid definition this one fits): nothing is copied by a copy
+// command.  filter_pull_begin starts the helper threads packing the caller's rows into the staging buffer at once; the caller then
+// enqueues the build (filter_device with the PullSource) — whose first kernel pulls the rows as they are published and leaves them in
+// d_rows — and packs too (filter_pull_join).
+bool filter_can_pull(lsa_voxel_filter *f, size_t n) {
+  return n >= 65536 && !f->pending && !f->no_pull && vi_spec_ready(f->vi, n, 0, f->leaf);
+}
+int filter_pull_begin(lsa_voxel_filter *f, const void *in_pts, size_t n, size_t in_stride, size_t in_w_off, float4 *d_rows, PullSource *pull) {
+  lsa_context *ctx = f->ctx;
+  int rc;
+  const size_t chunk = (size_t)1 << kPullChunkShift;
+  f->u_chunks = (unsigned)((n + chunk - 1) / chunk);
+  if ((rc = f->h_ready.reserve(ctx, (size_t)f->u_chunks * kPullFlagStride))) return rc;
+  if (++f->pull_seq == 0) f->pull_seq = 1;   // (the flags start zeroed and are never reset: a sequence number per call)
+  f->u_pts = in_pts; f->u_stride = in_stride; f->u_w_off = in_w_off; f->u_off = 0; f->u_n = n;
+  f->u_next.store(0, std::memory_order_relaxed);
+  pull->h_rows = reinterpret_cast<const float4 *>(f->h_stage.p);
+  pull->d_copy = d_rows;
+  pull->ready = f->h_ready.p;
+  pull->seq = f->pull_seq;
+  pull->chunk_shift = kPullChunkShift;
+  pull->patience_ticks = 200000000ull;   // 2 s
+  filter_post_job(f, 4);
+  if (!f->packer2_started) {
+    f->packer2 = std::thread(filter_packer2, f);
+    f->packer2_started = true;
+  }
+  {
+    std::lock_guard<std::mutex> lk(f->mu2);
+    f->p2_state.store(1, std::memory_order_release);
+  }
+  f->cv2.notify_one();
+  f->n_pulled++;
+  return LSA_OK;
+}
+}  // namespace
+
+// internal (front_end.hip): a HOST scan through the filter with BOTH results on the device — the packed rows in d_rows (the front
+// end keeps a key-frame's raw cloud) and the filtered cloud in d_out — by the pulled path above.  *pulled = 0: its preconditions do
+// not hold (first scan of a stream, a small cloud, LSA_FILTER_PULL=0): nothing was done, the caller uploads and filters the ordinary way.
+int lsa_voxel_filter_apply_host_to_device(lsa_voxel_filter *f, const void *in_pts, size_t n, size_t in_stride, size_t in_w_off, float *d_rows, float *d_out,
+                                          size_t *n_out, int *pulled) {
+  *pulled = 0;
+  *n_out = 0;
+  if (!f || !in_pts || !d_rows || !d_out) return LSA_ERR_INVALID;
+  lsa_context *ctx = f->ctx;
+  if (in_stride < 12 || (in_w_off != SIZE_MAX && in_w_off + 4 > in_stride)) return LSA_OK;   // (the ordinary path reports it)
+  if (!filter_can_pull(f, n)) return LSA_OK;
+  int rc;
+  if (n * 4 > f->h_stage.cap) LSA_HIP(ctx, hipStreamSynchronize(ctx->stream));   // (growing frees the old staging buffer)
+  if ((rc = f->h_stage.reserve(ctx, n * 4))) return rc;
+  PullSource pull;
+  if ((rc = filter_pull_begin(f, in_pts, n, in_stride, in_w_off, reinterpret_cast<float4 *>(d_rows), &pull))) return rc;
+  *pulled = 1;
+  return filter_device(f, reinterpret_cast<const float4 *>(d_rows), n, reinterpret_cast<float4 *>(d_out), n_out, &pull);
+}
+
 extern "C" int lsa_voxel_filter_apply(lsa_voxel_filter *f, const void *in_pts, size_t n, size_t in_stride, size_t in_w_off, void *out_pts,
                                       size_t out_cap, size_t out_stride, size_t out_w_off, size_t *n_out) {
   if (!f || !n_out || (n && (!in_pts || !out_pts))) return f ? lsa_fail(f->ctx, LSA_ERR_INVALID, "lsa_voxel_filter_apply: null argument") : LSA_ERR_INVALID;
@@ -491,34 +549,9 @@ extern "C" int lsa_voxel_filter_apply(lsa_voxel_filter *f, const void *in_pts, s
   // after ~85 us instead of ~100: the two packers share the memory system and the runtime's locks).
   bool pulled = false;
   PullSource pull;
-  if (n >= 65536 && !f->pending && !f->no_pull && vi_spec_ready(f->vi, n, 0, f->leaf)) {
-    // The steady state of a scan stream (the previous scan left a grid definition this one fits): nothing is copied by a copy
-    // command.  The helper thread starts packing at once, this thread enqueues the build — whose first kernel pulls the rows as
-    // they are published — and then packs too (filter_device -> filter_pull_join).
-    const size_t chunk = (size_t)1 << kPullChunkShift;
-    f->u_chunks = (unsigned)((n + chunk - 1) / chunk);
-    if ((rc = f->h_ready.reserve(ctx, (size_t)f->u_chunks * kPullFlagStride))) return rc;
-    if (++f->pull_seq == 0) f->pull_seq = 1;   // (the flags start zeroed and are never reset: a sequence number per call)
-    f->u_pts = in_pts; f->u_stride = in_stride; f->u_w_off = in_w_off; f->u_off = 0; f->u_n = n;
-    f->u_next.store(0, std::memory_order_relaxed);
-    pull.h_rows = reinterpret_cast<const float4 *>(f->h_stage.p);
-    pull.d_copy = f->d_in.p;
-    pull.ready = f->h_ready.p;
-    pull.seq = f->pull_seq;
-    pull.chunk_shift = kPullChunkShift;
-    pull.patience_ticks = 200000000ull;   // 2 s
-    filter_post_job(f, 4);
-    if (!f->packer2_started) {
-      f->packer2 = std::thread(filter_packer2, f);
-      f->packer2_started = true;
-    }
-    {
-      std::lock_guard<std::mutex> lk(f->mu2);
-      f->p2_state.store(1, std::memory_order_release);
-    }
-    f->cv2.notify_one();
+  if (filter_can_pull(f, n)) {
+    if ((rc = filter_pull_begin(f, in_pts, n, in_stride, in_w_off, f->d_in.p, &pull))) return rc;
     pulled = true;
-    f->n_pulled++;
   } else if (n >= 65536 && !f->pending) {
     if (!f->stream2) {
       LSA_HIP(ctx, hipStreamCreateWithFlags(&f->stream2, hipStreamNonBlocking));

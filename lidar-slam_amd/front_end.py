@@ -149,6 +149,16 @@ class FrontEndHip:
         self.ctx.check(capi.lib().lsa_front_end_map_counters(self.h, out))
         return dict(full_builds=out[0], updates=out[1], rebuilds=out[2], refits=out[3], adopted=out[4], switched_off=out[5])
 
+    def frame_filter_counters(self):
+        """lsa_voxel_filter_counters of the front end's frame filter: builds, speculative misses, bitmap growths, host scans pulled by the device."""
+        L = capi.lib()
+        L.lsa_front_end_frame_filter.argtypes = [C.c_void_p]
+        L.lsa_front_end_frame_filter.restype = C.c_void_p
+        L.lsa_voxel_filter_counters.argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]
+        out = (C.c_uint64 * 4)()
+        self.ctx.check(L.lsa_voxel_filter_counters(L.lsa_front_end_frame_filter(self.h), out))
+        return dict(builds=out[0], misses=out[1], growths=out[2], pulled=out[3])
+
     def armed_stats(self, reset=False):
         """lsa_ndt_armed_stats of the front end's own registration handle (every outcome of an armed pass other than the plain one)."""
         L = capi.lib()

@@ -308,6 +308,46 @@ def test_reserve_changes_no_result(scene, monkeypatch):
         assert got[2] == ref[2] and got[3] == ref[3], (name, got[2], ref[2], got[3], ref[3])
 
 
+def test_host_clouds_equal_device_clouds(scene, monkeypatch):
+    """lsa_front_end_update (host PointXYZI rows, what a ROS / PCL caller holds) against lsa_front_end_update_device on the same
+    full-size scans: from the second scan on the frame filter's first kernel pulls the packed rows over the link itself and leaves the
+    raw cloud on the device for the key-frame store (voxel_filter.hip: lsa_voxel_filter_apply_host_to_device) — poses, statistics and
+    the incremental map must be those of the device path, bit for bit; the same with the pull switched off (copy commands)."""
+    import torch
+    N = 12
+    poses = synth.trajectory(N, step=1.1)
+    scans = [synth.gen_scan(scene, poses[i], seed=3100 + i) for i in range(N)]
+    assert all(sc.shape[0] >= 65536 for sc in scans)
+    h = [synth.to_xyzi32(sc) for sc in scans]
+    d = [torch.from_numpy(np.ascontiguousarray(sc)).cuda() for sc in scans]
+    torch.cuda.synchronize()
+    cfg = front_end.default_config()
+    cfg.local_frame_num = 4
+    runs = {}
+    for name, clouds, env in (("device", d, None), ("host pulled", h, None), ("host copied", h, "0")):
+        if env is None:
+            monkeypatch.delenv("LSA_FILTER_PULL", raising=False)
+        else:
+            monkeypatch.setenv("LSA_FILTER_PULL", env)
+        ctx = capi.Context(0)
+        fe = front_end.FrontEndHip(ctx, cfg)
+        T_all, st_all = [], []
+        for c in clouds:
+            _, T = fe.Update(c)
+            T_all.append(T); st_all.append(_flat(fe.last_stats))
+        runs[name] = (np.stack(T_all), st_all, fe.map_verify(), fe.frame_filter_counters())
+        fe.close(); ctx.close()
+    monkeypatch.delenv("LSA_FILTER_PULL", raising=False)
+    ref = runs["device"]
+    assert sum(x["key_frame"] for x in ref[1]) >= 5 and ref[2]["mismatches"] == 0
+    assert runs["host pulled"][3]["pulled"] >= N - 3 and runs["host copied"][3]["pulled"] == 0 and ref[3]["pulled"] == 0
+    for name in ("host pulled", "host copied"):
+        got = runs[name]
+        assert np.array_equal(got[0], ref[0]), name
+        assert got[1] == ref[1], name
+        assert got[2] == ref[2], (name, got[2], ref[2])
+
+
 def test_update_batch_full_rebuild_and_no_frame_filter(scene):
     """The same equality with the incremental local map switched off (every key-frame rebuilds filter output and voxel table on the
     registration's stream, between two ScanMatches of the run) and, separately, without a frame filter (nothing to overlap: the run
