@@ -82,8 +82,9 @@ typedef struct lsa_voxel_filter lsa_voxel_filter;
 int lsa_voxel_filter_create(lsa_voxel_filter **out, lsa_context *ctx, float leaf_x, float leaf_y, float leaf_z);
 void lsa_voxel_filter_destroy(lsa_voxel_filter *f);
 /* Optional, no reference counterpart (PCL allocates per call): allocate now what filtering clouds of up to max_points needs,
- * so that the first Filter calls neither allocate nor have to grow the occupancy bitmap; async_too also starts the helper
- * thread of lsa_voxel_filter_apply_device_async.  Changes no result. */
+ * so that the first Filter calls neither allocate nor have to grow the occupancy bitmap; async_too: bit 0 also starts the helper
+ * thread of lsa_voxel_filter_apply_device_async, bit 1 prepares the host-cloud path (pinned staging rows, second packing thread).
+ * Changes no result. */
 int lsa_voxel_filter_reserve(lsa_voxel_filter *f, size_t max_points, int async_too);
 /* Diagnostics: out[0] synchronous builds, [1] builds repeated because a point fell outside the reused cell box, [2] bitmap growths,
  * [3] host clouds whose rows the device pulled over the link itself while they were being packed (lsa_voxel_filter_apply, from the

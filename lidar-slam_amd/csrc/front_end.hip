@@ -546,7 +546,7 @@ extern "C" int lsa_front_end_reserve(lsa_front_end *fe, size_t max_scan_points) 
   const size_t n = max_scan_points;
   int rc;
   if (fe->cfg.use_frame_filter) {
-    if ((rc = lsa_voxel_filter_reserve(fe->frame_filter, n, 0))) return rc;
+    if ((rc = lsa_voxel_filter_reserve(fe->frame_filter, n, 3))) return rc;   // (lsa_front_end_update's host scans go through its pulled path)
     if ((rc = fe->d_filtered.reserve(ctx, n, 1.25))) return rc;
     if ((rc = fe_batch_context(fe))) return rc;
     if ((rc = lsa_voxel_filter_reserve(fe->frame_filter_b, n, 1))) return lsa_fail(ctx, rc, "%s", lsa_last_error(fe->ctx_b));

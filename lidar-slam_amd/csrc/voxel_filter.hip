@@ -399,7 +399,8 @@ extern "C" int lsa_voxel_filter_create(lsa_voxel_filter **out, lsa_context *ctx,
 // 200 m x 200 m x 25 m box at a 0.5 m leaf with the speculative margin; the scan kernel's grid covers the capacity, so a much
 // larger one costs every build: 2^20 words made k_scan 9.3 instead of 7.2 us; a larger box still grows it once), and start the helper thread of the asynchronous entry
 // point if `async_too`: after this a Filter call over such a cloud allocates nothing and finds the bitmap large enough on its
-// first build.  Optional — every call sizes what it needs — and without effect on any result.
+// first build.  Optional — every call sizes what it needs — and without effect on any result.  async_too: bit 0 the helper thread of the
+// asynchronous entry point, bit 1 what the host-cloud entry points use (pinned staging rows, chunk flags, the second packing thread).
 extern "C" int lsa_voxel_filter_reserve(lsa_voxel_filter *f, size_t max_points, int async_too) {
   if (!f) return LSA_ERR_INVALID;
   LSA_HIP(f->ctx, lsa_enter(f->ctx));
@@ -413,9 +414,18 @@ extern "C" int lsa_voxel_filter_reserve(lsa_voxel_filter *f, size_t max_points, 
     vi.acc_ns = 4;
     vi.clean = true;
   }
-  if (async_too && !f->worker_started) {
+  if ((async_too & 1) && !f->worker_started) {
     f->worker = std::thread(filter_worker, f);
     f->worker_started = true;
+  }
+  if (async_too & 2) {   // the host-cloud path: pinned staging rows, chunk flags, the second packing thread
+    const size_t n = max_points ? max_points : 1, chunk = (size_t)1 << kPullChunkShift;
+    if ((rc = f->h_stage.reserve(f->ctx, n * 4))) return rc;
+    if ((rc = f->h_ready.reserve(f->ctx, ((n + chunk - 1) / chunk) * kPullFlagStride))) return rc;
+    if (!f->packer2_started) {
+      f->packer2 = std::thread(filter_packer2, f);
+      f->packer2_started = true;
+    }
   }
   return LSA_OK;
 }
