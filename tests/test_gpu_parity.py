@@ -407,6 +407,29 @@ def test_host_filter_pulled_rows_equal_copied_rows(scene, monkeypatch):
     assert rp[0].shape[0] > 5000
 
 
+def test_voxel_filter_reserve_changes_no_result(scan_pair):
+    """lsa_voxel_filter_reserve (buffers, a bitmap large enough for the first build, helper threads and pinned staging rows ahead of the
+    first call): the same outputs bit for bit as an unreserved handle on the host and on the device path, and no bitmap growth."""
+    import ctypes as C
+    import torch
+    s0, s1, _, _ = scan_pair
+    L = capi.lib()
+    L.lsa_voxel_filter_reserve.argtypes = [C.c_void_p, C.c_size_t, C.c_int]
+    ctx = capi.Context(0)
+    plain = cloud_filter.VoxelFilterHip(ctx, 0.5, 0.5, 0.5)
+    ahead = cloud_filter.VoxelFilterHip(ctx, 0.5, 0.5, 0.5)
+    ctx.check(L.lsa_voxel_filter_reserve(ahead.h, 160000, 3))
+    for pts in (s0, s1, s0[::3], s1):
+        p8 = synth.to_xyzi32(pts)
+        _, a = plain.Filter(p8)
+        _, b = ahead.Filter(p8)
+        assert a.shape == b.shape and np.array_equal(a.view(np.uint32), b.view(np.uint32))
+        d = torch.from_numpy(np.ascontiguousarray(pts)).cuda()
+        assert torch.equal(plain.filter_device(d), ahead.filter_device(d))
+    assert ahead.counters()["growths"] == 0 and plain.counters()["growths"] >= 1
+    plain.close(); ahead.close(); ctx.close()
+
+
 def test_pipeline_batch_equals_sequential_calls(oracle, scene):
     """lsa_pipeline_scan_match (filter of scan k+1 under the registration of scan k, inside the library) returns exactly
     what Filter + ScanMatch called scan by scan return."""
