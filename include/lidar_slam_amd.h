@@ -518,6 +518,12 @@ int lsa_front_end_map_stamps(lsa_front_end *fe, int enable, uint64_t *out, size_
  * returns; poses_out: 16 floats per scan; stats: `count` records or NULL.  On an error the scans before it have been applied. */
 int lsa_front_end_update_batch_device(lsa_front_end *fe, size_t count, const float *const *d_scans_xyzw, const size_t *n_points, float *poses_out,
                                       lsa_front_end_stats *stats);
+/* The same run fed with HOST clouds — what FrontEndFlow::Run's buffered clouds are (front_end_flow.cpp:18-36): `count` clouds of
+ * n_points[k] rows of `stride` bytes (x, y, z at 0, the intensity / static weight at w_off, SIZE_MAX = none), untouched until the call
+ * returns.  Scan k + 1 is packed and crosses the link (pulled by its frame filter's first kernel) while scan k is registered.  Poses,
+ * key-frame decisions, local map and statistics are those of `count` calls of lsa_front_end_update, bit for bit. */
+int lsa_front_end_update_batch(lsa_front_end *fe, size_t count, const void *const *clouds, const size_t *n_points, size_t stride, size_t w_off,
+                               float *poses_out, lsa_front_end_stats *stats);
 /* the NDT handle the front end owns (for GetFitnessScore / introspection); do not destroy it */
 lsa_ndt *lsa_front_end_registration(lsa_front_end *fe);
 /* ... and its frame filter (NULL without one): diagnostics (lsa_voxel_filter_counters: how many host scans the device pulled itself) */

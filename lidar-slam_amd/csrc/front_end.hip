@@ -16,6 +16,7 @@
 #include "local_map.h"
 #include "ndt_internal.h"
 
+#include <chrono>
 #include <cmath>
 #include <deque>
 #include <vector>
@@ -119,7 +120,12 @@ struct lsa_front_end {
   // lsa_front_end_update_batch_device: a second context (stream) with a frame filter of its own, three filtered clouds in rotation
   lsa_context *ctx_b = nullptr;
   lsa_voxel_filter *frame_filter_b = nullptr;
-  DevBuf<float4> d_batch[3];
+  DevBuf<float4> d_batch[4];   // (the device-cloud run rotates the first three, the host-cloud run all four)
+  DevBuf<float4> d_raw[4];     // lsa_front_end_update_batch (host scans): the raw rows of the scans in flight, in rotation like d_batch
+  // ... whose ingest is TWO scans deep (a host scan's filter — pack, link, kernels: ~95 us — is longer than a registration): a third
+  // context / frame filter takes every other scan
+  lsa_context *ctx_c = nullptr;
+  lsa_voxel_filter *frame_filter_c = nullptr;
   std::deque<KeyFrame *> frames;
   std::vector<KeyFrame *> pool;
   DevBuf<float4> d_in, d_filtered, d_map, d_map_f;
@@ -162,10 +168,12 @@ void ndt_prearm(lsa_ndt *h);
 bool ndt_defer_scope(lsa_ndt *h, bool on);
 int ndt_collect_deferred(lsa_ndt *h);
 int lsa_voxel_filter_apply_device_async_here(lsa_voxel_filter *f, const float *d_in_xyzw, size_t n, float *d_out_xyzw);   // voxel_filter.hip
+int lsa_voxel_filter_apply_host_async(lsa_voxel_filter *f, const void *in_pts, size_t n, size_t in_stride, size_t in_w_off, float *d_rows, float *d_out);
 int lsa_voxel_filter_apply_host_to_device(lsa_voxel_filter *f, const void *in_pts, size_t n, size_t in_stride, size_t in_w_off, float *d_rows, float *d_out,
                                           size_t *n_out, int *pulled);
 
 static int fe_batch_context(lsa_front_end *fe);
+static int fe_host_batch_context(lsa_front_end *fe);
 
 namespace {
 // The local map buffer is `local_frame_num` slots of slot_cap points; a key-frame's transformed cloud lives in its slot
@@ -493,6 +501,86 @@ int fe_update_batch(lsa_front_end *fe, size_t count, const float *const *d_scans
   // the caller's scans are his again when this returns: whatever he enqueues on his stream next comes behind the last map update
   return fe_map_join(fe);
 }
+
+// The same run fed with HOST scans (what FrontEndFlow::Run's buffered clouds are, front_end_flow.cpp:18-36): scan k + 1 is packed by the
+// second filter's helper threads and pulled over the link by that filter's first kernel (voxel_filter.hip: job kind 5) while scan k is
+// registered — the 44 us a 131 k-point scan needs on the link, and the packing, pass under the ~48 us of the registration.  The raw rows
+// land in one of three device buffers (a key-frame's cloud is copied from there), the filtered cloud in d_batch as above.
+int fe_update_batch_host(lsa_front_end *fe, size_t count, const void *const *h_scans, const size_t *n_points, size_t stride, size_t w_off, float *poses_out,
+                         lsa_front_end_stats *stats) {
+  lsa_context *ctx = fe->ctx;
+  int rc;
+  if (!fe->cfg.use_frame_filter) {  // nothing to overlap with: one Update per scan
+    for (size_t k = 0; k < count; k++)
+      if ((rc = lsa_front_end_update(fe, h_scans[k], n_points[k], stride, w_off, poses_out + 16 * k, stats ? stats + k : nullptr))) return rc;
+    return LSA_OK;
+  }
+  if ((rc = fe_batch_context(fe)) || (rc = fe_host_batch_context(fe))) return rc;
+  size_t n_max = 1;
+  for (size_t k = 0; k < count; k++) n_max = std::max(n_max, n_points[k]);
+  if (fe->d_batch[3].cap < n_max || fe->d_raw[3].cap < n_max) {   // before the reserves (they may free a buffer): no stream may still use the old ones
+    LSA_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    LSA_HIP(ctx, hipStreamSynchronize(fe->ctx_b->stream));
+    LSA_HIP(ctx, hipStreamSynchronize(fe->ctx_c->stream));
+    if ((rc = fe_map_drain(fe))) return rc;
+    for (int b = 0; b < 4; b++)
+      if ((rc = fe->d_batch[b].reserve(ctx, n_max, 1.25)) || (rc = fe->d_raw[b].reserve(ctx, n_max, 1.25))) return rc;
+  }
+  // scan j goes through filter j % 2 into buffers j % 4: k - 1 (its deferred final pass), k (being registered), k + 1 and k + 2 (in
+  // flight) never share one
+  lsa_voxel_filter *ff[2] = {fe->frame_filter_b, fe->frame_filter_c};
+  lsa_context *fc[2] = {fe->ctx_b, fe->ctx_c};
+  auto post = [&](size_t j) -> int {
+    int r = lsa_voxel_filter_apply_host_async(ff[j & 1], h_scans[j], n_points[j], stride, w_off, (float *)fe->d_raw[j & 3].p, (float *)fe->d_batch[j & 3].p);
+    return r ? lsa_fail(ctx, r, "%s", lsa_last_error(fc[j & 1])) : LSA_OK;
+  };
+  size_t posted = 0;
+  auto drain = [&](size_t from) { for (size_t j = from; j < posted; j++) { size_t dummy; (void)lsa_voxel_filter_wait(ff[j & 1], &dummy); } };
+  for (; posted < count && posted < 2; posted++)
+    if ((rc = post(posted))) { drain(0); return rc; }
+  const bool carry_user = ndt_carry_scope(fe->ndt, true);
+  const bool defer_user = ndt_defer_scope(fe->ndt, true);
+  fe->in_batch = true;
+  struct Restore {
+    lsa_front_end *fe; lsa_ndt *h; bool prev, prev_defer;
+    ~Restore() { fe->in_batch = false; (void)ndt_collect_deferred(h); (void)ndt_defer_scope(h, prev_defer); (void)ndt_carry_scope(h, prev); if (!prev) ndt_release_parked(h); }
+  } restore{fe, fe->ndt, carry_user, defer_user};
+  lsa_front_end_stats local;
+  // diagnostics (LSA_PIPE_TRACE=1, runs of <= 64 scans): when each scan's filter was there and its Update returned, on stderr
+  static const bool trace = getenv("LSA_PIPE_TRACE") != nullptr;
+  const auto tr0 = std::chrono::steady_clock::now();
+  std::vector<double> tr;
+  auto stamp = [&] { if (trace && count <= 64) tr.push_back(std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - tr0).count()); };
+  struct Dump {
+    std::vector<double> &t;
+    ~Dump() {
+      if (t.empty()) return;
+      fprintf(stderr, "[lsa fe host run] us since the loop began (wait begins / filter there / next posted / Update back):");
+      for (size_t i = 0; i + 3 < t.size(); i += 4) fprintf(stderr, " %.0f/%.0f/%.0f/%.0f", t[i], t[i + 1], t[i + 2], t[i + 3]);
+      fprintf(stderr, "\n");
+    }
+  } dump{tr};
+  for (size_t k = 0; k < count; k++) {
+    size_t m = 0;
+    stamp();
+    rc = lsa_voxel_filter_wait(ff[k & 1], &m);
+    stamp();
+    const float4 *raw = fe->d_raw[k & 3].p;
+    const float4 *src = fe->d_batch[k & 3].p;
+    if (rc == LSA_ERR_RANGE) { src = raw; m = n_points[k]; rc = LSA_OK; }   // PCL passes the input through
+    if (rc) { rc = lsa_fail(ctx, rc, "%s", lsa_last_error(fc[k & 1])); drain(k + 1); return rc; }
+    if (posted < count) {
+      if ((rc = post(posted))) { drain(k + 1); return rc; }
+      posted++;
+    }
+    stamp();
+    rc = fe_update_filtered(fe, raw, n_points[k], src, m, poses_out + 16 * k, stats ? stats + k : &local, true);
+    stamp();
+    if (!stats && (rc == LSA_OK)) rc = ndt_collect_deferred(fe->ndt);   // (`local` is about to be reused)
+    if (rc) { drain(k + 1); return rc; }   // leave no filter in flight behind an error
+  }
+  return fe_map_join(fe);
+}
 }  // namespace
 
 extern "C" int lsa_front_end_create(lsa_front_end **out, lsa_context *ctx, const lsa_front_end_config *cfg) {
@@ -530,6 +618,14 @@ static int fe_batch_context(lsa_front_end *fe) {
   return lsa_voxel_filter_create(&fe->frame_filter_b, fe->ctx_b, fe->cfg.frame_leaf[0], fe->cfg.frame_leaf[1], fe->cfg.frame_leaf[2]);
 }
 
+// ... and the third one of lsa_front_end_update_batch (host scans, ingest two deep)
+static int fe_host_batch_context(lsa_front_end *fe) {
+  if (fe->ctx_c) return LSA_OK;
+  int rc;
+  if ((rc = lsa_context_create(&fe->ctx_c, fe->ctx->device, nullptr))) return lsa_fail(fe->ctx, rc, "lsa_front_end_update_batch: third context: %s", lsa_last_global_error());
+  return lsa_voxel_filter_create(&fe->frame_filter_c, fe->ctx_c, fe->cfg.frame_leaf[0], fe->cfg.frame_leaf[1], fe->cfg.frame_leaf[2]);
+}
+
 int lsa_voxel_filter_reserve(lsa_voxel_filter *f, size_t max_points, int async_too);   // voxel_filter.hip
 
 // Allocate now everything Update would otherwise allocate on its way through the first scans of a session: the frame filters'
@@ -549,12 +645,14 @@ extern "C" int lsa_front_end_reserve(lsa_front_end *fe, size_t max_scan_points) 
     if ((rc = lsa_voxel_filter_reserve(fe->frame_filter, n, 3))) return rc;   // (lsa_front_end_update's host scans go through its pulled path)
     if ((rc = fe->d_filtered.reserve(ctx, n, 1.25))) return rc;
     if ((rc = fe_batch_context(fe))) return rc;
-    if ((rc = lsa_voxel_filter_reserve(fe->frame_filter_b, n, 1))) return lsa_fail(ctx, rc, "%s", lsa_last_error(fe->ctx_b));
-    if (fe->d_batch[0].cap < n) {
+    if ((rc = lsa_voxel_filter_reserve(fe->frame_filter_b, n, 3))) return lsa_fail(ctx, rc, "%s", lsa_last_error(fe->ctx_b));
+    if ((rc = fe_host_batch_context(fe))) return rc;
+    if ((rc = lsa_voxel_filter_reserve(fe->frame_filter_c, n, 3))) return lsa_fail(ctx, rc, "%s", lsa_last_error(fe->ctx_c));
+    if (fe->d_batch[3].cap < n || fe->d_raw[3].cap < n) {
       LSA_HIP(ctx, hipStreamSynchronize(ctx->stream));
       LSA_HIP(ctx, hipStreamSynchronize(fe->ctx_b->stream));
-      for (int b = 0; b < 3; b++)
-        if ((rc = fe->d_batch[b].reserve(ctx, n, 1.25))) return rc;
+      for (int b = 0; b < 4; b++)
+        if ((rc = fe->d_batch[b].reserve(ctx, n, 1.25)) || (rc = fe->d_raw[b].reserve(ctx, n, 1.25))) return rc;
     }
   }
   // key-frame clouds: one per slot of the window (an evicted key-frame's object and buffer are reused from then on)
@@ -569,6 +667,7 @@ extern "C" int lsa_front_end_reserve(lsa_front_end *fe, size_t max_scan_points) 
   LSA_HIP(ctx, hipStreamSynchronize(ctx->stream));
   LSA_HIP(ctx, hipStreamSynchronize(fe->ctx_m->stream));
   LSA_HIP(ctx, hipStreamSynchronize(fe->ctx_b ? fe->ctx_b->stream : ctx->stream));
+  LSA_HIP(ctx, hipStreamSynchronize(fe->ctx_c ? fe->ctx_c->stream : ctx->stream));
   return LSA_OK;
 }
 
@@ -586,7 +685,10 @@ extern "C" void lsa_front_end_destroy(lsa_front_end *fe) {
   lsa_ndt_destroy(fe->ndt);
   if (fe->ctx_b) (void)hipStreamSynchronize(fe->ctx_b->stream);
   lsa_voxel_filter_destroy(fe->frame_filter_b);
-  for (int b = 0; b < 3; b++) fe->d_batch[b].release();
+  for (int b = 0; b < 4; b++) { fe->d_batch[b].release(); fe->d_raw[b].release(); }
+  if (fe->ctx_c) (void)hipStreamSynchronize(fe->ctx_c->stream);
+  lsa_voxel_filter_destroy(fe->frame_filter_c);
+  if (fe->ctx_c) lsa_context_destroy(fe->ctx_c);
   if (fe->ctx_b) lsa_context_destroy(fe->ctx_b);
   if (fe->ev_map) (void)hipEventDestroy(fe->ev_map);
   if (fe->ev_in) (void)hipEventDestroy(fe->ev_in);
@@ -605,6 +707,17 @@ extern "C" int lsa_front_end_update_device(lsa_front_end *fe, const float *d_xyz
   if (!fe || !pose_out || (n && !d_xyzw)) return fe ? lsa_fail(fe->ctx, LSA_ERR_INVALID, "lsa_front_end_update_device: null argument") : LSA_ERR_INVALID;
   LSA_HIP(fe->ctx, lsa_enter(fe->ctx));
   return fe_update_device(fe, (const float4 *)d_xyzw, n, pose_out, stats);
+}
+
+extern "C" int lsa_front_end_update_batch(lsa_front_end *fe, size_t count, const void *const *clouds, const size_t *n_points, size_t stride, size_t w_off,
+                                          float *poses_out, lsa_front_end_stats *stats) {
+  if (!fe || (count && (!clouds || !n_points || !poses_out))) return fe ? lsa_fail(fe->ctx, LSA_ERR_INVALID, "lsa_front_end_update_batch: null argument") : LSA_ERR_INVALID;
+  for (size_t k = 0; k < count; k++)
+    if (n_points[k] && !clouds[k]) return lsa_fail(fe->ctx, LSA_ERR_INVALID, "lsa_front_end_update_batch: scan %zu is null", k);
+  if (stride < 12 || (w_off != SIZE_MAX && w_off + 4 > stride)) return lsa_fail(fe->ctx, LSA_ERR_INVALID, "lsa_front_end_update_batch: point rows of %zu bytes cannot hold xyz + an intensity at offset %zu", stride, w_off);
+  if (count == 0) return LSA_OK;
+  LSA_HIP(fe->ctx, lsa_enter(fe->ctx));
+  return fe_update_batch_host(fe, count, clouds, n_points, stride, w_off, poses_out, stats);
 }
 
 extern "C" int lsa_front_end_update_batch_device(lsa_front_end *fe, size_t count, const float *const *d_scans_xyzw, const size_t *n_points, float *poses_out,

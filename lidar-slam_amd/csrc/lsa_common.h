@@ -103,6 +103,7 @@ struct PinnedBuf {
 // host AoS (pcl::PointXYZI-like) -> packed float4 {x,y,z,w}; w_off == SIZE_MAX -> w = 1
 void lsa_pack_xyzw(const void *pts, size_t n, size_t stride, size_t w_off, float *out4);
 int lsa_upload_xyzw(lsa_context *ctx, const void *pts, size_t n, size_t stride, size_t w_off, float *h_stage, float4 *d_dst);
+hipError_t lsa_pull_rows(hipStream_t stream, const float *h_rows, float4 *d_rows, size_t n);
 
 static inline unsigned lsa_div_up(size_t a, size_t b) { return (unsigned)((a + b - 1) / b); }
 

@@ -57,6 +57,14 @@ __global__ __launch_bounds__(256) void k_pull_rows(const float4 *__restrict__ h_
   if (i < n) d_rows[i] = h_rows[i];
 }
 
+// packed rows in pinned memory -> device, by a kernel on `stream` (any size; no copy command: the first one on a fresh stream
+// sets up a copy queue, measured at ~7 ms)
+hipError_t lsa_pull_rows(hipStream_t stream, const float *h_rows, float4 *d_rows, size_t n) {
+  if (!n) return hipSuccess;
+  hipLaunchKernelGGL(k_pull_rows, dim3(lsa_div_up(n, 256)), dim3(256), 0, stream, reinterpret_cast<const float4 *>(h_rows), d_rows, n);
+  return hipGetLastError();
+}
+
 int lsa_upload_xyzw(lsa_context *ctx, const void *pts, size_t n, size_t stride, size_t w_off, float *h_stage, float4 *d_dst) {
   // an intensity offset that does not fit the row would read the next point (or past the buffer): (n,3) xyz rows have
   // no intensity and must say so with w_off == SIZE_MAX
@@ -72,7 +80,9 @@ int lsa_upload_xyzw(lsa_context *ctx, const void *pts, size_t n, size_t stride, 
   for (size_t off = 0; off < n; off += kChunk) {
     const size_t m = n - off < kChunk ? n - off : kChunk;
     lsa_pack_xyzw((const char *)pts + off * stride, m, stride, w_off, h_stage + 4 * off);
-    LSA_HIP(ctx, hipMemcpyAsync(d_dst + off, h_stage + 4 * off, m * sizeof(float4), hipMemcpyHostToDevice, ctx->stream));
+    // (a kernel per chunk, not a copy command: the same bytes at the link's rate, no copy queue to set up on a stream that has never
+    // copied — ~7 ms the first time —, no change of engine between this stream's kernels)
+    LSA_HIP(ctx, lsa_pull_rows(ctx->stream, h_stage + 4 * off, d_dst + off, m));
   }
   return LSA_OK;
 }

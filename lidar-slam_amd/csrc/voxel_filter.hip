@@ -139,7 +139,7 @@ int filter_device(lsa_voxel_filter *f, const float4 *d_in, size_t n, float4 *d_o
 
 // the enqueue half of filter_device (attempt 0 only); filter_wait() completes it and falls back to the synchronous path
 // if the bitmap capacity has to grow
-int filter_enqueue(lsa_voxel_filter *f, const float4 *d_in, size_t n, float4 *d_out) {
+int filter_enqueue(lsa_voxel_filter *f, const float4 *d_in, size_t n, float4 *d_out, const PullSource *pull = nullptr) {
   lsa_context *ctx = f->ctx;
   VoxelIndex &vi = f->vi;
   int rc;
@@ -147,7 +147,7 @@ int filter_enqueue(lsa_voxel_filter *f, const float4 *d_in, size_t n, float4 *d_
   // While the registration still waited for its stream after every pass, a lighter background filter made the overlapped
   // pipeline slower; since the passes hand their rows over without a stream wait it is the other way round (5 A/B pairs:
   // +6 %).  A point outside the reused cell box is caught by filter_wait(), which rebuilds exactly.
-  rc = vi_enqueue(ctx, vi, d_in, n, /*mode PCL*/ 0, f->leaf, 4, /*allow_spec*/ true);
+  rc = vi_enqueue(ctx, vi, d_in, n, /*mode PCL*/ 0, f->leaf, 4, /*allow_spec*/ true, pull);
   if (rc) return rc;
   hipLaunchKernelGGL(k_filter_finalize, dim3(lsa_div_up(n, kBlock)), dim3(kBlock), 0, ctx->stream, vi.acc.p, vi.cnt.p, vi.cell_of_rank.p, vi.dparams.p, d_out,
                      vi.h_params.p, vi.bits.p);
@@ -233,6 +233,54 @@ void filter_worker(lsa_voxel_filter *f) {
       if (!f->job_state.compare_exchange_strong(expect, 3, std::memory_order_acq_rel)) continue;
       (void)filter_pack_chunks(f);
       f->job_rc = LSA_OK;
+      f->job_state.store(2, std::memory_order_release);
+      continue;
+    }
+    if (f->job_kind == 5) {
+      // A HOST scan through the filter, asynchronously (lsa_voxel_filter_apply_host_async): with a reusable grid definition the
+      // build is enqueued first — its mark kernel pulls the rows over the link as they are published and leaves them in p_in —
+      // and this thread and the second packer then pack the caller's rows chunk by chunk; without one, the rows are packed and
+      // sent by copy commands in front of the ordinary build.  Either way the caller's thread is free meanwhile.
+      const size_t n = f->u_n;
+      int rc;
+      if (n >= 65536 && !f->no_pull && vi_spec_ready(f->vi, n, 0, f->leaf)) {
+        const size_t chunk = (size_t)1 << kPullChunkShift;
+        f->u_chunks = (unsigned)((n + chunk - 1) / chunk);
+        if (++f->pull_seq == 0) f->pull_seq = 1;
+        f->u_next.store(0, std::memory_order_relaxed);
+        PullSource pull;
+        pull.h_rows = reinterpret_cast<const float4 *>(f->h_stage.p);
+        pull.d_copy = const_cast<float4 *>(f->p_in);
+        pull.ready = f->h_ready.p;
+        pull.seq = f->pull_seq;
+        pull.chunk_shift = kPullChunkShift;
+        pull.patience_ticks = 200000000ull;
+        if (f->packer2_started) {
+          {
+            std::lock_guard<std::mutex> lk(f->mu2);
+            f->p2_state.store(1, std::memory_order_release);
+          }
+          f->cv2.notify_one();
+        }
+        f->n_pulled++;
+        rc = filter_enqueue(f, f->p_in, n, f->p_out, &pull);
+        (void)filter_pack_chunks(f);   // (also behind a failed enqueue: harmless, and the second packer may be at it)
+        for (;;) {   // the second packer: done, or never started on it
+          int st2 = f->p2_state.load(std::memory_order_acquire);
+          if (st2 == 0) break;
+          if (st2 == 2) { f->p2_state.store(0, std::memory_order_release); break; }
+          if (st2 == 1 && f->p2_state.compare_exchange_strong(st2, 0, std::memory_order_acq_rel)) break;
+          __builtin_ia32_pause();
+        }
+      } else {
+        // (no copy command: the first one on this handle's stream would set up a copy queue — ~7 ms, seen as the first filter of
+        // every other fresh front end taking that long — and a kernel reads pinned memory at the link's rate anyway)
+        lsa_pack_xyzw(f->u_pts, n, f->u_stride, f->u_w_off, f->h_stage.p);
+        hipError_t e = lsa_pull_rows(f->ctx->stream, f->h_stage.p, const_cast<float4 *>(f->p_in), n);
+        f->job_hip = e;
+        rc = e == hipSuccess ? filter_enqueue(f, f->p_in, n, f->p_out) : LSA_ERR_HIP;
+      }
+      f->job_rc = rc;
       f->job_state.store(2, std::memory_order_release);
       continue;
     }
@@ -341,6 +389,33 @@ float *lsa_voxel_filter_pipe_buffer(lsa_voxel_filter *f, size_t n) {
   if ((n ? n : 1) > f->d_pipe.cap && hipSetDevice(f->ctx->device) != hipSuccess) return nullptr;
   if (f->d_pipe.reserve(f->ctx, n ? n : 1, 1.1)) return nullptr;
   return (float *)f->d_pipe.p;
+}
+
+// internal (front_end.hip): the asynchronous Filter of a HOST scan — raw rows to d_rows, filtered cloud to d_out, both on the device —
+// completed by lsa_voxel_filter_wait like lsa_voxel_filter_apply_device_async.  The caller's rows must stay valid until the wait.
+int lsa_voxel_filter_apply_host_async(lsa_voxel_filter *f, const void *in_pts, size_t n, size_t in_stride, size_t in_w_off, float *d_rows, float *d_out) {
+  if (!f || (n && (!in_pts || !d_rows || !d_out))) return f ? lsa_fail(f->ctx, LSA_ERR_INVALID, "lsa_voxel_filter_apply_host_async: null argument") : LSA_ERR_INVALID;
+  if (f->pending) return lsa_fail(f->ctx, LSA_ERR_INVALID, "lsa_voxel_filter_apply_host_async: a filter is already in flight on this handle");
+  lsa_context *ctx = f->ctx;
+  if (n && (in_stride < 12 || (in_w_off != SIZE_MAX && in_w_off + 4 > in_stride)))
+    return lsa_fail(ctx, LSA_ERR_INVALID, "point rows of %zu bytes cannot hold xyz + an intensity at offset %zu (pass SIZE_MAX for clouds without one)", in_stride, in_w_off);
+  lsa_ctx_unpark(ctx);  // the helper thread enqueues on this context's stream
+  LSA_HIP(ctx, hipSetDevice(ctx->device));
+  int rc;
+  const size_t chunk = (size_t)1 << kPullChunkShift, chunks = (n + chunk - 1) / chunk;
+  if (n * 4 > f->h_stage.cap || chunks * kPullFlagStride > f->h_ready.cap) LSA_HIP(ctx, hipStreamSynchronize(ctx->stream));   // (growing frees the old buffers)
+  if ((rc = f->h_stage.reserve(ctx, (n ? n : 1) * 4))) return rc;
+  if ((rc = f->h_ready.reserve(ctx, (chunks ? chunks : 1) * kPullFlagStride))) return rc;
+  if (!f->packer2_started && n >= 65536 && !f->no_pull) {
+    f->packer2 = std::thread(filter_packer2, f);
+    f->packer2_started = true;
+  }
+  f->u_pts = in_pts; f->u_stride = in_stride; f->u_w_off = in_w_off; f->u_off = 0; f->u_n = n;
+  f->p_in = (const float4 *)d_rows; f->p_out = (float4 *)d_out; f->p_n = n;
+  f->pending = true;
+  if (n == 0) return LSA_OK;
+  filter_post_job(f, 5);
+  return LSA_OK;
 }
 
 // internal (pipeline.cpp): see job kind 3.  _begin posts it to the helper thread, _end waits for it.

@@ -125,6 +125,8 @@ class FrontEndHip:
         stats="key_frame" — just the list of key-frame flags (a replay that only wants poses does not pay for `count` dicts)."""
         from .registration import check_points_tensor
         count = len(clouds)
+        if count and not hasattr(clouds[0], "data_ptr"):
+            return self._update_batch_host(clouds, stats)
         for c in clouds:
             check_points_tensor(c, "FrontEnd.UpdateBatch")
         self._keep = list(clouds)
@@ -148,6 +150,28 @@ class FrontEndHip:
         out = (C.c_uint64 * 6)()
         self.ctx.check(capi.lib().lsa_front_end_map_counters(self.h, out))
         return dict(full_builds=out[0], updates=out[1], rebuilds=out[2], refits=out[3], adopted=out[4], switched_off=out[5])
+
+    def _update_batch_host(self, clouds, stats):
+        """lsa_front_end_update_batch: the run from HOST clouds ((n, k) float32 arrays of ONE row layout: xyz, xyzw or PointXYZI)."""
+        L = capi.lib()
+        L.lsa_front_end_update_batch.argtypes = [C.c_void_p, C.c_size_t, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t), C.c_size_t, C.c_size_t,
+                                                 C.POINTER(C.c_float), C.POINTER(FrontEndStats)]
+        count = len(clouds)
+        arrs = [np.ascontiguousarray(c, dtype=np.float32) for c in clouds]
+        cols = arrs[0].shape[1]
+        if any(a.ndim != 2 or a.shape[1] != cols for a in arrs):
+            raise ValueError("FrontEnd.UpdateBatch: host clouds of one run must share their row layout")
+        self._keep = arrs
+        ptrs = (C.c_void_p * count)(*[a.ctypes.data for a in arrs])
+        ns = (C.c_size_t * count)(*[a.shape[0] for a in arrs])
+        out = np.zeros((count, 16), dtype=np.float32)
+        st = (FrontEndStats * count)()
+        self.ctx.check(L.lsa_front_end_update_batch(self.h, count, ptrs, ns, arrs[0].strides[0] if arrs[0].shape[0] else cols * 4, capi.w_offset(cols), capi.fptr(out), st))
+        self._last_st, self._last_dict = st[count - 1], None
+        poses = np.ascontiguousarray(out.reshape(count, 4, 4).transpose(0, 2, 1))
+        if stats == "key_frame":
+            return poses, [int(st[i].key_frame) for i in range(count)]
+        return poses, ([self._stats_dict(st[i]) for i in range(count)] if stats else None)
 
     def frame_filter_counters(self):
         """lsa_voxel_filter_counters of the front end's frame filter: builds, speculative misses, bitmap growths, host scans pulled by the device."""

@@ -23,3 +23,13 @@ for mode, clouds in (("host clouds (lsa_front_end_update)", h_all), ("device clo
         print("%s rep %d: %d scans %.2f ms = %.0f scans/s; steady-state call (scans 20..29) median %.1f us; pose %s" % (
             mode, rep, len(clouds), tot * 1e3, len(clouds) / tot, np.median(ts[20:]), np.array2string(T[:3, 3], precision=4)), flush=True)
         fe.close()
+for rep in range(4):
+    fe = front_end.FrontEndHip(ctx); fe.SetInitPose(poses[0].astype(np.float32))
+    torch.cuda.synchronize()
+    t00 = time.perf_counter()
+    Ts, kf = fe.UpdateBatch(h_all, stats="key_frame")
+    torch.cuda.synchronize()
+    tot = time.perf_counter() - t00
+    print("host clouds as ONE run (lsa_front_end_update_batch) rep %d: %d scans %.2f ms = %.0f scans/s; pose %s  filter %s" % (
+        rep, len(h_all), tot * 1e3, len(h_all) / tot, np.array2string(Ts[-1][:3, 3], precision=4), fe.frame_filter_counters()), flush=True)
+    fe.close()

@@ -346,6 +346,28 @@ def test_host_clouds_equal_device_clouds(scene, monkeypatch):
         assert np.array_equal(got[0], ref[0]), name
         assert got[1] == ref[1], name
         assert got[2] == ref[2], (name, got[2], ref[2])
+    # ... and as ONE run of host clouds (lsa_front_end_update_batch: scan k + 1 packed and pulled over the link while scan k is
+    # registered), cut into uneven runs with a single host Update in between; pull on and off
+    for env in (None, "0"):
+        if env is None:
+            monkeypatch.delenv("LSA_FILTER_PULL", raising=False)
+        else:
+            monkeypatch.setenv("LSA_FILTER_PULL", env)
+        ctx = capi.Context(0)
+        fe = front_end.FrontEndHip(ctx, cfg)
+        T_all, st_all = [], []
+        for a, b in ((0, 1), (1, 4), (4, 5), (5, N)):
+            if b - a == 1 and a == 4:
+                _, T = fe.Update(h[a])
+                T_all.append(T); st_all.append(_flat(fe.last_stats))
+            else:
+                Ts, sts = fe.UpdateBatch(h[a:b])
+                T_all += list(Ts); st_all += [_flat(x) for x in sts]
+        assert np.array_equal(np.stack(T_all), ref[0]), env
+        assert st_all == ref[1], env
+        assert fe.map_verify() == ref[2]
+        fe.close(); ctx.close()
+    monkeypatch.delenv("LSA_FILTER_PULL", raising=False)
 
 
 def test_update_batch_full_rebuild_and_no_frame_filter(scene):
