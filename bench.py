@@ -80,6 +80,11 @@ def vector_f64(pairs, points, ms, kind="kind0"):
             "flops_per_launch": int(fl)}
 
 
+def spread(ts_ms):
+    ts_ms = np.asarray(ts_ms, dtype=np.float64)
+    return {"min": round(float(ts_ms.min()), 4), "median": round(float(np.median(ts_ms)), 4), "max": round(float(ts_ms.max()), 4), "n": int(ts_ms.size)}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -407,6 +412,50 @@ def main():
         split["host_boundary_filter_ms"] = float(np.median(tf_)) * 1e3
         split["host_boundary_align_ms"] = float(np.median(ta_)) * 1e3
         split["host_boundary_ms_per_scan"] = split["host_boundary_filter_ms"] + split["host_boundary_align_ms"]
+        # ... and the same boundary PIPELINED (lsa_pipeline_scan_match_host: a run of host clouds, the next two packed and crossing the
+        # link while the current one is registered): the PCIe-inclusive rate of the hot path when the caller can hand over a queue
+        host_pipe = None
+        try:
+            n_hf = int(os.environ.get("LSA_BENCH_HOST_FILTERS", "2"))   # (measured: 2 -> 12.7 k, 3 -> 11.4 k, 4 -> 11.8 k scans/s: not latency but host memory traffic bounds it)
+            chs = [capi.Context(dev_index, None) for _ in range(n_hf)]
+            fhs = [cloud_filter.VoxelFilterHip(c_, 0.5, 0.5, 0.5) for c_ in chs]
+            fh_arr = (C.c_void_p * n_hf)(*[f_.h for f_ in fhs])
+            raw_all = [synth.to_xyzi32(scans[kk]) for kk in TEST_SCANS]
+            Lh = capi.lib()
+            Lh.lsa_pipeline_scan_match_host.argtypes = [C.POINTER(C.c_void_p), C.c_int, C.c_void_p, C.c_size_t, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t), C.c_size_t, C.c_size_t,
+                                                        C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(capi.NdtStats), C.POINTER(C.c_size_t)]
+
+            def host_run(count):
+                idx_h = [i % ns for i in range(count)]
+                ptrs_h = (C.c_void_p * count)(*[raw_all[i].ctypes.data for i in idx_h])
+                nn_h = (C.c_size_t * count)(*[raw_all[i].shape[0] for i in idx_h])
+                pred_h = np.ascontiguousarray(guess_cm[idx_h])
+                out_h = np.zeros((count, 16), dtype=np.float32)
+                st_h = (capi.NdtStats * count)()
+                nf_h = (C.c_size_t * count)()
+                t0 = time.perf_counter()
+                rc_h = Lh.lsa_pipeline_scan_match_host(fh_arr, n_hf, ndt.h, count, ptrs_h, nn_h, 32, 16, capi.fptr(pred_h), capi.fptr(out_h), st_h, nf_h)
+                sync_all(local=True)
+                dt_h = time.perf_counter() - t0
+                if rc_h:
+                    ctx.check(rc_h)
+                return dt_h, out_h, idx_h
+            host_run(300)
+            dts_h = []
+            for _ in range(3):
+                dt_h, out_h, idx_h = host_run(1000)
+                dts_h.append(dt_h / 1000 * 1e3)
+            same_h = all(np.array_equal(capi.from_colmajor(out_h[i]), results[idx_h[i]][0]) for i in range(len(idx_h) - ns, len(idx_h)) if idx_h[i] in results)
+            host_pipe = {"value": round(1e3 / float(np.median(dts_h)), 1), "unit": "scans/s", "ms_per_scan": round(float(np.median(dts_h)), 4), "ms_per_scan_spread": spread(dts_h),
+                         "scans_pulled_by_the_device": int(sum(f_.counters()["pulled"] for f_ in fhs)), "poses_identical_to_the_device_path": bool(same_h), "filters": n_hf,
+                         "what": "lsa_pipeline_scan_match_host: 1000 host PointXYZI scans (32-byte rows) per call, pack + PCIe + filter + ScanMatch, ingest %d scans deep; PCIe-inclusive, never `value`" % n_hf}
+            for f_ in fhs:
+                f_.close()
+            for c_ in chs:
+                c_.close()
+        except Exception as exc:   # an extra key must not take the line down
+            host_pipe = {"error": repr(exc)}
+        split["host_pipeline"] = host_pipe
         ndt.set_source(f)
         L = capi.lib()
         p = np.zeros(6)
@@ -558,10 +607,6 @@ def main():
 
     # ---- a second, KITTI-residential-shaped workload through the same pipeline (workloads.dense_dataset: front gardens, hedges,
     # trees with volumetric crowns, second-row buildings; 100 m range): brackets the headline's bare street.  Extra key, rank 0.
-    def spread(ts_ms):
-        ts_ms = np.asarray(ts_ms, dtype=np.float64)
-        return {"min": round(float(ts_ms.min()), 4), "median": round(float(np.median(ts_ms)), 4), "max": round(float(ts_ms.max()), 4), "n": int(ts_ms.size)}
-
     def front_end_drive(lsa_fe, ctx, d_all, poses_drive, reps=5):
         """The drive through FrontEnd::Update twice over: scan by scan (one library call per scan; nothing is waited for between two
         scans, as front_end_node calls it), and as ONE run of lsa_front_end_update_batch_device (next scan's frame filter on a second

@@ -376,6 +376,14 @@ void lsa_ndt_gauss_constants(float res, float outlier_ratio, double *d1, double 
 int lsa_pipeline_scan_match(lsa_voxel_filter *frame_filter, lsa_ndt *ndt, size_t count, const float *const *d_scans_xyzw,
                             const size_t *n_points, const float *predict_poses, float *d_filtered_a, float *d_filtered_b,
                             int rank, int world, float *result_poses, lsa_ndt_stats *stats, size_t *n_filtered);
+/* The same batch fed with HOST clouds (`count` clouds of n_points[k] rows of `stride` bytes, intensity at w_off or SIZE_MAX; untouched
+ * until the call returns): Filter(host) + ScanMatch per scan as front_end.cpp:106-107,225 calls them, with the next n_filters scans
+ * packed and crossing the link while the current one is registered.  filters: 2 .. 8 distinct VoxelFilter handles of the same leaf,
+ * each on a context (stream) of its own other than the registration's; their device buffers are used (two suffice: measured, more do
+ * not help).  Poses and statistics are those of the sequential host calls. */
+int lsa_pipeline_scan_match_host(lsa_voxel_filter *const *filters, int n_filters, lsa_ndt *ndt, size_t count, const void *const *clouds,
+                                 const size_t *n_points, size_t stride, size_t w_off, const float *predict_poses, float *result_poses,
+                                 lsa_ndt_stats *stats, size_t *n_filtered);
 
 /* ---------------------------------------------------------------------------------------------
  * Position-only initialisation — replaces Matching::generateGauss2DMapCells / resetMapRange / getInitialYawAngle

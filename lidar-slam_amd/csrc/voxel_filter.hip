@@ -380,6 +380,18 @@ int lsa_voxel_filter_apply_device_async_here(lsa_voxel_filter *f, const float *d
 }
 
 // internal (pipeline.cpp): a device buffer of n points owned by this handle (grow-only)
+// internal (pipeline.cpp: lsa_pipeline_scan_match_host): the handle's own device buffers for a run of host scans — which = 0 the raw
+// rows (d_in), 1 / 2 two filtered clouds (d_out, d_pipe) — sized for n points (grow-only; the caller makes sure nothing is in flight)
+float *lsa_voxel_filter_host_buffer(lsa_voxel_filter *f, size_t n, int which) {
+  if (!f || which < 0 || which > 2) return nullptr;
+  DevBuf<float4> &b = which == 0 ? f->d_in : (which == 1 ? f->d_out : f->d_pipe);
+  if ((n ? n : 1) > b.cap) {
+    if (hipSetDevice(f->ctx->device) != hipSuccess || hipStreamSynchronize(f->ctx->stream) != hipSuccess) return nullptr;
+    if (b.reserve(f->ctx, n ? n : 1, 1.1)) return nullptr;
+  }
+  return (float *)b.p;
+}
+
 float *lsa_voxel_filter_pipe_buffer(lsa_voxel_filter *f, size_t n) {
   if (!f) return nullptr;
   // This is the first thing lsa_pipeline_scan_match does, BEFORE any call that enters the filter's context: a worker thread driving

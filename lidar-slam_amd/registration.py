@@ -342,6 +342,33 @@ def pipeline_scan_match(frame_filter, ndt, d_scans, predict_poses, d_bufs, rank=
     return [capi.from_colmajor(out[i]) for i in range(count)], [st[i].as_dict() for i in range(count)], [int(nf[i]) for i in range(count)]
 
 
+def pipeline_scan_match_host(filters, ndt, clouds, predict_poses):
+    """lsa_pipeline_scan_match_host: the same batch fed with HOST clouds ((n, k) float32 arrays of one row layout), ingest len(filters)
+    scans deep on that many filter handles (contexts of their own).  Returns (poses, stats dicts, filtered sizes)."""
+    L = capi.lib()
+    L.lsa_pipeline_scan_match_host.argtypes = [C.POINTER(C.c_void_p), C.c_int, C.c_void_p, C.c_size_t, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t), C.c_size_t, C.c_size_t,
+                                               C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(capi.NdtStats), C.POINTER(C.c_size_t)]
+    fh = (C.c_void_p * len(filters))(*[f.h for f in filters])
+    count = len(clouds)
+    arrs = [np.ascontiguousarray(c, dtype=np.float32) for c in clouds]
+    cols = arrs[0].shape[1] if count else 8
+    if any(a.ndim != 2 or a.shape[1] != cols for a in arrs):
+        raise ValueError("pipeline_scan_match_host: the clouds of one batch must share their row layout")
+    ptrs = (C.c_void_p * max(count, 1))(*[a.ctypes.data for a in arrs])
+    nn = (C.c_size_t * max(count, 1))(*[a.shape[0] for a in arrs])
+    pred = np.ascontiguousarray(np.stack([capi.colmajor(g) for g in predict_poses]).astype(np.float32)) if count else np.zeros((0, 16), np.float32)
+    out = np.zeros((count, 16), dtype=np.float32)
+    st = (capi.NdtStats * max(count, 1))()
+    nf = (C.c_size_t * max(count, 1))()
+    rc = L.lsa_pipeline_scan_match_host(fh, len(filters), ndt.h, count, ptrs, nn, cols * 4, capi.w_offset(cols), capi.fptr(pred), capi.fptr(out), st, nf)
+    if rc:
+        for f in filters:
+            f.ctx.check(rc)
+        ndt.ctx.check(rc)
+        raise capi.LsaError(rc, "lsa_pipeline_scan_match_host failed")
+    return [capi.from_colmajor(out[i]) for i in range(count)], [st[i].as_dict() for i in range(count)], [int(nf[i]) for i in range(count)]
+
+
 def unpack_out32(out):
     score = out[0]
     g = out[1:7].copy()

@@ -407,6 +407,45 @@ def test_host_filter_pulled_rows_equal_copied_rows(scene, monkeypatch):
     assert rp[0].shape[0] > 5000
 
 
+def test_pipeline_host_clouds_equal_sequential_host_calls(scene):
+    """lsa_pipeline_scan_match_host (host PointXYZI clouds, the next two scans packed and crossing the link while the current one is
+    registered; two or three filter handles on contexts of their own) against Filter(host) + ScanMatch(host) one scan at a time: poses,
+    statistics and filtered sizes bit for bit — with the device pulling the rows itself and with copy-free uploads only
+    (LSA_FILTER_PULL=0), for batches of 1, 2, 3 and 11 scans (every rotation of the buffers)."""
+    import os
+    poses = synth.trajectory(12, step=1.0)
+    scans = [synth.gen_scan(scene, poses[i], seed=5200 + i) for i in range(12)]
+    h = [synth.to_xyzi32(sc) for sc in scans]
+    ctx, ca, cb, cc = capi.Context(0), capi.Context(0), capi.Context(0), capi.Context(0)
+    import torch
+    ndt = registration.NDTRegistrationHip(ctx)
+    ndt.SetInputTarget(torch.from_numpy(np.ascontiguousarray(scans[0])).cuda())
+    guesses = [(np.linalg.inv(poses[0]) @ poses[max(i - 1, 0)]).astype(np.float32) for i in range(12)]
+    plain = cloud_filter.VoxelFilterHip(ctx, 0.5, 0.5, 0.5)
+    ref = []
+    for i in range(1, 12):
+        _, f8 = plain.Filter(h[i])
+        _, T = ndt.ScanMatch(f8, guesses[i])
+        ref.append((T, dict(ndt.last_stats), f8.shape[0]))
+    for env in (None, "0"):
+        if env is None:
+            os.environ.pop("LSA_FILTER_PULL", None)
+        else:
+            os.environ["LSA_FILTER_PULL"] = env
+        fa, fb, fc3 = cloud_filter.VoxelFilterHip(ca, 0.5, 0.5, 0.5), cloud_filter.VoxelFilterHip(cb, 0.5, 0.5, 0.5), cloud_filter.VoxelFilterHip(cc, 0.5, 0.5, 0.5)
+        for a, b, flt in ((1, 2, [fa, fb]), (2, 4, [fa, fb, fc3]), (4, 7, [fa, fb]), (1, 12, [fa, fb, fc3]), (1, 12, [fa, fb])):
+            Ts, sts, nfs = registration.pipeline_scan_match_host(flt, ndt, h[a:b], guesses[a:b])
+            for j in range(b - a):
+                T, st, nf = ref[a - 1 + j]
+                assert np.array_equal(Ts[j], T), (env, a, b, j)
+                assert nfs[j] == nf and sts[j]["iterations"] == st["iterations"] and sts[j]["passes"] == st["passes"] and sts[j]["score"] == st["score"], (env, a, b, j, sts[j], st)
+        if env is None:
+            assert fa.counters()["pulled"] + fb.counters()["pulled"] + fc3.counters()["pulled"] >= 12
+        fa.close(); fb.close(); fc3.close()
+    os.environ.pop("LSA_FILTER_PULL", None)
+    plain.close(); ndt.close(); ca.close(); cb.close(); cc.close(); ctx.close()
+
+
 def test_voxel_filter_reserve_changes_no_result(scan_pair):
     """lsa_voxel_filter_reserve (buffers, a bitmap large enough for the first build, helper threads and pinned staging rows ahead of the
     first call): the same outputs bit for bit as an unreserved handle on the host and on the device path, and no bitmap growth."""
