@@ -416,6 +416,8 @@ def main():
         # link while the current one is registered): the PCIe-inclusive rate of the hot path when the caller can hand over a queue
         host_pipe = None
         try:
+            if args.no_extra:
+                raise RuntimeError("skipped (--no-extra)")
             n_hf = int(os.environ.get("LSA_BENCH_HOST_FILTERS", "2"))   # (measured: 2 -> 12.7 k, 3 -> 11.4 k, 4 -> 11.8 k scans/s: not latency but host memory traffic bounds it)
             chs = [capi.Context(dev_index, None) for _ in range(n_hf)]
             fhs = [cloud_filter.VoxelFilterHip(c_, 0.5, 0.5, 0.5) for c_ in chs]
