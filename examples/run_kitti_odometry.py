@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """LiDAR odometry over a directory of KITTI velodyne scans with the device-resident front end.
 
-    python examples/run_kitti_odometry.py <velodyne_dir> <poses_out.txt> [--max-scans N] [--gpu 0] [--batch 16]
+    python examples/run_kitti_odometry.py <velodyne_dir> <poses_out.txt> [--max-scans N] [--gpu 0] [--batch 16] [--host-input]
 
 <velodyne_dir> holds 000000.bin, 000001.bin, ... (float32 x, y, z, reflectance per point: the KITTI raw / odometry layout,
 also what the reference's data_pretreat nodes republish).  Every scan goes through lsa_front_end_update* — frame filter,
@@ -31,7 +31,7 @@ def _load_pkg():
     spec.loader.exec_module(mod)
 
 
-def run(velodyne_dir, poses_out, max_scans=None, gpu=0, log=print, batch=16):
+def run(velodyne_dir, poses_out, max_scans=None, gpu=0, log=print, batch=16, host_input=False):
     import torch
     _load_pkg()
     from lidar_slam_amd import capi, cloud_io, front_end
@@ -50,7 +50,9 @@ def run(velodyne_dir, poses_out, max_scans=None, gpu=0, log=print, batch=16):
     # one; the same poses as one Update per scan, bit for bit).
     for k0 in range(0, len(files), batch):
         clouds = [cloud_io.remove_nan(cloud_io.read_kitti_bin(path))[0] for path in files[k0:k0 + batch]]
-        d_clouds = [torch.from_numpy(c).cuda(gpu) for c in clouds]
+        # --host-input: the (n, 4) host arrays go to the library as they are (lsa_front_end_update_batch / lsa_front_end_update: packed,
+        # sent over the link and filtered while the previous scan is registered), so the time per scan below includes PCIe
+        d_clouds = clouds if host_input else [torch.from_numpy(c).cuda(gpu) for c in clouds]
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         if batch > 1:
@@ -67,7 +69,8 @@ def run(velodyne_dir, poses_out, max_scans=None, gpu=0, log=print, batch=16):
     with open(poses_out, "w") as f:
         for T in poses:
             f.write(" ".join("%.9e" % v for v in T[:3, :].reshape(-1)) + "\n")
-    log("%d scans, %d key-frames, %.3f ms per scan in the front end (device-resident input)" % (len(files), key_frames, t_gpu / len(files) * 1e3))
+    log("%d scans, %d key-frames, %.3f ms per scan in the front end (%s)" % (len(files), key_frames, t_gpu / len(files) * 1e3,
+                                                                             "host input, PCIe included" if host_input else "device-resident input"))
     fe.close()
     ctx.close()
     return poses
@@ -80,5 +83,6 @@ if __name__ == "__main__":
     ap.add_argument("--max-scans", type=int, default=None)
     ap.add_argument("--gpu", type=int, default=0)
     ap.add_argument("--batch", type=int, default=16, help="scans per front-end call (1: one lsa_front_end_update_device call per scan)")
+    ap.add_argument("--host-input", action="store_true", help="hand the scans over as host arrays (pack + PCIe inside the library, overlapped with the registration)")
     a = ap.parse_args()
-    run(a.velodyne_dir, a.poses_out, a.max_scans, a.gpu, batch=max(1, a.batch))
+    run(a.velodyne_dir, a.poses_out, a.max_scans, a.gpu, batch=max(1, a.batch), host_input=a.host_input)

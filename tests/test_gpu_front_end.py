@@ -474,6 +474,8 @@ def test_kitti_directory_example(scene, tmp_path):
     assert rows.shape == (8, 12) and len(got) == 8
     one_by_one = ex.run(str(vdir), str(tmp_path / "poses1.txt"), log=lambda *a: None, batch=1)
     assert all(np.array_equal(a, b) for a, b in zip(got, one_by_one))
+    from_host = ex.run(str(vdir), str(tmp_path / "poses2.txt"), log=lambda *a: None, batch=3, host_input=True)   # the (n, 4) host arrays handed over as they are
+    assert all(np.array_equal(a, b) for a, b in zip(got, from_host))
     T_last = np.eye(4)
     T_last[:3, :] = rows[-1].reshape(3, 4)
     T_true = np.linalg.inv(poses[0]) @ poses[-1]
