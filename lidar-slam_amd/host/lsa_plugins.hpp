@@ -295,5 +295,53 @@ class ICPRegistrationHip : public RegistrationInterface {
   int mode_ = LSA_ICP_MODE_MANUAL;
 };
 
+// ---------------------------------------------------------------------------------------------- front end
+// FrontEnd (include/lidar_localization/mapping/front_end/front_end.hpp; front_end.cpp:30-424) with the sliding local map kept on the
+// device: SetInitPose, Update(cloud_data, cloud_pose) — one host cloud in, its pose out — and, for a caller that holds a queue of
+// clouds (front_end_flow.cpp:18-36), UpdateRun: the whole queue in one call with the next scans' packing / PCIe / frame filter under
+// the current scan's registration.  Constructed with the YAML defaults of config/mapping/front_end.yaml.
+class FrontEndHip {
+ public:
+  static lsa_front_end_config DefaultConfig() {
+    lsa_front_end_config c{};
+    c.key_frame_distance = 2.0f; c.local_frame_num = 20; c.use_frame_filter = 1; c.use_map_filter = 1;
+    for (int a = 0; a < 3; a++) { c.frame_leaf[a] = 0.5f; c.map_leaf[a] = 0.3f; }
+    c.ndt_res = 1.0f; c.ndt_step_size = 0.1f; c.ndt_trans_eps = 0.01f; c.ndt_outlier_ratio = 0.55f; c.ndt_max_iter = 30;
+    c.reset_intensity = 1;
+    return c;
+  }
+  explicit FrontEndHip(std::shared_ptr<Context> ctx, const lsa_front_end_config &cfg = DefaultConfig()) : ctx_(std::move(ctx)) {
+    int rc = lsa_front_end_create(&fe_, ctx_->get(), &cfg);
+    if (rc != LSA_OK) throw std::runtime_error(std::string("lsa_front_end_create: ") + lsa_last_error(ctx_->get()));
+  }
+  ~FrontEndHip() { lsa_front_end_destroy(fe_); }
+  FrontEndHip(const FrontEndHip &) = delete;
+  FrontEndHip &operator=(const FrontEndHip &) = delete;
+  bool SetInitPose(const Matrix4f &init_pose) { status_ = lsa_front_end_set_init_pose(fe_, init_pose.data()); return report("FrontEnd::SetInitPose", ctx_->get(), status_); }
+  bool Update(const CloudData::CLOUD_PTR &cloud, Matrix4f &cloud_pose) {   // front_end.cpp:88-341
+    status_ = lsa_front_end_update(fe_, cloud->points.data(), cloud->size(), sizeof(PointXYZI), offsetof(PointXYZI, intensity), cloud_pose.data(), &last_);
+    return report("FrontEnd::Update", ctx_->get(), status_);
+  }
+  bool UpdateRun(const std::vector<CloudData::CLOUD_PTR> &clouds, std::vector<Matrix4f> &poses) {   // front_end_flow.cpp:18-36 over a queue
+    std::vector<const void *> ptrs(clouds.size());
+    std::vector<size_t> n(clouds.size());
+    for (size_t k = 0; k < clouds.size(); k++) { ptrs[k] = clouds[k]->points.data(); n[k] = clouds[k]->size(); }
+    poses.assign(clouds.size(), Matrix4f::Identity());
+    static_assert(sizeof(Matrix4f) == 16 * sizeof(float), "poses are handed over as 16 floats each");
+    status_ = lsa_front_end_update_batch(fe_, clouds.size(), ptrs.data(), n.data(), sizeof(PointXYZI), offsetof(PointXYZI, intensity),
+                                         clouds.empty() ? nullptr : poses[0].data(), nullptr);
+    return report("FrontEnd::UpdateRun", ctx_->get(), status_);
+  }
+  const lsa_front_end_stats &last_stats() const { return last_; }
+  int last_status() const { return status_; }
+  lsa_front_end *get() const { return fe_; }
+
+ private:
+  std::shared_ptr<Context> ctx_;
+  lsa_front_end *fe_ = nullptr;
+  lsa_front_end_stats last_{};
+  int status_ = LSA_OK;
+};
+
 }  // namespace lsa
 #endif

@@ -8,6 +8,7 @@
 #include <cstdlib>
 #include <memory>
 #include <random>
+#include <vector>
 
 #include "lsa_oracle.h"
 #include "lsa_plugins.hpp"
@@ -194,6 +195,27 @@ int main() {
     orc_yaw_free(oy);
     CHECK(yaw == oyaw, "initial yaw %g vs oracle %g", yaw, oyaw);
     std::printf("box filter: %zu -> %zu points; initial yaw %.4f rad (oracle %.4f)\n", scan0->size(), cropped->size(), yaw, oyaw);
+  }
+
+  // ---- FrontEnd mirror: one Update per host cloud against the same clouds as ONE run (bit-identical), along a short drive
+  {
+    std::vector<CloudData::CLOUD_PTR> drive;
+    for (int i = 0; i < 10; i++) drive.push_back(make_cloud(100 + i, 0.5f * i, 0.004f * i, 70000));
+    FrontEndHip one(ctx), run(ctx);
+    std::vector<Matrix4f> single(drive.size(), Matrix4f::Identity()), batch;
+    int key_frames = 0;
+    for (size_t i = 0; i < drive.size(); i++) {
+      CHECK(one.Update(drive[i], single[i]) && one.last_status() == LSA_OK, "FrontEnd::Update %zu: status %d", i, one.last_status());
+      key_frames += one.last_stats().key_frame;
+    }
+    CHECK(run.UpdateRun(drive, batch) && run.last_status() == LSA_OK, "FrontEnd::UpdateRun: status %d", run.last_status());
+    bool same = batch.size() == single.size();
+    for (size_t i = 0; same && i < single.size(); i++)
+      for (int e = 0; e < 16; e++) same = same && batch[i].data()[e] == single[i].data()[e];
+    CHECK(same, "FrontEnd: the run and the single Updates disagree");
+    const float moved = single.back()(0, 3);
+    CHECK(key_frames >= 2 && std::fabs(moved - 4.5f) < 0.3f, "FrontEnd: %d key-frames, x = %.3f after 4.5 m", key_frames, moved);
+    std::printf("front end: 10 host clouds, %d key-frames, x = %.3f m (truth 4.50), run == single Updates\n", key_frames, moved);
   }
 
   std::printf(g_fail ? "FAILED (%d)\n" : "ALL OK\n", g_fail);
