@@ -224,8 +224,18 @@ __device__ __forceinline__ void pass_pre_init(PassPre &pre) {
     for (int j = 0; j < kRowRounds; j++) {
       const int q = lane + j * 64;
       if (q < kRowProbes) {  // (the last round has a few idle lanes: all-zero entry, live bit clear)
+#ifdef LSA_PROBE_POINT_MAJOR
         const int pl = q / kRowsPerPoint;
         const int o = q - pl * kRowsPerPoint;
+#else
+        // ROW-major: adjacent lanes probe the same (dy, dz) row of CONSECUTIVE points.  Consecutive points of a spatially coherent
+        // source share their cell box more often than not, so the lanes of a quad ask for the same 16 bytes and the texture addresser
+        // sends the L1 one access instead of four — and their survivors sit in adjacent queue slots, so the pair step's record loads
+        // coalesce the same way (point-major, a point's nine rows side by side, every lane of a load went to a line of its own:
+        // 46 L1 accesses per load instruction at 2 M points, `profiles/r04_cfg5_pass_l1_pmc.csv`)
+        const int o = q / kTilePts;
+        const int pl = q - o * kTilePts;
+#endif
         const int dz = o / 3, dy = o - dz * 3;
         probe_lut |= ((unsigned)pl | ((unsigned)dy << 8) | ((unsigned)dz << 10) | 0x8000u) << (16 * j);
       }
