@@ -21,6 +21,15 @@ constexpr int kBlockD = 256;
 #define LSA_PASS_WAVES_GRAD 4
 #endif
 constexpr int pass_waves(int kind) { return kind == 1 ? LSA_PASS_WAVES_GRAD : LSA_PASS_WAVES; }
+// Issue priority of a wave while it is on its way to its row loads (phase 0 and the probe of a tile); its pair math runs at 0.
+// The waves of a SIMD all walk the same phases, and left to round-robin arbitration they drift into the same one — all probing
+// (latency bound, the VALUs idle) or all in pair math (the next tile's loads not even issued).  Letting the wave that is about to
+// wait for memory go first keeps them apart: 190.5 -> 178.8 us per pass at 2 M points, 184 -> 171 us on the wide map, nothing at
+// KITTI size (one tile per wave).  Levels 1, 2, 3 measure the same; raising it in the pair math instead, or dropping it as soon as the
+// loads are issued, gets half of it; a fixed priority per wave slot none (`profiles/r04_pass_setprio_ab.log`).  0 = off.
+#ifndef LSA_PASS_SETPRIO
+#define LSA_PASS_SETPRIO 1
+#endif
 
 // The scalar part of PassParams a pass works with.  A kernel's arguments are fetched by scalar loads at the point of first use,
 // and right after a launch the scalar cache is cold: each such fetch is a trip to memory.  The pass kernels therefore copy
@@ -298,6 +307,7 @@ __device__ __forceinline__ double ndt_pass_body(const float4 *__restrict__ src, 
   int pbase = 0;         // which half of tp / terms this tile uses: 0 or kTileSlots
   for (size_t tile = tile0; tile < ntiles; tile += tstride, pbase ^= (NB == 2 ? kTileSlots : 0)) {
     // ---- phase 0
+    if (LSA_PASS_SETPRIO) __builtin_amdgcn_s_setprio(LSA_PASS_SETPRIO);
     {
       size_t i = tile * kTilePts + ppl;
       float4 s = s_next;
@@ -529,6 +539,7 @@ __device__ __forceinline__ double ndt_pass_body(const float4 *__restrict__ src, 
     // out with the first round, and if even carried + fresh stays below 64 while something was carried, the round is run
     // partly filled.
     {
+      if (LSA_PASS_SETPRIO) __builtin_amdgcn_s_setprio(0);
       total = (unsigned)__builtin_amdgcn_readfirstlane((int)total);  // wave-uniform by construction: keep the round bookkeeping scalar
       const unsigned full = total >> 6;
       unsigned left = total & 63u;
