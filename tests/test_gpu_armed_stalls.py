@@ -239,6 +239,10 @@ def test_source_buffer_refilled_on_another_stream_while_a_kernel_is_parked(rig):
     import torch
     n = _ndt(rig)
     n.set_armed_carry(True)
+    # (what the caller does between two ScanMatches here — a copy on a fresh stream, a whole unarmed ScanMatch on another context —
+    # is not bounded by the default 0.3 ms patience on a slow box: seen once, the kernel had left and the first pass was redone the
+    # ordinary way, correctly counted.  This test is about WHAT a parked kernel reads, so it gets the patience to stay parked.)
+    n.set_armed_patience(20000.0)
     # the comparison handle lives on a context of its OWN: any call on n's context would release n's parked kernel first
     ctx2 = capi.Context(0)
     plain = registration.NDTRegistrationHip(ctx2, **wl.NDT_PARAMS)
