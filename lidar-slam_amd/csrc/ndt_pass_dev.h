@@ -258,6 +258,27 @@ __device__ __forceinline__ void pass_pre_pin(PassPre &pre) {
   asm volatile("" : "+v"(pre.probe_lut));
 }
 
+// The three cells of one loaded row: pre-filter on the f32 distance, survivors to the pair queue in (cell, lane) order — one wave
+// ballot per cell gives every keeping lane its slot (count of keeping lanes below it) and the wave the running total as a SCALAR.
+// SHIFTED: some lane's row lost cells in front to the table's box, so entry ii of its load is cell ii + (cells lost) of the cube.
+template <bool SHIFTED>
+__device__ __forceinline__ void probe_cells(const float4 e0, const float4 e1, const float4 e2, float rx, float ry, float rz, int nx /* extent | lost << 2 */,
+                                            unsigned slot, float res, float r2f_pre, unsigned *queue, unsigned &total) {
+#pragma unroll
+  for (int i = 0; i < 3; i++) {
+    const int ii = SHIFTED ? i - (nx >> 2) : i;
+    const float4 en = SHIFTED ? (ii == 0 ? e0 : (ii == 1 ? e1 : e2)) : (i == 0 ? e0 : (i == 1 ? e1 : e2));
+    float dx = (rx - (float)i * res) - en.x, dy = ry - en.y, dz = rz - en.z;
+    float d2 = dx * dx + dy * dy + dz * dz;
+    const int rank = __float_as_int(en.w);  // -1: unoccupied, too few points or rejected eigenvalues (VoxelGrid.cpp:465)
+    const bool ok = (unsigned)ii < (unsigned)(nx & 3) && rank >= 0 && d2 <= r2f_pre;
+    const unsigned long long m = __ballot(ok);
+    const unsigned below = __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
+    if (ok) queue[total + below] = slot | ((unsigned)rank << 6);  // point slot incl. its buffer half
+    total += (unsigned)__popcll(m);
+  }
+}
+
 // DENSE: the probe reads a dense per-cell table {centroid - cell corner (f32 x 3), record rank or -1} (16 B per cell,
 // built when the cell box is small enough, ndt_grid.hip) instead of the bitmap words: one 48-B row load answers "valid?",
 // "which record?" and "roughly how far?" for 3 cells, so the candidate stage (A2: a dependent centroid load from the
@@ -422,20 +443,12 @@ __device__ __forceinline__ double ndt_pass_body(const float4 *__restrict__ src, 
 #pragma unroll
       for (int j = 0; j < kRowRounds; j++) {
         const float rx = tp[pbase + r_pl[j]].rx;
-        const float4 ev[3] = {e0[j], e1[j], e2[j]};
-#pragma unroll
-        for (int i = 0; i < 3; i++) {
-          const int ii = i - (r_nx[j] >> 2);   // cell i of the unclipped cube = entry ii of the loaded (clipped) row
-          const float4 en = ii == 0 ? ev[0] : (ii == 1 ? ev[1] : ev[2]);
-          float dx = (rx - (float)i * P.res) - en.x, dy = r_y[j] - en.y, dz = r_z[j] - en.z;
-          float d2 = dx * dx + dy * dy + dz * dz;
-          int rank = __float_as_int(en.w);  // -1: unoccupied, too few points or rejected eigenvalues (VoxelGrid.cpp:465)
-          bool ok = (unsigned)ii < (unsigned)(r_nx[j] & 3) && rank >= 0 && d2 <= P.r2f_pre;
-          const unsigned long long m = __ballot(ok);
-          const unsigned below = __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
-          if (ok) queue[total + below] = ((unsigned)(pbase + r_pl[j])) | ((unsigned)rank << 6);  // point slot incl. its buffer half
-          total += (unsigned)__popcll(m);
-        }
+        // Entry ii of the loaded (clipped) row is cell i = ii + (cells clipped off in front) of the unclipped cube.  Nothing is clipped
+        // unless the point sits within a cell of the table's low faces — for a whole wave almost never: then entry i IS cell i and the
+        // eight selects per cell that pick the entry are skipped (a wave-uniform branch; 48 of the ~480 VALU instructions of a tile).
+        const bool clipped = __ballot((r_nx[j] >> 2) != 0) != 0ull;
+        if (clipped) probe_cells<true>(e0[j], e1[j], e2[j], rx, r_y[j], r_z[j], r_nx[j], (unsigned)(pbase + r_pl[j]), P.res, P.r2f_pre, queue, total);
+        else probe_cells<false>(e0[j], e1[j], e2[j], rx, r_y[j], r_z[j], r_nx[j], (unsigned)(pbase + r_pl[j]), P.res, P.r2f_pre, queue, total);
       }
       wave_sync();
     } else {
