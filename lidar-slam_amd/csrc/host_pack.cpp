@@ -43,3 +43,43 @@ void lsa_pack_xyzw(const void *pts, size_t n, size_t stride, size_t w_off, float
     }
   }
 }
+
+// ---- check-worded workgroup rows (ndt_derivatives.hip: ndt_reduce_partials_host), the rows that are already there --------------
+// A pass delivers one 32-double row per workgroup into host-mapped memory; column 31 = key ^ XOR_c rotl(word_c, c + 1) over the
+// other 31 words (voxel_index_dev.h: lsa_store_row32).  The calling thread sits between the last row's arrival and the next pass's
+// mail, so what it spends per row is on the critical path of every ScanMatch: 31 scalar rotates + XORs, a 256-byte copy and 32
+// scalar additions per row, 135 rows per KITTI-sized pass.  Here: eight 32-byte loads, the rotation by per-lane shift counts, the
+// additions four at a time straight into the partial sums.  Takes rows b, b + 1, ... while their check words match and returns the
+// index of the first one that does not (the caller waits for that one the ordinary, timed way and comes back).  Same additions in
+// the same order as the scalar loop: sm[b % 32][col] += row_b[col], ascending b.
+#if defined(__x86_64__)
+bool lsa_rows_fast_available() {
+  static const bool ok = __builtin_cpu_supports("avx2") && getenv("LSA_ROWS_SCALAR") == nullptr;
+  return ok;
+}
+__attribute__((target("avx2"))) unsigned lsa_rows_take_fast(const double *partials, unsigned b, unsigned nb, unsigned long long key, double (*sm)[32]) {
+  __m256i shl[8], shr[8];
+  for (int k = 0; k < 8; k++) {
+    shl[k] = _mm256_set_epi64x(4 * k + 4, 4 * k + 3, 4 * k + 2, 4 * k + 1);   // lane i of vector k is column 4k + i: rotate by column + 1
+    shr[k] = _mm256_sub_epi64(_mm256_set1_epi64x(64), shl[k]);
+  }
+  const __m256i payload = _mm256_set_epi64x(0, -1, -1, -1);   // of the last vector: columns 28..30; column 31 is the check word
+  for (; b < nb; b++) {
+    const __m256i *row = reinterpret_cast<const __m256i *>(partials + (size_t)b * 32);
+    __m256i w[8], x = _mm256_setzero_si256();
+    for (int k = 0; k < 8; k++) w[k] = _mm256_loadu_si256(row + k);
+    const unsigned long long check = (unsigned long long)_mm256_extract_epi64(w[7], 3);
+    w[7] = _mm256_and_si256(w[7], payload);   // (a zero rotates to zero; and the sums' column 31 takes +0.0, as in the scalar loop)
+    for (int k = 0; k < 8; k++) x = _mm256_xor_si256(x, _mm256_or_si256(_mm256_sllv_epi64(w[k], shl[k]), _mm256_srlv_epi64(w[k], shr[k])));
+    const __m128i y = _mm_xor_si128(_mm256_castsi256_si128(x), _mm256_extracti128_si256(x, 1));
+    const unsigned long long xx = (unsigned long long)_mm_extract_epi64(y, 0) ^ (unsigned long long)_mm_extract_epi64(y, 1);
+    if ((xx ^ key) != check) break;
+    double *dst = sm[b & 31];
+    for (int k = 0; k < 8; k++) _mm256_storeu_pd(dst + 4 * k, _mm256_add_pd(_mm256_loadu_pd(dst + 4 * k), _mm256_castsi256_pd(w[k])));
+  }
+  return b;
+}
+#else
+bool lsa_rows_fast_available() { return false; }
+unsigned lsa_rows_take_fast(const double *, unsigned b, unsigned, unsigned long long, double (*)[32]) { return b; }
+#endif

@@ -519,6 +519,9 @@ bool ndt_fetch_row_host(const double *row, unsigned long long key, double limit_
   return ok;
 }
 
+bool lsa_rows_fast_available();   // host_pack.cpp
+unsigned lsa_rows_take_fast(const double *partials, unsigned b, unsigned nb, unsigned long long key, double (*sm)[32]);
+
 bool ndt_reduce_partials_host(const double *partials, unsigned nb, unsigned long long key, double limit_ms, double out32[32],
                               const volatile unsigned long long *abort_word, unsigned long long abort_value) {
   RowClock clk;
@@ -527,7 +530,15 @@ bool ndt_reduce_partials_host(const double *partials, unsigned nb, unsigned long
   double sm[32][32];
   for (int rl = 0; rl < 32; rl++)
     for (int col = 0; col < 32; col++) sm[rl][col] = 0.0;
+  const bool fast = key != 0 && lsa_rows_fast_available();
   for (unsigned b = 0; b < nb; b++) {
+    if (fast) {   // the rows that are there already, four columns at a time (host_pack.cpp); comes back at the first that is not
+      b = lsa_rows_take_fast(partials, b, nb, key, sm);
+      const unsigned long long now = __builtin_ia32_rdtsc();   // the stall detector's checkpoint: pure host time since the last stamp
+      if (clk.last && now - clk.last > clk.gap_max) clk.gap_max = now - clk.last;
+      clk.last = now;
+      if (b == nb) break;
+    }
     const double *row = partials + (size_t)b * kOutDoubles;
     double v[32];
     if (key) {

@@ -307,7 +307,51 @@ static void test_pack_and_io() {
   }
 }
 
+// The vectorised taker of check-worded workgroup rows (host_pack.cpp) against the scalar rule it restates (voxel_index_dev.h:
+// column 31 = key ^ XOR_c rotl(word_c, c + 1); ndt_reduce_partials_host: sm[b % 32][col] += row_b[col] in ascending b).
+bool lsa_rows_fast_available();
+unsigned lsa_rows_take_fast(const double *partials, unsigned b, unsigned nb, unsigned long long key, double (*sm)[32]);
+static void test_rows_fast() {
+  if (!lsa_rows_fast_available()) { std::printf("rows: no AVX2 on this host, fast path not exercised\n"); return; }
+  std::mt19937_64 rng(11);
+  const unsigned nb = 135;
+  const unsigned long long key = 0x9e3779b97f4a7c15ull;
+  std::vector<double> rows((size_t)nb * 32 + 4);   // (+4: the last row ends inside the allocation whatever the loads' width)
+  std::uniform_real_distribution<double> U(-1e6, 1e6);
+  auto seal = [&](unsigned b) {
+    unsigned long long x = 0;
+    for (int c = 0; c < 31; c++) {
+      unsigned long long w; memcpy(&w, &rows[(size_t)b * 32 + c], 8);
+      const int r = c + 1;
+      x ^= (w << r) | (w >> (64 - r));
+    }
+    x ^= key;
+    memcpy(&rows[(size_t)b * 32 + 31], &x, 8);
+  };
+  for (unsigned b = 0; b < nb; b++) {
+    for (int c = 0; c < 31; c++) rows[(size_t)b * 32 + c] = (c % 7 == 3) ? 0.0 : U(rng);
+    seal(b);
+  }
+  double ref[32][32] = {}, got[32][32] = {};
+  for (unsigned b = 0; b < nb; b++)
+    for (int c = 0; c < 31; c++) ref[b & 31][c] += rows[(size_t)b * 32 + c];
+  CHECK(lsa_rows_take_fast(rows.data(), 0, nb, key, got) == nb, "rows: a complete pass not taken whole");
+  CHECK(memcmp(ref, got, sizeof(ref)) == 0, "rows: vector sums differ from the scalar ones");
+  // a stale row (sealed under the previous pass's key), a half-arrived one (one payload word still old) and a wrong key: taken up to there
+  unsigned long long stale = key + 2; memcpy(&stale, &rows[(size_t)40 * 32 + 31], 8); stale ^= key ^ (key - 2); memcpy(&rows[(size_t)40 * 32 + 31], &stale, 8);
+  rows[(size_t)90 * 32 + 17] += 1.0;
+  double part[32][32] = {};
+  CHECK(lsa_rows_take_fast(rows.data(), 0, nb, key, part) == 40, "rows: a row of another pass accepted");
+  CHECK(lsa_rows_take_fast(rows.data(), 41, nb, key, part) == 90, "rows: a half-arrived row accepted");
+  CHECK(lsa_rows_take_fast(rows.data(), 91, nb, key, part) == nb && lsa_rows_take_fast(rows.data(), 0, nb, key + 1, part) == 0, "rows: tail / wrong key");
+  for (int c = 0; c < 31; c++) { part[40 & 31][c] += rows[(size_t)40 * 32 + c]; part[90 & 31][c] += rows[(size_t)90 * 32 + c] - (c == 17 ? 1.0 : 0.0); }
+  bool close = true;   // (the two rows were added out of order here, so only to rounding)
+  for (int r = 0; r < 32; r++) for (int c = 0; c < 31; c++) close = close && std::fabs(part[r][c] - ref[r][c]) <= 1e-6;
+  CHECK(close, "rows: resumed sums wrong");
+}
+
 int main() {
+  test_rows_fast();
   test_math();
   test_eigen_f32_blocks();
   test_pack_and_io();
