@@ -57,7 +57,7 @@ bool lsa_rows_fast_available() {
   static const bool ok = __builtin_cpu_supports("avx2") && getenv("LSA_ROWS_SCALAR") == nullptr;
   return ok;
 }
-__attribute__((target("avx2"))) unsigned lsa_rows_take_fast(const double *partials, unsigned b, unsigned nb, unsigned long long key, double (*sm)[32]) {
+__attribute__((target("avx2"))) static unsigned rows_take_avx2(const double *partials, unsigned b, unsigned nb, unsigned long long key, double (*sm)[32]) {
   __m256i shl[8], shr[8];
   for (int k = 0; k < 8; k++) {
     shl[k] = _mm256_set_epi64x(4 * k + 4, 4 * k + 3, 4 * k + 2, 4 * k + 1);   // lane i of vector k is column 4k + i: rotate by column + 1
@@ -78,6 +78,32 @@ __attribute__((target("avx2"))) unsigned lsa_rows_take_fast(const double *partia
     for (int k = 0; k < 8; k++) _mm256_storeu_pd(dst + 4 * k, _mm256_add_pd(_mm256_loadu_pd(dst + 4 * k), _mm256_castsi256_pd(w[k])));
   }
   return b;
+}
+// the same with 64-byte registers and the rotate instruction AVX-512 has (vprolvq): four loads, four rotates, four additions per row
+__attribute__((target("avx512f"))) static unsigned rows_take_avx512(const double *partials, unsigned b, unsigned nb, unsigned long long key, double (*sm)[32]) {
+  __m512i rot[4];
+  for (int k = 0; k < 4; k++) rot[k] = _mm512_set_epi64(8 * k + 8, 8 * k + 7, 8 * k + 6, 8 * k + 5, 8 * k + 4, 8 * k + 3, 8 * k + 2, 8 * k + 1);
+  const __mmask8 payload = 0x7f;   // of the last vector: columns 24..30; column 31 is the check word
+  for (; b < nb; b++) {
+    const char *row = reinterpret_cast<const char *>(partials + (size_t)b * 32);
+    __m512i w[4];
+    for (int k = 0; k < 4; k++) w[k] = _mm512_loadu_si512(row + 64 * k);
+    const unsigned long long check = (unsigned long long)_mm_extract_epi64(_mm512_extracti32x4_epi32(w[3], 3), 1);
+    w[3] = _mm512_maskz_mov_epi64(payload, w[3]);
+    const __m512i x = _mm512_xor_si512(_mm512_xor_si512(_mm512_rolv_epi64(w[0], rot[0]), _mm512_rolv_epi64(w[1], rot[1])),
+                                       _mm512_xor_si512(_mm512_rolv_epi64(w[2], rot[2]), _mm512_rolv_epi64(w[3], rot[3])));
+    const __m256i y4 = _mm256_xor_si256(_mm512_castsi512_si256(x), _mm512_extracti64x4_epi64(x, 1));
+    const __m128i y2 = _mm_xor_si128(_mm256_castsi256_si128(y4), _mm256_extracti128_si256(y4, 1));
+    const unsigned long long xx = (unsigned long long)_mm_extract_epi64(y2, 0) ^ (unsigned long long)_mm_extract_epi64(y2, 1);
+    if ((xx ^ key) != check) break;
+    double *dst = sm[b & 31];
+    for (int k = 0; k < 4; k++) _mm512_storeu_pd(dst + 8 * k, _mm512_add_pd(_mm512_loadu_pd(dst + 8 * k), _mm512_castsi512_pd(w[k])));
+  }
+  return b;
+}
+unsigned lsa_rows_take_fast(const double *partials, unsigned b, unsigned nb, unsigned long long key, double (*sm)[32]) {
+  static const bool wide = __builtin_cpu_supports("avx512f") && getenv("LSA_ROWS_AVX2") == nullptr;
+  return wide ? rows_take_avx512(partials, b, nb, key, sm) : rows_take_avx2(partials, b, nb, key, sm);
 }
 #else
 bool lsa_rows_fast_available() { return false; }
