@@ -90,6 +90,11 @@ int lsa_voxel_filter_reserve(lsa_voxel_filter *f, size_t max_points, int async_t
  * [3] host clouds whose rows the device pulled over the link itself while they were being packed (lsa_voxel_filter_apply, from the
  * second scan of a stream on; environment LSA_FILTER_PULL=0 selects the copy-command path). */
 int lsa_voxel_filter_counters(lsa_voxel_filter *f, uint64_t out[4]);
+/* Diagnostics: builds of a host cloud whose first kernel gave up waiting for the rows the host was packing (2 s; the packing threads
+ * were held up that long).  lsa_voxel_filter_apply fails with LSA_ERR_HIP in that case; the asynchronous host-cloud paths
+ * (lsa_front_end_update_batch, lsa_pipeline_scan_match_host) send the rows again once they are packed and filter them the ordinary
+ * way, so their results never come from a half-delivered cloud.  Counted here either way. */
+int lsa_voxel_filter_pull_timeouts(lsa_voxel_filter *f, uint64_t *out);
 
 /* Filter(input_cloud_ptr, filtered_cloud_ptr): host AoS in, host AoS out.
  * out may alias in (viewer.cpp:207 calls Filter with in == out); out_cap in points (n is always
@@ -507,10 +512,12 @@ int lsa_front_end_set_init_pose(lsa_front_end *fe, const float pose[16]);
 /* FrontEnd::Update(cloud_data, cloud_pose): one scan in, its pose (map <- lidar, column-major) out */
 int lsa_front_end_update(lsa_front_end *fe, const void *cloud, size_t n, size_t stride, size_t w_off, float pose_out[16],
                          lsa_front_end_stats *stats);
-/* the same on a cloud already in device memory (packed x, y, z, w rows, produced on the context's stream).  When the scan becomes a
- * key-frame the local map's update reads it on a stream of the map's own AFTER this call has returned, beside the caller's next scan
- * (FrontEnd keeps the key-frame's cloud as well: front_end.cpp:375): leave the buffer unchanged until the next call on this handle
- * has returned (or the device has been synchronised). */
+/* the same on a cloud already in device memory (packed x, y, z, w rows, produced on the context's stream).  The cloud is the caller's
+ * again when the call returns, as with FrontEnd::Update: the reference keeps a key-frame's raw cloud (front_end.cpp:375) and so does
+ * this handle — in a copy the frame filter's first kernel leaves in a buffer of the handle — so the local map's update, which runs on
+ * a stream of its own after the call has returned, never reads the caller's buffer.  (Without a frame filter, or with the incremental
+ * map switched off, the key-frame's cloud is read on / in front of the context's stream: work enqueued on that stream afterwards is
+ * ordered behind the read; a writer on another stream, or the host, synchronises the context's stream first.) */
 int lsa_front_end_update_device(lsa_front_end *fe, const float *d_xyzw, size_t n, float pose_out[16], lsa_front_end_stats *stats);
 /* diagnostics: with out == NULL, enable != 0 makes the three kernels of every following incremental map update note the device's
  * 100 MHz wall clock at their phase boundaries (8 values per workgroup); with out != NULL the 3 x *per_kernel values are copied out

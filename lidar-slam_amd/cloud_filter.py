@@ -67,6 +67,14 @@ class VoxelFilterHip(CloudFilterInterface):
         self.ctx.check(L.lsa_voxel_filter_counters(self.h, out))
         return dict(builds=out[0], misses=out[1], growths=out[2], pulled=out[3])
 
+    def pull_timeouts(self):
+        """lsa_voxel_filter_pull_timeouts: pulled builds whose first kernel gave up waiting for the packed rows of a host cloud."""
+        out = C.c_uint64(0)
+        L = capi.lib()
+        L.lsa_voxel_filter_pull_timeouts.argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]
+        self.ctx.check(L.lsa_voxel_filter_pull_timeouts(self.h, C.byref(out)))
+        return int(out.value)
+
     def filter_device(self, d_in, d_out=None):
         """Device path: d_in a CUDA float32 tensor (n, 4) {x,y,z,intensity}; returns a view of d_out[:m]."""
         import torch

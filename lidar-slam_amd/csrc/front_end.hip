@@ -149,10 +149,15 @@ struct lsa_front_end {
   // last kernel ends, against 0 on one stream).
   lsa_context *ctx_m = nullptr;
   bool in_batch = false;
-  hipEvent_t ev_map = nullptr, ev_in = nullptr;
+  hipEvent_t ev_map = nullptr, ev_in = nullptr, ev_cloud = nullptr;   // ev_cloud: behind the last read of the caller's cloud on the map's stream
   bool map_inflight = false;   // an update has been enqueued on ctx_m's stream that the registration's stream is not yet ordered behind
   DevBuf<float4> d_in_alt;     // lsa_front_end_update (host clouds): the upload alternates between two buffers (see there)
   bool in_alt = false;
+  bool cloud_is_callers = false;   // the cloud handed to fe_update_filtered is the caller's own buffer (not a copy this handle owns)
+  // how a key-frame's read of a caller-owned device cloud is made safe: 2 (default) the frame filter's first kernel leaves a copy in a
+  // buffer of this handle; 1 the context's stream is ordered behind the update's read (what remains without a frame filter);
+  // 0 neither — the pre-round-5 contract, the A/B arm of profiles/r05_fe_cloud_ab.log only.  LSA_FE_CLOUD=keep|event|none
+  int cloud_mode = !getenv("LSA_FE_CLOUD") ? 2 : (!strcmp(getenv("LSA_FE_CLOUD"), "none") ? 0 : (!strcmp(getenv("LSA_FE_CLOUD"), "event") ? 1 : 2));
   bool incremental = getenv("LSA_FE_INCREMENTAL") ? atoi(getenv("LSA_FE_INCREMENTAL")) != 0 : true;
   bool lm_off = false;       // fell back to the full build for good (window / table limits, coordinates out of range)
   bool lm_adopted = false;   // the NDT handle currently runs on the local map's table
@@ -168,6 +173,7 @@ void ndt_prearm(lsa_ndt *h);
 bool ndt_defer_scope(lsa_ndt *h, bool on);
 int ndt_collect_deferred(lsa_ndt *h);
 int lsa_voxel_filter_apply_device_async_here(lsa_voxel_filter *f, const float *d_in_xyzw, size_t n, float *d_out_xyzw);   // voxel_filter.hip
+int lsa_voxel_filter_apply_device_keep(lsa_voxel_filter *f, const float *d_in_xyzw, size_t n, float *d_out_xyzw, size_t *n_out, float *d_keep);
 int lsa_voxel_filter_apply_host_async(lsa_voxel_filter *f, const void *in_pts, size_t n, size_t in_stride, size_t in_w_off, float *d_rows, float *d_out);
 int lsa_voxel_filter_apply_host_to_device(lsa_voxel_filter *f, const void *in_pts, size_t n, size_t in_stride, size_t in_w_off, float *d_rows, float *d_out,
                                           size_t *n_out, int *pulled);
@@ -339,6 +345,15 @@ int fe_rebuild_map(lsa_front_end *fe, KeyFrame *added, bool evicted, const float
   for (int r = 0; r < 3; r++)
     for (int c = 0; c < 4; c++) T[r * 4 + c] = added->pose[c * 4 + r];
   if ((rc = lm_swap(fe->lm, slot, fe->slot_cap, evicted, d_cloud, added->n, T, added->pts.p, reset_w))) return rc;
+  if (own_stream && fe->cloud_is_callers && fe->cloud_mode >= 1) {
+    // (Only without a frame filter: with one, a device cloud reaches this point as the copy the filter's first kernel left in a
+    // buffer of this handle, fe_update_device.)  lm_swap's one kernel is the last reader of the CALLER's cloud (it keeps the
+    // key-frame's copy and writes the slot); it runs on the map's stream after this call has returned.  The registration's stream —
+    // the caller's — is ordered behind it here, so that whatever the caller enqueues next on its stream (a refill of the same scan
+    // buffer) comes after that read, while the rest of the update (dirty cells of both levels) still runs beside it.
+    LSA_HIP(ctx, hipEventRecord(fe->ev_cloud, fe->ctx_m->stream));
+    LSA_HIP(ctx, hipStreamWaitEvent(ctx->stream, fe->ev_cloud, 0));
+  }
   if ((rc = lm_finish(fe->lm))) return rc;
   if (own_stream) {
     LSA_HIP(ctx, hipEventRecord(fe->ev_map, fe->ctx_m->stream));
@@ -429,18 +444,39 @@ int fe_update_filtered(lsa_front_end *fe, const float4 *d_cloud, size_t n, const
   return LSA_OK;
 }
 
-int fe_update_device(lsa_front_end *fe, const float4 *d_cloud, size_t n, float pose_out[16], lsa_front_end_stats *stats) {
+// callers_buffer: d_cloud belongs to the caller (lsa_front_end_update_device), who gets it back when the call returns — as
+// FrontEnd::Update(const CloudData &) leaves its argument alone afterwards.  A key-frame's map update reads the raw cloud AFTER the
+// call has returned (on the map's stream, beside the next scan's frame filter), so the frame filter's first kernel, which has every
+// row in registers anyway, leaves a copy in a buffer of this handle (two, alternating: the update that reads one is seen complete
+// by the next call, which fills the other) and everything behind the filter works on that copy: 2 MB of stores per scan inside a
+// latency-bound kernel instead of an event that holds the next scan's filter back behind the update's first kernel (measured:
+// profiles/r05_fe_cloud_ab.log).  Without a frame filter the event is what orders the caller's stream (fe_rebuild_map).
+int fe_update_device(lsa_front_end *fe, const float4 *d_cloud, size_t n, float pose_out[16], lsa_front_end_stats *stats, bool callers_buffer) {
   lsa_context *ctx = fe->ctx;
   int rc;
   // frame filter (:106-107)
   const float4 *src = d_cloud;
   size_t n_src = n;
+  fe->cloud_is_callers = callers_buffer;
   if (fe->cfg.use_frame_filter) {
     if ((rc = fe->d_filtered.reserve(ctx, n ? n : 1, 1.25))) return rc;
     size_t V = 0;
-    rc = lsa_voxel_filter_apply_device(fe->frame_filter, (const float *)d_cloud, n, (float *)fe->d_filtered.p, &V);
+    if (callers_buffer && n && fe->incremental && !fe->lm_off && fe->cloud_mode == 2) {
+      DevBuf<float4> &keep = fe->in_alt ? fe->d_in_alt : fe->d_in;
+      fe->in_alt = !fe->in_alt;
+      if (n > keep.cap) {   // before the reserve: it frees a buffer an earlier copy / update may still read
+        LSA_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        if ((rc = fe_map_drain(fe))) return rc;
+        if ((rc = keep.reserve(ctx, n, 1.25))) return rc;
+      }
+      rc = lsa_voxel_filter_apply_device_keep(fe->frame_filter, (const float *)d_cloud, n, (float *)fe->d_filtered.p, &V, (float *)keep.p);
+      if (rc == LSA_OK || rc == LSA_ERR_RANGE) { d_cloud = keep.p; fe->cloud_is_callers = false; }
+    } else {
+      rc = lsa_voxel_filter_apply_device(fe->frame_filter, (const float *)d_cloud, n, (float *)fe->d_filtered.p, &V);
+    }
     if (rc == LSA_OK) { src = fe->d_filtered.p; n_src = V; }
     else if (rc != LSA_ERR_RANGE) return rc;
+    else if (src != d_cloud) src = d_cloud;   // (PCL passes the input through: the copy, if there is one)
   }
   lsa_front_end_stats local;
   return fe_update_filtered(fe, d_cloud, n, src, n_src, pose_out, stats ? stats : &local, false);
@@ -457,7 +493,7 @@ int fe_update_batch(lsa_front_end *fe, size_t count, const float *const *d_scans
   int rc;
   if (!fe->cfg.use_frame_filter) {  // nothing to overlap
     for (size_t k = 0; k < count; k++)
-      if ((rc = fe_update_device(fe, (const float4 *)d_scans[k], n_points[k], poses_out + 16 * k, stats ? stats + k : nullptr))) return rc;
+      if ((rc = fe_update_device(fe, (const float4 *)d_scans[k], n_points[k], poses_out + 16 * k, stats ? stats + k : nullptr, true))) return rc;
     return LSA_OK;
   }
   if ((rc = fe_batch_context(fe))) return rc;
@@ -598,7 +634,8 @@ extern "C" int lsa_front_end_create(lsa_front_end **out, lsa_context *ctx, const
   // ScanMatches: an armed kernel parked across them would only have to be released again
   if (!rc) rc = lsa_ndt_set_armed_carry(fe->ndt, 0);
   if (!rc && (rc = lsa_context_create(&fe->ctx_m, ctx->device, nullptr))) rc = lsa_fail(ctx, rc, "lsa_front_end_create: the local map's context: %s", lsa_last_global_error());
-  if (!rc && (hipEventCreateWithFlags(&fe->ev_map, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&fe->ev_in, hipEventDisableTiming) != hipSuccess))
+  if (!rc && (hipEventCreateWithFlags(&fe->ev_map, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&fe->ev_in, hipEventDisableTiming) != hipSuccess ||
+              hipEventCreateWithFlags(&fe->ev_cloud, hipEventDisableTiming) != hipSuccess))
     rc = lsa_fail(ctx, LSA_ERR_HIP, "lsa_front_end_create: hipEventCreate failed");
   if (rc) { lsa_front_end_destroy(fe); return rc; }
   identity16(fe->init_pose); identity16(fe->last_pose); identity16(fe->predict_pose); identity16(fe->step_pose); identity16(fe->last_kf_pose);
@@ -644,6 +681,8 @@ extern "C" int lsa_front_end_reserve(lsa_front_end *fe, size_t max_scan_points) 
   if (fe->cfg.use_frame_filter) {
     if ((rc = lsa_voxel_filter_reserve(fe->frame_filter, n, 3))) return rc;   // (lsa_front_end_update's host scans go through its pulled path)
     if ((rc = fe->d_filtered.reserve(ctx, n, 1.25))) return rc;
+    // the two buffers a scan's raw rows are kept in (device clouds: the filter's copy; host clouds: where the pulled rows land)
+    if ((rc = fe->d_in.reserve(ctx, n, 1.25)) || (rc = fe->d_in_alt.reserve(ctx, n, 1.25))) return rc;
     if ((rc = fe_batch_context(fe))) return rc;
     if ((rc = lsa_voxel_filter_reserve(fe->frame_filter_b, n, 3))) return lsa_fail(ctx, rc, "%s", lsa_last_error(fe->ctx_b));
     if ((rc = fe_host_batch_context(fe))) return rc;
@@ -692,6 +731,7 @@ extern "C" void lsa_front_end_destroy(lsa_front_end *fe) {
   if (fe->ctx_b) lsa_context_destroy(fe->ctx_b);
   if (fe->ev_map) (void)hipEventDestroy(fe->ev_map);
   if (fe->ev_in) (void)hipEventDestroy(fe->ev_in);
+  if (fe->ev_cloud) (void)hipEventDestroy(fe->ev_cloud);
   fe->d_in_alt.release();
   if (fe->ctx_m) lsa_context_destroy(fe->ctx_m);
   delete fe;
@@ -706,7 +746,7 @@ extern "C" int lsa_front_end_set_init_pose(lsa_front_end *fe, const float pose[1
 extern "C" int lsa_front_end_update_device(lsa_front_end *fe, const float *d_xyzw, size_t n, float pose_out[16], lsa_front_end_stats *stats) {
   if (!fe || !pose_out || (n && !d_xyzw)) return fe ? lsa_fail(fe->ctx, LSA_ERR_INVALID, "lsa_front_end_update_device: null argument") : LSA_ERR_INVALID;
   LSA_HIP(fe->ctx, lsa_enter(fe->ctx));
-  return fe_update_device(fe, (const float4 *)d_xyzw, n, pose_out, stats);
+  return fe_update_device(fe, (const float4 *)d_xyzw, n, pose_out, stats, true);
 }
 
 extern "C" int lsa_front_end_update_batch(lsa_front_end *fe, size_t count, const void *const *clouds, const size_t *n_points, size_t stride, size_t w_off,
@@ -765,7 +805,7 @@ extern "C" int lsa_front_end_update(lsa_front_end *fe, const void *cloud, size_t
   LSA_HIP(ctx, hipStreamSynchronize(ctx->stream));  // (the staging buffer may still feed an earlier copy)
   if ((rc = fe->h_stage.reserve(ctx, (n ? n : 1) * 4))) return rc;
   if ((rc = lsa_upload_xyzw(ctx, cloud, n, stride, w_off, fe->h_stage.p, din.p))) return rc;
-  return fe_update_device(fe, din.p, n, pose_out, stats);
+  return fe_update_device(fe, din.p, n, pose_out, stats, false);
 }
 
 extern "C" lsa_ndt *lsa_front_end_registration(lsa_front_end *fe) { return fe ? fe->ndt : nullptr; }

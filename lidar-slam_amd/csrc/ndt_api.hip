@@ -30,7 +30,9 @@ int upload_points(lsa_ndt *h, const void *pts, size_t n, size_t stride, size_t w
   if ((rc = h->h_stage.reserve(ctx, n * 4))) return rc;
   if ((rc = dst.reserve(ctx, n, 1.25))) return rc;
   if ((rc = lsa_upload_xyzw(ctx, pts, n, stride, w_off, h->h_stage.p, dst.p))) return rc;
-  if (n == 0 || n > kPullRowsMax) return LSA_OK;
+  if (n == 0) return LSA_OK;
+  // behind EVERY upload, the chunked one of a large cloud included: its kernels read the staging buffer too, and the next (small)
+  // upload repacks it after waiting for this event alone
   if (!h->ev_upload) LSA_HIP(ctx, hipEventCreateWithFlags(&h->ev_upload, hipEventDisableTiming));
   LSA_HIP(ctx, hipEventRecord(h->ev_upload, ctx->stream));
   h->upload_pending = true;

@@ -30,7 +30,7 @@ struct lsa_voxel_filter {
   size_t p_n = 0;
   // The ~10 kernel launches of one filter cost ~30 us of HOST time; the async entry point hands them to a helper
   // thread so that the caller's thread is free to drive the registration of the previous scan meanwhile.
-  // job_state: 0 idle, 1 posted, 2 enqueued (job_rc valid), -1 shut down.
+  // job_state: 0 idle, 1 posted, 3 claimed by the helper, 2 done (job_rc valid), -1 shut down.
   std::thread worker;
   std::mutex mu;
   std::condition_variable cv;
@@ -60,6 +60,14 @@ struct lsa_voxel_filter {
   unsigned u_chunks = 0, pull_seq = 0;
   bool no_pull = getenv("LSA_FILTER_PULL") ? atoi(getenv("LSA_FILTER_PULL")) == 0 : false;
   unsigned long long n_pulled = 0;
+  // a pulled build whose first kernel gave up waiting for the packed rows (PullSource::patience_ticks, 2 s: the packing threads were
+  // held up for seconds).  The synchronous call fails with LSA_ERR_HIP; the asynchronous one, whose rows are complete in the staging
+  // buffer by the time it is waited for, sends them again and builds the ordinary way.  Counted either way.
+  unsigned long long n_pull_timeouts = 0;
+  // LSA_PULL_TEST="patience_ticks,delay_us" (tests only): the kernel's patience in 100 MHz ticks and a sleep in front of every packing
+  // thread's first chunk, so that the time-out can be met on purpose
+  unsigned long long pull_patience = 200000000ull;   // 2 s
+  unsigned pull_test_delay_us = 0;
   // LSA_FILTER_STATS: where a pulled call spends its time (sums of microseconds) and how many chunks the caller's thread packed itself
   bool stats_on = getenv("LSA_FILTER_STATS") != nullptr;
   double st_enqueue = 0, st_pack = 0, st_join = 0, st_wait = 0, st_unpack = 0;
@@ -99,7 +107,8 @@ void filter_pull_join(lsa_voxel_filter *f);
 // pull (host path only): the first attempt's mark kernel takes the rows out of pinned memory while both threads are still packing
 // them (filter_pull_join: this thread packs too, then waits for the helper); d_in is where the kernel leaves them, so a rebuild
 // after a speculative miss finds them resident
-int filter_device(lsa_voxel_filter *f, const float4 *d_in, size_t n, float4 *d_out, size_t *n_out, const PullSource *pull = nullptr) {
+// d_keep: the mark kernel of every attempt also copies the rows it reads there (lsa_voxel_filter_apply_device_keep)
+int filter_device(lsa_voxel_filter *f, const float4 *d_in, size_t n, float4 *d_out, size_t *n_out, const PullSource *pull = nullptr, float4 *d_keep = nullptr) {
   lsa_context *ctx = f->ctx;
   *n_out = 0;
   if (n == 0) return LSA_OK;
@@ -111,7 +120,7 @@ int filter_device(lsa_voxel_filter *f, const float4 *d_in, size_t n, float4 *d_o
   for (int attempt = 0; attempt < 3; attempt++) {
     const bool pulling = pull && attempt == 0;
     const auto tq0 = std::chrono::steady_clock::now();
-    rc = vi_enqueue(ctx, vi, d_in, n, /*mode PCL*/ 0, f->leaf, 4, /*allow_spec*/ true, pulling ? pull : nullptr);
+    rc = vi_enqueue(ctx, vi, d_in, n, /*mode PCL*/ 0, f->leaf, 4, /*allow_spec*/ true, pulling ? pull : nullptr, d_keep);
     if (!rc) {
       hipLaunchKernelGGL(k_filter_finalize, dim3(lsa_div_up(n, kBlock)), dim3(kBlock), 0, ctx->stream, vi.acc.p, vi.cnt.p, vi.cell_of_rank.p, vi.dparams.p,
                          d_out, vi.h_params.p, vi.bits.p);
@@ -125,7 +134,10 @@ int filter_device(lsa_voxel_filter *f, const float4 *d_in, size_t n, float4 *d_o
     if ((rc = vi_wait(ctx, vi, &status))) return rc;
     if (pulling && f->stats_on) f->st_wait += std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - tw0).count();
     vi.clean = (status == VI_OK || status == VI_SPEC_MISS);  // the finalize kernel zeroed what this build touched
-    if (status == VI_SPEC_MISS && vi.last_pull_timeout) return lsa_fail(ctx, LSA_ERR_HIP, "voxel filter: the device waited in vain for the packed rows of the host cloud");
+    if (status == VI_SPEC_MISS && vi.last_pull_timeout) {
+      f->n_pull_timeouts++;
+      return lsa_fail(ctx, LSA_ERR_HIP, "voxel filter: the device waited in vain for the packed rows of the host cloud");
+    }
     if (status == VI_SPEC_MISS) { f->n_miss++; continue; }  // a point fell outside the reused cell box: rebuild from the bounding box
     if (status != VI_CAPACITY) break;
     f->n_cap++;
@@ -161,6 +173,7 @@ constexpr unsigned kPullChunkShift = 13;   // 8 192 rows = 128 KB per chunk: ~4 
 // claim chunks until none is left: pack, then publish (rows before the flag; the kernel acquires the flag at system scope)
 unsigned filter_pack_chunks(lsa_voxel_filter *f) {
   const size_t chunk = (size_t)1 << kPullChunkShift;
+  if (f->pull_test_delay_us) std::this_thread::sleep_for(std::chrono::microseconds(f->pull_test_delay_us));
   for (unsigned done = 0;; done++) {
     const unsigned c = f->u_next.fetch_add(1, std::memory_order_relaxed);
     if (c >= f->u_chunks) return done;
@@ -214,11 +227,20 @@ void filter_worker(lsa_voxel_filter *f) {
       st = f->job_state.load(std::memory_order_acquire);
     }
     if (st == -1) return;
-    if (f->job_kind == 0) {  // wake-up call only (the first filter of a batch is enqueued by the caller itself): back to spinning
+    // Claimed (1 -> 3), not just seen, and the kind read only BEHIND the claim: the caller of the pulled path withdraws a job the
+    // helper has not picked up by the time every chunk is packed (1 -> 0; a helper that was asleep needs ~50 us to wake — longer
+    // than the whole cloud takes to pack) and may post a different one at once; a kind read in front of the claim could belong to
+    // the withdrawn job.  From the claim to state 2 (or 0, the wake-up call) the job's fields are this thread's.
+    {
+      int expect = 1;
+      if (!f->job_state.compare_exchange_strong(expect, 3, std::memory_order_acq_rel)) continue;
+    }
+    const int kind = f->job_kind;
+    if (kind == 0) {  // wake-up call only (the first filter of a batch is enqueued by the caller itself): back to spinning
       f->job_state.store(0, std::memory_order_release);
       continue;
     }
-    if (f->job_kind == 3) {
+    if (kind == 3) {
       // retire the stream's completed commands (the last filter of a batch has delivered; its stream would otherwise cost the
       // caller's next wait on the device ~11 us of bookkeeping) while the caller's thread drives the last registration
       f->job_hip = hipStreamSynchronize(f->ctx->stream);
@@ -226,17 +248,13 @@ void filter_worker(lsa_voxel_filter *f) {
       f->job_state.store(2, std::memory_order_release);
       continue;
     }
-    if (f->job_kind == 4) {
-      // claimed, not just seen: the caller withdraws a job the helper has not picked up by the time every chunk is packed (a helper
-      // that was asleep needs ~50 us to wake — longer than the whole cloud takes to pack)
-      int expect = 1;
-      if (!f->job_state.compare_exchange_strong(expect, 3, std::memory_order_acq_rel)) continue;
+    if (kind == 4) {
       (void)filter_pack_chunks(f);
       f->job_rc = LSA_OK;
       f->job_state.store(2, std::memory_order_release);
       continue;
     }
-    if (f->job_kind == 5) {
+    if (kind == 5) {
       // A HOST scan through the filter, asynchronously (lsa_voxel_filter_apply_host_async): with a reusable grid definition the
       // build is enqueued first — its mark kernel pulls the rows over the link as they are published and leaves them in p_in —
       // and this thread and the second packer then pack the caller's rows chunk by chunk; without one, the rows are packed and
@@ -254,7 +272,7 @@ void filter_worker(lsa_voxel_filter *f) {
         pull.ready = f->h_ready.p;
         pull.seq = f->pull_seq;
         pull.chunk_shift = kPullChunkShift;
-        pull.patience_ticks = 200000000ull;
+        pull.patience_ticks = f->pull_patience;
         if (f->packer2_started) {
           {
             std::lock_guard<std::mutex> lk(f->mu2);
@@ -284,7 +302,7 @@ void filter_worker(lsa_voxel_filter *f) {
       f->job_state.store(2, std::memory_order_release);
       continue;
     }
-    if (f->job_kind == 2) {
+    if (kind == 2) {
       // second half of a host cloud down the second copy queue.  The helper touches neither the context nor its error text
       // (the caller's thread may be writing it): stride / offset were validated by the caller, a HIP failure comes back as
       // a code in job_hip and the caller's thread reports it
@@ -312,7 +330,11 @@ void filter_post_job(lsa_voxel_filter *f, int kind) {
     f->worker = std::thread(filter_worker, f);
     f->worker_started = true;
   }
-  while (f->job_state.load(std::memory_order_acquire) == 1) __builtin_ia32_pause();   // (a wake-up call the helper has not taken yet)
+  for (;;) {   // (a wake-up call the helper has not taken yet, or is just taking)
+    const int s = f->job_state.load(std::memory_order_acquire);
+    if (s != 1 && s != 3) break;
+    __builtin_ia32_pause();
+  }
   f->job_kind = kind;
   {
     std::lock_guard<std::mutex> lk(f->mu);
@@ -374,7 +396,7 @@ int lsa_voxel_filter_apply_device_async_here(lsa_voxel_filter *f, const float *d
   if (n == 0) return LSA_OK;
   filter_post_job(f, 0);
   f->job_rc = filter_enqueue(f, f->p_in, f->p_n, f->p_out);
-  while (f->job_state.load(std::memory_order_acquire) == 1) __builtin_ia32_pause();   // the wake-up call has been taken
+  while (f->job_state.load(std::memory_order_acquire) != 0) __builtin_ia32_pause();   // the wake-up call has been taken (1 -> 3 -> 0)
   f->job_state.store(2, std::memory_order_release);
   return LSA_OK;
 }
@@ -457,6 +479,16 @@ extern "C" int lsa_voxel_filter_wait(lsa_voxel_filter *f, size_t *n_out) {
   int rc = vi_wait(f->ctx, f->vi, &status);
   if (rc) return rc;
   f->vi.clean = (status == VI_OK || status == VI_SPEC_MISS);  // the finalize kernel zeroed what this build touched
+  if (status == VI_SPEC_MISS && f->vi.last_pull_timeout) {
+    // Not a point outside the reused box: the pulling kernel's tiles gave up waiting for their chunks and never wrote those rows
+    // into p_in — a rebuild from p_in would filter whatever the buffer held before.  The rows themselves are complete by now (the
+    // helper reports the job done only behind the last packed chunk, both packers joined) and still in the staging buffer (the
+    // asynchronous paths deliver into device memory, not into it): send them again and build the ordinary way.
+    f->n_pull_timeouts++;
+    hipError_t e = lsa_pull_rows(f->ctx->stream, f->h_stage.p, const_cast<float4 *>(f->p_in), f->p_n);
+    if (e != hipSuccess) return lsa_fail(f->ctx, LSA_ERR_HIP, "voxel filter: re-sending the rows of a host cloud failed: %s", hipGetErrorString(e));
+    return filter_device(f, f->p_in, f->p_n, f->p_out, n_out);
+  }
   if (status == VI_SPEC_MISS) return filter_device(f, f->p_in, f->p_n, f->p_out, n_out);  // rare: rebuild exactly
   if (status == VI_CAPACITY) {  // rare: extent larger than ever seen; size the bitmap and run the synchronous path
     if ((rc = vi_grow(f->ctx, f->vi))) return rc;
@@ -478,6 +510,11 @@ extern "C" int lsa_voxel_filter_create(lsa_voxel_filter **out, lsa_context *ctx,
   lsa_voxel_filter *f = new lsa_voxel_filter();
   f->ctx = ctx;
   f->leaf[0] = lx; f->leaf[1] = ly; f->leaf[2] = lz;
+  if (const char *t = getenv("LSA_PULL_TEST")) {
+    unsigned long long ticks = 0;
+    unsigned delay = 0;
+    if (sscanf(t, "%llu,%u", &ticks, &delay) >= 1 && ticks) { f->pull_patience = ticks; f->pull_test_delay_us = delay; }
+  }
   *out = f;
   return LSA_OK;
 }
@@ -525,6 +562,12 @@ extern "C" int lsa_voxel_filter_counters(lsa_voxel_filter *f, uint64_t out[4]) {
   return LSA_OK;
 }
 
+extern "C" int lsa_voxel_filter_pull_timeouts(lsa_voxel_filter *f, uint64_t *out) {
+  if (!f || !out) return LSA_ERR_INVALID;
+  *out = f->n_pull_timeouts;
+  return LSA_OK;
+}
+
 extern "C" void lsa_voxel_filter_destroy(lsa_voxel_filter *f) {
   if (!f) return;
   if (getenv("LSA_FILTER_STATS")) fprintf(stderr, "voxel filter: %llu sync calls, %llu speculative misses, %llu capacity growths, W_cap %zu, last W %zu dims %d %d %d\n", f->n_calls, f->n_miss, f->n_cap, f->vi.W_cap, f->vi.W, f->vi.map.dim[0], f->vi.map.dim[1], f->vi.map.dim[2]);
@@ -564,6 +607,16 @@ extern "C" int lsa_voxel_filter_apply_device(lsa_voxel_filter *f, const float *d
   return filter_device(f, (const float4 *)d_in_xyzw, n, (float4 *)d_out_xyzw, n_out);
 }
 
+// internal (front_end.hip): lsa_voxel_filter_apply_device that also leaves a copy of the input rows in d_keep (n rows) — written by
+// the build's first kernel from the rows it has in registers anyway.  FrontEnd::Update keeps a key-frame's raw cloud
+// (front_end.cpp:375) and reads it after the call has returned; with the copy the CALLER's buffer is not read any more once this
+// returns.  The copy is complete whenever the call returns LSA_OK or LSA_ERR_RANGE.
+int lsa_voxel_filter_apply_device_keep(lsa_voxel_filter *f, const float *d_in_xyzw, size_t n, float *d_out_xyzw, size_t *n_out, float *d_keep) {
+  if (!f || !n_out || (n && (!d_in_xyzw || !d_out_xyzw || !d_keep))) return f ? lsa_fail(f->ctx, LSA_ERR_INVALID, "lsa_voxel_filter_apply_device_keep: null argument") : LSA_ERR_INVALID;
+  LSA_HIP(f->ctx, lsa_enter(f->ctx));
+  return filter_device(f, (const float4 *)d_in_xyzw, n, (float4 *)d_out_xyzw, n_out, nullptr, (float4 *)d_keep);
+}
+
 namespace {
 // The steady state of a stream of host scans (the previous scan left a grid definition this one fits): nothing is copied by a copy
 // command.  filter_pull_begin starts the helper threads packing the caller's rows into the staging buffer at once; the caller then
@@ -586,7 +639,7 @@ int filter_pull_begin(lsa_voxel_filter *f, const void *in_pts, size_t n, size_t 
   pull->ready = f->h_ready.p;
   pull->seq = f->pull_seq;
   pull->chunk_shift = kPullChunkShift;
-  pull->patience_ticks = 200000000ull;   // 2 s
+  pull->patience_ticks = f->pull_patience;
   filter_post_job(f, 4);
   if (!f->packer2_started) {
     f->packer2 = std::thread(filter_packer2, f);

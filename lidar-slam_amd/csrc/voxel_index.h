@@ -69,7 +69,8 @@ struct KnownParams {
 constexpr unsigned kPullFlagStride = 16;   // ready flags are 16 words (one 64-byte line) apart
 struct PullSource {
   const float4 *h_rows;               // the pinned rows (device-visible address)
-  float4 *d_copy;                     // where the kernel leaves them in device memory (k_accum reads them there)
+  float4 *d_copy;                     // where the kernel leaves them in device memory (k_accum reads them there).  Without h_rows (a
+                                      // device cloud): a second copy of the rows the kernel marks, for a caller that wants to keep them
   const unsigned *ready;              // [chunks * kPullFlagStride], device-visible: ready[c * kPullFlagStride] == seq once chunk c's rows are packed
   unsigned seq, chunk_shift;          // a chunk is 1 << chunk_shift rows
   unsigned long long patience_ticks;  // 100 MHz ticks a tile waits for its chunk before it flags the build (spec_miss = 2)
@@ -127,7 +128,7 @@ struct VoxelIndex {
 // pull (optional, only when vi_spec_ready() holds): k_mark reads the rows from pull->h_rows as the host delivers them and copies
 // them to pull->d_copy == d_pts on the way.
 int vi_enqueue(lsa_context *ctx, VoxelIndex &vi, const float4 *d_pts, size_t n, int mode, const float leaf[3], int ns, bool allow_spec = false,
-               const PullSource *pull = nullptr);
+               const PullSource *pull = nullptr, float4 *d_keep = nullptr);
 // will the next vi_enqueue(.., allow_spec = true) over n points reuse the grid definition the device holds?
 bool vi_spec_ready(const VoxelIndex &vi, size_t n, int mode, const float leaf[3]);
 // Allocate now what a build over up to `n` points with `ns` sums per cell will need, with a bitmap of at least w_min words

@@ -230,7 +230,17 @@ template <int TILE, bool PULL>
 __global__ __launch_bounds__(kBlock) void k_mark(const float4 *__restrict__ pts, size_t n, DevParams *__restrict__ dp, KnownParams kp,
                                                  uint32_t *__restrict__ bits, int32_t *__restrict__ cell_idx, PullSource pull) {
   constexpr int kTile = TILE, kHashCap = TILE / 2;
-  if (!kp.valid && dp->status != VI_OK) return;
+  if (!kp.valid && dp->status != VI_OK) {
+    // KEEP (a device cloud the caller wants a copy of, pull.d_copy without pull.h_rows): the copy does not depend on the grid
+    // definition — a build that ends in a range or an empty report still leaves it complete
+    if (!PULL && pull.d_copy) {
+      for (int k = 0; k < kTile / kBlock; k++) {
+        size_t i = (size_t)blockIdx.x * kTile + (size_t)k * kBlock + threadIdx.x;
+        if (i < n) pull.d_copy[i] = pts[i];
+      }
+    }
+    return;
+  }
   const CellMap m = kp.valid ? kp.map : dp->map;
   __shared__ int pull_ok;
   if (PULL && threadIdx.x == 0) {
@@ -273,7 +283,7 @@ __global__ __launch_bounds__(kBlock) void k_mark(const float4 *__restrict__ pts,
     size_t i = base + (size_t)k * kBlock + threadIdx.x;
     pv[k] = (i < n) ? (PULL ? pull.h_rows[i] : pts[i]) : make_float4(NAN, NAN, NAN, 0.f);
   }
-  if (PULL) {
+  if (PULL || pull.d_copy) {   // (KEEP: wave-uniform; the rows are in registers anyway, the stores are not waited for)
 #pragma unroll
     for (int k = 0; k < kTile / kBlock; k++) {
       size_t i = base + (size_t)k * kBlock + threadIdx.x;
@@ -650,7 +660,8 @@ bool vi_spec_ready(const VoxelIndex &vi, size_t n, int mode, const float leaf[3]
          (unsigned long long)n <= vi.spec_n_cap && vi.spec_W_cap == vi.W_cap && vi.W_cap != 0;
 }
 
-int vi_enqueue(lsa_context *ctx, VoxelIndex &vi, const float4 *d_pts, size_t n, int mode, const float leaf[3], int ns, bool allow_spec, const PullSource *pull) {
+int vi_enqueue(lsa_context *ctx, VoxelIndex &vi, const float4 *d_pts, size_t n, int mode, const float leaf[3], int ns, bool allow_spec, const PullSource *pull,
+               float4 *d_keep) {
   int rc;
   unsigned nb = stream_grid(ctx, n);
   if ((rc = vi_prepare(ctx, vi, n, ns, 0))) return rc;
@@ -701,6 +712,7 @@ int vi_enqueue(lsa_context *ctx, VoxelIndex &vi, const float4 *d_pts, size_t n, 
   }
   PullSource no_pull;
   memset(&no_pull, 0, sizeof(no_pull));
+  no_pull.d_copy = d_keep;   // (a pulled build leaves the rows in pull->d_copy already)
   if (pull) {
     if (!spec) return lsa_fail(ctx, LSA_ERR_INVALID, "vi_enqueue: rows can only be pulled into a known grid definition (vi_spec_ready)");
     hipLaunchKernelGGL((k_mark<kTilePull, true>), dim3(lsa_div_up(n, kTilePull)), dim3(kBlock), 0, ctx->stream, d_pts, n, dp, kp, vi.bits.p, vi.cell_idx.p, *pull);

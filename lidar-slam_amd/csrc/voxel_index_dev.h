@@ -113,6 +113,21 @@ __device__ __forceinline__ unsigned long long vi_round_ll(double x, bool fast) {
   }
   return (unsigned long long)__double2ll_rn(x);
 }
+// The intensity term.  Unlike the coordinate terms (a point lies in its cell: |d| <= leaf by construction) nothing bounds an
+// intensity: the scales assume |w| < 1024 (KITTI reflectance and the reference's static weights are in [0, 1]), and only the
+// coordinates are tested for finiteness.  The magic-number rounding turns anything at or beyond 2^51 — a 16-bit reflectance at
+// kw = 40, an infinity, a NaN — into arbitrary integer bits, which the incremental local map would then keep in its persistent
+// sums until the key-frame is evicted.  So: a non-finite intensity counts as 0, a finite one beyond the fast range takes the exact
+// conversion (clamped to +-2^62: a cell's sum of such terms can still overflow, the documented limit is |w| < 1024).  The branch is
+// never taken on in-range data (one compare per point).
+__device__ __forceinline__ unsigned long long vi_weight_term(float w, const FixScales &fs) {
+#pragma clang fp contract(off)
+  const double x = (double)w * fs.sw;
+  if (__builtin_expect(fs.fast_round != 0 && fabs(x) < 2251799813685248.0 /* 2^51 */, 1)) return vi_round_ll(x, true);
+  if (!isfinite(w)) return 0ull;
+  const double lim = 4611686018427387904.0;   // 2^62
+  return (unsigned long long)__double2ll_rn(fmin(fmax(x, -lim), lim));
+}
 template <int NS>
 __device__ __forceinline__ void vi_point_terms(const double o[3], const FixScales &fs, const float4 &p, unsigned long long v[NS]) {
 #pragma clang fp contract(off)
@@ -129,7 +144,7 @@ __device__ __forceinline__ void vi_point_terms(const double o[3], const FixScale
     v[7] = vi_round_ll(dy * dz * fs.s2, fast);
     v[8] = vi_round_ll(dz * dz * fs.s2, fast);
   }
-  v[NS - 1] = vi_round_ll((double)p.w * fs.sw, fast);
+  v[NS - 1] = vi_weight_term(p.w, fs);
 }
 
 // the VoxelFilter's output point of a cell: the f32 mean of x, y, z and the intensity from the cell's four sums

@@ -86,7 +86,12 @@ class FrontEndHip:
         return True
 
     def Update(self, cloud):  # noqa: N802
-        """cloud: (n, 8) float32 host array in PointXYZI layout, or a CUDA float32 tensor (n, 4). Returns (True, pose 4x4)."""
+        """cloud: (n, 8) float32 host array in PointXYZI layout, or a CUDA float32 tensor (n, 4). Returns (True, pose 4x4).
+
+        A device cloud is the caller's again when this returns (lsa_front_end_update_device): a key-frame's raw cloud is kept in a
+        copy the frame filter's first kernel makes, so the local map's update — which runs after this returns — does not read
+        the tensor.  Only without a frame filter is the read stream-ordered instead: then refill the tensor by work on the
+        context's stream (torch.cuda.ExternalStream(ctx.stream)) or synchronise that stream first."""
         out = np.zeros(16, dtype=np.float32)
         st = FrontEndStats()
         if hasattr(cloud, "data_ptr"):
