@@ -132,6 +132,7 @@ int nn_fitness(lsa_context *ctx, NNGrid &g, const float4 *d_src, size_t n, const
 
 int nn_grid_build(lsa_context *ctx, NNGrid &g, const float4 *d_pts, size_t n, float cell, const char *who) {
   VoxelIndex &vi = g.vi;
+  vi.want_cell_idx = true;   // k_count / k_scatter below walk the points by their cell
   g.built = false;
   if (!(cell > 0.05f)) cell = 0.05f;
   const float leaf[3] = {cell, cell, cell};

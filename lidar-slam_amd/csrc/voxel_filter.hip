@@ -562,6 +562,30 @@ extern "C" int lsa_voxel_filter_counters(lsa_voxel_filter *f, uint64_t out[4]) {
   return LSA_OK;
 }
 
+// diagnostics: see lidar_slam_amd.h
+extern "C" int lsa_voxel_filter_stamps(lsa_voxel_filter *f, int enable, uint64_t *out, size_t cap, size_t *per_kernel) {
+  if (!f) return LSA_ERR_INVALID;
+  lsa_context *ctx = f->ctx;
+  LSA_HIP(ctx, lsa_enter(ctx));
+  const size_t n = 2 * kViStampWgs * 8;
+  if (per_kernel) *per_kernel = kViStampWgs * 8;
+  if (!out) {
+    LSA_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (!enable) { f->vi.stamps.release(); return LSA_OK; }
+    int rc = f->vi.stamps.reserve(ctx, n);
+    if (rc) return rc;
+    LSA_HIP(ctx, hipMemsetAsync(f->vi.stamps.p, 0, n * sizeof(unsigned long long), ctx->stream));
+    LSA_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return LSA_OK;
+  }
+  if (!f->vi.stamps.p) return lsa_fail(ctx, LSA_ERR_INVALID, "lsa_voxel_filter_stamps: not enabled");
+  LSA_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  LSA_HIP(ctx, hipMemcpy(out, f->vi.stamps.p, (n < cap ? n : cap) * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+  LSA_HIP(ctx, hipMemsetAsync(f->vi.stamps.p, 0, n * sizeof(unsigned long long), ctx->stream));
+  LSA_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return LSA_OK;
+}
+
 extern "C" int lsa_voxel_filter_pull_timeouts(lsa_voxel_filter *f, uint64_t *out) {
   if (!f || !out) return LSA_ERR_INVALID;
   *out = f->n_pull_timeouts;

@@ -76,14 +76,25 @@ struct PullSource {
   unsigned long long patience_ticks;  // 100 MHz ticks a tile waits for its chunk before it flags the build (spec_miss = 2)
 };
 
+constexpr size_t kViStampWgs = 8192;   // workgroups per kernel the stamp buffer holds
 struct VoxelIndex {
   DevBuf<uint32_t> bits, prefix;
+  // large clouds (>= 512 k points) mark their cells by plain BYTE stores (occ[cell] = 1: idempotent, no read-modify-write, no atomics —
+  // at 2 M points the bitmap's atomic ORs, one per distinct word and tile, all hitting the same few thousand words at the memory
+  // side, held k_mark at 20-29 us for a 32 MB read), and a small kernel packs the bytes of the cell box into the bitmap's words
+  // and clears them again (k_occ_to_bits).  W_cap * 32 bytes, zero between builds; allocated on the first large build.
+  DevBuf<uint8_t> occ;
+  size_t occ_words = 0;   // the bitmap capacity occ[] was allocated and cleared for
   DevBuf<unsigned long long> scan_state;  // decoupled look-back states, one per 2048-word tile
   DevBuf<unsigned> tickets;               // [1] scan tile ticket (self-resetting); [0] spare
   unsigned scan_epoch = 0;
   DevBuf<int32_t> cell_of_rank, cnt, cell_idx;
+  bool want_cell_idx = false;   // the owner reads cell_idx[] (the linear cell of every point, -1 = none) behind the build: nn_grid.hip
   DevBuf<long long> acc;
   DevBuf<float> scratch;  // bbox partials
+  // diagnostics (lsa_voxel_filter_stamps): thread 0 of every workgroup of k_mark ([0 ..)) and k_accum ([kViStampWgs * 8 ..)) notes the
+  // 100 MHz wall clock at its phase boundaries, 8 values per workgroup; null = off (the kernels test the pointer, nothing else)
+  DevBuf<unsigned long long> stamps;
   DevBuf<DevParams> dparams;
   PinnedBuf<DevParams> h_params;
   hipEvent_t ev_done = nullptr;
@@ -109,8 +120,8 @@ struct VoxelIndex {
   CellMap map{};
   FixScales fs{};
   void release() {
-    bits.release(); prefix.release(); scan_state.release(); tickets.release(); cell_of_rank.release(); cnt.release(); cell_idx.release();
-    acc.release(); scratch.release(); dparams.release(); h_params.release();
+    bits.release(); prefix.release(); occ.release(); occ_words = 0; scan_state.release(); tickets.release(); cell_of_rank.release(); cnt.release(); cell_idx.release();
+    acc.release(); scratch.release(); dparams.release(); h_params.release(); stamps.release();
     if (ev_done) { (void)hipEventDestroy(ev_done); ev_done = nullptr; }
     W_cap = 0; acc_rows = 0; clean = false;
   }

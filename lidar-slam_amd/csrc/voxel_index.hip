@@ -221,6 +221,56 @@ __device__ __forceinline__ int lds_insert(int *keys, int cell) {
   return -1;
 }
 
+// diagnostics (lsa_voxel_filter_stamps): thread 0 of a workgroup notes the 100 MHz wall clock at a phase boundary
+__device__ __forceinline__ void vi_stamp(unsigned long long *stamps, int k) {
+  if (stamps && threadIdx.x == 0 && blockIdx.x < kViStampWgs) stamps[(size_t)blockIdx.x * 8 + k] = wall_clock64();
+}
+
+// Which point a lane holds in its k-th register: wave w of a tile takes the tile's 64-point groups w * PER .. w * PER + PER - 1, its
+// lane l the l-th point of each — every load instruction still reads 64 consecutive points (1 KB), and a lane's PER points are 64
+// apart in the cloud.  A spinning lidar delivers its beams azimuth step by azimuth step, so points 64 (or 128) apart are neighbours
+// on one ring: at 2 M points / 0.3 m a lane's eight points fall into 3.0 runs of equal cells on average (4.8 with the lanes 256
+// apart, 5.1 for eight consecutive points), at 1.0 m into 2.0 — and a run costs the LDS one set of adds, not one per point
+// (vi_stamps: the adds of eight points per lane were 10-12 us of a workgroup's 22, the LDS array busy throughout).  Any other
+// order of the cloud only merges less; nothing but speed depends on it.
+template <int PER>
+__device__ __forceinline__ size_t vi_point_index(size_t base, int k) {
+  return base + (size_t)(((threadIdx.x >> 6) * PER + k) << 6) + (threadIdx.x & 63);
+}
+
+// The same for B cells of one lane at once: the B key reads are issued together, then the B compare-and-swaps of the lanes that met an
+// empty slot, then the next probe step for whoever is still unplaced — a lane's cells walk their probe sequences side by side instead of one
+// after the other.  (Phase stamps of the 2 M-point build, `profiles/r05_vi_stamps_before.log`: eight dependent insert + add chains per lane
+// took 10.5 us of a workgroup's 22 in k_accum and 5.4 of 13 in k_mark, whether 768 workgroups were resident or 209: latency, not
+// throughput.)  cell < 0: nothing to place.  A lane's own duplicates resolve like anybody else's: LDS operations of a wave execute in order,
+// the second compare-and-swap finds the first one's key.  Which slot a cell lands in may differ from the one-by-one walk; nothing depends on it.
+template <int CAP, int B>
+__device__ __forceinline__ void lds_insert_batch(int *keys, const int (&cell)[B], int (&slot)[B]) {
+  unsigned h[B];
+  unsigned pending = 0;
+#pragma unroll
+  for (int k = 0; k < B; k++) {
+    h[k] = lds_hash(cell[k]) & (CAP - 1);
+    slot[k] = -1;
+    if (cell[k] >= 0) pending |= 1u << k;
+  }
+  for (int probe = 0; probe < kMaxProbes; probe++) {
+    if (!__any(pending != 0)) break;
+    int old[B];
+#pragma unroll
+    for (int k = 0; k < B; k++) old[k] = (pending >> k) & 1u ? keys[h[k]] : 0;
+#pragma unroll
+    for (int k = 0; k < B; k++)
+      if (((pending >> k) & 1u) && old[k] == -1) old[k] = atomicCAS(&keys[h[k]], -1, cell[k]);
+#pragma unroll
+    for (int k = 0; k < B; k++) {
+      if (!((pending >> k) & 1u)) continue;
+      if (old[k] == -1 || old[k] == cell[k]) { slot[k] = (int)h[k]; pending &= ~(1u << k); }
+      else h[k] = (h[k] + 1) & (CAP - 1);
+    }
+  }
+}
+
 // PULL (host clouds, lsa_voxel_filter_apply): the rows are not resident yet when this kernel starts.  The host packs them into
 // device-visible pinned memory chunk by chunk and sets ready[chunk] = seq behind each; a tile waits for its chunk, reads its rows
 // over the link itself (no copy command: four 0.5 MB copies cost 73 us on one queue against 44 us for the bytes), leaves them in
@@ -228,8 +278,10 @@ __device__ __forceinline__ int lds_insert(int *keys, int cell) {
 // Only with a known grid definition (kp.valid: the speculative box of the previous scan), so nothing has to see all rows first.
 template <int TILE, bool PULL>
 __global__ __launch_bounds__(kBlock) void k_mark(const float4 *__restrict__ pts, size_t n, DevParams *__restrict__ dp, KnownParams kp,
-                                                 uint32_t *__restrict__ bits, int32_t *__restrict__ cell_idx, PullSource pull) {
+                                                 uint32_t *__restrict__ bits, int32_t *__restrict__ cell_idx, PullSource pull,
+                                                 unsigned long long *__restrict__ stamps) {
   constexpr int kTile = TILE, kHashCap = TILE / 2;
+  vi_stamp(stamps, 0);
   if (!kp.valid && dp->status != VI_OK) {
     // KEEP (a device cloud the caller wants a copy of, pull.d_copy without pull.h_rows): the copy does not depend on the grid
     // definition — a build that ends in a range or an empty report still leaves it complete
@@ -264,12 +316,13 @@ __global__ __launch_bounds__(kBlock) void k_mark(const float4 *__restrict__ pts,
   __shared__ uint32_t vals[kHashCap];
   for (int k = threadIdx.x; k < kHashCap; k += kBlock) { keys[k] = -1; vals[k] = 0u; }
   __syncthreads();
+  vi_stamp(stamps, 1);
   size_t base = (size_t)blockIdx.x * kTile;
   if (PULL) {
     if (!pull_ok) {   // the host never delivered (it is gone, or held up for seconds): flag the build, touch nothing else
       for (int k = 0; k < kTile / kBlock; k++) {
         size_t i = base + (size_t)k * kBlock + threadIdx.x;
-        if (i < n) cell_idx[i] = -1;
+        if (i < n && cell_idx) cell_idx[i] = -1;
       }
       if (threadIdx.x == 0) atomicMax(&dp->spec_miss, 2);
       return;
@@ -277,40 +330,60 @@ __global__ __launch_bounds__(kBlock) void k_mark(const float4 *__restrict__ pts,
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");   // (every wave: its loads of the rows come behind the flag thread 0 saw)
   }
   // all 8 loads of a lane are issued before the first use: one HBM latency per tile instead of eight
-  float4 pv[kTile / kBlock];
+  constexpr int kPer = kTile / kBlock;
+  float4 pv[kPer];
 #pragma unroll
-  for (int k = 0; k < kTile / kBlock; k++) {
-    size_t i = base + (size_t)k * kBlock + threadIdx.x;
+  for (int k = 0; k < kPer; k++) {
+    size_t i = vi_point_index<kPer>(base, k);
     pv[k] = (i < n) ? (PULL ? pull.h_rows[i] : pts[i]) : make_float4(NAN, NAN, NAN, 0.f);
   }
   if (PULL || pull.d_copy) {   // (KEEP: wave-uniform; the rows are in registers anyway, the stores are not waited for)
 #pragma unroll
-    for (int k = 0; k < kTile / kBlock; k++) {
-      size_t i = base + (size_t)k * kBlock + threadIdx.x;
+    for (int k = 0; k < kPer; k++) {
+      size_t i = vi_point_index<kPer>(base, k);
       if (i < n) pull.d_copy[i] = pv[k];
     }
   }
+  // a lane's points run by run (equal bitmap words in a row): a run's bits are OR-ed in a register and reach the table once.  A
+  // finished run is noted at the point that ends it (the first of the next run), the last one in an extra entry: every index static.
+  int word[kPer + 1];
+  uint32_t rbits[kPer + 1];
+  {
+    int cw = -1;
+    uint32_t cb = 0u;
 #pragma unroll
-  for (int k = 0; k < kTile / kBlock; k++) {
-    size_t i = base + (size_t)k * kBlock + threadIdx.x;
-    if (i >= n) break;
-    float4 p = pv[k];
-    int cell = -1;
-    if (lsa_finite3(p.x, p.y, p.z)) {
-      int ijk[3];
-      lsa_cell_ijk(m, p.x, p.y, p.z, ijk);
-      cell = lsa_cell_linear(m, ijk);
-      if (cell < 0) atomicMax(&dp->spec_miss, 1);  // only possible when the grid definition was reused from an earlier build (rare; never hides a 2)
-    }
-    cell_idx[i] = cell;
-    if (cell >= 0) {
+    for (int k = 0; k < kPer; k++) {
+      size_t i = vi_point_index<kPer>(base, k);
+      word[k] = -1; rbits[k] = 0u;
+      if (i >= n) continue;
+      float4 p = pv[k];
+      int cell = -1;
+      if (lsa_finite3(p.x, p.y, p.z)) {
+        int ijk[3];
+        lsa_cell_ijk(m, p.x, p.y, p.z, ijk);
+        cell = lsa_cell_linear(m, ijk);
+        if (cell < 0) atomicMax(&dp->spec_miss, 1);  // only possible when the grid definition was reused from an earlier build (rare; never hides a 2)
+      }
+      if (cell_idx) cell_idx[i] = cell;   // (only for an owner that asked for it: VoxelIndex::want_cell_idx)
+      if (cell < 0) continue;
+      const int w = cell >> 5;
       const uint32_t bit = 1u << (cell & 31);
-      int slot = lds_insert<kHashCap>(keys, cell >> 5);
-      if (slot < 0) atomicOr(bits + (cell >> 5), bit);
-      else if (!(vals[slot] & bit)) atomicOr(&vals[slot], bit);  // racy read: at worst a redundant LDS atomic
+      if (w == cw) cb |= bit;
+      else { word[k] = cw; rbits[k] = cb; cw = w; cb = bit; }
     }
+    word[kPer] = cw; rbits[kPer] = cb;
   }
+  int slot[kPer + 1];
+  lds_insert_batch<kHashCap, kPer + 1>(keys, word, slot);
+#pragma unroll
+  for (int k = 0; k <= kPer; k++) {
+    if (word[k] < 0) continue;
+    if (slot[k] < 0) atomicOr(bits + word[k], rbits[k]);
+    else if ((vals[slot[k]] & rbits[k]) != rbits[k]) atomicOr(&vals[slot[k]], rbits[k]);  // racy read: at worst a redundant LDS atomic
+  }
+  vi_stamp(stamps, 2);
   __syncthreads();
+  vi_stamp(stamps, 3);
   // one fire-and-forget atomic per distinct word of the tile.  No read-before-write: a plain load may be served from a
   // stale L2 line, and a device-scope load of words that hundreds of tiles hit at once was measured slower than the
   // atomics it saves (k_mark at 2 M points: 29 us without, 59 us with)
@@ -318,6 +391,86 @@ __global__ __launch_bounds__(kBlock) void k_mark(const float4 *__restrict__ pts,
   for (int k = 0; k < kHashCap / kBlock; k++) {
     int word = keys[k * kBlock + threadIdx.x];
     if (word >= 0) atomicOr(bits + word, vals[k * kBlock + threadIdx.x]);
+  }
+  vi_stamp(stamps, 4);
+  if (stamps) { __builtin_amdgcn_s_waitcnt(0); vi_stamp(stamps, 5); }   // (diagnostics only: until the flush has been acknowledged)
+}
+
+// ---- large clouds: cells marked by plain byte stores, packed into the bitmap afterwards (VoxelIndex::occ) -----------------------
+// A streaming kernel: no LDS table, no barrier, no flush.  A lane's PER points are 64 apart in the cloud (vi_point_index): runs of
+// equal cells among them are stored once.
+template <int PER>
+__global__ __launch_bounds__(kBlock) void k_mark_bytes(const float4 *__restrict__ pts, size_t n, DevParams *__restrict__ dp, KnownParams kp,
+                                                       uint8_t *__restrict__ occ, int32_t *__restrict__ cell_idx, float4 *__restrict__ d_keep,
+                                                       unsigned long long *__restrict__ stamps) {
+  vi_stamp(stamps, 0);
+  const size_t base = (size_t)blockIdx.x * (kBlock * PER);
+  if (!kp.valid && dp->status != VI_OK) {
+    if (d_keep) {   // (see k_mark: the caller's copy does not depend on the grid definition)
+      for (int k = 0; k < PER; k++) {
+        size_t i = vi_point_index<PER>(base, k);
+        if (i < n) d_keep[i] = pts[i];
+      }
+    }
+    return;
+  }
+  const CellMap m = kp.valid ? kp.map : dp->map;
+  float4 pv[PER];
+#pragma unroll
+  for (int k = 0; k < PER; k++) {
+    size_t i = vi_point_index<PER>(base, k);
+    pv[k] = (i < n) ? pts[i] : make_float4(NAN, NAN, NAN, 0.f);
+  }
+  if (d_keep) {
+#pragma unroll
+    for (int k = 0; k < PER; k++) {
+      size_t i = vi_point_index<PER>(base, k);
+      if (i < n) d_keep[i] = pv[k];
+    }
+  }
+  vi_stamp(stamps, 1);
+  int run = -1;
+#pragma unroll
+  for (int k = 0; k < PER; k++) {
+    size_t i = vi_point_index<PER>(base, k);
+    if (i >= n) continue;
+    const float4 p = pv[k];
+    int cell = -1;
+    if (lsa_finite3(p.x, p.y, p.z)) {
+      int ijk[3];
+      lsa_cell_ijk(m, p.x, p.y, p.z, ijk);
+      cell = lsa_cell_linear(m, ijk);
+      if (cell < 0) atomicMax(&dp->spec_miss, 1);  // only possible when the grid definition was reused from an earlier build
+    }
+    if (cell_idx) cell_idx[i] = cell;
+    if (cell >= 0 && cell != run) { occ[cell] = (uint8_t)1; run = cell; }
+  }
+  vi_stamp(stamps, 2);
+  if (stamps) {   // (diagnostics only: the remaining phase slots of k_mark's record, and when the stores have been acknowledged)
+    vi_stamp(stamps, 3); vi_stamp(stamps, 4);
+    __builtin_amdgcn_s_waitcnt(0);
+    vi_stamp(stamps, 5);
+  }
+}
+
+// one lane per bitmap word: its 32 cells' bytes -> bits, and the bytes cleared for the next build.  Every word of the build's box is
+// written (zero where nothing was marked); the grid covers the bitmap's capacity, the box's word count is only known on the device.
+__device__ __forceinline__ uint32_t occ_nibble(uint32_t x) {   // bytes b0..b3 (0 / 1) -> b0 | b1 << 1 | b2 << 2 | b3 << 3
+  x &= 0x01010101u;
+  return (x | (x >> 7) | (x >> 14) | (x >> 21)) & 0xfu;
+}
+__global__ __launch_bounds__(kBlock) void k_occ_to_bits(uint4 *__restrict__ occ16, const DevParams *__restrict__ dp, KnownParams kp, uint32_t *__restrict__ bits) {
+  if (!kp.valid && dp->status != VI_OK) return;   // (nothing was marked)
+  const size_t W = kp.valid ? (size_t)kp.W : (size_t)dp->W;
+  const size_t w = (size_t)blockIdx.x * kBlock + threadIdx.x;
+  if (w >= W) return;
+  const uint4 a = occ16[2 * w], b = occ16[2 * w + 1];
+  const uint32_t word = occ_nibble(a.x) | (occ_nibble(a.y) << 4) | (occ_nibble(a.z) << 8) | (occ_nibble(a.w) << 12) | (occ_nibble(b.x) << 16) |
+                        (occ_nibble(b.y) << 20) | (occ_nibble(b.z) << 24) | (occ_nibble(b.w) << 28);
+  bits[w] = word;
+  if (word) {
+    occ16[2 * w] = make_uint4(0u, 0u, 0u, 0u);
+    occ16[2 * w + 1] = make_uint4(0u, 0u, 0u, 0u);
   }
 }
 
@@ -501,34 +654,32 @@ __global__ __launch_bounds__(kBlock) void k_scan(const uint32_t *__restrict__ bi
   }
 }
 
-template <int NS>
-__device__ __forceinline__ void point_terms(const CellMap &m, const FixScales &fs, int cell, const float4 &p, unsigned long long v[NS]) {
-  double o[3];
-  lsa_cell_origin(m, cell, o);
-  vi_point_terms<NS>(o, fs, p, v);
-}
-
 __device__ __forceinline__ unsigned cell_rank(const uint32_t *__restrict__ bits, const uint32_t *__restrict__ prefix, int cell) {
   return prefix[cell >> 5] + __popc(bits[cell >> 5] & ((1u << (cell & 31)) - 1u));
 }
 
 // per-cell fixed-point sums: LDS pre-aggregation per tile, then one set of global atomics per distinct cell
 template <int NS, int TILE>
-__global__ __launch_bounds__(kBlock) void k_accum(const float4 *__restrict__ pts, const int32_t *__restrict__ cell_idx, size_t n,
+__global__ __launch_bounds__(kBlock) void k_accum(const float4 *__restrict__ pts, size_t n,
                                                   const DevParams *__restrict__ dp, KnownParams kp, const uint32_t *__restrict__ bits,
-                                                  const uint32_t *__restrict__ prefix, long long *__restrict__ acc, int32_t *__restrict__ cnt) {
+                                                  const uint32_t *__restrict__ prefix, long long *__restrict__ acc, int32_t *__restrict__ cnt,
+                                                  unsigned long long *__restrict__ stamps) {
+  vi_stamp(stamps, 0);
   // table slots: TILE / 2, but TILE / 4 for the 10-sum rows (80 B each): 46 KB instead of 92 KB of LDS lets three
-  // workgroups share a CU instead of one; a tile with more distinct cells than slots overflows to direct atomics
-  constexpr int kTile = TILE, kHashCap = (NS > 4 && TILE >= 1024) ? TILE / 4 : TILE / 2;
+  // workgroups share a CU instead of one; a tile with more distinct cells than slots overflows to direct atomics.
+  // NS = 4, TILE = 2048: keys + counts + sums = 4 + 4 + 32 KB = exactly a quarter of the CU's 160 KB, so the 977 tiles of a 2 M-point
+  // cloud are all resident at once (with a fourth array they came to 44 KB: 768 resident, and the 209 left over ran a second round
+  // of their own — 14 of the kernel's 44 us).
+  constexpr int kTile = TILE, kPer = TILE / kBlock, kHashCap = (NS > 4 && TILE >= 1024) ? TILE / 4 : TILE / 2;
   if (!kp.valid && dp->status != VI_OK) return;
+  // a build k_mark has flagged (a point outside the reused cell box; rows of a host cloud that never arrived and were not copied)
+  // is thrown away by the host: nothing to sum — and, for the second kind, nothing to be trusted in the rows
+  if (dp->spec_miss) return;
   const CellMap m = kp.valid ? kp.map : dp->map;
   const FixScales fs = kp.valid ? kp.fs : dp->fs;
   __shared__ int keys[kHashCap];
   __shared__ int counts[kHashCap];
   __shared__ unsigned long long sums[kHashCap][NS];
-  __shared__ unsigned ranks[kHashCap];
-  __shared__ int n_used;
-  if (threadIdx.x == 0) n_used = 0;
   for (int k = threadIdx.x; k < kHashCap; k += kBlock) {
     keys[k] = -1;
     counts[k] = 0;
@@ -536,38 +687,89 @@ __global__ __launch_bounds__(kBlock) void k_accum(const float4 *__restrict__ pts
     for (int j = 0; j < NS; j++) sums[k][j] = 0ull;
   }
   __syncthreads();
+  vi_stamp(stamps, 1);
   size_t base = (size_t)blockIdx.x * kTile;
-  float4 pv[kTile / kBlock];
-  int cv[kTile / kBlock];
+  float4 pv[kPer];
+  int cv[kPer];
 #pragma unroll
-  for (int k = 0; k < kTile / kBlock; k++) {  // issue every load of the lane up front
-    size_t i = base + (size_t)k * kBlock + threadIdx.x;
-    cv[k] = (i < n) ? cell_idx[i] : -1;
-    pv[k] = (i < n) ? pts[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int k = 0; k < kPer; k++) {  // issue every load of the lane up front
+    size_t i = vi_point_index<kPer>(base, k);
+    pv[k] = (i < n) ? pts[i] : make_float4(NAN, NAN, NAN, 0.f);
   }
+  // a point's cell by the very expressions k_mark marked it with (the per-point cell index k_mark used to leave in memory was an
+  // 8 MB store, an 8 MB load and a kernel-end write-back at 2 M points, for ~20 instructions per point)
 #pragma unroll
-  for (int k = 0; k < kTile / kBlock; k++) {
-    int cell = cv[k];
-    if (cell < 0) continue;
-    float4 p = pv[k];
-    unsigned long long v[NS];
-    point_terms<NS>(m, fs, cell, p, v);
-    int slot = lds_insert<kHashCap>(keys, cell);
-    if (slot >= 0) {
+  for (int k = 0; k < kPer; k++) {
+    cv[k] = -1;
+    if (lsa_finite3(pv[k].x, pv[k].y, pv[k].z)) {
+      int ijk[3];
+      lsa_cell_ijk(m, pv[k].x, pv[k].y, pv[k].z, ijk);
+      cv[k] = lsa_cell_linear(m, ijk);
+    }
+  }
+  // the first cell of every run of equal cells among the lane's points finds its slot (one probe chain for all of them) ...
+  int hc[kPer];
+  {
+    int prev = -1;
 #pragma unroll
-      for (int j = 0; j < NS; j++) atomicAdd(&sums[slot][j], v[j]);
-      atomicAdd(&counts[slot], 1);
+    for (int k = 0; k < kPer; k++) {
+      hc[k] = (cv[k] >= 0 && cv[k] != prev) ? cv[k] : -1;
+      if (cv[k] >= 0) prev = cv[k];
+    }
+  }
+  int slot[kPer];
+  lds_insert_batch<kHashCap, kPer>(keys, hc, slot);
+  // ... then point after point: the terms (vector arithmetic only) are summed in registers while the run lasts; a finished run's
+  // sums go to its slot by adds that return nothing and are not waited for
+  auto emit = [&](int sl, int cell, const unsigned long long (&rs)[NS], int rn) {
+    if (sl >= 0) {
+#pragma unroll
+      for (int j = 0; j < NS; j++) atomicAdd(&sums[sl][j], rs[j]);
+      atomicAdd(&counts[sl], rn);
     } else {  // table full: straight to memory
       unsigned rank = cell_rank(bits, prefix, cell);
       unsigned long long *a = (unsigned long long *)(acc + (size_t)rank * NS);
 #pragma unroll
-      for (int j = 0; j < NS; j++) atomicAdd(a + j, v[j]);
-      atomicAdd(cnt + rank, 1);
+      for (int j = 0; j < NS; j++) atomicAdd(a + j, rs[j]);
+      atomicAdd(cnt + rank, rn);
+    }
+  };
+  bool open = false;
+  int oslot = -1, ocell = -1, on = 0;
+  unsigned long long os[NS];
+#pragma unroll
+  for (int j = 0; j < NS; j++) os[j] = 0ull;
+#pragma unroll
+  for (int k = 0; k < kPer; k++) {
+    const int cell = cv[k];
+    if (cell < 0) continue;
+    const float4 p = pv[k];
+    // the cell's low corner from the point itself (the very expression k_mark took the cell from) instead of unravelling the linear
+    // index: two integer divisions, ~80 instructions, a quarter of this kernel's vector instructions at 2 M points
+    int ijk[3];
+    lsa_cell_ijk(m, p.x, p.y, p.z, ijk);
+    const int abs_ijk[3] = {ijk[0] + m.min_b[0], ijk[1] + m.min_b[1], ijk[2] + m.min_b[2]};
+    double o[3];
+    lsa_abs_origin(abs_ijk, m.leaf, o);
+    unsigned long long v[NS];
+    vi_point_terms<NS>(o, fs, p, v);
+    if (hc[k] >= 0) {   // a new run starts here
+      if (open) emit(oslot, ocell, os, on);
+      open = true; oslot = slot[k]; ocell = cell; on = 1;
+#pragma unroll
+      for (int j = 0; j < NS; j++) os[j] = v[j];
+    } else {
+      on++;
+#pragma unroll
+      for (int j = 0; j < NS; j++) os[j] += v[j];
     }
   }
+  if (open) emit(oslot, ocell, os, on);
+  vi_stamp(stamps, 2);
   __syncthreads();
-  // flush, step 1: the 4 slots of a lane are independent; their rank look-ups are issued together.  Used slots are
-  // compacted into used[] (slot | rank), in any order: the sums are integers, the result does not depend on it.
+  vi_stamp(stamps, 3);
+  // flush, step 1: a lane's slots are independent, their rank look-ups are issued together; the rank replaces the cell in keys[]
+  // (each slot is read and rewritten by its one lane; -1 stays -1)
   int fcell[kHashCap / kBlock];
   uint32_t fw[kHashCap / kBlock], fp[kHashCap / kBlock];
 #pragma unroll
@@ -577,26 +779,34 @@ __global__ __launch_bounds__(kBlock) void k_accum(const float4 *__restrict__ pts
     fw[k] = bits[c >> 5];
     fp[k] = prefix[c >> 5];
   }
-  __syncthreads();  // every lane has read its keys: the array is reused for the compacted list
 #pragma unroll
-  for (int k = 0; k < kHashCap / kBlock; k++) {
-    if (fcell[k] < 0) continue;
-    unsigned rank = fp[k] + __popc(fw[k] & ((1u << (fcell[k] & 31)) - 1u));
-    int u = atomicAdd(&n_used, 1);
-    keys[u] = k * kBlock + threadIdx.x;
-    ranks[u] = rank;
-  }
+  for (int k = 0; k < kHashCap / kBlock; k++)
+    if (fcell[k] >= 0) keys[k * kBlock + threadIdx.x] = (int)(fp[k] + __popc(fw[k] & ((1u << (fcell[k] & 31)) - 1u)));
   __syncthreads();
-  // step 2: one lane per (cell, term): the NS atomics of a cell leave from adjacent lanes and land in one or two 64-byte
-  // lines of acc[], instead of NS instructions whose 64 lanes each touch a different line
-  const int total = n_used * (NS + 1);
-  for (int e = threadIdx.x; e < total; e += kBlock) {
-    int u = e / (NS + 1), j = e - u * (NS + 1);
-    int slot = keys[u];
-    unsigned rank = ranks[u];
-    if (j < NS) atomicAdd((unsigned long long *)(acc + (size_t)rank * NS) + j, sums[slot][j]);
-    else atomicAdd(cnt + rank, counts[slot]);
+  vi_stamp(stamps, 4);
+  // step 2: one lane per (slot, term): the NS atomics of a cell leave from adjacent lanes and land in one or two 64-byte
+  // lines of acc[], instead of NS instructions whose 64 lanes each touch a different line.  Every slot is visited (a quarter of them
+  // is in use: the walk is 5 reads per lane more than over a compacted list, and the list's array is what the fourth resident
+  // workgroup needed)
+  constexpr int kFlush = kHashCap * (NS + 1);
+  for (int e0 = 0; e0 < kFlush; e0 += 4 * kBlock) {
+    int rk[4];
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+      const int e = e0 + q * kBlock + (int)threadIdx.x;
+      rk[q] = e < kFlush ? keys[e / (NS + 1)] : -1;
+    }
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+      const int e = e0 + q * kBlock + (int)threadIdx.x;
+      if (rk[q] < 0) continue;
+      const int sl = e / (NS + 1), j = e - sl * (NS + 1);
+      if (j < NS) atomicAdd((unsigned long long *)(acc + (size_t)(unsigned)rk[q] * NS) + j, sums[sl][j]);
+      else atomicAdd(cnt + (unsigned)rk[q], counts[sl]);
+    }
   }
+  vi_stamp(stamps, 5);
+  if (stamps) { __builtin_amdgcn_s_waitcnt(0); vi_stamp(stamps, 6); }   // (diagnostics only: until the flush has been acknowledged)
 }
 
 // zero what this build touched: the bitmap words of the occupied cells and the V rows of sums / counts
@@ -631,7 +841,7 @@ int vi_prepare(lsa_context *ctx, VoxelIndex &vi, size_t n, int ns, size_t w_min)
   if (!vi.ev_done) LSA_HIP(ctx, hipEventCreateWithFlags(&vi.ev_done, hipEventDisableTiming | hipEventReleaseToSystem));
   // buffers sized by the point count (#occupied <= #points)
   size_t old_cor = vi.cell_of_rank.cap, old_cnt = vi.cnt.cap, old_acc = vi.acc.cap;
-  if ((rc = vi.cell_idx.reserve(ctx, n, 1.25))) return rc;
+  if (vi.want_cell_idx && (rc = vi.cell_idx.reserve(ctx, n, 1.25))) return rc;
   if ((rc = vi.cell_of_rank.reserve(ctx, n, 1.25))) return rc;
   if ((rc = vi.cnt.reserve(ctx, n + 1, 1.25))) return rc;
   if ((rc = vi.acc.reserve(ctx, (n + 1) * (size_t)ns, 1.25))) return rc;
@@ -715,14 +925,26 @@ int vi_enqueue(lsa_context *ctx, VoxelIndex &vi, const float4 *d_pts, size_t n, 
   no_pull.d_copy = d_keep;   // (a pulled build leaves the rows in pull->d_copy already)
   if (pull) {
     if (!spec) return lsa_fail(ctx, LSA_ERR_INVALID, "vi_enqueue: rows can only be pulled into a known grid definition (vi_spec_ready)");
-    hipLaunchKernelGGL((k_mark<kTilePull, true>), dim3(lsa_div_up(n, kTilePull)), dim3(kBlock), 0, ctx->stream, d_pts, n, dp, kp, vi.bits.p, vi.cell_idx.p, *pull);
-  } else if (small) hipLaunchKernelGGL((k_mark<kTileSmall, false>), dim3(lsa_div_up(n, kTileSmall)), dim3(kBlock), 0, ctx->stream, d_pts, n, dp, kp, vi.bits.p, vi.cell_idx.p, no_pull);
-  else hipLaunchKernelGGL((k_mark<kTileBig, false>), dim3(lsa_div_up(n, kTileBig)), dim3(kBlock), 0, ctx->stream, d_pts, n, dp, kp, vi.bits.p, vi.cell_idx.p, no_pull);
+    hipLaunchKernelGGL((k_mark<kTilePull, true>), dim3(lsa_div_up(n, kTilePull)), dim3(kBlock), 0, ctx->stream, d_pts, n, dp, kp, vi.bits.p, vi.cell_idx.p, *pull, vi.stamps.p);
+  } else if (small) hipLaunchKernelGGL((k_mark<kTileSmall, false>), dim3(lsa_div_up(n, kTileSmall)), dim3(kBlock), 0, ctx->stream, d_pts, n, dp, kp, vi.bits.p, vi.cell_idx.p, no_pull, vi.stamps.p);
+  else {
+    // large clouds: byte marks, then the bytes of the box packed into the bitmap (see VoxelIndex::occ)
+    if (vi.occ_words != vi.W_cap) {
+      if (vi.occ.p) LSA_HIP(ctx, hipStreamSynchronize(ctx->stream));   // (the reserve frees the old map)
+      vi.occ.release();
+      if ((rc = vi.occ.reserve(ctx, vi.W_cap * 32))) return rc;
+      LSA_HIP(ctx, hipMemsetAsync(vi.occ.p, 0, vi.W_cap * 32, ctx->stream));
+      vi.occ_words = vi.W_cap;
+    }
+    hipLaunchKernelGGL((k_mark_bytes<kTileBig / kBlock>), dim3(lsa_div_up(n, kTileBig)), dim3(kBlock), 0, ctx->stream, d_pts, n, dp, kp, vi.occ.p, vi.cell_idx.p, d_keep,
+                       vi.stamps.p);
+    hipLaunchKernelGGL(k_occ_to_bits, dim3(lsa_div_up(vi.W_cap, kBlock)), dim3(kBlock), 0, ctx->stream, reinterpret_cast<uint4 *>(vi.occ.p), dp, kp, vi.bits.p);
+  }
   hipLaunchKernelGGL(k_scan, dim3(nsb_cap), dim3(kBlock), 0, ctx->stream, vi.bits.p, vi.dparams.p, kp, vi.scan_state.p, vi.tickets.p + 1, vi.scan_epoch,
                      vi.prefix.p, vi.cell_of_rank.p, vi.mirror_at_scan ? vi.h_params.p : (DevParams *)nullptr);
   if (vi.mirror_at_scan) LSA_HIP(ctx, hipEventRecord(vi.ev_done, ctx->stream));   // vi_wait() returns behind the scan; the accumulation is still running then
   unsigned g = lsa_div_up(n, small ? kTileSmall : kTileBig);
-#define LSA_LAUNCH_ACCUM(NS_, TILE_) hipLaunchKernelGGL((k_accum<NS_, TILE_>), dim3(g), dim3(kBlock), 0, ctx->stream, d_pts, vi.cell_idx.p, n, dp, kp, vi.bits.p, vi.prefix.p, vi.acc.p, vi.cnt.p)
+#define LSA_LAUNCH_ACCUM(NS_, TILE_) hipLaunchKernelGGL((k_accum<NS_, TILE_>), dim3(g), dim3(kBlock), 0, ctx->stream, d_pts, n, dp, kp, vi.bits.p, vi.prefix.p, vi.acc.p, vi.cnt.p, vi.stamps.p ? vi.stamps.p + kViStampWgs * 8 : nullptr)
   if (ns == 4) { if (small) LSA_LAUNCH_ACCUM(4, kTileSmall); else LSA_LAUNCH_ACCUM(4, kTileBig); }
   else { if (small) LSA_LAUNCH_ACCUM(10, kTileSmall); else LSA_LAUNCH_ACCUM(10, kTileBig); }
 #undef LSA_LAUNCH_ACCUM
