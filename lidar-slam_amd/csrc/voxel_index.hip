@@ -233,8 +233,12 @@ __device__ __forceinline__ void vi_stamp(unsigned long long *stamps, int k) {
 // apart, 5.1 for eight consecutive points), at 1.0 m into 2.0 — and a run costs the LDS one set of adds, not one per point
 // (vi_stamps: the adds of eight points per lane were 10-12 us of a workgroup's 22, the LDS array busy throughout).  Any other
 // order of the cloud only merges less; nothing but speed depends on it.
-template <int PER>
+template <int PER, bool LINEAR = false>
 __device__ __forceinline__ size_t vi_point_index(size_t base, int k) {
+  // LINEAR: the workgroup's k-th 256 points.  The kernel that pulls its rows over the link keeps this order: with the wave-group order
+  // the same bytes took 66 instead of 57 us to arrive (131 k rows; `profiles/r05_voxel_index_ab.log`) — a load step of the whole
+  // workgroup then asks for four separate 1 KB pieces instead of one 4 KB piece
+  if (LINEAR) return base + (size_t)k * kBlock + threadIdx.x;
   return base + (size_t)(((threadIdx.x >> 6) * PER + k) << 6) + (threadIdx.x & 63);
 }
 
@@ -334,13 +338,13 @@ __global__ __launch_bounds__(kBlock) void k_mark(const float4 *__restrict__ pts,
   float4 pv[kPer];
 #pragma unroll
   for (int k = 0; k < kPer; k++) {
-    size_t i = vi_point_index<kPer>(base, k);
+    size_t i = vi_point_index<kPer, PULL>(base, k);
     pv[k] = (i < n) ? (PULL ? pull.h_rows[i] : pts[i]) : make_float4(NAN, NAN, NAN, 0.f);
   }
   if (PULL || pull.d_copy) {   // (KEEP: wave-uniform; the rows are in registers anyway, the stores are not waited for)
 #pragma unroll
     for (int k = 0; k < kPer; k++) {
-      size_t i = vi_point_index<kPer>(base, k);
+      size_t i = vi_point_index<kPer, PULL>(base, k);
       if (i < n) pull.d_copy[i] = pv[k];
     }
   }
@@ -353,7 +357,7 @@ __global__ __launch_bounds__(kBlock) void k_mark(const float4 *__restrict__ pts,
     uint32_t cb = 0u;
 #pragma unroll
     for (int k = 0; k < kPer; k++) {
-      size_t i = vi_point_index<kPer>(base, k);
+      size_t i = vi_point_index<kPer, PULL>(base, k);
       word[k] = -1; rbits[k] = 0u;
       if (i >= n) continue;
       float4 p = pv[k];
@@ -374,7 +378,14 @@ __global__ __launch_bounds__(kBlock) void k_mark(const float4 *__restrict__ pts,
     word[kPer] = cw; rbits[kPer] = cb;
   }
   int slot[kPer + 1];
-  lds_insert_batch<kHashCap, kPer + 1>(keys, word, slot);
+  if constexpr (kPer > 2) {
+    lds_insert_batch<kHashCap, kPer + 1>(keys, word, slot);
+  } else {
+    // (two points per lane — a lidar scan cut into 512-point tiles: nothing to walk side by side, and the batch's wave-wide exit test
+    // is a dependent step more in a kernel that is one latency chain: 5.96 -> 6.59 us with it at 131 k points)
+#pragma unroll
+    for (int k = 0; k <= kPer; k++) slot[k] = word[k] >= 0 ? lds_insert<kHashCap>(keys, word[k]) : -1;
+  }
 #pragma unroll
   for (int k = 0; k <= kPer; k++) {
     if (word[k] < 0) continue;
@@ -718,10 +729,17 @@ __global__ __launch_bounds__(kBlock) void k_accum(const float4 *__restrict__ pts
     }
   }
   int slot[kPer];
-  lds_insert_batch<kHashCap, kPer>(keys, hc, slot);
+  if constexpr (kPer > 2) {
+    lds_insert_batch<kHashCap, kPer>(keys, hc, slot);
+  } else {
+#pragma unroll
+    for (int k = 0; k < kPer; k++) slot[k] = hc[k] >= 0 ? lds_insert<kHashCap>(keys, hc[k]) : -1;
+  }
   // ... then point after point: the terms (vector arithmetic only) are summed in registers while the run lasts; a finished run's
   // sums go to its slot by adds that return nothing and are not waited for
+  int n_direct = 0;   // (diagnostics: runs of this lane that found no slot)
   auto emit = [&](int sl, int cell, const unsigned long long (&rs)[NS], int rn) {
+    if (sl < 0) n_direct++;
     if (sl >= 0) {
 #pragma unroll
       for (int j = 0; j < NS; j++) atomicAdd(&sums[sl][j], rs[j]);
@@ -755,6 +773,11 @@ __global__ __launch_bounds__(kBlock) void k_accum(const float4 *__restrict__ pts
     vi_point_terms<NS>(o, fs, p, v);
     if (hc[k] >= 0) {   // a new run starts here
       if (open) emit(oslot, ocell, os, on);
+  if (stamps) {   // stamp 7 of the workgroup's record: how many of its runs went straight to memory (table full)
+    if (threadIdx.x == 0 && blockIdx.x < kViStampWgs) stamps[(size_t)blockIdx.x * 8 + 7] = 0ull;
+    __syncthreads();
+    if (n_direct && blockIdx.x < kViStampWgs) atomicAdd(stamps + (size_t)blockIdx.x * 8 + 7, (unsigned long long)n_direct);
+  }
       open = true; oslot = slot[k]; ocell = cell; on = 1;
 #pragma unroll
       for (int j = 0; j < NS; j++) os[j] = v[j];

@@ -46,6 +46,14 @@ for k, (name, ph) in enumerate(names):
     for i, p in enumerate(ph):
         d = (s[:, i + 1] - s[:, i]) / 100.0
         print("  %-12s median %.2f us, mean %.2f, 90 %% %.2f, max %.2f" % (p, np.median(d), d.mean(), np.percentile(d, 90), d.max()))
+    if name == "k_accum":
+        order = np.argsort(life)
+        slow = s[order[-20:]]
+        print("  runs that found no slot (went straight to memory): total %d in %d workgroups; the 20 slowest workgroups: %s" % (
+            s[:, 7].sum(), (s[:, 7] > 0).sum(), " ".join(str(int(x)) for x in slow[:, 7])))
+        print("  the 20 slowest: lifetimes %s" % " ".join("%.1f" % x for x in life[order[-20:]]))
+        for i, p in enumerate(ph):
+            print("    %-12s of the 20 slowest: median %.2f" % (p, np.median((slow[:, i + 1] - slow[:, i]) / 100.0)))
     early = s[(s[:, 0] - t0) < 100]   # workgroups that started within the first microsecond
     late = s[(s[:, 0] - t0) >= 100]
     for nm, g in (("first round", early), ("later", late)):
