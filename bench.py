@@ -563,6 +563,40 @@ def main():
             roofline_cfg5["align_iterations"] = int(ndt5.last_stats["iterations"])
             roofline_cfg5["align_passes"] = int(ndt5.last_stats["passes"])
             ndt5.close()
+            # ---- the two stages SURVEY.md 8d expects at the HBM roofline, at the same size: VoxelFilter (formula A: 16 N + 16 V bytes)
+            # and the target voxelisation (formula B: 16 N_t + 48 V) of the 2 M-point cloud.  Whole calls (every kernel of the build +
+            # the one host wait), median of 30 behind 10 warm-up calls; DESIGN.md has the per-kernel split (profiles/r05_*).
+            with guarded("2 M-point build"):
+                def med_ms(fn, reps=30, warm=10):
+                    for _ in range(warm):
+                        fn()
+                    torch.cuda.synchronize()
+                    ts = []
+                    for _ in range(reps):
+                        t0 = time.perf_counter()
+                        fn()
+                        torch.cuda.synchronize()
+                        ts.append((time.perf_counter() - t0) * 1e3)
+                    return float(np.median(ts)), float(np.min(ts)), float(np.max(ts))
+                f5 = cloud_filter.VoxelFilterHip(ctx, 0.3, 0.3, 0.3)
+                out5 = torch.empty((d_t5.shape[0], 4), dtype=torch.float32, device=dev)
+                V5 = int(f5.filter_device(d_t5, out5).shape[0])
+                fm, fmin, fmax = med_ms(lambda: f5.filter_device(d_t5, out5))
+                ndt6 = registration.NDTRegistrationHip(ctx, 1.0, 0.1, 0.0, 30, 0.55)
+                tm, tmin, tmax = med_ms(lambda: ndt6.SetInputTarget(d_t5))
+                gi6 = ndt6.grid_info()
+                N5 = int(d_t5.shape[0])
+                algA, algB = 16.0 * N5 + 16.0 * V5, 16.0 * N5 + 48.0 * int(gi6["occupied"])
+                roofline_cfg5["build"] = {
+                    "what": "the 2 M-point target through VoxelFilter 0.3 m (SURVEY 8d formula A) and through SetInputTarget at 1.0 m (formula B): whole calls, "
+                            "median of 30; bound hbm, peak %.0f GB/s" % HBM_PEAK_GBS,
+                    "filter": {"ms": round(fm, 4), "min_ms": round(fmin, 4), "max_ms": round(fmax, 4), "points": N5, "voxels": V5, "alg_bytes": int(algA),
+                               "achieved": round(algA / (fm * 1e-3) / 1e9, 1), "unit": "GB/s", "frac": round(algA / (fm * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)},
+                    "set_input_target": {"ms": round(tm, 4), "min_ms": round(tmin, 4), "max_ms": round(tmax, 4), "points": N5, "voxels_occupied": int(gi6["occupied"]),
+                                         "alg_bytes": int(algB), "achieved": round(algB / (tm * 1e-3) / 1e9, 1), "unit": "GB/s",
+                                         "frac": round(algB / (tm * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}}
+                ndt6.close(); f5.close()
+                del out5
             del d_t5, d_s5
 
     # ---- the same kernel against a target that cannot live in a 4 MiB per-XCD L2 (wide_map: >= 100 k valid voxels over

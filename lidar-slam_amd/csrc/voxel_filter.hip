@@ -79,7 +79,8 @@ constexpr int kBlock = 256;
 
 __global__ __launch_bounds__(kBlock) void k_filter_finalize(long long *__restrict__ acc, int32_t *__restrict__ cnt,
                                                             const int32_t *__restrict__ cell_of_rank, DevParams *__restrict__ dp,
-                                                            float4 *__restrict__ out, DevParams *__restrict__ host_mirror, uint32_t *__restrict__ bits) {
+                                                            float4 *__restrict__ out, DevParams *__restrict__ host_mirror, uint32_t *__restrict__ bits,
+                                                            int by_cell /* rows of acc / cnt are keyed by the cell, not by the rank (VoxelIndex::by_cell) */) {
   // the grid definition + voxel count + status go straight into host-mapped pinned memory (no copy kernel): the host
   // reads them after the completion event.  The miss flag of a speculative build is consumed here (no other thread of
   // this kernel reads it), so the definition left on the device is ready for the next build.
@@ -89,16 +90,17 @@ __global__ __launch_bounds__(kBlock) void k_filter_finalize(long long *__restric
   if (r >= dp->V) return;  // the grid is sized for the point count; the occupied-cell count only exists on the device
   const CellMap m = dp->map;
   const FixScales fs = dp->fs;
-  long long *a = acc + r * 4;
   double o[3];
   const int cell = cell_of_rank[r];
+  const size_t key = by_cell ? (size_t)cell : r;
+  long long *a = acc + key * 4;
   lsa_cell_origin(m, cell, o);
   const long long av[4] = {a[0], a[1], a[2], a[3]};
-  out[r] = vi_filter_mean(av, cnt[r], o, fs);
+  out[r] = vi_filter_mean(av, cnt[key], o, fs);
   // leave the index clean for the next scan (was a separate clean-up launch): this cell's sums, its count and its
   // bitmap word (cells sharing the word all store the same zero)
   a[0] = 0; a[1] = 0; a[2] = 0; a[3] = 0;
-  cnt[r] = 0;
+  cnt[key] = 0;
   bits[cell >> 5] = 0u;
 }
 
@@ -123,7 +125,7 @@ int filter_device(lsa_voxel_filter *f, const float4 *d_in, size_t n, float4 *d_o
     rc = vi_enqueue(ctx, vi, d_in, n, /*mode PCL*/ 0, f->leaf, 4, /*allow_spec*/ true, pulling ? pull : nullptr, d_keep);
     if (!rc) {
       hipLaunchKernelGGL(k_filter_finalize, dim3(lsa_div_up(n, kBlock)), dim3(kBlock), 0, ctx->stream, vi.acc.p, vi.cnt.p, vi.cell_of_rank.p, vi.dparams.p,
-                         d_out, vi.h_params.p, vi.bits.p);
+                         d_out, vi.h_params.p, vi.bits.p, vi.by_cell ? 1 : 0);
       if (hipGetLastError() != hipSuccess) rc = lsa_fail(ctx, LSA_ERR_HIP, "voxel filter: launch failed");
     }
     if (!rc) rc = vi_mark_done(ctx, vi);
@@ -162,7 +164,7 @@ int filter_enqueue(lsa_voxel_filter *f, const float4 *d_in, size_t n, float4 *d_
   rc = vi_enqueue(ctx, vi, d_in, n, /*mode PCL*/ 0, f->leaf, 4, /*allow_spec*/ true, pull);
   if (rc) return rc;
   hipLaunchKernelGGL(k_filter_finalize, dim3(lsa_div_up(n, kBlock)), dim3(kBlock), 0, ctx->stream, vi.acc.p, vi.cnt.p, vi.cell_of_rank.p, vi.dparams.p, d_out,
-                     vi.h_params.p, vi.bits.p);
+                     vi.h_params.p, vi.bits.p, vi.by_cell ? 1 : 0);
   LSA_HIP(ctx, hipGetLastError());
   return vi_mark_done(ctx, vi);  // filter_wait() marks the index clean once the status is known
 }
@@ -510,6 +512,7 @@ extern "C" int lsa_voxel_filter_create(lsa_voxel_filter **out, lsa_context *ctx,
   lsa_voxel_filter *f = new lsa_voxel_filter();
   f->ctx = ctx;
   f->leaf[0] = lx; f->leaf[1] = ly; f->leaf[2] = lz;
+  f->vi.allow_by_cell = true;   // k_filter_finalize reads and clears the rows by their key
   if (const char *t = getenv("LSA_PULL_TEST")) {
     unsigned long long ticks = 0;
     unsigned delay = 0;

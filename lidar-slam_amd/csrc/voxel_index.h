@@ -89,6 +89,11 @@ struct VoxelIndex {
   DevBuf<unsigned> tickets;               // [1] scan tile ticket (self-resetting); [0] spare
   unsigned scan_epoch = 0;
   DevBuf<int32_t> cell_of_rank, cnt, cell_idx;
+  // Large clouds (>= 512 k points) of an owner whose finalize kernel clears the rows it reads BY KEY may be summed into rows indexed
+  // by the cell (k_accum<.., BY_CELL>): by_cell says how the LAST build keyed acc[] / cnt[] — row cell_of_rank[r] instead of row r.
+  // Rows: W_cap * 32 cells x (ns * 8 + 4) bytes (151 MB for the reserved 2^17-word bitmap at ns = 4), only while that stays below
+  // kByCellMaxBytes; all zero between builds like the rank-keyed rows.
+  bool allow_by_cell = false, by_cell = false;
   bool want_cell_idx = false;   // the owner reads cell_idx[] (the linear cell of every point, -1 = none) behind the build: nn_grid.hip
   DevBuf<long long> acc;
   DevBuf<float> scratch;  // bbox partials
@@ -157,5 +162,6 @@ int vi_grow(lsa_context *ctx, VoxelIndex &vi);
 // Enqueue the clean-up (zero the bitmap words / sums / counts this build touched) so the next build needs no memset.
 // Runs behind the completion event, i.e. off the caller's critical path.
 int vi_cleanup(lsa_context *ctx, VoxelIndex &vi, size_t n);
+constexpr size_t kByCellMaxBytes = (size_t)1 << 30;
 
 #endif

@@ -670,11 +670,16 @@ __device__ __forceinline__ unsigned cell_rank(const uint32_t *__restrict__ bits,
 }
 
 // per-cell fixed-point sums: LDS pre-aggregation per tile, then one set of global atomics per distinct cell
-template <int NS, int TILE>
+// BY_CELL (large clouds of an owner that cleans up by key, VoxelIndex::allow_by_cell): the rows of acc[] / cnt[] are indexed by the
+// CELL, not by its rank among the occupied cells — the sums then need nothing the scan produces, and this kernel is the build's
+// only pass over the points: it also leaves the byte marks of the cells it met (no k_mark_bytes: one 32 MB read, one launch and
+// the rank look-ups of the flush less; 134 MB of rows for a 4.2 M-cell box, which 288 GB do not notice).  The scan runs behind it
+// for the output order alone, and the owner's finalize kernel reads row cell_of_rank[r] instead of row r.
+template <int NS, int TILE, bool BY_CELL>
 __global__ __launch_bounds__(kBlock) void k_accum(const float4 *__restrict__ pts, size_t n,
-                                                  const DevParams *__restrict__ dp, KnownParams kp, const uint32_t *__restrict__ bits,
+                                                  DevParams *__restrict__ dp, KnownParams kp, const uint32_t *__restrict__ bits,
                                                   const uint32_t *__restrict__ prefix, long long *__restrict__ acc, int32_t *__restrict__ cnt,
-                                                  unsigned long long *__restrict__ stamps) {
+                                                  uint8_t *__restrict__ occ, float4 *__restrict__ d_keep, unsigned long long *__restrict__ stamps) {
   vi_stamp(stamps, 0);
   // table slots: TILE / 2, but TILE / 4 for the 10-sum rows (80 B each): 46 KB instead of 92 KB of LDS lets three
   // workgroups share a CU instead of one; a tile with more distinct cells than slots overflows to direct atomics.
@@ -682,10 +687,19 @@ __global__ __launch_bounds__(kBlock) void k_accum(const float4 *__restrict__ pts
   // cloud are all resident at once (with a fourth array they came to 44 KB: 768 resident, and the 209 left over ran a second round
   // of their own — 14 of the kernel's 44 us).
   constexpr int kTile = TILE, kPer = TILE / kBlock, kHashCap = (NS > 4 && TILE >= 1024) ? TILE / 4 : TILE / 2;
-  if (!kp.valid && dp->status != VI_OK) return;
+  if (!kp.valid && dp->status != VI_OK) {
+    if (BY_CELL && d_keep) {   // (see k_mark: the caller's copy does not depend on the grid definition)
+      for (int k = 0; k < kPer; k++) {
+        size_t i = vi_point_index<kPer>((size_t)blockIdx.x * kTile, k);
+        if (i < n) d_keep[i] = pts[i];
+      }
+    }
+    return;
+  }
   // a build k_mark has flagged (a point outside the reused cell box; rows of a host cloud that never arrived and were not copied)
-  // is thrown away by the host: nothing to sum — and, for the second kind, nothing to be trusted in the rows
-  if (dp->spec_miss) return;
+  // is thrown away by the host: nothing to sum — and, for the second kind, nothing to be trusted in the rows.  (BY_CELL: this
+  // kernel is the one that finds such points; what it has summed by then the owner's finalize kernel clears with the rest.)
+  if (!BY_CELL && dp->spec_miss) return;
   const CellMap m = kp.valid ? kp.map : dp->map;
   const FixScales fs = kp.valid ? kp.fs : dp->fs;
   __shared__ int keys[kHashCap];
@@ -707,6 +721,13 @@ __global__ __launch_bounds__(kBlock) void k_accum(const float4 *__restrict__ pts
     size_t i = vi_point_index<kPer>(base, k);
     pv[k] = (i < n) ? pts[i] : make_float4(NAN, NAN, NAN, 0.f);
   }
+  if (BY_CELL && d_keep) {
+#pragma unroll
+    for (int k = 0; k < kPer; k++) {
+      size_t i = vi_point_index<kPer>(base, k);
+      if (i < n) d_keep[i] = pv[k];
+    }
+  }
   // a point's cell by the very expressions k_mark marked it with (the per-point cell index k_mark used to leave in memory was an
   // 8 MB store, an 8 MB load and a kernel-end write-back at 2 M points, for ~20 instructions per point)
 #pragma unroll
@@ -716,6 +737,7 @@ __global__ __launch_bounds__(kBlock) void k_accum(const float4 *__restrict__ pts
       int ijk[3];
       lsa_cell_ijk(m, pv[k].x, pv[k].y, pv[k].z, ijk);
       cv[k] = lsa_cell_linear(m, ijk);
+      if (BY_CELL && cv[k] < 0) atomicMax(&dp->spec_miss, 1);  // only possible when the grid definition was reused from an earlier build
     }
   }
   // the first cell of every run of equal cells among the lane's points finds its slot (one probe chain for all of them) ...
@@ -745,11 +767,12 @@ __global__ __launch_bounds__(kBlock) void k_accum(const float4 *__restrict__ pts
       for (int j = 0; j < NS; j++) atomicAdd(&sums[sl][j], rs[j]);
       atomicAdd(&counts[sl], rn);
     } else {  // table full: straight to memory
-      unsigned rank = cell_rank(bits, prefix, cell);
+      unsigned rank = BY_CELL ? (unsigned)cell : cell_rank(bits, prefix, cell);
       unsigned long long *a = (unsigned long long *)(acc + (size_t)rank * NS);
 #pragma unroll
       for (int j = 0; j < NS; j++) atomicAdd(a + j, rs[j]);
       atomicAdd(cnt + rank, rn);
+      if (BY_CELL) occ[cell] = (uint8_t)1;
     }
   };
   bool open = false;
@@ -792,20 +815,22 @@ __global__ __launch_bounds__(kBlock) void k_accum(const float4 *__restrict__ pts
   __syncthreads();
   vi_stamp(stamps, 3);
   // flush, step 1: a lane's slots are independent, their rank look-ups are issued together; the rank replaces the cell in keys[]
-  // (each slot is read and rewritten by its one lane; -1 stays -1)
-  int fcell[kHashCap / kBlock];
-  uint32_t fw[kHashCap / kBlock], fp[kHashCap / kBlock];
+  // (each slot is read and rewritten by its one lane; -1 stays -1).  BY_CELL: the cell IS the row.
+  if constexpr (!BY_CELL) {
+    int fcell[kHashCap / kBlock];
+    uint32_t fw[kHashCap / kBlock], fp[kHashCap / kBlock];
 #pragma unroll
-  for (int k = 0; k < kHashCap / kBlock; k++) {
-    fcell[k] = keys[k * kBlock + threadIdx.x];
-    int c = fcell[k] < 0 ? 0 : fcell[k];
-    fw[k] = bits[c >> 5];
-    fp[k] = prefix[c >> 5];
+    for (int k = 0; k < kHashCap / kBlock; k++) {
+      fcell[k] = keys[k * kBlock + threadIdx.x];
+      int c = fcell[k] < 0 ? 0 : fcell[k];
+      fw[k] = bits[c >> 5];
+      fp[k] = prefix[c >> 5];
+    }
+#pragma unroll
+    for (int k = 0; k < kHashCap / kBlock; k++)
+      if (fcell[k] >= 0) keys[k * kBlock + threadIdx.x] = (int)(fp[k] + __popc(fw[k] & ((1u << (fcell[k] & 31)) - 1u)));
+    __syncthreads();
   }
-#pragma unroll
-  for (int k = 0; k < kHashCap / kBlock; k++)
-    if (fcell[k] >= 0) keys[k * kBlock + threadIdx.x] = (int)(fp[k] + __popc(fw[k] & ((1u << (fcell[k] & 31)) - 1u)));
-  __syncthreads();
   vi_stamp(stamps, 4);
   // step 2: one lane per (slot, term): the NS atomics of a cell leave from adjacent lanes and land in one or two 64-byte
   // lines of acc[], instead of NS instructions whose 64 lanes each touch a different line.  Every slot is visited (a quarter of them
@@ -825,7 +850,10 @@ __global__ __launch_bounds__(kBlock) void k_accum(const float4 *__restrict__ pts
       if (rk[q] < 0) continue;
       const int sl = e / (NS + 1), j = e - sl * (NS + 1);
       if (j < NS) atomicAdd((unsigned long long *)(acc + (size_t)(unsigned)rk[q] * NS) + j, sums[sl][j]);
-      else atomicAdd(cnt + (unsigned)rk[q], counts[sl]);
+      else {
+        atomicAdd(cnt + (unsigned)rk[q], counts[sl]);
+        if (BY_CELL) occ[(unsigned)rk[q]] = (uint8_t)1;   // the cell's byte mark (plain store: see k_mark_bytes)
+      }
     }
   }
   vi_stamp(stamps, 5);
@@ -834,13 +862,15 @@ __global__ __launch_bounds__(kBlock) void k_accum(const float4 *__restrict__ pts
 
 // zero what this build touched: the bitmap words of the occupied cells and the V rows of sums / counts
 __global__ __launch_bounds__(kBlock) void k_cleanup(const DevParams *__restrict__ dp, const int32_t *__restrict__ cell_of_rank, uint32_t *__restrict__ bits,
-                                                    long long *__restrict__ acc, int32_t *__restrict__ cnt, int ns) {
+                                                    long long *__restrict__ acc, int32_t *__restrict__ cnt, int ns, int by_cell) {
   if (dp->status != VI_OK) return;
   size_t r = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (r >= dp->V) return;
-  bits[cell_of_rank[r] >> 5] = 0u;
-  for (int j = 0; j < ns; j++) acc[r * ns + j] = 0;
-  cnt[r] = 0;
+  const int cell = cell_of_rank[r];
+  const size_t key = by_cell ? (size_t)cell : r;
+  bits[cell >> 5] = 0u;
+  for (int j = 0; j < ns; j++) acc[key * ns + j] = 0;
+  cnt[key] = 0;
 }
 
 inline unsigned stream_grid(lsa_context *ctx, size_t n) {
@@ -898,6 +928,19 @@ int vi_enqueue(lsa_context *ctx, VoxelIndex &vi, const float4 *d_pts, size_t n, 
   int rc;
   unsigned nb = stream_grid(ctx, n);
   if ((rc = vi_prepare(ctx, vi, n, ns, 0))) return rc;
+  // rows by cell (see VoxelIndex::allow_by_cell): large device clouds whose box capacity keeps the rows below kByCellMaxBytes
+  const size_t cells_cap = vi.W_cap * 32;
+  // (not for an owner that waits behind the scan while the sums are still running, mirror_at_scan: by cell the sums come FIRST,
+  // and SetInputTarget of 2 M points measured 0.106 ms that way against 0.098 with its host work under the accumulation)
+  const bool by_cell = vi.allow_by_cell && !vi.mirror_at_scan && !pull && n >= kSmallInput && cells_cap * ((size_t)ns * 8 + 4) <= kByCellMaxBytes &&
+                       !(getenv("LSA_VI_BY_CELL") && atoi(getenv("LSA_VI_BY_CELL")) == 0);
+  if (by_cell && (vi.acc.cap < cells_cap * (size_t)ns || vi.cnt.cap < cells_cap)) {
+    LSA_HIP(ctx, hipStreamSynchronize(ctx->stream));   // (the reserves free the old rows)
+    if ((rc = vi.acc.reserve(ctx, cells_cap * (size_t)ns))) return rc;
+    if ((rc = vi.cnt.reserve(ctx, cells_cap))) return rc;
+    vi.clean = false;
+  }
+  vi.by_cell = by_cell;
   if (++vi.scan_epoch >= (1u << 30)) {  // epoch wrap: invalidate every state word the old way
     LSA_HIP(ctx, hipMemsetAsync(vi.scan_state.p, 0, vi.scan_state.cap * sizeof(unsigned long long), ctx->stream));
     vi.scan_epoch = 1;
@@ -952,6 +995,7 @@ int vi_enqueue(lsa_context *ctx, VoxelIndex &vi, const float4 *d_pts, size_t n, 
   } else if (small) hipLaunchKernelGGL((k_mark<kTileSmall, false>), dim3(lsa_div_up(n, kTileSmall)), dim3(kBlock), 0, ctx->stream, d_pts, n, dp, kp, vi.bits.p, vi.cell_idx.p, no_pull, vi.stamps.p);
   else {
     // large clouds: byte marks, then the bytes of the box packed into the bitmap (see VoxelIndex::occ)
+    unsigned long long *st_acc = vi.stamps.p ? vi.stamps.p + kViStampWgs * 8 : nullptr;
     if (vi.occ_words != vi.W_cap) {
       if (vi.occ.p) LSA_HIP(ctx, hipStreamSynchronize(ctx->stream));   // (the reserve frees the old map)
       vi.occ.release();
@@ -959,17 +1003,26 @@ int vi_enqueue(lsa_context *ctx, VoxelIndex &vi, const float4 *d_pts, size_t n, 
       LSA_HIP(ctx, hipMemsetAsync(vi.occ.p, 0, vi.W_cap * 32, ctx->stream));
       vi.occ_words = vi.W_cap;
     }
-    hipLaunchKernelGGL((k_mark_bytes<kTileBig / kBlock>), dim3(lsa_div_up(n, kTileBig)), dim3(kBlock), 0, ctx->stream, d_pts, n, dp, kp, vi.occ.p, vi.cell_idx.p, d_keep,
-                       vi.stamps.p);
+    if (by_cell) {   // ONE pass over the points: the sums by cell and the byte marks (k_accum<.., BY_CELL>); pack and scan run behind it
+      if (ns == 4) hipLaunchKernelGGL((k_accum<4, kTileBig, true>), dim3(lsa_div_up(n, kTileBig)), dim3(kBlock), 0, ctx->stream, d_pts, n, dp, kp, vi.bits.p, vi.prefix.p,
+                                      vi.acc.p, vi.cnt.p, vi.occ.p, d_keep, st_acc);
+      else hipLaunchKernelGGL((k_accum<10, kTileBig, true>), dim3(lsa_div_up(n, kTileBig)), dim3(kBlock), 0, ctx->stream, d_pts, n, dp, kp, vi.bits.p, vi.prefix.p,
+                              vi.acc.p, vi.cnt.p, vi.occ.p, d_keep, st_acc);
+    } else {
+      hipLaunchKernelGGL((k_mark_bytes<kTileBig / kBlock>), dim3(lsa_div_up(n, kTileBig)), dim3(kBlock), 0, ctx->stream, d_pts, n, dp, kp, vi.occ.p, vi.cell_idx.p, d_keep,
+                         vi.stamps.p);
+    }
     hipLaunchKernelGGL(k_occ_to_bits, dim3(lsa_div_up(vi.W_cap, kBlock)), dim3(kBlock), 0, ctx->stream, reinterpret_cast<uint4 *>(vi.occ.p), dp, kp, vi.bits.p);
   }
   hipLaunchKernelGGL(k_scan, dim3(nsb_cap), dim3(kBlock), 0, ctx->stream, vi.bits.p, vi.dparams.p, kp, vi.scan_state.p, vi.tickets.p + 1, vi.scan_epoch,
                      vi.prefix.p, vi.cell_of_rank.p, vi.mirror_at_scan ? vi.h_params.p : (DevParams *)nullptr);
   if (vi.mirror_at_scan) LSA_HIP(ctx, hipEventRecord(vi.ev_done, ctx->stream));   // vi_wait() returns behind the scan; the accumulation is still running then
   unsigned g = lsa_div_up(n, small ? kTileSmall : kTileBig);
-#define LSA_LAUNCH_ACCUM(NS_, TILE_) hipLaunchKernelGGL((k_accum<NS_, TILE_>), dim3(g), dim3(kBlock), 0, ctx->stream, d_pts, n, dp, kp, vi.bits.p, vi.prefix.p, vi.acc.p, vi.cnt.p, vi.stamps.p ? vi.stamps.p + kViStampWgs * 8 : nullptr)
-  if (ns == 4) { if (small) LSA_LAUNCH_ACCUM(4, kTileSmall); else LSA_LAUNCH_ACCUM(4, kTileBig); }
-  else { if (small) LSA_LAUNCH_ACCUM(10, kTileSmall); else LSA_LAUNCH_ACCUM(10, kTileBig); }
+#define LSA_LAUNCH_ACCUM(NS_, TILE_) hipLaunchKernelGGL((k_accum<NS_, TILE_, false>), dim3(g), dim3(kBlock), 0, ctx->stream, d_pts, n, dp, kp, vi.bits.p, vi.prefix.p, vi.acc.p, vi.cnt.p, (uint8_t *)nullptr, (float4 *)nullptr, vi.stamps.p ? vi.stamps.p + kViStampWgs * 8 : nullptr)
+  if (!by_cell) {   // (rows by rank: behind the scan)
+    if (ns == 4) { if (small) LSA_LAUNCH_ACCUM(4, kTileSmall); else LSA_LAUNCH_ACCUM(4, kTileBig); }
+    else { if (small) LSA_LAUNCH_ACCUM(10, kTileSmall); else LSA_LAUNCH_ACCUM(10, kTileBig); }
+  }
 #undef LSA_LAUNCH_ACCUM
   LSA_HIP(ctx, hipGetLastError());
   return LSA_OK;
@@ -1023,7 +1076,7 @@ int vi_grow(lsa_context *ctx, VoxelIndex &vi) {
 
 int vi_cleanup(lsa_context *ctx, VoxelIndex &vi, size_t n) {
   hipLaunchKernelGGL(k_cleanup, dim3(lsa_div_up(n, kBlock)), dim3(kBlock), 0, ctx->stream, vi.dparams.p, vi.cell_of_rank.p, vi.bits.p, vi.acc.p, vi.cnt.p,
-                     vi.acc_ns);
+                     vi.acc_ns, vi.by_cell ? 1 : 0);
   LSA_HIP(ctx, hipGetLastError());
   vi.clean = true;
   return LSA_OK;
