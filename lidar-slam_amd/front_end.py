@@ -10,6 +10,15 @@ import numpy as np
 from . import capi
 
 
+def _L():
+    return capi.lib()
+
+
+def _check_points_tensor(t, what):
+    from .registration import check_points_tensor
+    check_points_tensor(t, what)
+
+
 class FrontEndConfig(C.Structure):
     _fields_ = [
         ("key_frame_distance", C.c_float),
@@ -75,6 +84,9 @@ class FrontEndHip:
         ctx.check(L.lsa_front_end_create(C.byref(h), ctx.h, C.byref(self.cfg)))
         self.h = h
         self._last_st, self._last_dict = None, None
+        # the pose comes back through one buffer kept for the object's life (a fresh array + its ctypes view cost ~5 us per Update)
+        self._out = np.zeros(16, dtype=np.float32)
+        self._out_c = capi.fptr(self._out)
 
     def reserve(self, max_scan_points):
         """lsa_front_end_reserve: allocate now what Update would allocate under the first scans (create already does it for 160 k points)."""
@@ -92,20 +104,20 @@ class FrontEndHip:
         copy the frame filter's first kernel makes, so the local map's update — which runs after this returns — does not read
         the tensor.  Only without a frame filter is the read stream-ordered instead: then refill the tensor by work on the
         context's stream (torch.cuda.ExternalStream(ctx.stream)) or synchronise that stream first."""
-        out = np.zeros(16, dtype=np.float32)
+        out, out_c = self._out, self._out_c
         st = FrontEndStats()
         if hasattr(cloud, "data_ptr"):
-            from .registration import check_points_tensor
-            check_points_tensor(cloud, "FrontEnd.Update")
+            _check_points_tensor(cloud, "FrontEnd.Update")
             self._keep = cloud
-            rc = capi.lib().lsa_front_end_update_device(self.h, cloud.data_ptr(), cloud.shape[0], capi.fptr(out), C.byref(st))
+            rc = _L().lsa_front_end_update_device(self.h, cloud.data_ptr(), cloud.shape[0], out_c, C.byref(st))
         else:
             pts = np.ascontiguousarray(cloud, dtype=np.float32)
             w_off = capi.w_offset(pts.shape[1])
-            rc = capi.lib().lsa_front_end_update(self.h, pts.ctypes.data, pts.shape[0], pts.strides[0], w_off, capi.fptr(out), C.byref(st))
-        self.ctx.check(rc)
+            rc = _L().lsa_front_end_update(self.h, pts.ctypes.data, pts.shape[0], pts.strides[0], w_off, out_c, C.byref(st))
+        if rc:
+            self.ctx.check(rc)
         self._last_st, self._last_dict = st, None   # (the dict is built when somebody asks for it: a few us per scan otherwise)
-        return True, capi.from_colmajor(out)
+        return True, out.reshape(4, 4).T.copy()
 
     @staticmethod
     def _stats_dict(s):

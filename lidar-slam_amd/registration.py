@@ -60,7 +60,9 @@ class NDTRegistrationHip(RegistrationInterface):
         """trace=True additionally records one row per derivative pass ({p(6), score, step length, kind}) in
         last_stats["trace"] (lsa_ndt_set_trace; diagnostics for the parity tests)."""
         guess = capi.colmajor(predict_pose)
-        out = np.zeros(16, dtype=np.float32)
+        out = getattr(self, "_out", None)
+        if out is None:   # one result buffer for the object's life (a fresh array and its ctypes view per call cost ~5 us of a 45 us ScanMatch)
+            out = self._out = np.zeros(16, dtype=np.float32)
         st = capi.NdtStats()
         tr, ntr = None, C.c_int(0)
         if trace:
