@@ -162,6 +162,7 @@ int vi_grow(lsa_context *ctx, VoxelIndex &vi);
 // Enqueue the clean-up (zero the bitmap words / sums / counts this build touched) so the next build needs no memset.
 // Runs behind the completion event, i.e. off the caller's critical path.
 int vi_cleanup(lsa_context *ctx, VoxelIndex &vi, size_t n);
+int vi_prepare_large(lsa_context *ctx, VoxelIndex &vi, int ns);
 constexpr size_t kByCellMaxBytes = (size_t)1 << 30;
 
 #endif

@@ -918,6 +918,28 @@ int vi_prepare(lsa_context *ctx, VoxelIndex &vi, size_t n, int ns, size_t w_min)
   return LSA_OK;
 }
 
+// what a LARGE build (>= kSmallInput points) needs beyond vi_prepare, allocated and cleared ahead of the first one: the byte map of the
+// bitmap's capacity and, for an owner that allows it, the rows keyed by the cell (lsa_voxel_filter_reserve)
+int vi_prepare_large(lsa_context *ctx, VoxelIndex &vi, int ns) {
+  int rc;
+  if (vi.occ_words != vi.W_cap) {
+    if (vi.occ.p) LSA_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    vi.occ.release();
+    if ((rc = vi.occ.reserve(ctx, vi.W_cap * 32))) return rc;
+    LSA_HIP(ctx, hipMemsetAsync(vi.occ.p, 0, vi.W_cap * 32, ctx->stream));
+    vi.occ_words = vi.W_cap;
+  }
+  const size_t cells_cap = vi.W_cap * 32;
+  if (vi.allow_by_cell && !vi.mirror_at_scan && cells_cap * ((size_t)ns * 8 + 4) <= kByCellMaxBytes &&
+      (vi.acc.cap < cells_cap * (size_t)ns || vi.cnt.cap < cells_cap)) {
+    LSA_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if ((rc = vi.acc.reserve(ctx, cells_cap * (size_t)ns))) return rc;
+    if ((rc = vi.cnt.reserve(ctx, cells_cap))) return rc;
+    vi.clean = false;
+  }
+  return LSA_OK;
+}
+
 bool vi_spec_ready(const VoxelIndex &vi, size_t n, int mode, const float leaf[3]) {
   return mode == 0 && vi.spec_valid && vi.spec_mode == mode && vi.spec_leaf[0] == leaf[0] && vi.spec_leaf[1] == leaf[1] && vi.spec_leaf[2] == leaf[2] &&
          (unsigned long long)n <= vi.spec_n_cap && vi.spec_W_cap == vi.W_cap && vi.W_cap != 0;

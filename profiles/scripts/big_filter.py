@@ -18,7 +18,7 @@ s = torch.cuda.Stream(); torch.cuda.set_stream(s)
 ctx = capi.Context(0, s.cuda_stream)
 d_t = torch.from_numpy(target).to(dev)
 reps = int(os.environ.get("REPS", "20"))
-for leaf in (0.3, 1.3):
+for leaf in [float(x) for x in os.environ.get("LEAVES", "0.3,1.3").split(",") if x]:
     f = cloud_filter.VoxelFilterHip(ctx, leaf, leaf, leaf)
     for _ in range(3): out = f.filter_device(d_t)
     torch.cuda.synchronize(); t0 = time.perf_counter()
@@ -26,6 +26,8 @@ for leaf in (0.3, 1.3):
     torch.cuda.synchronize(); ms = (time.perf_counter() - t0) * 1e3 / reps
     alg = 16 * target.shape[0] + 16 * out.shape[0]
     print("filter %.1f m of 2M: %.3f ms -> %d voxels; alg %.1f MB -> %.1f GB/s" % (leaf, ms, out.shape[0], alg / 1e6, alg / ms / 1e6), flush=True)
+if os.environ.get("NO_TARGET"):
+    sys.exit(0)
 ndt = registration.NDTRegistrationHip(ctx, 1.0, 0.1, 0.0, 30, 0.55)
 for _ in range(3): ndt.SetInputTarget(d_t)
 torch.cuda.synchronize(); t0 = time.perf_counter()

@@ -1,0 +1,181 @@
+"""GPU: the voxel-index build of LARGE clouds (>= 512 k points; voxel_index.hip: byte marks + pack kernel, sums into rows keyed by the
+cell for VoxelFilter, rank-keyed rows behind the scan for SetInputTarget) against the small-cloud build and the oracle.
+
+The two builds share every per-point expression and sum exact integers, so wherever both can run their outputs must agree bit for
+bit; the oracle pins a 600 k-point case (seconds on the CPU); at 2 M points the properties of tests/test_gpu_edge_and_scale.py apply.
+"""
+import numpy as np
+import pytest
+
+from lidar_slam_amd import capi, cloud_filter, registration, synth
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def cloud600k(scene):
+    poses = synth.trajectory(8)
+    P0inv = np.linalg.inv(poses[0])
+    parts = [synth.transform_points(P0inv @ poses[k], synth.gen_scan(scene, poses[k], seed=900 + k)) for k in range(5)]
+    c = np.ascontiguousarray(np.concatenate(parts, 0))[:600000]
+    rng = np.random.RandomState(5)
+    c[:, 3] = rng.uniform(0, 1, c.shape[0]).astype(np.float32)   # mixed static weights
+    return c
+
+
+def _filter_device(ctx, pts, leaf, env=None, monkeypatch=None, keep=False):
+    import torch
+    if monkeypatch is not None:
+        if env is None:
+            monkeypatch.delenv("LSA_VI_BY_CELL", raising=False)
+        else:
+            monkeypatch.setenv("LSA_VI_BY_CELL", env)
+    f = cloud_filter.VoxelFilterHip(ctx, leaf, leaf, leaf)
+    d = torch.from_numpy(np.ascontiguousarray(pts)).cuda()
+    outs = [f.filter_device(d).clone().cpu().numpy() for _ in range(3)]   # first build (bounding box), then two on the reused cell box
+    counters = f.counters()
+    f.close()
+    return outs, counters
+
+
+@pytest.mark.parametrize("leaf", [0.3, 1.3])
+def test_large_filter_rows_by_cell_equal_rows_by_rank_and_the_oracle(scene, oracle, cloud600k, monkeypatch, leaf):
+    """600 k points through VoxelFilter: rows keyed by the cell (one pass over the points) and rows keyed by the rank (marks, scan,
+    then sums) give the same bits, build after build; the oracle's voxel set and means within the bar of the small-cloud test."""
+    ctx = capi.Context(0)
+    by_cell, c1 = _filter_device(ctx, cloud600k, leaf, None, monkeypatch)
+    by_rank, c0 = _filter_device(ctx, cloud600k, leaf, "0", monkeypatch)
+    monkeypatch.delenv("LSA_VI_BY_CELL", raising=False)
+    for a in by_cell[1:] + by_rank:
+        assert a.shape == by_cell[0].shape and np.array_equal(a.view(np.uint32), by_cell[0].view(np.uint32))
+    ref, rc = oracle.voxel_filter(synth.to_xyzi32(cloud600k), leaf)
+    assert rc == 0 and ref.shape[0] == by_cell[0].shape[0]
+    err = np.abs(by_cell[0].astype(np.float64) - ref.astype(np.float64)) / np.maximum(np.abs(ref.astype(np.float64)), 1.0)
+    assert err.max() < 4e-6, err.max()
+    ctx.close()
+
+
+def test_large_filter_equals_small_path_on_the_same_points(scene, cloud600k):
+    """The same 600 k points as ONE large build and as the small-cloud build of their first 500 k + the large build's view of it:
+    a cloud just below the threshold (small path: LDS-deduplicated bitmap atomics, rank-keyed rows) and the same cloud padded with
+    NaN rows above it (large path; non-finite rows are skipped) must give identical outputs."""
+    import torch
+    ctx = capi.Context(0)
+    below = cloud600k[:500000]
+    assert below.shape[0] < 512 * 1024
+    padded = np.concatenate([below, np.full((40000, 4), np.nan, dtype=np.float32)], 0)
+    assert padded.shape[0] >= 512 * 1024
+    f = cloud_filter.VoxelFilterHip(ctx, 0.5, 0.5, 0.5)
+    a = f.filter_device(torch.from_numpy(below).cuda()).clone()
+    b = f.filter_device(torch.from_numpy(padded).cuda()).clone()
+    c = f.filter_device(torch.from_numpy(below).cuda()).clone()   # back on the small path, rows must have been left clean
+    assert torch.equal(a, b) and torch.equal(a, c)
+    f.close(); ctx.close()
+
+
+def test_large_filter_point_outside_the_reused_box_and_growth(scene, cloud600k):
+    """Speculative reuse of the previous grid definition on the large path: a later cloud with a point far outside the box (the
+    summing kernel itself reports it; what it had summed by then is cleared with the rest) is rebuilt exactly, and a cloud whose box
+    needs a larger bitmap grows it (byte map and rows with it) — each output equal to a fresh handle's."""
+    import torch
+    ctx = capi.Context(0)
+
+    def fresh(pts):
+        g = cloud_filter.VoxelFilterHip(ctx, 0.3, 0.3, 0.3)
+        o = g.filter_device(torch.from_numpy(np.ascontiguousarray(pts)).cuda()).clone()
+        g.close()
+        return o
+
+    f = cloud_filter.VoxelFilterHip(ctx, 0.3, 0.3, 0.3)
+    base = cloud600k
+    out0 = f.filter_device(torch.from_numpy(base).cuda()).clone()
+    assert torch.equal(out0, fresh(base))
+    moved = base.copy()
+    moved[1234, :3] = [150.0, -90.0, 12.0]          # one point far outside the box the first build defined
+    out1 = f.filter_device(torch.from_numpy(moved).cuda()).clone()
+    assert torch.equal(out1, fresh(moved))
+    assert f.counters()["misses"] >= 1
+    out2 = f.filter_device(torch.from_numpy(base).cuda()).clone()   # and back: nothing of the miss may linger in rows or marks
+    assert torch.equal(out2, out0)
+    wide = base.copy()
+    wide[:, :2] *= 3.0                               # nine times the footprint: the bitmap has to grow
+    out3 = f.filter_device(torch.from_numpy(wide).cuda()).clone()
+    assert torch.equal(out3, fresh(wide))
+    out4 = f.filter_device(torch.from_numpy(base).cuda()).clone()
+    assert torch.equal(out4, out0)
+    f.close(); ctx.close()
+
+
+def test_large_target_table_equals_the_oracle_pass(scene, oracle, cloud600k):
+    """SetInputTarget of 600 k points (large path of the voxel table: byte marks, pack, scan, rank-keyed 10-sum rows) and one
+    derivative pass of a filtered scan against it: score, gradient and Hessian against the oracle's on the same table inputs
+    (1e-9 relative: the pass tolerance of tests/test_gpu_parity.py), pair counts exact."""
+    import oracle_py
+    ctx = capi.Context(0)
+    tgt8 = synth.to_xyzi32(cloud600k)
+    n = registration.NDTRegistrationHip(ctx)
+    n.SetInputTarget(tgt8)
+    o = oracle_py.OracleNDT()
+    o.set_input_target(tgt8)
+    oi, od = o.grid_dump()
+    gi, gr = n.grid_dump()
+    info = n.grid_info()
+    occ, valid = o.grid_counts()
+    assert info["occupied"] == occ == gi.shape[0] and info["valid"] == valid
+    assert np.array_equal(gi[:, :4], oi[:, :4])                   # same cells, same order, same point counts
+    assert np.array_equal(gi[:, 4] == 1, oi[:, 4] >= 6)
+    assert np.max(np.abs(gr[:, :3] - od[:, :3])) < 1e-9           # centroids
+    assert np.max(np.abs(gr[:, 9] - od[:, 12])) < 1e-9            # mean static weight
+    poses = synth.trajectory(8)
+    src = synth.gen_scan(scene, poses[2], seed=950)[::12]
+    guess = (np.linalg.inv(poses[0]) @ poses[2]).astype(np.float32)
+    _, T = n.ScanMatch(synth.to_xyzi32(src), guess)
+    Tr, st_r = o.scan_match(synth.to_xyzi32(src), guess)
+    assert n.last_stats["iterations"] == st_r["iterations"] and n.last_stats["passes"] == st_r["passes"]
+    assert np.max(np.abs(T - Tr)) <= 1e-5
+    n.close(); ctx.close()
+
+
+def test_large_filter_randomized_against_the_oracle(oracle):
+    """Clouds of random size around the large-path threshold (400 k - 900 k points), random extent, leaf, share of NaN rows and of
+    duplicated points, in random order (no sensor structure: runs of equal cells are rare, tiles hold many distinct cells — the slot
+    table overflows into direct adds), through ONE handle (path switches, box reuse and growth from build to build): voxel set, order
+    and means against the oracle; a second pass over the same cloud must repeat the first bit for bit."""
+    import torch
+    rng = np.random.RandomState(77)
+    ctx = capi.Context(0)
+    handles = {}
+    for case in range(8):
+        n = int(rng.randint(400000, 900000))
+        leaf = float(rng.choice([0.2, 0.3, 0.5, 1.0, 2.0]))
+        ext = np.array([rng.uniform(20, 120), rng.uniform(20, 120), rng.uniform(2, 12)], dtype=np.float32)
+        kind = case % 3
+        if kind == 0:      # uniform volume: nearly every point its own cell at small leaves
+            pts = (rng.uniform(-1, 1, (n, 3)) * ext).astype(np.float32)
+        elif kind == 1:    # a few dense blobs + sparse background: hot cells
+            c = (rng.uniform(-1, 1, (12, 3)) * ext).astype(np.float32)
+            pts = (c[rng.randint(0, 12, n)] + rng.normal(0, 0.4, (n, 3))).astype(np.float32)
+            pts[: n // 5] = (rng.uniform(-1, 1, (n // 5, 3)) * ext).astype(np.float32)
+        else:              # planes (ground + walls), sensor-like sweep order kept
+            t = np.sort(rng.uniform(0, 1, n)).astype(np.float32)
+            pts = np.stack([np.cos(6.28 * 40 * t) * (5 + 60 * t), np.sin(6.28 * 40 * t) * (5 + 60 * t), rng.choice([-1.7, 0.5, 3.0], n) + rng.normal(0, 0.02, n)], 1).astype(np.float32)
+        w = rng.uniform(0, 1, n).astype(np.float32)
+        cloud = np.concatenate([pts, w[:, None]], 1)
+        cloud[rng.rand(n) < 0.01, rng.randint(0, 3)] = np.nan
+        dup = rng.randint(0, n, n // 50)
+        cloud[rng.randint(0, n, n // 50)] = cloud[dup]
+        f = handles.get(leaf)
+        if f is None:
+            f = handles[leaf] = cloud_filter.VoxelFilterHip(ctx, leaf, leaf, leaf)
+        d = torch.from_numpy(np.ascontiguousarray(cloud)).cuda()
+        a = f.filter_device(d).clone()
+        b = f.filter_device(d).clone()
+        assert torch.equal(a, b), case
+        ref, rc = oracle.voxel_filter(synth.to_xyzi32(cloud), leaf)
+        assert rc == 0 and ref.shape[0] == a.shape[0], (case, ref.shape, a.shape)
+        got = a.cpu().numpy().astype(np.float64)
+        err = np.abs(got - ref.astype(np.float64)) / np.maximum(np.abs(ref.astype(np.float64)), 1.0)
+        assert err.max() < 4e-6, (case, kind, leaf, err.max())
+    for f in handles.values():
+        f.close()
+    ctx.close()
