@@ -951,11 +951,13 @@ int vi_enqueue(lsa_context *ctx, VoxelIndex &vi, const float4 *d_pts, size_t n, 
   unsigned nb = stream_grid(ctx, n);
   if ((rc = vi_prepare(ctx, vi, n, ns, 0))) return rc;
   // rows by cell (see VoxelIndex::allow_by_cell): large device clouds whose box capacity keeps the rows below kByCellMaxBytes
+  // (LSA_VI_BY_CELL=0: the A/B arm and the equality test of the two keyings)
+  const bool by_cell_on = !(getenv("LSA_VI_BY_CELL") && atoi(getenv("LSA_VI_BY_CELL")) == 0);
   const size_t cells_cap = vi.W_cap * 32;
   // (not for an owner that waits behind the scan while the sums are still running, mirror_at_scan: by cell the sums come FIRST,
   // and SetInputTarget of 2 M points measured 0.106 ms that way against 0.098 with its host work under the accumulation)
   const bool by_cell = vi.allow_by_cell && !vi.mirror_at_scan && !pull && n >= kSmallInput && cells_cap * ((size_t)ns * 8 + 4) <= kByCellMaxBytes &&
-                       !(getenv("LSA_VI_BY_CELL") && atoi(getenv("LSA_VI_BY_CELL")) == 0);
+                       by_cell_on;
   if (by_cell && (vi.acc.cap < cells_cap * (size_t)ns || vi.cnt.cap < cells_cap)) {
     LSA_HIP(ctx, hipStreamSynchronize(ctx->stream));   // (the reserves free the old rows)
     if ((rc = vi.acc.reserve(ctx, cells_cap * (size_t)ns))) return rc;
