@@ -58,6 +58,46 @@ __device__ __forceinline__ void pass_scalars_pin(PassScalars &q) {
   asm volatile("" : "+s"(q.min_b0), "+s"(q.min_b1), "+s"(q.min_b2), "+s"(q.dim0), "+s"(q.dim1), "+s"(q.dim2));
 }
 
+// exp(x) as the device library computes it — the same range reduction, the same eleven Horner steps with the same constants, hence the
+// same bits (tests/test_gpu_parity.py pins the pass against the oracle's libm to 1e-11 either way) — with each coefficient brought
+// into a SCALAR register pair right where it is used.  The library's form keeps every step as `coefficient += r * p`, which needs
+// the coefficient in a fresh vector register per step and call: nine 64-bit moves per pair round of the pass, 35 vector instructions
+// per exp in all; a three-address FMA reads the constant from scalar registers (two s_mov on the scalar unit, which has nothing else
+// to do here) and needs none of the moves.  The range checks of the general function go too: ldexp saturates to 0 / inf by itself,
+// and the argument here is -d2 q / 2 of a finite pair.  Same box, alternating processes (`profiles/r05_pass_exp_ab.log`): 2 M-point
+// pass 172.9 -> 170.2 us, wide map 171 -> 162 us, armed KITTI-sized body 4.39 -> 4.30 us; every sum keeps its bits.
+#ifndef LSA_PASS_EXP_SCALAR
+#define LSA_PASS_EXP_SCALAR 1
+#endif
+__device__ __forceinline__ double lsa_sconst(unsigned long long bits) {
+  double c = __longlong_as_double((long long)bits);
+  // (without this the compiler goes back to the two-address form and its moves; with it every step is s_mov_b64 + v_fma_f64)
+  asm volatile("" : "+s"(c));
+  return c;
+}
+__device__ __forceinline__ double lsa_pass_exp(double x) {
+#if LSA_PASS_EXP_SCALAR
+#pragma clang fp contract(off)
+  const double n = __builtin_rint(x * lsa_sconst(0x3ff71547652b82feull));
+  double r = __builtin_fma(lsa_sconst(0xbfe62e42fefa39efull), n, x);
+  r = __builtin_fma(lsa_sconst(0xbc7abc9e3b39803full), n, r);
+  double p = __builtin_fma(lsa_sconst(0x3e5ade156a5dcb37ull), r, lsa_sconst(0x3e928af3fca7ab0cull));
+  p = __builtin_fma(r, p, lsa_sconst(0x3ec71dee623fde64ull));
+  p = __builtin_fma(r, p, lsa_sconst(0x3efa01997c89e6b0ull));
+  p = __builtin_fma(r, p, lsa_sconst(0x3f2a01a014761f6eull));
+  p = __builtin_fma(r, p, lsa_sconst(0x3f56c16c1852b7b0ull));
+  p = __builtin_fma(r, p, lsa_sconst(0x3f81111111122322ull));
+  p = __builtin_fma(r, p, lsa_sconst(0x3fa55555555502a1ull));
+  p = __builtin_fma(r, p, lsa_sconst(0x3fc5555555555511ull));
+  p = __builtin_fma(r, p, lsa_sconst(0x3fe000000000000bull));
+  p = __builtin_fma(r, p, 1.0);
+  p = __builtin_fma(r, p, 1.0);
+  return ldexp(p, (int)n);
+#else
+  return exp(x);
+#endif
+}
+
 template <int KIND>
 __device__ __forceinline__ void pair_update(const PassScalars P, const double *__restrict__ R, float tx, float ty, float tz,
                                             const double pg[8], const double *ph /* LDS, read at the point of use */, double acc[28],
@@ -76,7 +116,7 @@ __device__ __forceinline__ void pair_update(const PassScalars P, const double *_
   double u1 = C01 * d0 + C11 * d1 + C12 * d2;
   double u2 = C02 * d0 + C12 * d1 + C22 * d2;
   double q = d0 * u0 + d1 * u1 + d2 * u2;
-  double e = exp(-P.d2 * q / 2);  // :494
+  double e = lsa_pass_exp(-P.d2 * q / 2);  // :494
   double f = P.d2 * e;
   if (f > 1 || f < 0 || f != f) return;  // :499-501 / :884-886
   if (KIND != 2) acc[0] += R[9] * (-P.d1 * e);  // static weight multiplies the score only (:440-441)

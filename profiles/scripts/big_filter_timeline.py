@@ -8,15 +8,15 @@ def short(n):
     m = re.search(r"(k_\w+(<[^>]*>)?)", n)
     return m.group(1) if m else n[:28]
 ks = [(short(r["Kernel_Name"]), int(r["Start_Timestamp"]), int(r["End_Timestamp"])) for r in rows]
-# a call = k_mark .. k_filter_finalize
+# a call = the kernels up to and including k_filter_finalize (its first one differs by path: bounding box, a mark kernel, or the
+# by-cell accumulate kernel)
 calls, cur = [], []
 for k in ks:
-    if k[0].startswith("k_bbox_partial") or (k[0].startswith("k_mark") and not cur):
-        cur = [k]
-    elif cur:
-        cur.append(k)
-        if k[0].startswith("k_filter_finalize"):
-            calls.append(cur); cur = []
+    if not k[0].startswith("k_"):
+        continue
+    cur.append(k)
+    if k[0].startswith("k_filter_finalize"):
+        calls.append(cur); cur = []
 for c in calls[-3:]:
     t0 = c[0][1]
     prev = None
