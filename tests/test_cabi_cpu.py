@@ -194,3 +194,21 @@ def test_public_header_is_plain_c(tmp_path):
     inc = os.path.join(os.path.dirname(HERE), "include")
     subprocess.run(["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-I", inc, "-fsyntax-only", str(src)], check=True)
     subprocess.run(["g++", "-std=c++11", "-Wall", "-Werror", "-I", inc, "-fsyntax-only", "-x", "c++", str(src)], check=True)
+
+
+def test_fptr_points_at_the_array_for_every_kind_of_float32_array():
+    """capi.fptr hands `float *` arguments to the C-ABI: the fast path (a ctypes array over the buffer) and the general one (read-only
+    or non-contiguous arrays) must both address the array's own memory, and a write through the pointer must land in the array."""
+    import ctypes as C
+    a = np.arange(16, dtype=np.float32)
+    p = capi.fptr(a)
+    assert C.addressof(p) == a.ctypes.data if not isinstance(p, C._Pointer) else C.cast(p, C.c_void_p).value == a.ctypes.data
+    C.memmove(p, (C.c_float * 2)(7.0, 9.0), 8)
+    assert a[0] == 7.0 and a[1] == 9.0
+    ro = np.arange(16, dtype=np.float32)
+    ro.setflags(write=False)
+    q = capi.fptr(ro)
+    assert C.cast(q, C.c_void_p).value == ro.ctypes.data
+    T = capi.colmajor(np.arange(16, dtype=np.float32).reshape(4, 4))
+    assert np.array_equal(capi.from_colmajor(T), np.arange(16, dtype=np.float32).reshape(4, 4))
+    assert np.array_equal(capi.from_colmajor(list(T)), np.arange(16, dtype=np.float32).reshape(4, 4))
