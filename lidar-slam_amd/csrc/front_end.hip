@@ -157,6 +157,10 @@ struct lsa_front_end {
   // how a key-frame's read of a caller-owned device cloud is made safe: 2 (default) the frame filter's first kernel leaves a copy in a
   // buffer of this handle; 1 the context's stream is ordered behind the update's read (what remains without a frame filter);
   // 0 neither — the pre-round-5 contract, the A/B arm of profiles/r05_fe_cloud_ab.log only.  LSA_FE_CLOUD=keep|event|none
+  // a single Update enqueues the registration's first pass kernel (parked for its mail) BEHIND the frame filter's kernels before it
+  // waits for the filter: launch + dispatch of that kernel pass under the filter instead of between the filter and the first pass
+  // (kernel trace of the scan-by-scan loop: 18.5 us of idle GPU there, `profiles/r05_fe_prearm_ab.log`).  LSA_FE_PREARM=0: off.
+  bool prearm_single = getenv("LSA_FE_PREARM") ? atoi(getenv("LSA_FE_PREARM")) != 0 : true;
   int cloud_mode = !getenv("LSA_FE_CLOUD") ? 2 : (!strcmp(getenv("LSA_FE_CLOUD"), "none") ? 0 : (!strcmp(getenv("LSA_FE_CLOUD"), "event") ? 1 : 2));
   bool incremental = getenv("LSA_FE_INCREMENTAL") ? atoi(getenv("LSA_FE_INCREMENTAL")) != 0 : true;
   bool lm_off = false;       // fell back to the full build for good (window / table limits, coordinates out of range)
@@ -174,6 +178,8 @@ bool ndt_defer_scope(lsa_ndt *h, bool on);
 int ndt_collect_deferred(lsa_ndt *h);
 int lsa_voxel_filter_apply_device_async_here(lsa_voxel_filter *f, const float *d_in_xyzw, size_t n, float *d_out_xyzw);   // voxel_filter.hip
 int lsa_voxel_filter_apply_device_keep(lsa_voxel_filter *f, const float *d_in_xyzw, size_t n, float *d_out_xyzw, size_t *n_out, float *d_keep);
+int lsa_voxel_filter_enqueue_device(lsa_voxel_filter *f, const float *d_in_xyzw, size_t n, float *d_out_xyzw, float *d_keep);
+int lsa_voxel_filter_wait_parked(lsa_voxel_filter *f, size_t *n_out);
 int lsa_voxel_filter_apply_host_async(lsa_voxel_filter *f, const void *in_pts, size_t n, size_t in_stride, size_t in_w_off, float *d_rows, float *d_out);
 int lsa_voxel_filter_apply_host_to_device(lsa_voxel_filter *f, const void *in_pts, size_t n, size_t in_stride, size_t in_w_off, float *d_rows, float *d_out,
                                           size_t *n_out, int *pulled);
@@ -461,6 +467,7 @@ int fe_update_device(lsa_front_end *fe, const float4 *d_cloud, size_t n, float p
   if (fe->cfg.use_frame_filter) {
     if ((rc = fe->d_filtered.reserve(ctx, n ? n : 1, 1.25))) return rc;
     size_t V = 0;
+    float4 *keep_p = nullptr;
     if (callers_buffer && n && fe->incremental && !fe->lm_off && fe->cloud_mode == 2) {
       DevBuf<float4> &keep = fe->in_alt ? fe->d_in_alt : fe->d_in;
       fe->in_alt = !fe->in_alt;
@@ -469,11 +476,17 @@ int fe_update_device(lsa_front_end *fe, const float4 *d_cloud, size_t n, float p
         if ((rc = fe_map_drain(fe))) return rc;
         if ((rc = keep.reserve(ctx, n, 1.25))) return rc;
       }
-      rc = lsa_voxel_filter_apply_device_keep(fe->frame_filter, (const float *)d_cloud, n, (float *)fe->d_filtered.p, &V, (float *)keep.p);
-      if (rc == LSA_OK || rc == LSA_ERR_RANGE) { d_cloud = keep.p; fe->cloud_is_callers = false; }
-    } else {
-      rc = lsa_voxel_filter_apply_device(fe->frame_filter, (const float *)d_cloud, n, (float *)fe->d_filtered.p, &V);
+      keep_p = keep.p;
     }
+    // the filter's launches, then — where a ScanMatch follows — the registration's first pass kernel behind them, then the wait
+    if ((rc = lsa_voxel_filter_enqueue_device(fe->frame_filter, (const float *)d_cloud, n, (float *)fe->d_filtered.p, (float *)keep_p))) return rc;
+    if (fe->prearm_single && n && !fe->frames.empty()) {
+      // (the pass reads the table: the stream goes behind a map update still in flight first, as fe_lm_settle would order it)
+      if ((rc = fe_map_join(fe))) return rc;
+      ndt_prearm(fe->ndt);
+    }
+    rc = lsa_voxel_filter_wait_parked(fe->frame_filter, &V);
+    if (keep_p && (rc == LSA_OK || rc == LSA_ERR_RANGE)) { d_cloud = keep_p; fe->cloud_is_callers = false; }
     if (rc == LSA_OK) { src = fe->d_filtered.p; n_src = V; }
     else if (rc != LSA_ERR_RANGE) return rc;
     else if (src != d_cloud) src = d_cloud;   // (PCL passes the input through: the copy, if there is one)

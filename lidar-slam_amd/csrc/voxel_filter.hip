@@ -153,7 +153,7 @@ int filter_device(lsa_voxel_filter *f, const float4 *d_in, size_t n, float4 *d_o
 
 // the enqueue half of filter_device (attempt 0 only); filter_wait() completes it and falls back to the synchronous path
 // if the bitmap capacity has to grow
-int filter_enqueue(lsa_voxel_filter *f, const float4 *d_in, size_t n, float4 *d_out, const PullSource *pull = nullptr) {
+int filter_enqueue(lsa_voxel_filter *f, const float4 *d_in, size_t n, float4 *d_out, const PullSource *pull = nullptr, float4 *d_keep = nullptr) {
   lsa_context *ctx = f->ctx;
   VoxelIndex &vi = f->vi;
   int rc;
@@ -161,7 +161,7 @@ int filter_enqueue(lsa_voxel_filter *f, const float4 *d_in, size_t n, float4 *d_
   // While the registration still waited for its stream after every pass, a lighter background filter made the overlapped
   // pipeline slower; since the passes hand their rows over without a stream wait it is the other way round (5 A/B pairs:
   // +6 %).  A point outside the reused cell box is caught by filter_wait(), which rebuilds exactly.
-  rc = vi_enqueue(ctx, vi, d_in, n, /*mode PCL*/ 0, f->leaf, 4, /*allow_spec*/ true, pull);
+  rc = vi_enqueue(ctx, vi, d_in, n, /*mode PCL*/ 0, f->leaf, 4, /*allow_spec*/ true, pull, d_keep);
   if (rc) return rc;
   hipLaunchKernelGGL(k_filter_finalize, dim3(lsa_div_up(n, kBlock)), dim3(kBlock), 0, ctx->stream, vi.acc.p, vi.cnt.p, vi.cell_of_rank.p, vi.dparams.p, d_out,
                      vi.h_params.p, vi.bits.p, vi.by_cell ? 1 : 0);
@@ -467,13 +467,38 @@ void lsa_voxel_filter_retire_end(lsa_voxel_filter *f) {
   f->retiring = false;
 }
 
-extern "C" int lsa_voxel_filter_wait(lsa_voxel_filter *f, size_t *n_out) {
+// internal (front_end.hip): lsa_voxel_filter_apply_device[_keep] in two halves on the CALLER's thread — the launches now, the wait in
+// lsa_voxel_filter_wait_parked — so that the caller can enqueue something of its own behind the filter's kernels in between (the
+// registration's first pass kernel, parked for its mail: FrontEnd::Update).  d_keep may be null.
+int lsa_voxel_filter_enqueue_device(lsa_voxel_filter *f, const float *d_in_xyzw, size_t n, float *d_out_xyzw, float *d_keep) {
+  if (!f || (n && (!d_in_xyzw || !d_out_xyzw))) return f ? lsa_fail(f->ctx, LSA_ERR_INVALID, "lsa_voxel_filter_enqueue_device: null argument") : LSA_ERR_INVALID;
+  if (f->pending) return lsa_fail(f->ctx, LSA_ERR_INVALID, "lsa_voxel_filter_enqueue_device: a filter is already in flight on this handle");
+  LSA_HIP(f->ctx, lsa_enter(f->ctx));
+  f->p_in = (const float4 *)d_in_xyzw; f->p_out = (float4 *)d_out_xyzw; f->p_n = n;
+  f->pending = true;
+  if (n == 0) return LSA_OK;
+  f->job_rc = filter_enqueue(f, f->p_in, n, f->p_out, nullptr, (float4 *)d_keep);
+  f->job_state.store(2, std::memory_order_release);
+  return LSA_OK;
+}
+
+static int filter_wait_impl(lsa_voxel_filter *f, size_t *n_out, bool keep_parked);
+
+// ... the second half: like lsa_voxel_filter_wait, but a kernel parked on this context's stream behind the filter's stays parked
+// unless the build has to be repeated (a point outside the reused cell box, a bitmap to grow: then it is released first — the
+// repeat's kernels would queue behind it for its whole patience)
+int lsa_voxel_filter_wait_parked(lsa_voxel_filter *f, size_t *n_out) { return filter_wait_impl(f, n_out, true); }
+
+extern "C" int lsa_voxel_filter_wait(lsa_voxel_filter *f, size_t *n_out) { return filter_wait_impl(f, n_out, false); }
+
+static int filter_wait_impl(lsa_voxel_filter *f, size_t *n_out, bool keep_parked) {
   if (!f || !n_out) return f ? lsa_fail(f->ctx, LSA_ERR_INVALID, "lsa_voxel_filter_wait: null argument") : LSA_ERR_INVALID;
   if (!f->pending) return lsa_fail(f->ctx, LSA_ERR_INVALID, "lsa_voxel_filter_wait: nothing in flight");
   f->pending = false;
   *n_out = 0;
   if (f->p_n == 0) return LSA_OK;
-  LSA_HIP(f->ctx, lsa_enter(f->ctx));
+  if (keep_parked) LSA_HIP(f->ctx, hipSetDevice(f->ctx->device));
+  else LSA_HIP(f->ctx, lsa_enter(f->ctx));
   while (f->job_state.load(std::memory_order_acquire) != 2) {}  // the helper is still issuing the launches (<= ~30 us)
   f->job_state.store(0, std::memory_order_release);
   if (f->job_rc) return f->job_rc;
@@ -481,6 +506,12 @@ extern "C" int lsa_voxel_filter_wait(lsa_voxel_filter *f, size_t *n_out) {
   int rc = vi_wait(f->ctx, f->vi, &status);
   if (rc) return rc;
   f->vi.clean = (status == VI_OK || status == VI_SPEC_MISS);  // the finalize kernel zeroed what this build touched
+  if (keep_parked) {
+    if (status == VI_OK || status == VI_RANGE) f->n_calls++;   // (a repeat counts itself, in filter_device)
+    if (status == VI_SPEC_MISS && !f->vi.last_pull_timeout) f->n_miss++;
+    if (status == VI_CAPACITY) f->n_cap++;
+    if (status == VI_SPEC_MISS || status == VI_CAPACITY) lsa_ctx_unpark(f->ctx);   // (the repeat goes in front of nothing parked)
+  }
   if (status == VI_SPEC_MISS && f->vi.last_pull_timeout) {
     // Not a point outside the reused box: the pulling kernel's tiles gave up waiting for their chunks and never wrote those rows
     // into p_in — a rebuild from p_in would filter whatever the buffer held before.  The rows themselves are complete by now (the
