@@ -182,7 +182,7 @@ int lsa_voxel_filter_enqueue_device(lsa_voxel_filter *f, const float *d_in_xyzw,
 int lsa_voxel_filter_wait_parked(lsa_voxel_filter *f, size_t *n_out);
 int lsa_voxel_filter_apply_host_async(lsa_voxel_filter *f, const void *in_pts, size_t n, size_t in_stride, size_t in_w_off, float *d_rows, float *d_out);
 int lsa_voxel_filter_apply_host_to_device(lsa_voxel_filter *f, const void *in_pts, size_t n, size_t in_stride, size_t in_w_off, float *d_rows, float *d_out,
-                                          size_t *n_out, int *pulled);
+                                          size_t *n_out, int *pulled, void (*after_enqueue)(void *), void *after_user);
 
 static int fe_batch_context(lsa_front_end *fe);
 static int fe_host_batch_context(lsa_front_end *fe);
@@ -457,6 +457,11 @@ int fe_update_filtered(lsa_front_end *fe, const float4 *d_cloud, size_t n, const
 // by the next call, which fills the other) and everything behind the filter works on that copy: 2 MB of stores per scan inside a
 // latency-bound kernel instead of an event that holds the next scan's filter back behind the update's first kernel (measured:
 // profiles/r05_fe_cloud_ab.log).  Without a frame filter the event is what orders the caller's stream (fe_rebuild_map).
+void fe_prearm_cb(void *user) {
+  lsa_front_end *fe = (lsa_front_end *)user;
+  if (fe_map_join(fe) == LSA_OK) ndt_prearm(fe->ndt);
+}
+
 int fe_update_device(lsa_front_end *fe, const float4 *d_cloud, size_t n, float pose_out[16], lsa_front_end_stats *stats, bool callers_buffer) {
   lsa_context *ctx = fe->ctx;
   int rc;
@@ -806,7 +811,9 @@ extern "C" int lsa_front_end_update(lsa_front_end *fe, const void *cloud, size_t
     if ((rc = fe->d_filtered.reserve(ctx, n, 1.25))) return rc;
     size_t V = 0;
     int pulled = 0;
-    rc = lsa_voxel_filter_apply_host_to_device(fe->frame_filter, cloud, n, stride, w_off, (float *)din.p, (float *)fe->d_filtered.p, &V, &pulled);
+    // (behind the pulled build's kernels, before this thread joins the packing: the registration's first pass kernel, as in fe_update_device)
+    rc = lsa_voxel_filter_apply_host_to_device(fe->frame_filter, cloud, n, stride, w_off, (float *)din.p, (float *)fe->d_filtered.p, &V, &pulled,
+                                               (fe->prearm_single && !fe->frames.empty()) ? fe_prearm_cb : nullptr, fe);
     if (pulled) {
       if (rc && rc != LSA_ERR_RANGE) return rc;
       lsa_front_end_stats local;

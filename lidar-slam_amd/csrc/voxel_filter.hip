@@ -110,7 +110,10 @@ void filter_pull_join(lsa_voxel_filter *f);
 // them (filter_pull_join: this thread packs too, then waits for the helper); d_in is where the kernel leaves them, so a rebuild
 // after a speculative miss finds them resident
 // d_keep: the mark kernel of every attempt also copies the rows it reads there (lsa_voxel_filter_apply_device_keep)
-int filter_device(lsa_voxel_filter *f, const float4 *d_in, size_t n, float4 *d_out, size_t *n_out, const PullSource *pull = nullptr, float4 *d_keep = nullptr) {
+// after_enqueue (pulled attempt only): called once the first attempt's kernels are enqueued, before this thread starts packing —
+// the caller's own launch behind the filter's (FrontEnd::Update: the registration's first pass kernel, parked for its mail)
+int filter_device(lsa_voxel_filter *f, const float4 *d_in, size_t n, float4 *d_out, size_t *n_out, const PullSource *pull = nullptr, float4 *d_keep = nullptr,
+                  void (*after_enqueue)(void *) = nullptr, void *after_user = nullptr) {
   lsa_context *ctx = f->ctx;
   *n_out = 0;
   if (n == 0) return LSA_OK;
@@ -130,6 +133,7 @@ int filter_device(lsa_voxel_filter *f, const float4 *d_in, size_t n, float4 *d_o
     }
     if (!rc) rc = vi_mark_done(ctx, vi);
     if (pulling && f->stats_on) f->st_enqueue += std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - tq0).count();
+    if (pulling && !rc && after_enqueue) after_enqueue(after_user);
     if (pulling) filter_pull_join(f);   // (also behind a failed enqueue: the helper thread is packing the caller's cloud and must be done before this returns)
     if (rc) return rc;
     const auto tw0 = std::chrono::steady_clock::now();
@@ -140,6 +144,7 @@ int filter_device(lsa_voxel_filter *f, const float4 *d_in, size_t n, float4 *d_o
       f->n_pull_timeouts++;
       return lsa_fail(ctx, LSA_ERR_HIP, "voxel filter: the device waited in vain for the packed rows of the host cloud");
     }
+    if (after_enqueue && (status == VI_SPEC_MISS || status == VI_CAPACITY)) lsa_ctx_unpark(ctx);   // (the repeat goes in front of nothing parked)
     if (status == VI_SPEC_MISS) { f->n_miss++; continue; }  // a point fell outside the reused cell box: rebuild from the bounding box
     if (status != VI_CAPACITY) break;
     f->n_cap++;
@@ -720,7 +725,7 @@ int filter_pull_begin(lsa_voxel_filter *f, const void *in_pts, size_t n, size_t 
 // end keeps a key-frame's raw cloud) and the filtered cloud in d_out — by the pulled path above.  *pulled = 0: its preconditions do
 // not hold (first scan of a stream, a small cloud, LSA_FILTER_PULL=0): nothing was done, the caller uploads and filters the ordinary way.
 int lsa_voxel_filter_apply_host_to_device(lsa_voxel_filter *f, const void *in_pts, size_t n, size_t in_stride, size_t in_w_off, float *d_rows, float *d_out,
-                                          size_t *n_out, int *pulled) {
+                                          size_t *n_out, int *pulled, void (*after_enqueue)(void *), void *after_user) {
   *pulled = 0;
   *n_out = 0;
   if (!f || !in_pts || !d_rows || !d_out) return LSA_ERR_INVALID;
@@ -733,7 +738,7 @@ int lsa_voxel_filter_apply_host_to_device(lsa_voxel_filter *f, const void *in_pt
   PullSource pull;
   if ((rc = filter_pull_begin(f, in_pts, n, in_stride, in_w_off, reinterpret_cast<float4 *>(d_rows), &pull))) return rc;
   *pulled = 1;
-  return filter_device(f, reinterpret_cast<const float4 *>(d_rows), n, reinterpret_cast<float4 *>(d_out), n_out, &pull);
+  return filter_device(f, reinterpret_cast<const float4 *>(d_rows), n, reinterpret_cast<float4 *>(d_out), n_out, &pull, nullptr, after_enqueue, after_user);
 }
 
 extern "C" int lsa_voxel_filter_apply(lsa_voxel_filter *f, const void *in_pts, size_t n, size_t in_stride, size_t in_w_off, void *out_pts,
