@@ -21,13 +21,12 @@ constexpr int kBlock = 256;
 __global__ __launch_bounds__(kBlock) void k_ndt_finalize(long long *__restrict__ acc, int32_t *__restrict__ cnt,
                                                          const int32_t *__restrict__ cell_of_rank, size_t nocc, CellMap m, FixScales fs,
                                                          double *__restrict__ rec, int32_t *__restrict__ state, int32_t *__restrict__ counts,
-                                                         uint32_t *__restrict__ vbits, int pcl, int by_cell /* VoxelIndex::by_cell */) {
+                                                         uint32_t *__restrict__ vbits, int pcl) {
   size_t r = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (r >= nocc) return;
+  long long *a = acc + r * 10;
+  int ni = cnt[r];
   int cell = cell_of_rank[r];
-  const size_t key = by_cell ? (size_t)cell : r;
-  long long *a = acc + key * 10;
-  int ni = cnt[key];
   double o[3];
   lsa_cell_origin(m, cell, o);
   long long av[10];
@@ -41,7 +40,7 @@ __global__ __launch_bounds__(kBlock) void k_ndt_finalize(long long *__restrict__
   counts[r] = ni;
 #pragma unroll
   for (int k = 0; k < 10; k++) a[k] = 0;
-  cnt[key] = 0;
+  cnt[r] = 0;
 }
 
 // {occupancy, valid, prefix} per 32 cells in one 16-byte word; the index's own bitmap word is cleared on the way (the
@@ -158,7 +157,6 @@ int ndt_build_grid(lsa_ndt *h, const float4 *d_pts, size_t n) {
   h->rec_ext = nullptr; h->dense_ext = nullptr;   // an ordinary table from here on
   int rc, status = VI_OK;
   const float leaf[3] = {h->resolution, h->resolution, h->resolution};
-  vi.allow_by_cell = true;    // k_ndt_finalize reads and clears the rows by their key (used when mirror_at_scan is off)
   vi.mirror_at_scan = true;   // the definition and the occupied-cell count reach the host behind k_scan (no copy command, k_accum still running)
   for (int attempt = 0; attempt < 2; attempt++) {
     if ((rc = vi_enqueue(ctx, vi, d_pts, n, /*mode NDT*/ 1, leaf, 10))) return rc;
@@ -177,7 +175,7 @@ int ndt_build_grid(lsa_ndt *h, const float4 *d_pts, size_t n) {
   if ((rc = h->counts.reserve(ctx, V + 1, 1.25))) return rc;
   fill16(ctx, h->vbits.p, vi.W * sizeof(uint32_t), 0u);
   hipLaunchKernelGGL(k_ndt_finalize, dim3(lsa_div_up(V, kBlock)), dim3(kBlock), 0, ctx->stream, vi.acc.p, vi.cnt.p, vi.cell_of_rank.p, V, vi.map, vi.fs,
-                     h->rec.p, h->state.p, h->counts.p, h->vbits.p, h->mode == LSA_NDT_MODE_PCL ? 1 : 0, vi.by_cell ? 1 : 0);
+                     h->rec.p, h->state.p, h->counts.p, h->vbits.p, h->mode == LSA_NDT_MODE_PCL ? 1 : 0);
   hipLaunchKernelGGL(k_pack_words, dim3(lsa_div_up(vi.W, kBlock)), dim3(kBlock), 0, ctx->stream, vi.bits.p, h->vbits.p, vi.prefix.p, vi.W, h->words.p);
   vi.clean = true;  // sums, counts and bitmap words of this build are zero again
   // dense probe table when the cell box is small enough (16 B per cell; default limit 16 Mi cells = 256 MiB)

@@ -92,15 +92,14 @@ __global__ __launch_bounds__(kBlock) void k_filter_finalize(long long *__restric
   const FixScales fs = dp->fs;
   double o[3];
   const int cell = cell_of_rank[r];
-  const size_t key = by_cell ? (size_t)cell : r;
-  long long *a = acc + key * 4;
+  // one 64-byte row per occupied cell, keyed by the cell or by its rank: four sums and, as the fifth word, the count
+  long long *a = acc + (by_cell ? (size_t)cell : r) * kByCellStride;
   lsa_cell_origin(m, cell, o);
   const long long av[4] = {a[0], a[1], a[2], a[3]};
-  out[r] = vi_filter_mean(av, cnt[key], o, fs);
+  out[r] = vi_filter_mean(av, (int)a[4], o, fs);
   // leave the index clean for the next scan (was a separate clean-up launch): this cell's sums, its count and its
   // bitmap word (cells sharing the word all store the same zero)
-  a[0] = 0; a[1] = 0; a[2] = 0; a[3] = 0;
-  cnt[key] = 0;
+  a[0] = 0; a[1] = 0; a[2] = 0; a[3] = 0; a[4] = 0;
   bits[cell >> 5] = 0u;
 }
 

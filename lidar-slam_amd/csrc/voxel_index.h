@@ -91,8 +91,11 @@ struct VoxelIndex {
   DevBuf<int32_t> cell_of_rank, cnt, cell_idx;
   // Large clouds (>= 512 k points) of an owner whose finalize kernel clears the rows it reads BY KEY may be summed into rows indexed
   // by the cell (k_accum<.., BY_CELL>): by_cell says how the LAST build keyed acc[] / cnt[] — row cell_of_rank[r] instead of row r.
-  // Rows: W_cap * 32 cells x (ns * 8 + 4) bytes (151 MB for the reserved 2^17-word bitmap at ns = 4), only while that stays below
-  // kByCellMaxBytes; all zero between builds like the rank-keyed rows.
+  // Such a row is ONE 64-byte line — the ns = 4 sums and the count as a fifth 64-bit word, padded to kByCellStride words — so that a
+  // tile's adds for a cell leave as one atomic instruction touching one line: one request to the memory side per (tile, cell) pair,
+  // where the rank-keyed layout (32-byte row + a count array of its own) sends two, and the request rate is what the flush of a 0.3 m
+  // build runs at.  W_cap * 32 cells x 64 bytes (268 MB for the reserved 2^17-word bitmap), only while that stays below
+  // kByCellMaxBytes; all zero between builds like the rank-keyed rows.  VoxelFilter (ns = 4) only.
   bool allow_by_cell = false, by_cell = false;
   bool want_cell_idx = false;   // the owner reads cell_idx[] (the linear cell of every point, -1 = none) behind the build: nn_grid.hip
   DevBuf<long long> acc;
@@ -164,5 +167,10 @@ int vi_grow(lsa_context *ctx, VoxelIndex &vi);
 int vi_cleanup(lsa_context *ctx, VoxelIndex &vi, size_t n);
 int vi_prepare_large(lsa_context *ctx, VoxelIndex &vi, int ns);
 constexpr size_t kByCellMaxBytes = (size_t)1 << 30;
+constexpr size_t kByCellStride = 8;   // 64-bit words per cell-keyed row (ns = 4: four sums, the count, three spare)
+// 64-bit words per row of acc[], whatever the key: the ns = 4 rows of VoxelFilter are one 64-byte line each with the count as their
+// fifth word (cnt[] unused) — one atomic request per (tile, cell) pair instead of two; the ns = 10 rows of the voxel table stay
+// 80 bytes + cnt[] (their finalize kernels are shared with the incremental map's arithmetic and read them as they are)
+constexpr size_t vi_row_stride(int ns) { return ns == 4 ? kByCellStride : (size_t)ns; }
 
 #endif

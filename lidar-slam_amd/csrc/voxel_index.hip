@@ -767,12 +767,20 @@ __global__ __launch_bounds__(kBlock) void k_accum(const float4 *__restrict__ pts
       for (int j = 0; j < NS; j++) atomicAdd(&sums[sl][j], rs[j]);
       atomicAdd(&counts[sl], rn);
     } else {  // table full: straight to memory
-      unsigned rank = BY_CELL ? (unsigned)cell : cell_rank(bits, prefix, cell);
-      unsigned long long *a = (unsigned long long *)(acc + (size_t)rank * NS);
+      if constexpr (BY_CELL) {
+        unsigned long long *a = (unsigned long long *)acc + (size_t)(unsigned)cell * kByCellStride;
 #pragma unroll
-      for (int j = 0; j < NS; j++) atomicAdd(a + j, rs[j]);
-      atomicAdd(cnt + rank, rn);
-      if (BY_CELL) occ[cell] = (uint8_t)1;
+        for (int j = 0; j < NS; j++) atomicAdd(a + j, rs[j]);
+        atomicAdd(a + NS, (unsigned long long)(unsigned)rn);
+        occ[cell] = (uint8_t)1;
+      } else {
+        unsigned rank = cell_rank(bits, prefix, cell);
+        unsigned long long *a = (unsigned long long *)acc + (size_t)rank * vi_row_stride(NS);
+#pragma unroll
+        for (int j = 0; j < NS; j++) atomicAdd(a + j, rs[j]);
+        if (NS == 4) atomicAdd(a + NS, (unsigned long long)(unsigned)rn);
+        else atomicAdd(cnt + rank, rn);
+      }
     }
   };
   bool open = false;
@@ -849,10 +857,15 @@ __global__ __launch_bounds__(kBlock) void k_accum(const float4 *__restrict__ pts
       const int e = e0 + q * kBlock + (int)threadIdx.x;
       if (rk[q] < 0) continue;
       const int sl = e / (NS + 1), j = e - sl * (NS + 1);
-      if (j < NS) atomicAdd((unsigned long long *)(acc + (size_t)(unsigned)rk[q] * NS) + j, sums[sl][j]);
-      else {
-        atomicAdd(cnt + (unsigned)rk[q], counts[sl]);
-        if (BY_CELL) occ[(unsigned)rk[q]] = (uint8_t)1;   // the cell's byte mark (plain store: see k_mark_bytes)
+      if constexpr (BY_CELL) {
+        // the cell's NS sums and its count: NS + 1 adjacent lanes, ONE 64-bit atomic instruction, one 64-byte line
+        atomicAdd((unsigned long long *)acc + (size_t)(unsigned)rk[q] * kByCellStride + j, j < NS ? sums[sl][j < NS ? j : 0] : (unsigned long long)(unsigned)counts[sl]);
+        if (j == NS) occ[(unsigned)rk[q]] = (uint8_t)1;   // the cell's byte mark (plain store: see k_mark_bytes)
+      } else if constexpr (NS == 4) {   // (the same one-line rows, keyed by the rank)
+        atomicAdd((unsigned long long *)acc + (size_t)(unsigned)rk[q] * kByCellStride + j, j < NS ? sums[sl][j < NS ? j : 0] : (unsigned long long)(unsigned)counts[sl]);
+      } else {
+        if (j < NS) atomicAdd((unsigned long long *)(acc + (size_t)(unsigned)rk[q] * NS) + j, sums[sl][j]);
+        else atomicAdd(cnt + (unsigned)rk[q], counts[sl]);
       }
     }
   }
@@ -867,10 +880,14 @@ __global__ __launch_bounds__(kBlock) void k_cleanup(const DevParams *__restrict_
   size_t r = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (r >= dp->V) return;
   const int cell = cell_of_rank[r];
-  const size_t key = by_cell ? (size_t)cell : r;
   bits[cell >> 5] = 0u;
-  for (int j = 0; j < ns; j++) acc[key * ns + j] = 0;
-  cnt[key] = 0;
+  const size_t key = by_cell ? (size_t)cell : r;
+  if (ns == 4) {
+    for (int j = 0; j <= ns; j++) acc[key * kByCellStride + j] = 0;
+  } else {
+    for (int j = 0; j < ns; j++) acc[key * ns + j] = 0;
+    cnt[key] = 0;
+  }
 }
 
 inline unsigned stream_grid(lsa_context *ctx, size_t n) {
@@ -897,7 +914,7 @@ int vi_prepare(lsa_context *ctx, VoxelIndex &vi, size_t n, int ns, size_t w_min)
   if (vi.want_cell_idx && (rc = vi.cell_idx.reserve(ctx, n, 1.25))) return rc;
   if ((rc = vi.cell_of_rank.reserve(ctx, n, 1.25))) return rc;
   if ((rc = vi.cnt.reserve(ctx, n + 1, 1.25))) return rc;
-  if ((rc = vi.acc.reserve(ctx, (n + 1) * (size_t)ns, 1.25))) return rc;
+  if ((rc = vi.acc.reserve(ctx, (n + 1) * vi_row_stride(ns), 1.25))) return rc;
   if (vi.cnt.cap != old_cnt || vi.acc.cap != old_acc || vi.cell_of_rank.cap != old_cor || vi.acc_ns != ns) vi.clean = false;
   if (vi.W_cap == 0 && w_min < 4096) w_min = 4096;
   if (vi.W_cap < w_min) {
@@ -930,11 +947,9 @@ int vi_prepare_large(lsa_context *ctx, VoxelIndex &vi, int ns) {
     vi.occ_words = vi.W_cap;
   }
   const size_t cells_cap = vi.W_cap * 32;
-  if (vi.allow_by_cell && !vi.mirror_at_scan && cells_cap * ((size_t)ns * 8 + 4) <= kByCellMaxBytes &&
-      (vi.acc.cap < cells_cap * (size_t)ns || vi.cnt.cap < cells_cap)) {
+  if (vi.allow_by_cell && ns == 4 && !vi.mirror_at_scan && cells_cap * kByCellStride * 8 <= kByCellMaxBytes && vi.acc.cap < cells_cap * kByCellStride) {
     LSA_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    if ((rc = vi.acc.reserve(ctx, cells_cap * (size_t)ns))) return rc;
-    if ((rc = vi.cnt.reserve(ctx, cells_cap))) return rc;
+    if ((rc = vi.acc.reserve(ctx, cells_cap * kByCellStride))) return rc;
     vi.clean = false;
   }
   return LSA_OK;
@@ -956,12 +971,11 @@ int vi_enqueue(lsa_context *ctx, VoxelIndex &vi, const float4 *d_pts, size_t n, 
   const size_t cells_cap = vi.W_cap * 32;
   // (not for an owner that waits behind the scan while the sums are still running, mirror_at_scan: by cell the sums come FIRST,
   // and SetInputTarget of 2 M points measured 0.106 ms that way against 0.098 with its host work under the accumulation)
-  const bool by_cell = vi.allow_by_cell && !vi.mirror_at_scan && !pull && n >= kSmallInput && cells_cap * ((size_t)ns * 8 + 4) <= kByCellMaxBytes &&
+  const bool by_cell = vi.allow_by_cell && ns == 4 && !vi.mirror_at_scan && !pull && n >= kSmallInput && cells_cap * kByCellStride * 8 <= kByCellMaxBytes &&
                        by_cell_on;
-  if (by_cell && (vi.acc.cap < cells_cap * (size_t)ns || vi.cnt.cap < cells_cap)) {
-    LSA_HIP(ctx, hipStreamSynchronize(ctx->stream));   // (the reserves free the old rows)
-    if ((rc = vi.acc.reserve(ctx, cells_cap * (size_t)ns))) return rc;
-    if ((rc = vi.cnt.reserve(ctx, cells_cap))) return rc;
+  if (by_cell && vi.acc.cap < cells_cap * kByCellStride) {
+    LSA_HIP(ctx, hipStreamSynchronize(ctx->stream));   // (the reserve frees the old rows)
+    if ((rc = vi.acc.reserve(ctx, cells_cap * kByCellStride))) return rc;
     vi.clean = false;
   }
   vi.by_cell = by_cell;
@@ -1028,10 +1042,8 @@ int vi_enqueue(lsa_context *ctx, VoxelIndex &vi, const float4 *d_pts, size_t n, 
       vi.occ_words = vi.W_cap;
     }
     if (by_cell) {   // ONE pass over the points: the sums by cell and the byte marks (k_accum<.., BY_CELL>); pack and scan run behind it
-      if (ns == 4) hipLaunchKernelGGL((k_accum<4, kTileBig, true>), dim3(lsa_div_up(n, kTileBig)), dim3(kBlock), 0, ctx->stream, d_pts, n, dp, kp, vi.bits.p, vi.prefix.p,
-                                      vi.acc.p, vi.cnt.p, vi.occ.p, d_keep, st_acc);
-      else hipLaunchKernelGGL((k_accum<10, kTileBig, true>), dim3(lsa_div_up(n, kTileBig)), dim3(kBlock), 0, ctx->stream, d_pts, n, dp, kp, vi.bits.p, vi.prefix.p,
-                              vi.acc.p, vi.cnt.p, vi.occ.p, d_keep, st_acc);
+      hipLaunchKernelGGL((k_accum<4, kTileBig, true>), dim3(lsa_div_up(n, kTileBig)), dim3(kBlock), 0, ctx->stream, d_pts, n, dp, kp, vi.bits.p, vi.prefix.p,
+                         vi.acc.p, vi.cnt.p, vi.occ.p, d_keep, st_acc);
     } else {
       hipLaunchKernelGGL((k_mark_bytes<kTileBig / kBlock>), dim3(lsa_div_up(n, kTileBig)), dim3(kBlock), 0, ctx->stream, d_pts, n, dp, kp, vi.occ.p, vi.cell_idx.p, d_keep,
                          vi.stamps.p);
