@@ -491,10 +491,10 @@ def main():
         # what rocprofv3's kernel trace of the same command says for that kernel (committed summary under profiles/; the traced run
         # is slower on the host side — the tracer sits in every API call — so its kernels wait longer for their mail than here)
         rocprof_avg = None
-        # (r04_final_headline_*: the trace of `bench.py --steps 2000 --warmup 20 --ramp-seconds 0.5 --no-cpu-baseline --no-large --streams 0 --no-extra`,
+        # (r05_final_headline_*: the trace of `bench.py --steps 2000 --warmup 20 --ramp-seconds 0.5 --no-cpu-baseline --no-large --streams 0 --no-extra`,
         # i.e. of the headline's own dispatches; the *_bench_kernel_stats.csv beside it averages over every section of the full command —
         # the front-end loops' armed kernels wait through a frame filter for their mail)
-        for pname in ("r04_final_headline_kernel_stats.csv", "r04_final_bench_kernel_stats.csv", "r03_final_bench_kernel_stats.csv", "r03_a_bench_kernel_stats.csv"):
+        for pname in ("r05_final_headline_kernel_stats.csv", "r05_final_bench_kernel_stats.csv", "r04_final_headline_kernel_stats.csv", "r04_final_bench_kernel_stats.csv", "r03_final_bench_kernel_stats.csv", "r03_a_bench_kernel_stats.csv"):
             ppath = os.path.join(ROOT, "profiles", pname)
             if os.path.exists(ppath):
                 try:

@@ -568,7 +568,7 @@ extern "C" int lsa_voxel_filter_reserve(lsa_voxel_filter *f, size_t max_points, 
   LSA_HIP(f->ctx, lsa_enter(f->ctx));
   int rc = vi_prepare(f->ctx, f->vi, max_points ? max_points : 1, 4, (size_t)1 << 17);
   if (rc) return rc;
-  // clouds of half a million points and more take the large path of the build: its byte map and cell-keyed rows (155 MB at this
+  // clouds of half a million points and more take the large path of the build: its byte map and cell-keyed rows (272 MB at this
   // bitmap capacity) now, not under the first such call
   if (max_points >= 512 * 1024 && (rc = vi_prepare_large(f->ctx, f->vi, 4))) return rc;
   if (!f->vi.clean) {   // the bitmap and the accumulator rows are cleared here instead of under the first Filter call

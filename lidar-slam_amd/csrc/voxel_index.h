@@ -93,8 +93,8 @@ struct VoxelIndex {
   // by the cell (k_accum<.., BY_CELL>): by_cell says how the LAST build keyed acc[] / cnt[] — row cell_of_rank[r] instead of row r.
   // Such a row is ONE 64-byte line — the ns = 4 sums and the count as a fifth 64-bit word, padded to kByCellStride words — so that a
   // tile's adds for a cell leave as one atomic instruction touching one line: one request to the memory side per (tile, cell) pair,
-  // where the rank-keyed layout (32-byte row + a count array of its own) sends two, and the request rate is what the flush of a 0.3 m
-  // build runs at.  W_cap * 32 cells x 64 bytes (268 MB for the reserved 2^17-word bitmap), only while that stays below
+  // where a 32-byte row + a count array of its own sent two, and the request rate is what the flush of a 0.3 m build runs at (the
+  // rank-keyed rows of VoxelFilter have the same one-line layout, vi_row_stride).  W_cap * 32 cells x 64 bytes (268 MB for the reserved 2^17-word bitmap), only while that stays below
   // kByCellMaxBytes; all zero between builds like the rank-keyed rows.  VoxelFilter (ns = 4) only.
   bool allow_by_cell = false, by_cell = false;
   bool want_cell_idx = false;   // the owner reads cell_idx[] (the linear cell of every point, -1 = none) behind the build: nn_grid.hip
