@@ -669,11 +669,13 @@ __device__ __forceinline__ unsigned cell_rank(const uint32_t *__restrict__ bits,
   return prefix[cell >> 5] + __popc(bits[cell >> 5] & ((1u << (cell & 31)) - 1u));
 }
 
-// per-cell fixed-point sums: LDS pre-aggregation per tile, then one set of global atomics per distinct cell
-// BY_CELL (large clouds of an owner that cleans up by key, VoxelIndex::allow_by_cell): the rows of acc[] / cnt[] are indexed by the
+// per-cell fixed-point sums: LDS pre-aggregation per tile, then one set of global atomics per distinct cell.  Rows of acc[]: NS = 4
+// (VoxelFilter) one 64-byte line per key — four sums and the count as the fifth 64-bit word, so that a cell's adds are ONE atomic
+// instruction touching ONE line, one request to the memory side (vi_row_stride) —, NS = 10 (voxel table) ten words + cnt[].
+// BY_CELL (large clouds of an owner that cleans up by key, VoxelIndex::allow_by_cell; NS = 4 only): the rows are keyed by the
 // CELL, not by its rank among the occupied cells — the sums then need nothing the scan produces, and this kernel is the build's
 // only pass over the points: it also leaves the byte marks of the cells it met (no k_mark_bytes: one 32 MB read, one launch and
-// the rank look-ups of the flush less; 134 MB of rows for a 4.2 M-cell box, which 288 GB do not notice).  The scan runs behind it
+// the rank look-ups of the flush less; 268 MB of rows for a 4.2 M-cell box, which 288 GB do not notice).  The scan runs behind it
 // for the output order alone, and the owner's finalize kernel reads row cell_of_rank[r] instead of row r.
 template <int NS, int TILE, bool BY_CELL>
 __global__ __launch_bounds__(kBlock) void k_accum(const float4 *__restrict__ pts, size_t n,
