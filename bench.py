@@ -470,7 +470,7 @@ def main():
         alg_bytes = M * (16.0 + 4.0 * 27.0 + 48.0 * kbar)
         achieved = alg_bytes / (ms * 1e-3) / 1e9
         traffic = None
-        for tname in ("r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json"):   # PMC passes of this command, see profiles/README.md
+        for tname in ("r05_pmc_traffic.json", "r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json"):   # PMC passes of this command, see profiles/README.md
             tpath = os.path.join(ROOT, "profiles", tname)
             if os.path.exists(tpath):
                 try:
