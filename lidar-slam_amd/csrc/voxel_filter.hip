@@ -568,9 +568,9 @@ extern "C" int lsa_voxel_filter_reserve(lsa_voxel_filter *f, size_t max_points, 
   LSA_HIP(f->ctx, lsa_enter(f->ctx));
   int rc = vi_prepare(f->ctx, f->vi, max_points ? max_points : 1, 4, (size_t)1 << 17);
   if (rc) return rc;
-  // clouds of half a million points and more take the large path of the build: its byte map and cell-keyed rows (272 MB at this
-  // bitmap capacity) now, not under the first such call
-  if (max_points >= 512 * 1024 && (rc = vi_prepare_large(f->ctx, f->vi, 4))) return rc;
+  // the rows keyed by the cell (one 64-byte line per cell of the bitmap's capacity: 272 MB here) and, for clouds of half a million
+  // points and more, the byte map of the large path: now, not under the first call
+  if ((rc = vi_prepare_large(f->ctx, f->vi, 4, max_points >= 512 * 1024))) return rc;
   if (!f->vi.clean) {   // the bitmap and the accumulator rows are cleared here instead of under the first Filter call
     VoxelIndex &vi = f->vi;
     LSA_HIP(f->ctx, hipMemsetAsync(vi.bits.p, 0, vi.W_cap * sizeof(uint32_t), f->ctx->stream));

@@ -165,7 +165,7 @@ int vi_grow(lsa_context *ctx, VoxelIndex &vi);
 // Enqueue the clean-up (zero the bitmap words / sums / counts this build touched) so the next build needs no memset.
 // Runs behind the completion event, i.e. off the caller's critical path.
 int vi_cleanup(lsa_context *ctx, VoxelIndex &vi, size_t n);
-int vi_prepare_large(lsa_context *ctx, VoxelIndex &vi, int ns);
+int vi_prepare_large(lsa_context *ctx, VoxelIndex &vi, int ns, bool with_occ);
 constexpr size_t kByCellMaxBytes = (size_t)1 << 30;
 constexpr size_t kByCellStride = 8;   // 64-bit words per cell-keyed row (ns = 4: four sums, the count, three spare)
 // 64-bit words per row of acc[], whatever the key: the ns = 4 rows of VoxelFilter are one 64-byte line each with the count as their

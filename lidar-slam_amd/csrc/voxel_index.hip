@@ -681,8 +681,11 @@ template <int NS, int TILE, bool BY_CELL>
 __global__ __launch_bounds__(kBlock) void k_accum(const float4 *__restrict__ pts, size_t n,
                                                   DevParams *__restrict__ dp, KnownParams kp, const uint32_t *__restrict__ bits,
                                                   const uint32_t *__restrict__ prefix, long long *__restrict__ acc, int32_t *__restrict__ cnt,
-                                                  uint8_t *__restrict__ occ, float4 *__restrict__ d_keep, unsigned long long *__restrict__ stamps) {
+                                                  uint8_t *__restrict__ occ, uint32_t *__restrict__ mark_bits, float4 *__restrict__ d_keep,
+                                                  unsigned long long *__restrict__ stamps) {
   vi_stamp(stamps, 0);
+  // (BY_CELL marks: byte stores into occ[] for large clouds — a pack kernel follows —, or, occ == null, one fire-and-forget atomic OR
+  // per cell and tile straight into the bitmap for scans, where the pack kernel would cost more than the ~20 k atomics)
   // table slots: TILE / 2, but TILE / 4 for the 10-sum rows (80 B each): 46 KB instead of 92 KB of LDS lets three
   // workgroups share a CU instead of one; a tile with more distinct cells than slots overflows to direct atomics.
   // NS = 4, TILE = 2048: keys + counts + sums = 4 + 4 + 32 KB = exactly a quarter of the CU's 160 KB, so the 977 tiles of a 2 M-point
@@ -774,7 +777,8 @@ __global__ __launch_bounds__(kBlock) void k_accum(const float4 *__restrict__ pts
 #pragma unroll
         for (int j = 0; j < NS; j++) atomicAdd(a + j, rs[j]);
         atomicAdd(a + NS, (unsigned long long)(unsigned)rn);
-        occ[cell] = (uint8_t)1;
+        if (occ) occ[cell] = (uint8_t)1;
+        else atomicOr(mark_bits + (cell >> 5), 1u << (cell & 31));
       } else {
         unsigned rank = cell_rank(bits, prefix, cell);
         unsigned long long *a = (unsigned long long *)acc + (size_t)rank * vi_row_stride(NS);
@@ -862,7 +866,10 @@ __global__ __launch_bounds__(kBlock) void k_accum(const float4 *__restrict__ pts
       if constexpr (BY_CELL) {
         // the cell's NS sums and its count: NS + 1 adjacent lanes, ONE 64-bit atomic instruction, one 64-byte line
         atomicAdd((unsigned long long *)acc + (size_t)(unsigned)rk[q] * kByCellStride + j, j < NS ? sums[sl][j < NS ? j : 0] : (unsigned long long)(unsigned)counts[sl]);
-        if (j == NS) occ[(unsigned)rk[q]] = (uint8_t)1;   // the cell's byte mark (plain store: see k_mark_bytes)
+        if (j == NS) {   // the cell's mark: a byte (plain store: see k_mark_bytes) or, for scans, its bit
+          if (occ) occ[(unsigned)rk[q]] = (uint8_t)1;
+          else atomicOr(mark_bits + ((unsigned)rk[q] >> 5), 1u << ((unsigned)rk[q] & 31u));
+        }
       } else if constexpr (NS == 4) {   // (the same one-line rows, keyed by the rank)
         atomicAdd((unsigned long long *)acc + (size_t)(unsigned)rk[q] * kByCellStride + j, j < NS ? sums[sl][j < NS ? j : 0] : (unsigned long long)(unsigned)counts[sl]);
       } else {
@@ -939,9 +946,9 @@ int vi_prepare(lsa_context *ctx, VoxelIndex &vi, size_t n, int ns, size_t w_min)
 
 // what a LARGE build (>= kSmallInput points) needs beyond vi_prepare, allocated and cleared ahead of the first one: the byte map of the
 // bitmap's capacity and, for an owner that allows it, the rows keyed by the cell (lsa_voxel_filter_reserve)
-int vi_prepare_large(lsa_context *ctx, VoxelIndex &vi, int ns) {
+int vi_prepare_large(lsa_context *ctx, VoxelIndex &vi, int ns, bool with_occ) {
   int rc;
-  if (vi.occ_words != vi.W_cap) {
+  if (with_occ && vi.occ_words != vi.W_cap) {
     if (vi.occ.p) LSA_HIP(ctx, hipStreamSynchronize(ctx->stream));
     vi.occ.release();
     if ((rc = vi.occ.reserve(ctx, vi.W_cap * 32))) return rc;
@@ -973,8 +980,11 @@ int vi_enqueue(lsa_context *ctx, VoxelIndex &vi, const float4 *d_pts, size_t n, 
   const size_t cells_cap = vi.W_cap * 32;
   // (not for an owner that waits behind the scan while the sums are still running, mirror_at_scan: by cell the sums come FIRST,
   // and SetInputTarget of 2 M points measured 0.106 ms that way against 0.098 with its host work under the accumulation)
-  const bool by_cell = vi.allow_by_cell && ns == 4 && !vi.mirror_at_scan && !pull && n >= kSmallInput && cells_cap * kByCellStride * 8 <= kByCellMaxBytes &&
-                       by_cell_on;
+  // (scans too, LSA_VI_BY_CELL_SMALL=0 switches that off: one kernel — sums by cell + the cells' bits — instead of mark and accumulate
+  // on either side of the scan; every dependent launch of this chain costs ~4.5 us whatever it does)
+  static const bool by_cell_small = !(getenv("LSA_VI_BY_CELL_SMALL") && atoi(getenv("LSA_VI_BY_CELL_SMALL")) == 0);
+  const bool by_cell = vi.allow_by_cell && ns == 4 && !vi.mirror_at_scan && !pull && (n >= kSmallInput || by_cell_small) &&
+                       cells_cap * kByCellStride * 8 <= kByCellMaxBytes && by_cell_on;
   if (by_cell && vi.acc.cap < cells_cap * kByCellStride) {
     LSA_HIP(ctx, hipStreamSynchronize(ctx->stream));   // (the reserve frees the old rows)
     if ((rc = vi.acc.reserve(ctx, cells_cap * kByCellStride))) return rc;
@@ -1032,6 +1042,9 @@ int vi_enqueue(lsa_context *ctx, VoxelIndex &vi, const float4 *d_pts, size_t n, 
   if (pull) {
     if (!spec) return lsa_fail(ctx, LSA_ERR_INVALID, "vi_enqueue: rows can only be pulled into a known grid definition (vi_spec_ready)");
     hipLaunchKernelGGL((k_mark<kTilePull, true>), dim3(lsa_div_up(n, kTilePull)), dim3(kBlock), 0, ctx->stream, d_pts, n, dp, kp, vi.bits.p, vi.cell_idx.p, *pull, vi.stamps.p);
+  } else if (small && by_cell) {
+    hipLaunchKernelGGL((k_accum<4, kTileSmall, true>), dim3(lsa_div_up(n, kTileSmall)), dim3(kBlock), 0, ctx->stream, d_pts, n, dp, kp, vi.bits.p, vi.prefix.p,
+                       vi.acc.p, vi.cnt.p, (uint8_t *)nullptr, vi.bits.p, d_keep, vi.stamps.p ? vi.stamps.p + kViStampWgs * 8 : nullptr);
   } else if (small) hipLaunchKernelGGL((k_mark<kTileSmall, false>), dim3(lsa_div_up(n, kTileSmall)), dim3(kBlock), 0, ctx->stream, d_pts, n, dp, kp, vi.bits.p, vi.cell_idx.p, no_pull, vi.stamps.p);
   else {
     // large clouds: byte marks, then the bytes of the box packed into the bitmap (see VoxelIndex::occ)
@@ -1045,7 +1058,7 @@ int vi_enqueue(lsa_context *ctx, VoxelIndex &vi, const float4 *d_pts, size_t n, 
     }
     if (by_cell) {   // ONE pass over the points: the sums by cell and the byte marks (k_accum<.., BY_CELL>); pack and scan run behind it
       hipLaunchKernelGGL((k_accum<4, kTileBig, true>), dim3(lsa_div_up(n, kTileBig)), dim3(kBlock), 0, ctx->stream, d_pts, n, dp, kp, vi.bits.p, vi.prefix.p,
-                         vi.acc.p, vi.cnt.p, vi.occ.p, d_keep, st_acc);
+                         vi.acc.p, vi.cnt.p, vi.occ.p, (uint32_t *)nullptr, d_keep, st_acc);
     } else {
       hipLaunchKernelGGL((k_mark_bytes<kTileBig / kBlock>), dim3(lsa_div_up(n, kTileBig)), dim3(kBlock), 0, ctx->stream, d_pts, n, dp, kp, vi.occ.p, vi.cell_idx.p, d_keep,
                          vi.stamps.p);
@@ -1056,7 +1069,7 @@ int vi_enqueue(lsa_context *ctx, VoxelIndex &vi, const float4 *d_pts, size_t n, 
                      vi.prefix.p, vi.cell_of_rank.p, vi.mirror_at_scan ? vi.h_params.p : (DevParams *)nullptr);
   if (vi.mirror_at_scan) LSA_HIP(ctx, hipEventRecord(vi.ev_done, ctx->stream));   // vi_wait() returns behind the scan; the accumulation is still running then
   unsigned g = lsa_div_up(n, small ? kTileSmall : kTileBig);
-#define LSA_LAUNCH_ACCUM(NS_, TILE_) hipLaunchKernelGGL((k_accum<NS_, TILE_, false>), dim3(g), dim3(kBlock), 0, ctx->stream, d_pts, n, dp, kp, vi.bits.p, vi.prefix.p, vi.acc.p, vi.cnt.p, (uint8_t *)nullptr, (float4 *)nullptr, vi.stamps.p ? vi.stamps.p + kViStampWgs * 8 : nullptr)
+#define LSA_LAUNCH_ACCUM(NS_, TILE_) hipLaunchKernelGGL((k_accum<NS_, TILE_, false>), dim3(g), dim3(kBlock), 0, ctx->stream, d_pts, n, dp, kp, vi.bits.p, vi.prefix.p, vi.acc.p, vi.cnt.p, (uint8_t *)nullptr, (uint32_t *)nullptr, (float4 *)nullptr, vi.stamps.p ? vi.stamps.p + kViStampWgs * 8 : nullptr)
   if (!by_cell) {   // (rows by rank: behind the scan)
     if (ns == 4) { if (small) LSA_LAUNCH_ACCUM(4, kTileSmall); else LSA_LAUNCH_ACCUM(4, kTileBig); }
     else { if (small) LSA_LAUNCH_ACCUM(10, kTileSmall); else LSA_LAUNCH_ACCUM(10, kTileBig); }
