@@ -982,7 +982,7 @@ int vi_enqueue(lsa_context *ctx, VoxelIndex &vi, const float4 *d_pts, size_t n, 
   // and SetInputTarget of 2 M points measured 0.106 ms that way against 0.098 with its host work under the accumulation)
   // (scans too, LSA_VI_BY_CELL_SMALL=0 switches that off: one kernel — sums by cell + the cells' bits — instead of mark and accumulate
   // on either side of the scan; every dependent launch of this chain costs ~4.5 us whatever it does)
-  static const bool by_cell_small = !(getenv("LSA_VI_BY_CELL_SMALL") && atoi(getenv("LSA_VI_BY_CELL_SMALL")) == 0);
+  const bool by_cell_small = !(getenv("LSA_VI_BY_CELL_SMALL") && atoi(getenv("LSA_VI_BY_CELL_SMALL")) == 0);
   const bool by_cell = vi.allow_by_cell && ns == 4 && !vi.mirror_at_scan && !pull && (n >= kSmallInput || by_cell_small) &&
                        cells_cap * kByCellStride * 8 <= kByCellMaxBytes && by_cell_on;
   if (by_cell && vi.acc.cap < cells_cap * kByCellStride) {

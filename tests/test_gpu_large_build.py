@@ -179,3 +179,31 @@ def test_large_filter_randomized_against_the_oracle(oracle):
     for f in handles.values():
         f.close()
     ctx.close()
+
+
+def test_scan_filter_one_kernel_equals_mark_scan_accumulate(scene, oracle, monkeypatch):
+    """A 131 k-point scan through VoxelFilter with the sums keyed by the cell (one kernel sums and sets the cells' bits, then scan and
+    finalize: the default) and with LSA_VI_BY_CELL_SMALL=0 (mark, scan, accumulate by rank, finalize): the same bits on the device
+    path, scan after scan through one handle (box reuse, a scan that leaves the box, NaN rows), and the oracle's voxel set."""
+    import torch
+    poses = synth.trajectory(6, step=1.5)
+    scans = [synth.gen_scan(scene, poses[i], seed=4400 + i) for i in range(6)]
+    scans[3] = scans[3].copy(); scans[3][100:140, 0] = np.nan
+    scans[4] = scans[4].copy(); scans[4][7, :3] = [140.0, -95.0, 20.0]     # outside the box the earlier scans defined
+    outs = {}
+    for env in (None, "0"):
+        if env is None:
+            monkeypatch.delenv("LSA_VI_BY_CELL_SMALL", raising=False)
+        else:
+            monkeypatch.setenv("LSA_VI_BY_CELL_SMALL", env)
+        ctx = capi.Context(0)
+        f = cloud_filter.VoxelFilterHip(ctx, 0.5, 0.5, 0.5)
+        outs[env] = [f.filter_device(torch.from_numpy(np.ascontiguousarray(s)).cuda()).clone().cpu().numpy() for s in scans]
+        f.close(); ctx.close()
+    monkeypatch.delenv("LSA_VI_BY_CELL_SMALL", raising=False)
+    for a, b, s in zip(outs[None], outs["0"], scans):
+        assert a.shape == b.shape and np.array_equal(a.view(np.uint32), b.view(np.uint32))
+        ref, rc = oracle.voxel_filter(synth.to_xyzi32(s), 0.5)
+        assert rc == 0 and ref.shape[0] == a.shape[0]
+        err = np.abs(a.astype(np.float64) - ref.astype(np.float64)) / np.maximum(np.abs(ref.astype(np.float64)), 1.0)
+        assert err.max() < 4e-6, err.max()
