@@ -677,12 +677,16 @@ __device__ __forceinline__ unsigned cell_rank(const uint32_t *__restrict__ bits,
 // only pass over the points: it also leaves the byte marks of the cells it met (no k_mark_bytes: one 32 MB read, one launch and
 // the rank look-ups of the flush less; 268 MB of rows for a 4.2 M-cell box, which 288 GB do not notice).  The scan runs behind it
 // for the output order alone, and the owner's finalize kernel reads row cell_of_rank[r] instead of row r.
-template <int NS, int TILE, bool BY_CELL>
+// PULL (BY_CELL only; host clouds, see k_mark<.., PULL>): the rows are still being packed by the host when this kernel starts; a tile
+// waits for its chunk's flag, reads its rows over the link (workgroup-linear order), leaves them in pull.d_copy and sums them in the same
+// pass — mark, pull and accumulate of a host scan in one kernel.
+template <int NS, int TILE, bool BY_CELL, bool PULL = false>
 __global__ __launch_bounds__(kBlock) void k_accum(const float4 *__restrict__ pts, size_t n,
                                                   DevParams *__restrict__ dp, KnownParams kp, const uint32_t *__restrict__ bits,
                                                   const uint32_t *__restrict__ prefix, long long *__restrict__ acc, int32_t *__restrict__ cnt,
                                                   uint8_t *__restrict__ occ, uint32_t *__restrict__ mark_bits, float4 *__restrict__ d_keep,
-                                                  unsigned long long *__restrict__ stamps) {
+                                                  unsigned long long *__restrict__ stamps, PullSource pull) {
+  static_assert(!PULL || BY_CELL, "the pulling variant sums by cell");
   vi_stamp(stamps, 0);
   // (BY_CELL marks: byte stores into occ[] for large clouds — a pack kernel follows —, or, occ == null, one fire-and-forget atomic OR
   // per cell and tile straight into the bitmap for scans, where the pack kernel would cost more than the ~20 k atomics)
@@ -707,6 +711,18 @@ __global__ __launch_bounds__(kBlock) void k_accum(const float4 *__restrict__ pts
   if (!BY_CELL && dp->spec_miss) return;
   const CellMap m = kp.valid ? kp.map : dp->map;
   const FixScales fs = kp.valid ? kp.fs : dp->fs;
+  __shared__ int pull_ok;
+  if (PULL && threadIdx.x == 0) {   // (as in k_mark<.., PULL>: a flag per 64-byte line, a look about once a microsecond)
+    const size_t first = (size_t)blockIdx.x * kTile, last = (first + kTile < n ? first + kTile : n) - 1;
+    const unsigned long long t0 = wall_clock64();
+    int ok = 1;
+    for (size_t c = first >> pull.chunk_shift; ok && c <= (last >> pull.chunk_shift); c++)
+      while (__hip_atomic_load(pull.ready + c * kPullFlagStride, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) != pull.seq) {
+        if (wall_clock64() - t0 > pull.patience_ticks) { ok = 0; break; }
+        __builtin_amdgcn_s_sleep(32);
+      }
+    pull_ok = ok;
+  }
   __shared__ int keys[kHashCap];
   __shared__ int counts[kHashCap];
   __shared__ unsigned long long sums[kHashCap][NS];
@@ -719,18 +735,26 @@ __global__ __launch_bounds__(kBlock) void k_accum(const float4 *__restrict__ pts
   __syncthreads();
   vi_stamp(stamps, 1);
   size_t base = (size_t)blockIdx.x * kTile;
+  if (PULL) {
+    if (!pull_ok) {   // the host never delivered: flag the build (the owner sends the rows again or fails), touch nothing else
+      if (threadIdx.x == 0) atomicMax(&dp->spec_miss, 2);
+      return;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");   // (every wave: its loads of the rows come behind the flag thread 0 saw)
+  }
   float4 pv[kPer];
   int cv[kPer];
 #pragma unroll
   for (int k = 0; k < kPer; k++) {  // issue every load of the lane up front
-    size_t i = vi_point_index<kPer>(base, k);
-    pv[k] = (i < n) ? pts[i] : make_float4(NAN, NAN, NAN, 0.f);
+    size_t i = vi_point_index<kPer, PULL>(base, k);
+    pv[k] = (i < n) ? (PULL ? pull.h_rows[i] : pts[i]) : make_float4(NAN, NAN, NAN, 0.f);
   }
-  if (BY_CELL && d_keep) {
+  if (BY_CELL && (PULL || d_keep)) {
+    float4 *dst = PULL ? pull.d_copy : d_keep;
 #pragma unroll
     for (int k = 0; k < kPer; k++) {
-      size_t i = vi_point_index<kPer>(base, k);
-      if (i < n) d_keep[i] = pv[k];
+      size_t i = vi_point_index<kPer, PULL>(base, k);
+      if (i < n) dst[i] = pv[k];
     }
   }
   // a point's cell by the very expressions k_mark marked it with (the per-point cell index k_mark used to leave in memory was an
@@ -983,8 +1007,8 @@ int vi_enqueue(lsa_context *ctx, VoxelIndex &vi, const float4 *d_pts, size_t n, 
   // (scans too, LSA_VI_BY_CELL_SMALL=0 switches that off: one kernel — sums by cell + the cells' bits — instead of mark and accumulate
   // on either side of the scan; every dependent launch of this chain costs ~4.5 us whatever it does)
   const bool by_cell_small = !(getenv("LSA_VI_BY_CELL_SMALL") && atoi(getenv("LSA_VI_BY_CELL_SMALL")) == 0);
-  const bool by_cell = vi.allow_by_cell && ns == 4 && !vi.mirror_at_scan && !pull && (n >= kSmallInput || by_cell_small) &&
-                       cells_cap * kByCellStride * 8 <= kByCellMaxBytes && by_cell_on;
+  const bool by_cell = vi.allow_by_cell && ns == 4 && !vi.mirror_at_scan && (n >= kSmallInput || by_cell_small || pull) &&
+                       cells_cap * kByCellStride * 8 <= kByCellMaxBytes && by_cell_on && !(pull && !by_cell_small);
   if (by_cell && vi.acc.cap < cells_cap * kByCellStride) {
     LSA_HIP(ctx, hipStreamSynchronize(ctx->stream));   // (the reserve frees the old rows)
     if ((rc = vi.acc.reserve(ctx, cells_cap * kByCellStride))) return rc;
@@ -1041,10 +1065,14 @@ int vi_enqueue(lsa_context *ctx, VoxelIndex &vi, const float4 *d_pts, size_t n, 
   no_pull.d_copy = d_keep;   // (a pulled build leaves the rows in pull->d_copy already)
   if (pull) {
     if (!spec) return lsa_fail(ctx, LSA_ERR_INVALID, "vi_enqueue: rows can only be pulled into a known grid definition (vi_spec_ready)");
-    hipLaunchKernelGGL((k_mark<kTilePull, true>), dim3(lsa_div_up(n, kTilePull)), dim3(kBlock), 0, ctx->stream, d_pts, n, dp, kp, vi.bits.p, vi.cell_idx.p, *pull, vi.stamps.p);
+    if (by_cell)   // pull, marks and sums of a host scan in ONE kernel (bits set by atomic ORs: a scan-sized cloud whatever n says)
+      hipLaunchKernelGGL((k_accum<4, kTilePull, true, true>), dim3(lsa_div_up(n, kTilePull)), dim3(kBlock), 0, ctx->stream, d_pts, n, dp, kp, vi.bits.p, vi.prefix.p,
+                         vi.acc.p, vi.cnt.p, (uint8_t *)nullptr, vi.bits.p, (float4 *)nullptr, vi.stamps.p ? vi.stamps.p + kViStampWgs * 8 : nullptr, *pull);
+    else
+      hipLaunchKernelGGL((k_mark<kTilePull, true>), dim3(lsa_div_up(n, kTilePull)), dim3(kBlock), 0, ctx->stream, d_pts, n, dp, kp, vi.bits.p, vi.cell_idx.p, *pull, vi.stamps.p);
   } else if (small && by_cell) {
     hipLaunchKernelGGL((k_accum<4, kTileSmall, true>), dim3(lsa_div_up(n, kTileSmall)), dim3(kBlock), 0, ctx->stream, d_pts, n, dp, kp, vi.bits.p, vi.prefix.p,
-                       vi.acc.p, vi.cnt.p, (uint8_t *)nullptr, vi.bits.p, d_keep, vi.stamps.p ? vi.stamps.p + kViStampWgs * 8 : nullptr);
+                       vi.acc.p, vi.cnt.p, (uint8_t *)nullptr, vi.bits.p, d_keep, vi.stamps.p ? vi.stamps.p + kViStampWgs * 8 : nullptr, no_pull);
   } else if (small) hipLaunchKernelGGL((k_mark<kTileSmall, false>), dim3(lsa_div_up(n, kTileSmall)), dim3(kBlock), 0, ctx->stream, d_pts, n, dp, kp, vi.bits.p, vi.cell_idx.p, no_pull, vi.stamps.p);
   else {
     // large clouds: byte marks, then the bytes of the box packed into the bitmap (see VoxelIndex::occ)
@@ -1058,7 +1086,7 @@ int vi_enqueue(lsa_context *ctx, VoxelIndex &vi, const float4 *d_pts, size_t n, 
     }
     if (by_cell) {   // ONE pass over the points: the sums by cell and the byte marks (k_accum<.., BY_CELL>); pack and scan run behind it
       hipLaunchKernelGGL((k_accum<4, kTileBig, true>), dim3(lsa_div_up(n, kTileBig)), dim3(kBlock), 0, ctx->stream, d_pts, n, dp, kp, vi.bits.p, vi.prefix.p,
-                         vi.acc.p, vi.cnt.p, vi.occ.p, (uint32_t *)nullptr, d_keep, st_acc);
+                         vi.acc.p, vi.cnt.p, vi.occ.p, (uint32_t *)nullptr, d_keep, st_acc, no_pull);
     } else {
       hipLaunchKernelGGL((k_mark_bytes<kTileBig / kBlock>), dim3(lsa_div_up(n, kTileBig)), dim3(kBlock), 0, ctx->stream, d_pts, n, dp, kp, vi.occ.p, vi.cell_idx.p, d_keep,
                          vi.stamps.p);
@@ -1069,7 +1097,7 @@ int vi_enqueue(lsa_context *ctx, VoxelIndex &vi, const float4 *d_pts, size_t n, 
                      vi.prefix.p, vi.cell_of_rank.p, vi.mirror_at_scan ? vi.h_params.p : (DevParams *)nullptr);
   if (vi.mirror_at_scan) LSA_HIP(ctx, hipEventRecord(vi.ev_done, ctx->stream));   // vi_wait() returns behind the scan; the accumulation is still running then
   unsigned g = lsa_div_up(n, small ? kTileSmall : kTileBig);
-#define LSA_LAUNCH_ACCUM(NS_, TILE_) hipLaunchKernelGGL((k_accum<NS_, TILE_, false>), dim3(g), dim3(kBlock), 0, ctx->stream, d_pts, n, dp, kp, vi.bits.p, vi.prefix.p, vi.acc.p, vi.cnt.p, (uint8_t *)nullptr, (uint32_t *)nullptr, (float4 *)nullptr, vi.stamps.p ? vi.stamps.p + kViStampWgs * 8 : nullptr)
+#define LSA_LAUNCH_ACCUM(NS_, TILE_) hipLaunchKernelGGL((k_accum<NS_, TILE_, false>), dim3(g), dim3(kBlock), 0, ctx->stream, d_pts, n, dp, kp, vi.bits.p, vi.prefix.p, vi.acc.p, vi.cnt.p, (uint8_t *)nullptr, (uint32_t *)nullptr, (float4 *)nullptr, vi.stamps.p ? vi.stamps.p + kViStampWgs * 8 : nullptr, no_pull)
   if (!by_cell) {   // (rows by rank: behind the scan)
     if (ns == 4) { if (small) LSA_LAUNCH_ACCUM(4, kTileSmall); else LSA_LAUNCH_ACCUM(4, kTileBig); }
     else { if (small) LSA_LAUNCH_ACCUM(10, kTileSmall); else LSA_LAUNCH_ACCUM(10, kTileBig); }
