@@ -207,3 +207,43 @@ def test_scan_filter_one_kernel_equals_mark_scan_accumulate(scene, oracle, monke
         assert rc == 0 and ref.shape[0] == a.shape[0]
         err = np.abs(a.astype(np.float64) - ref.astype(np.float64)) / np.maximum(np.abs(ref.astype(np.float64)), 1.0)
         assert err.max() < 4e-6, err.max()
+
+
+def test_one_handle_through_every_build_path(scene, oracle, cloud600k):
+    """ONE VoxelFilter handle driven through every build path in random order — host scans (first one copied, later ones pulled over the
+    link by the summing kernel), device scans (one kernel: sums by cell + bits), a 600 k-point device cloud (byte marks + pack), a scan
+    that leaves the reused cell box, an empty and an all-NaN cloud — each output against the oracle's voxel set and means: whatever a
+    build leaves behind (rows, bits, byte marks, the reused grid definition) must not show in the next one."""
+    import torch
+    rng = np.random.RandomState(31)
+    poses = synth.trajectory(5, step=1.3)
+    scans = [synth.gen_scan(scene, poses[i], seed=4700 + i) for i in range(5)]
+    far = scans[2].copy(); far[11, :3] = [-160.0, 120.0, 25.0]
+    clouds = {"scan0": scans[0], "scan1": scans[1], "scan2": scans[2], "scan3": scans[3], "scan4": scans[4], "far": far, "big": cloud600k,
+              "empty": np.zeros((0, 4), dtype=np.float32), "nan": np.full((70000, 4), np.nan, dtype=np.float32)}
+    refs = {}
+    for k, c in clouds.items():
+        if c.shape[0] and np.isfinite(c[:, :3]).all(axis=1).any():
+            refs[k] = oracle.voxel_filter(synth.to_xyzi32(c), 0.5)[0]
+        else:
+            refs[k] = np.zeros((0, 4), dtype=np.float32)
+    ctx = capi.Context(0)
+    f = cloud_filter.VoxelFilterHip(ctx, 0.5, 0.5, 0.5)
+    names = list(clouds)
+    for step in range(40):
+        k = names[rng.randint(len(names))]
+        host = rng.rand() < 0.5 and k != "big"
+        c = clouds[k]
+        if host:
+            _, out = f.Filter(synth.to_xyzi32(c))
+            got = out[:, [0, 1, 2, 4]]
+        else:
+            got = f.filter_device(torch.from_numpy(np.ascontiguousarray(c)).cuda()).cpu().numpy()
+        ref = refs[k]
+        assert got.shape[0] == ref.shape[0], (step, k, host, got.shape, ref.shape)
+        if ref.shape[0]:
+            err = np.abs(got.astype(np.float64) - ref.astype(np.float64)) / np.maximum(np.abs(ref.astype(np.float64)), 1.0)
+            assert err.max() < 4e-6, (step, k, host, err.max())
+    c = f.counters()
+    assert c["pulled"] >= 3 and c["misses"] >= 1
+    f.close(); ctx.close()
