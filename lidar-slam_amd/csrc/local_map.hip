@@ -624,16 +624,27 @@ __global__ __launch_bounds__(kBlock) void k_lm_bounds(const LmCellN *__restrict_
     lm_unpack(cells[s].key, ijk);
     for (int a = 0; a < 3; a++) { mn[a] = min(mn[a], ijk[a]); mx[a] = max(mx[a], ijk[a]); }
   }
+  // wave, then workgroup (LDS), then ONE set of six atomics per workgroup: the valid voxels are hash-spread over the table, so every
+  // wave has some, and six same-address atomics from each of 2 048 waves were most of this kernel (46 us in the trace of the cold
+  // front-end drives against ~5 us for reading the 16 MB; the memory side serialises on an address)
+  __shared__ int s_mn[kBlock / 64][3], s_mx[kBlock / 64][3];
   for (int a = 0; a < 3; a++) {
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) { mn[a] = min(mn[a], __shfl_down(mn[a], off, 64)); mx[a] = max(mx[a], __shfl_down(mx[a], off, 64)); }
-    if ((threadIdx.x & 63) == 0) {
-      if (mn[a] != INT_MAX) atomicMin(&st->bmin[a], mn[a]);
-      if (mx[a] != INT_MIN) atomicMax(&st->bmax[a], mx[a]);
-    }
+    if ((threadIdx.x & 63) == 0) { s_mn[threadIdx.x >> 6][a] = mn[a]; s_mx[threadIdx.x >> 6][a] = mx[a]; }
   }
-  // every wave drains its own atomics (the fence waits for the wave's outstanding memory operations), then the workgroup counts itself done
-  __threadfence();
+  __syncthreads();
+  if (threadIdx.x < 3) {
+    const int a = (int)threadIdx.x;
+    int lo = INT_MAX, hi = INT_MIN;
+#pragma unroll
+    for (int w = 0; w < kBlock / 64; w++) { lo = min(lo, s_mn[w][a]); hi = max(hi, s_mx[w][a]); }
+    if (lo != INT_MAX) atomicMin(&st->bmin[a], lo);
+    if (hi != INT_MIN) atomicMax(&st->bmax[a], hi);
+  }
+  // the issuing wave drains its own atomics (they are performed at the memory side: nothing to write back, a wait for the wave's
+  // outstanding operations is enough — an agent-scope fence here wrote back the L2 once per workgroup), then the workgroup counts itself done
+  __builtin_amdgcn_s_waitcnt(0);
   __syncthreads();
   if (threadIdx.x == 0) {
     const unsigned t = atomicAdd(&st->pad, 1u);
