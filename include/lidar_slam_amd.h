@@ -95,10 +95,12 @@ int lsa_voxel_filter_counters(lsa_voxel_filter *f, uint64_t out[4]);
  * (lsa_front_end_update_batch, lsa_pipeline_scan_match_host) send the rows again once they are packed and filter them the ordinary
  * way, so their results never come from a half-delivered cloud.  Counted here either way. */
 int lsa_voxel_filter_pull_timeouts(lsa_voxel_filter *f, uint64_t *out);
-/* Diagnostics (profiles/scripts/vi_stamps.py): with out == NULL, enable != 0 makes the mark and the accumulate kernel of every following
- * build note the device's 100 MHz wall clock at their phase boundaries (8 values per workgroup, thread 0; 0 switches it off); with
- * out != NULL the 2 x *per_kernel values of the LAST build are copied out (kernel k's workgroup w at out[k * *per_kernel + 8 w ...]:
- * entry, table cleared, points done, barrier passed, [accumulate: ranks known,] flush issued, flush acknowledged) and cleared. */
+/* Diagnostics (profiles/scripts/vi_stamps.py): with out == NULL, enable != 0 makes the mark, the accumulate and the scan kernel of every
+ * following build note the device's 100 MHz wall clock at their phase boundaries (8 values per workgroup, thread 0; 0 switches it off);
+ * with out != NULL the 3 x *per_kernel values of the LAST build are copied out (kernel k's workgroup w at out[k * *per_kernel + 8 w ...]:
+ * entry, table cleared, points done, barrier passed, [accumulate: ranks known,] flush issued, flush acknowledged; scan: entry, grid
+ * definition read, bits in front of the tile counted, own tile counted, prefix known, prefix written, cells of the ranks issued,
+ * acknowledged) and cleared. */
 int lsa_voxel_filter_stamps(lsa_voxel_filter *f, int enable, uint64_t *out, size_t cap, size_t *per_kernel);
 
 /* Filter(input_cloud_ptr, filtered_cloud_ptr): host AoS in, host AoS out.

@@ -258,10 +258,16 @@ int fe_lm_adopt(lsa_front_end *fe) {
 
 // the persistent sums from scratch from the occupied slots; a map the tables / the window cannot hold switches the
 // incremental path off for good and builds the target the full way
-int fe_lm_rebuild(lsa_front_end *fe, bool filtered) {
+// in_flight (the map has a stream of its own): the rebuild's last kernels are left running and the registration's stream is ordered
+// behind them by the map's event, as after an ordinary update (fe_map_join)
+int fe_lm_rebuild(lsa_front_end *fe, bool filtered, bool in_flight = false) {
   const float4 *range = fe->d_map.p;
   const size_t n = fe->slot_cap * fe->frames.size();
-  int rc = lm_rebuild(fe->lm, &range, &n, 1, filtered);
+  int rc = lm_rebuild(fe->lm, &range, &n, 1, filtered, in_flight);
+  if (!rc && in_flight) {
+    LSA_HIP(fe->ctx, hipEventRecord(fe->ev_map, fe->ctx_m->stream));
+    fe->map_inflight = true;
+  }
   if (rc == LSA_ERR_CAPACITY || rc == LSA_ERR_RANGE) {
     fe->lm_off = true;
     return fe_full_target(fe);
@@ -343,7 +349,7 @@ int fe_rebuild_map(lsa_front_end *fe, KeyFrame *added, bool evicted, const float
   if (!steady) {
     if (!relayout) fe_transform_into_slot(fe, added);
     if (!want_filtered) fe->target_points = sum;
-    return fe_lm_rebuild(fe, want_filtered);
+    return fe_lm_rebuild(fe, want_filtered, own_stream);
   }
   // the steady state: the evicted key-frame's points (still in the slot) leave the sums, the new key-frame's enter
   float4 *slot = fe->d_map.p + (size_t)added->slot * fe->slot_cap;

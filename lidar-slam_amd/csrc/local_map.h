@@ -124,7 +124,9 @@ int lm_swap(LocalMap &lm, float4 *d_slot, size_t slot_cap, bool evict, const flo
 int lm_finish(LocalMap &lm);
 // Everything from scratch from `nranges` ranges of the local-map buffer (first key-frame, the switch to the filtered map,
 // a table that filled up, a re-laid-out buffer): clears, re-adds, finalises every cell, fits the window.  Waits for the stream.
-int lm_rebuild(LocalMap &lm, const float4 *const *d_ranges, const size_t *n_ranges, int nranges, bool filtered);
+// leave_in_flight: the window's last two kernels (clear + fill of the dense table) are not waited for — the caller orders the table's
+// readers behind lm.ctx->stream itself (an event); everything the host reads has arrived by then either way
+int lm_rebuild(LocalMap &lm, const float4 *const *d_ranges, const size_t *n_ranges, int nranges, bool filtered, bool leave_in_flight = false);
 // Re-fit the dense window around the valid voxels (waits for the stream).  LSA_ERR_CAPACITY: the window would exceed dense_max_cells.
 int lm_refit_window(LocalMap &lm);
 // Look at the status of the last update (the caller guarantees its kernels have completed): 0 fine, 1 window re-fit needed,

@@ -604,9 +604,16 @@ __global__ __launch_bounds__(kBlock) void k_lm_ndt_dirty(TableView<10> N, DirtyV
   }
 }
 
-// window re-fit, first launch: the sentinels the bounds are reduced into (a kernel, not a copy command: the runtime's copy path costs the host more)
-__global__ void k_lm_bounds_init(LmStatus *__restrict__ st) {
+// a rebuild's first launch: the status block zeroed, the sentinels the window re-fit reduces the bounds into (k_lm_bounds leaves them
+// in place again for the next re-fit), the overflow regions' lengths of both dirty lists zeroed.  One kernel instead of three copy
+// commands: the runtime's fill path costs the host 6-26 us a call, a launch 4-5.
+__global__ void k_lm_reset(LmStatus *__restrict__ st, unsigned *__restrict__ len_f, unsigned *__restrict__ len_n) {
+  unsigned *w = reinterpret_cast<unsigned *>(st);
+  for (unsigned i = threadIdx.x; i < sizeof(LmStatus) / sizeof(unsigned); i += blockDim.x) w[i] = 0u;
+  __syncthreads();
   if (threadIdx.x < 3) { st->bmin[threadIdx.x] = INT_MAX; st->bmax[threadIdx.x] = INT_MIN; }
+  if (threadIdx.x == 3 && len_f) len_f[0] = 0u;
+  if (threadIdx.x == 4 && len_n) len_n[0] = 0u;
 }
 // 16-byte fill (the dense window's "no voxel" entries are all-ones)
 __global__ __launch_bounds__(kBlock) void k_lm_fill16(uint4 *__restrict__ p, size_t n16, unsigned v) {
@@ -651,7 +658,8 @@ __global__ __launch_bounds__(kBlock) void k_lm_bounds(const LmCellN *__restrict_
     if (t == gridDim.x - 1) {
       st->pad = 0u;
       for (int a = 0; a < 3; a++) {
-        const int lo = __hip_atomic_load(&st->bmin[a], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), hi = __hip_atomic_load(&st->bmax[a], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        // (exchanged for the sentinels: the block is ready for the next re-fit, no initialising launch in front of this kernel)
+        const int lo = __hip_atomic_exchange(&st->bmin[a], INT_MAX, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), hi = __hip_atomic_exchange(&st->bmax[a], INT_MIN, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __hip_atomic_store(&host_mirror->bmin[a], lo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         __hip_atomic_store(&host_mirror->bmax[a], hi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
       }
@@ -875,14 +883,30 @@ int lm_finish(LocalMap &lm) {
   return LSA_OK;
 }
 
-int lm_refit_window(LocalMap &lm) {
+namespace {
+// window re-fit, first half: the bounds of the valid voxels, reduced into the status block's sentinels (set by k_lm_reset, left in place
+// again by the kernel's last workgroup) and handed to the host through the host-mapped block
+int lm_bounds_launch(LocalMap &lm) {
   lsa_context *ctx = lm.ctx;
-  // bounds of the valid voxels
-  hipLaunchKernelGGL(k_lm_bounds_init, dim3(1), dim3(64), 0, ctx->stream, lm.d_status.p);
   // (one cell per thread: 16 MB of table lines at the default capacity, ~5 us over 512 workgroups; 128 workgroups of 4 cells per thread took 17)
   hipLaunchKernelGGL(k_lm_bounds, dim3(lsa_div_up(lm.cap_n, kBlock)), dim3(kBlock), 0, ctx->stream, lm.n.p, lm.cap_n, lm.d_status.p, lm.h_status.p);
   LSA_HIP(ctx, hipGetLastError());
-  LSA_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return LSA_OK;
+}
+int lm_window_from_bounds(LocalMap &lm, bool wait = true);
+}  // namespace
+
+int lm_refit_window(LocalMap &lm) {
+  int rc;
+  if ((rc = lm_bounds_launch(lm))) return rc;
+  LSA_HIP(lm.ctx, hipStreamSynchronize(lm.ctx->stream));
+  return lm_window_from_bounds(lm);
+}
+
+namespace {
+// second half, behind a host wait for the bounds: the dense window sized, cleared and filled
+int lm_window_from_bounds(LocalMap &lm, bool wait) {
+  lsa_context *ctx = lm.ctx;
   LmStatus got = *lm.h_status.p;   // (bmin / bmax: written by the kernel's last workgroup)
   int mn[3], dm[3];
   // margin: 24 m of travel horizontally (a dozen key-frames at the 2 m default), 8 m vertically, in cells
@@ -910,14 +934,17 @@ int lm_refit_window(LocalMap &lm) {
   }
   hipLaunchKernelGGL(k_lm_dense_fill, dim3(lsa_div_up(lm.cap_n, kBlock)), dim3(kBlock), 0, ctx->stream, lm.n.p, lm.rec.p, lm.cap_n, ndt_args(lm, true), lm.dense.p, lm.d_status.p);
   LSA_HIP(ctx, hipGetLastError());
-  // (the table is read next on the REGISTRATION's stream, which is not necessarily this one: the re-fit ends with a wait)
-  LSA_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  // (the table is read next on the REGISTRATION's stream, which is not necessarily this one: the re-fit ends with a wait — unless the
+  // caller orders that stream behind this one by an event of its own.  The host-side flag below is the mirror's: nothing on the device
+  // writes the mirror before the next update's last kernel.)
+  if (wait) LSA_HIP(ctx, hipStreamSynchronize(ctx->stream));
   lm.h_status.p->window_miss = 0;
   lm.refits++;
   return LSA_OK;
 }
+}  // namespace
 
-int lm_rebuild(LocalMap &lm, const float4 *const *d_ranges, const size_t *n_ranges, int nranges, bool filtered) {
+int lm_rebuild(LocalMap &lm, const float4 *const *d_ranges, const size_t *n_ranges, int nranges, bool filtered, bool leave_in_flight) {
   lsa_context *ctx = lm.ctx;
   int rc;
   lm.valid = false;
@@ -927,13 +954,13 @@ int lm_rebuild(LocalMap &lm, const float4 *const *d_ranges, const size_t *n_rang
     if ((rc = alloc_level_n(lm, cap_n))) return rc;
     if (filtered && (rc = alloc_level_f(lm, cap_f))) return rc;
     // (tables fresh from lm_reserve are zero already: the first build of a session — and the first filtered one — skip the 16 / 64 MB fill)
-    if (!lm.n_zero) LSA_HIP(ctx, hipMemsetAsync(lm.n.p, 0, (size_t)lm.cap_n * sizeof(LmCellN), ctx->stream));
-    if (filtered && !lm.f_zero) LSA_HIP(ctx, hipMemsetAsync(lm.f.p, 0, (size_t)lm.cap_f * sizeof(LmCellF), ctx->stream));
+    static_assert(sizeof(LmCellN) % 16 == 0 && sizeof(LmCellF) % 16 == 0, "the tables are cleared 16 bytes at a time");
+    if (!lm.n_zero) hipLaunchKernelGGL(k_lm_fill16, dim3(2048), dim3(kBlock), 0, ctx->stream, reinterpret_cast<uint4 *>(lm.n.p), (size_t)lm.cap_n * (sizeof(LmCellN) / 16), 0u);
+    if (filtered && !lm.f_zero) hipLaunchKernelGGL(k_lm_fill16, dim3(2048), dim3(kBlock), 0, ctx->stream, reinterpret_cast<uint4 *>(lm.f.p), (size_t)lm.cap_f * (sizeof(LmCellF) / 16), 0u);
     lm.n_zero = false;
     if (filtered) lm.f_zero = false;
-    LSA_HIP(ctx, hipMemsetAsync(lm.d_status.p, 0, sizeof(LmStatus), ctx->stream));
-    if (lm.dirty_f.len.p) LSA_HIP(ctx, hipMemsetAsync(lm.dirty_f.len.p, 0, sizeof(unsigned), ctx->stream));
-    if (lm.dirty_n.len.p) LSA_HIP(ctx, hipMemsetAsync(lm.dirty_n.len.p, 0, sizeof(unsigned), ctx->stream));
+    hipLaunchKernelGGL(k_lm_reset, dim3(1), dim3(64), 0, ctx->stream, lm.d_status.p, lm.dirty_f.len.p, lm.dirty_n.len.p);
+    LSA_HIP(ctx, hipGetLastError());
     // every cell ends up in the dirty lists: finalise them all (no window yet: the table is filled by the re-fit below), in rounds
     // of at most kMaxTiles tiles — a round's dirty list has one region per tile
     lm.window_set = false;
@@ -945,6 +972,9 @@ int lm_rebuild(LocalMap &lm, const float4 *const *d_ranges, const size_t *n_rang
         if ((rc = lm_finish(lm))) return rc;
       }
     }
+    // (the re-fit's bounds ride behind the build: one host wait serves the build's status and the window's bounds; a build that has to be
+    // repeated larger throws them away)
+    if ((rc = lm_bounds_launch(lm))) return rc;
     LSA_HIP(ctx, hipStreamSynchronize(ctx->stream));
     const LmStatus &s = *lm.h_status.p;
     if (s.overflow & 2u) return lsa_fail(ctx, LSA_ERR_RANGE, "incremental local map: a point lies beyond +-2^20 cells");
@@ -955,7 +985,7 @@ int lm_rebuild(LocalMap &lm, const float4 *const *d_ranges, const size_t *n_rang
     if (grow_f) cap_f *= 2;
     if (grow_n) cap_n *= 2;
   }
-  if ((rc = lm_refit_window(lm))) return rc;
+  if ((rc = lm_window_from_bounds(lm, !leave_in_flight))) return rc;
   lm.pending = false;
   lm.valid = true;
   lm.rebuilds++;

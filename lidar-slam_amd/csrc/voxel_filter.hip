@@ -608,7 +608,7 @@ extern "C" int lsa_voxel_filter_stamps(lsa_voxel_filter *f, int enable, uint64_t
   if (!f) return LSA_ERR_INVALID;
   lsa_context *ctx = f->ctx;
   LSA_HIP(ctx, lsa_enter(ctx));
-  const size_t n = 2 * kViStampWgs * 8;
+  const size_t n = 3 * kViStampWgs * 8;
   if (per_kernel) *per_kernel = kViStampWgs * 8;
   if (!out) {
     LSA_HIP(ctx, hipStreamSynchronize(ctx->stream));

@@ -100,7 +100,7 @@ struct VoxelIndex {
   bool want_cell_idx = false;   // the owner reads cell_idx[] (the linear cell of every point, -1 = none) behind the build: nn_grid.hip
   DevBuf<long long> acc;
   DevBuf<float> scratch;  // bbox partials
-  // diagnostics (lsa_voxel_filter_stamps): thread 0 of every workgroup of k_mark ([0 ..)) and k_accum ([kViStampWgs * 8 ..)) notes the
+  // diagnostics (lsa_voxel_filter_stamps): thread 0 of every workgroup of k_mark ([0 ..)), k_accum ([kViStampWgs * 8 ..)) and k_scan ([2 kViStampWgs * 8 ..)) notes the
   // 100 MHz wall clock at its phase boundaries, 8 values per workgroup; null = off (the kernels test the pointer, nothing else)
   DevBuf<unsigned long long> stamps;
   DevBuf<DevParams> dparams;

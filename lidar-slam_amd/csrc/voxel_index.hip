@@ -499,14 +499,22 @@ __device__ __forceinline__ unsigned long long scan_word(unsigned epoch, unsigned
   return ((unsigned long long)epoch << 34) | (flag << 32) | (unsigned long long)value;
 }
 
-__global__ __launch_bounds__(kBlock) void k_scan(const uint32_t *__restrict__ bits, DevParams *__restrict__ dp, KnownParams kp,
+// 512 threads of 4 words each (was 256 of 8): the kernel is one dependent chain per wave — loads of the bits in front, a scan, then a
+// bit-by-bit walk whose every step is a store — and at one wave per SIMD nothing hides a step's latency; two waves per SIMD share a
+// tile's walk (phase stamps, profiles/r05_scan_stamps.log: the one tile that holds the ground around the sensor, 10-15 k of a
+// 2 M-point map's 48 k cells at 0.3 m, spent 10 us of the kernel's 12.8 writing its cells' list)
+constexpr int kScanBlock = 512, kScanPer = kScanTile / kScanBlock;
+static_assert(kScanPer == 4, "a thread's words are one 16-byte vector");
+__global__ __launch_bounds__(kScanBlock) void k_scan(const uint32_t *__restrict__ bits, DevParams *__restrict__ dp, KnownParams kp,
                                                  unsigned long long *__restrict__ state, unsigned *__restrict__ ticket, unsigned epoch,
-                                                 uint32_t *__restrict__ prefix, int32_t *__restrict__ cell_of_rank, DevParams *__restrict__ host_mirror) {
+                                                 uint32_t *__restrict__ prefix, int32_t *__restrict__ cell_of_rank, DevParams *__restrict__ host_mirror,
+                                                 unsigned long long *__restrict__ stamps) {
+  vi_stamp(stamps, 0);
   // host_mirror (optional, host-mapped pinned memory): the grid definition + occupied-cell count + status as soon as they exist, i.e.
   // behind this kernel — the caller that has to size its own buffers by them (the NDT table) waits for THIS kernel's event while the
   // sums are still being accumulated, instead of for a copy command behind everything
   __shared__ unsigned s_tile, s_excl;
-  __shared__ unsigned wt[kBlock / 64], wr[kBlock / 64];
+  __shared__ unsigned wt[kScanBlock / 64], wr[kScanBlock / 64];
   // Small bitmaps (a lidar scan at 0.5 m: ~24 tiles) do not go through the look-back at all: the chain of tile-to-tile
   // hand-offs through memory is serial (~0.5 us per hop across XCDs: k_scan took 12.8 us of the 31 us filter chain), while
   // every workgroup can simply count the bits in FRONT of its tile itself — at most kScanRedundantMax x 8 KB of an
@@ -515,8 +523,7 @@ __global__ __launch_bounds__(kBlock) void k_scan(const uint32_t *__restrict__ bi
   // the tile this workgroup will most likely own is loaded before anything is known of the grid definition (the grid
   // covers the bitmap's capacity, so the address is valid whatever the definition says): its latency overlaps the
   // definition's
-  const uint4 *spec_src = reinterpret_cast<const uint4 *>(bits + (size_t)blockIdx.x * kScanTile + (size_t)threadIdx.x * 8);
-  uint4 lo = spec_src[0], hi = spec_src[1];
+  uint4 lo = *reinterpret_cast<const uint4 *>(bits + (size_t)blockIdx.x * kScanTile + (size_t)threadIdx.x * kScanPer);
   const unsigned nsb = kp.valid ? kp.nsb : dp->nsb;
   const bool redundant = nsb <= kScanRedundantMax;
   if (!redundant) {
@@ -533,40 +540,39 @@ __global__ __launch_bounds__(kBlock) void k_scan(const uint32_t *__restrict__ bi
     return;
   }
   const size_t W = kp.valid ? (size_t)kp.W : (size_t)dp->W;
+  vi_stamp(stamps, 1);
   unsigned front = 0;  // redundant path: this thread's share of the popcount of words [0, tile * kScanTile)
   if (redundant) {
-    // a predecessor tile is kScanTile / 4 = 512 uint4 = 2 per thread: both loads of up to eight tiles are issued before the
-    // first popcount (sixteen 16-byte loads in flight per lane), so the front count costs ~one L2 latency per eight tiles
+    // a predecessor tile is kScanTile / 4 = 512 uint4 = one per thread: the loads of up to sixteen tiles are issued before the
+    // first popcount, so the front count costs ~one L2 latency per sixteen tiles
     const uint4 *all = reinterpret_cast<const uint4 *>(bits) + threadIdx.x;
     unsigned t = 0;
-    for (; t + 8 <= tile; t += 8) {
+    for (; t + 16 <= tile; t += 16) {
       uint4 v[16];
 #pragma unroll
-      for (int k = 0; k < 16; k++) v[k] = all[(size_t)(t * 2 + k) * kBlock];
+      for (int k = 0; k < 16; k++) v[k] = all[(size_t)(t + k) * kScanBlock];
 #pragma unroll
       for (int k = 0; k < 16; k++) front += __popc(v[k].x) + __popc(v[k].y) + __popc(v[k].z) + __popc(v[k].w);
     }
-    for (; t + 2 <= tile; t += 2) {
+    for (; t + 4 <= tile; t += 4) {
       uint4 v[4];
 #pragma unroll
-      for (int k = 0; k < 4; k++) v[k] = all[(size_t)(t * 2 + k) * kBlock];
+      for (int k = 0; k < 4; k++) v[k] = all[(size_t)(t + k) * kScanBlock];
 #pragma unroll
       for (int k = 0; k < 4; k++) front += __popc(v[k].x) + __popc(v[k].y) + __popc(v[k].z) + __popc(v[k].w);
     }
     for (; t < tile; t++) {
-      uint4 v0 = all[(size_t)(t * 2) * kBlock], v1 = all[(size_t)(t * 2 + 1) * kBlock];
-      front += __popc(v0.x) + __popc(v0.y) + __popc(v0.z) + __popc(v0.w) + __popc(v1.x) + __popc(v1.y) + __popc(v1.z) + __popc(v1.w);
+      uint4 v0 = all[(size_t)t * kScanBlock];
+      front += __popc(v0.x) + __popc(v0.y) + __popc(v0.z) + __popc(v0.w);
     }
   }
-  size_t base = (size_t)tile * kScanTile + (size_t)threadIdx.x * 8;
-  if (tile != blockIdx.x) {  // look-back path: tiles are handed out by ticket
-    const uint4 *src = reinterpret_cast<const uint4 *>(bits + base);
-    lo = src[0]; hi = src[1];
-  }
-  uint32_t wv[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+  if (stamps) { __builtin_amdgcn_s_waitcnt(0); vi_stamp(stamps, 2); }   // (diagnostics only: the bits in front of this tile have arrived)
+  size_t base = (size_t)tile * kScanTile + (size_t)threadIdx.x * kScanPer;
+  if (tile != blockIdx.x) lo = *reinterpret_cast<const uint4 *>(bits + base);  // look-back path: tiles are handed out by ticket
+  uint32_t wv[kScanPer] = {lo.x, lo.y, lo.z, lo.w};
   unsigned local = 0;
 #pragma unroll
-  for (int k = 0; k < 8; k++) {
+  for (int k = 0; k < kScanPer; k++) {
     if (base + k >= W) wv[k] = 0u;
     local += __popc(wv[k]);
   }
@@ -584,14 +590,15 @@ __global__ __launch_bounds__(kBlock) void k_scan(const uint32_t *__restrict__ bi
     if (lane == 0) wr[wave] = front;
   }
   __syncthreads();
+  vi_stamp(stamps, 3);
   unsigned agg = 0;
 #pragma unroll
-  for (int w = 0; w < kBlock / 64; w++) agg += wt[w];
+  for (int w = 0; w < kScanBlock / 64; w++) agg += wt[w];
   if (redundant) {
     if (threadIdx.x == 0) {
       unsigned excl = 0;
 #pragma unroll
-      for (int w = 0; w < kBlock / 64; w++) excl += wr[w];
+      for (int w = 0; w < kScanBlock / 64; w++) excl += wr[w];
       s_excl = excl;
       if (tile == nsb - 1) {
         dp->V = excl + agg;  // #occupied cells
@@ -632,29 +639,29 @@ __global__ __launch_bounds__(kBlock) void k_scan(const uint32_t *__restrict__ bi
     }
   }
   __syncthreads();
+  vi_stamp(stamps, 4);
   unsigned run = s_excl + incl - local;
   for (int w = 0; w < wave; w++) run += wt[w];
-  unsigned pf[8];
+  unsigned pf[kScanPer];
 #pragma unroll
-  for (int k = 0; k < 8; k++) {
+  for (int k = 0; k < kScanPer; k++) {
     pf[k] = run;
     run += __popc(wv[k]);
   }
-  uint4 *dst = reinterpret_cast<uint4 *>(prefix + base);
-  dst[0] = make_uint4(pf[0], pf[1], pf[2], pf[3]);
-  dst[1] = make_uint4(pf[4], pf[5], pf[6], pf[7]);
-  // inverse map (rank -> cell).  A lane's 8 consecutive words are 256 x-adjacent cells, and occupied cells come in x-runs
+  *reinterpret_cast<uint4 *>(prefix + base) = make_uint4(pf[0], pf[1], pf[2], pf[3]);
+  // inverse map (rank -> cell).  A lane's 4 consecutive words are 128 x-adjacent cells, and occupied cells come in x-runs
   // (the ground next to the sensor, a wall): written by the lane that scanned them, the densest lane set the kernel's
   // duration (3.5 us for a tile whose other lanes had nothing to write).  The words and their ranks go through LDS and are
   // dealt out again round-robin, so that a run of n dense words is written by n different lanes.
   __shared__ uint32_t s_w[kScanTile], s_pf[kScanTile];
 #pragma unroll
-  for (int k = 0; k < 8; k++) { s_w[threadIdx.x * 8 + k] = wv[k]; s_pf[threadIdx.x * 8 + k] = pf[k]; }
+  for (int k = 0; k < kScanPer; k++) { s_w[threadIdx.x * kScanPer + k] = wv[k]; s_pf[threadIdx.x * kScanPer + k] = pf[k]; }
   __syncthreads();
+  vi_stamp(stamps, 5);
   const size_t tile_cell0 = (size_t)tile * kScanTile * 32;
 #pragma unroll 2
-  for (int k = 0; k < 8; k++) {
-    const int wi = k * kBlock + threadIdx.x;
+  for (int k = 0; k < kScanPer; k++) {
+    const int wi = k * kScanBlock + threadIdx.x;
     uint32_t b = s_w[wi];
     unsigned r = s_pf[wi];
     while (b) {
@@ -663,6 +670,8 @@ __global__ __launch_bounds__(kBlock) void k_scan(const uint32_t *__restrict__ bi
       cell_of_rank[r++] = (int32_t)(tile_cell0 + (size_t)wi * 32 + bit);
     }
   }
+  vi_stamp(stamps, 6);
+  if (stamps) { __builtin_amdgcn_s_waitcnt(0); vi_stamp(stamps, 7); }   // (diagnostics only: until the stores have been acknowledged)
 }
 
 __device__ __forceinline__ unsigned cell_rank(const uint32_t *__restrict__ bits, const uint32_t *__restrict__ prefix, int cell) {
@@ -834,11 +843,6 @@ __global__ __launch_bounds__(kBlock) void k_accum(const float4 *__restrict__ pts
     vi_point_terms<NS>(o, fs, p, v);
     if (hc[k] >= 0) {   // a new run starts here
       if (open) emit(oslot, ocell, os, on);
-  if (stamps) {   // stamp 7 of the workgroup's record: how many of its runs went straight to memory (table full)
-    if (threadIdx.x == 0 && blockIdx.x < kViStampWgs) stamps[(size_t)blockIdx.x * 8 + 7] = 0ull;
-    __syncthreads();
-    if (n_direct && blockIdx.x < kViStampWgs) atomicAdd(stamps + (size_t)blockIdx.x * 8 + 7, (unsigned long long)n_direct);
-  }
       open = true; oslot = slot[k]; ocell = cell; on = 1;
 #pragma unroll
       for (int j = 0; j < NS; j++) os[j] = v[j];
@@ -852,6 +856,11 @@ __global__ __launch_bounds__(kBlock) void k_accum(const float4 *__restrict__ pts
   vi_stamp(stamps, 2);
   __syncthreads();
   vi_stamp(stamps, 3);
+  if (stamps) {   // stamp 7 of the workgroup's record: how many of its runs went straight to memory (table full)
+    if (threadIdx.x == 0 && blockIdx.x < kViStampWgs) stamps[(size_t)blockIdx.x * 8 + 7] = 0ull;
+    __syncthreads();
+    if (n_direct && blockIdx.x < kViStampWgs) atomicAdd(stamps + (size_t)blockIdx.x * 8 + 7, (unsigned long long)n_direct);
+  }
   // flush, step 1: a lane's slots are independent, their rank look-ups are issued together; the rank replaces the cell in keys[]
   // (each slot is read and rewritten by its one lane; -1 stays -1).  BY_CELL: the cell IS the row.
   if constexpr (!BY_CELL) {
@@ -1093,8 +1102,8 @@ int vi_enqueue(lsa_context *ctx, VoxelIndex &vi, const float4 *d_pts, size_t n, 
     }
     hipLaunchKernelGGL(k_occ_to_bits, dim3(lsa_div_up(vi.W_cap, kBlock)), dim3(kBlock), 0, ctx->stream, reinterpret_cast<uint4 *>(vi.occ.p), dp, kp, vi.bits.p);
   }
-  hipLaunchKernelGGL(k_scan, dim3(nsb_cap), dim3(kBlock), 0, ctx->stream, vi.bits.p, vi.dparams.p, kp, vi.scan_state.p, vi.tickets.p + 1, vi.scan_epoch,
-                     vi.prefix.p, vi.cell_of_rank.p, vi.mirror_at_scan ? vi.h_params.p : (DevParams *)nullptr);
+  hipLaunchKernelGGL(k_scan, dim3(nsb_cap), dim3(kScanBlock), 0, ctx->stream, vi.bits.p, vi.dparams.p, kp, vi.scan_state.p, vi.tickets.p + 1, vi.scan_epoch,
+                     vi.prefix.p, vi.cell_of_rank.p, vi.mirror_at_scan ? vi.h_params.p : (DevParams *)nullptr, vi.stamps.p ? vi.stamps.p + 2 * kViStampWgs * 8 : nullptr);
   if (vi.mirror_at_scan) LSA_HIP(ctx, hipEventRecord(vi.ev_done, ctx->stream));   // vi_wait() returns behind the scan; the accumulation is still running then
   unsigned g = lsa_div_up(n, small ? kTileSmall : kTileBig);
 #define LSA_LAUNCH_ACCUM(NS_, TILE_) hipLaunchKernelGGL((k_accum<NS_, TILE_, false>), dim3(g), dim3(kBlock), 0, ctx->stream, d_pts, n, dp, kp, vi.bits.p, vi.prefix.p, vi.acc.p, vi.cnt.p, (uint8_t *)nullptr, (uint32_t *)nullptr, (float4 *)nullptr, vi.stamps.p ? vi.stamps.p + kViStampWgs * 8 : nullptr, no_pull)

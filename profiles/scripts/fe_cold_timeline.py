@@ -4,8 +4,12 @@ usage: fe_cold_timeline.py <rocprofv3 output dir>   (a --kernel-trace run of fe_
 import csv, glob, re, sys
 f = glob.glob(sys.argv[1] + "/**/*kernel_trace.csv", recursive=True)[0]
 rows = list(csv.DictReader(open(f)))
+mc = glob.glob(sys.argv[1] + "/**/*memory_copy_trace.csv", recursive=True)
+for r in (csv.DictReader(open(mc[0])) if mc else []):
+    rows.append({"Kernel_Name": "copy_" + r.get("Direction", "?") + "_%sB" % r.get("Size", "?"), "Start_Timestamp": r["Start_Timestamp"], "End_Timestamp": r["End_Timestamp"]})
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
 def short(n):
+    if n.startswith("copy_"): return n
     m = re.search(r"(k_\w+(<[^>]*>)?)", n)
     return m.group(1) if m else n[:40]
 ks = [(short(r["Kernel_Name"]), int(r["Start_Timestamp"]), int(r["End_Timestamp"])) for r in rows]

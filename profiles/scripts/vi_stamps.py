@@ -25,14 +25,15 @@ per = C.c_size_t(0)
 ctx.check(L.lsa_voxel_filter_stamps(f.h, 1, None, 0, C.byref(per)))
 for _ in range(3):
     out = f.filter_device(d_t)
-buf = (C.c_uint64 * (2 * per.value))()
-ctx.check(L.lsa_voxel_filter_stamps(f.h, 0, buf, 2 * per.value, C.byref(per)))
-a = np.frombuffer(buf, dtype=np.uint64).reshape(2, -1, 8).astype(np.int64)
+buf = (C.c_uint64 * (3 * per.value))()
+ctx.check(L.lsa_voxel_filter_stamps(f.h, 0, buf, 3 * per.value, C.byref(per)))
+a = np.frombuffer(buf, dtype=np.uint64).reshape(3, -1, 8).astype(np.int64)
 names = (("k_mark", ["clear", "points", "barrier", "flush issue", "flush ack"]),
-         ("k_accum", ["clear", "points", "barrier", "ranks", "flush issue", "flush ack"]))
+         ("k_accum", ["clear", "points", "barrier", "ranks", "flush issue", "flush ack"]),
+         ("k_scan", ["definition", "front count", "own tile", "prefix known", "prefix out", "cells issue", "cells ack"]))
 for k, (name, ph) in enumerate(names):
     s = a[k]
-    s = s[s[:, 0] != 0]
+    s = s[(s[:, 0] != 0) & (s[:, len(ph)] != 0)]   # (k_scan: workgroups beyond the bitmap's tiles leave at once)
     if not len(s):
         continue
     t0 = s[:, 0].min()
