@@ -13,6 +13,8 @@ poses = synth.trajectory(30)
 P0inv = np.linalg.inv(poses[0])
 parts = [synth.transform_points(P0inv @ poses[k], synth.gen_scan(scene, poses[k], seed=100 + k)) for k in range(0, 17)]
 target = np.ascontiguousarray(np.concatenate(parts, 0))[:2000000]
+if os.environ.get("SCAN"):   # one raw scan (the frame filter's input) instead of the 2 M-point map
+    target = np.ascontiguousarray(synth.gen_scan(scene, poses[8], seed=56))
 ctx = capi.Context(0)
 d_t = torch.from_numpy(target).cuda()
 leaf = float(os.environ.get("LEAF", "0.3"))
