@@ -247,3 +247,34 @@ def test_one_handle_through_every_build_path(scene, oracle, cloud600k):
     c = f.counters()
     assert c["pulled"] >= 3 and c["misses"] >= 1
     f.close(); ctx.close()
+
+
+@pytest.mark.parametrize("n_points", [120000, 600000])
+def test_phase_stamps_change_nothing_and_are_ordered(scene, cloud600k, n_points):
+    """lsa_voxel_filter_stamps (diagnostics, include/lidar_slam_amd.h): with the stamps on, a scan-sized and a large cloud give the
+    bits they give without; every workgroup's record of the accumulate and the scan kernel is non-decreasing in time (the waits and
+    the extra barrier that only exist in this mode sit where every wave of the workgroup reaches them); off again: same bits."""
+    import ctypes as C
+    import torch
+    ctx = capi.Context(0)
+    d = torch.from_numpy(np.ascontiguousarray(cloud600k[:n_points])).cuda()
+    f = cloud_filter.VoxelFilterHip(ctx, 0.5, 0.5, 0.5)
+    plain = [f.filter_device(d).clone() for _ in range(2)]
+    L = capi.lib()
+    L.lsa_voxel_filter_stamps.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_uint64), C.c_size_t, C.POINTER(C.c_size_t)]
+    per = C.c_size_t(0)
+    ctx.check(L.lsa_voxel_filter_stamps(f.h, 1, None, 0, C.byref(per)))
+    stamped = [f.filter_device(d).clone() for _ in range(2)]
+    buf = (C.c_uint64 * (3 * per.value))()
+    ctx.check(L.lsa_voxel_filter_stamps(f.h, 0, buf, 3 * per.value, C.byref(per)))
+    ctx.check(L.lsa_voxel_filter_stamps(f.h, 0, None, 0, C.byref(per)))
+    after = f.filter_device(d).clone()
+    for o in plain[1:] + stamped + [after]:
+        assert torch.equal(o, plain[0])
+    a = np.frombuffer(buf, dtype=np.uint64).reshape(3, -1, 8).astype(np.int64)
+    acc = a[1][a[1][:, 0] != 0]          # k_accum: entry .. flush acknowledged in columns 0..6 (7: a counter)
+    assert len(acc) >= n_points // 2048 and (np.diff(acc[:, :7], axis=1) >= 0).all()
+    scn = a[2][(a[2][:, 0] != 0) & (a[2][:, 7] != 0)]   # k_scan: workgroups that own a tile of the bitmap
+    assert len(scn) >= 1 and (np.diff(scn, axis=1) >= 0).all()
+    assert (acc[:, 6].max() - acc[:, 0].min()) < 100 * 1000   # < 1 ms at 100 MHz: the clock is the device's wall clock
+    f.close(); ctx.close()
