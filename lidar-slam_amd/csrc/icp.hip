@@ -341,8 +341,8 @@ __global__ __launch_bounds__(kBlock) void k_plane_normals(const long long *__res
                                                           float4 *__restrict__ normals) {
   size_t r = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (r >= nocc) return;
-  const long long *a = acc + r * 10;
-  int ni = cnt[r];
+  const long long *a = acc + r * vi_row_stride(10);   // ten sums and, behind them, the count (voxel_index.h)
+  int ni = (int)a[10];
   float4 out = make_float4(0.f, 0.f, 0.f, 0.f);
   if (ni >= 6) {
     double n = (double)ni;

@@ -24,8 +24,8 @@ __global__ __launch_bounds__(kBlock) void k_ndt_finalize(long long *__restrict__
                                                          uint32_t *__restrict__ vbits, int pcl) {
   size_t r = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (r >= nocc) return;
-  long long *a = acc + r * 10;
-  int ni = cnt[r];
+  long long *a = acc + r * vi_row_stride(10);   // ten sums and, behind them, the count (voxel_index.h)
+  int ni = (int)a[10];
   int cell = cell_of_rank[r];
   double o[3];
   lsa_cell_origin(m, cell, o);
@@ -39,8 +39,7 @@ __global__ __launch_bounds__(kBlock) void k_ndt_finalize(long long *__restrict__
   // the point count, which lsa_ndt_grid_dump reports, moves to its own array
   counts[r] = ni;
 #pragma unroll
-  for (int k = 0; k < 10; k++) a[k] = 0;
-  cnt[r] = 0;
+  for (int k = 0; k <= 10; k++) a[k] = 0;
 }
 
 // {occupancy, valid, prefix} per 32 cells in one 16-byte word; the index's own bitmap word is cleared on the way (the

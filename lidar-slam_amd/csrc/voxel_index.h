@@ -168,9 +168,10 @@ int vi_cleanup(lsa_context *ctx, VoxelIndex &vi, size_t n);
 int vi_prepare_large(lsa_context *ctx, VoxelIndex &vi, int ns, bool with_occ);
 constexpr size_t kByCellMaxBytes = (size_t)1 << 30;
 constexpr size_t kByCellStride = 8;   // 64-bit words per cell-keyed row (ns = 4: four sums, the count, three spare)
-// 64-bit words per row of acc[], whatever the key: the ns = 4 rows of VoxelFilter are one 64-byte line each with the count as their
-// fifth word (cnt[] unused) — one atomic request per (tile, cell) pair instead of two; the ns = 10 rows of the voxel table stay
-// 80 bytes + cnt[] (their finalize kernels are shared with the incremental map's arithmetic and read them as they are)
-constexpr size_t vi_row_stride(int ns) { return ns == 4 ? kByCellStride : (size_t)ns; }
+// 64-bit words per row of acc[], whatever the key, the count being the word behind the ns sums (cnt[] unused): the ns = 4 rows of
+// VoxelFilter are one 64-byte line each — one atomic request per (tile, cell) pair instead of two —, the ns = 10 rows of the voxel
+// table two lines (sums 0..7 | sums 8, 9 and the count) instead of an unaligned 80 bytes + cnt[]: two requests per pair instead of three
+constexpr size_t kRow10Stride = 16;
+constexpr size_t vi_row_stride(int ns) { return ns == 4 ? kByCellStride : (ns == 10 ? kRow10Stride : (size_t)ns + 1); }
 
 #endif

@@ -680,7 +680,7 @@ __device__ __forceinline__ unsigned cell_rank(const uint32_t *__restrict__ bits,
 
 // per-cell fixed-point sums: LDS pre-aggregation per tile, then one set of global atomics per distinct cell.  Rows of acc[]: NS = 4
 // (VoxelFilter) one 64-byte line per key — four sums and the count as the fifth 64-bit word, so that a cell's adds are ONE atomic
-// instruction touching ONE line, one request to the memory side (vi_row_stride) —, NS = 10 (voxel table) ten words + cnt[].
+// instruction touching ONE line, one request to the memory side (vi_row_stride) —, NS = 10 (voxel table) two lines: ten sums and the count.
 // BY_CELL (large clouds of an owner that cleans up by key, VoxelIndex::allow_by_cell; NS = 4 only): the rows are keyed by the
 // CELL, not by its rank among the occupied cells — the sums then need nothing the scan produces, and this kernel is the build's
 // only pass over the points: it also leaves the byte marks of the cells it met (no k_mark_bytes: one 32 MB read, one launch and
@@ -817,8 +817,7 @@ __global__ __launch_bounds__(kBlock) void k_accum(const float4 *__restrict__ pts
         unsigned long long *a = (unsigned long long *)acc + (size_t)rank * vi_row_stride(NS);
 #pragma unroll
         for (int j = 0; j < NS; j++) atomicAdd(a + j, rs[j]);
-        if (NS == 4) atomicAdd(a + NS, (unsigned long long)(unsigned)rn);
-        else atomicAdd(cnt + rank, rn);
+        atomicAdd(a + NS, (unsigned long long)(unsigned)rn);
       }
     }
   };
@@ -903,11 +902,8 @@ __global__ __launch_bounds__(kBlock) void k_accum(const float4 *__restrict__ pts
           if (occ) occ[(unsigned)rk[q]] = (uint8_t)1;
           else atomicOr(mark_bits + ((unsigned)rk[q] >> 5), 1u << ((unsigned)rk[q] & 31u));
         }
-      } else if constexpr (NS == 4) {   // (the same one-line rows, keyed by the rank)
-        atomicAdd((unsigned long long *)acc + (size_t)(unsigned)rk[q] * kByCellStride + j, j < NS ? sums[sl][j < NS ? j : 0] : (unsigned long long)(unsigned)counts[sl]);
-      } else {
-        if (j < NS) atomicAdd((unsigned long long *)(acc + (size_t)(unsigned)rk[q] * NS) + j, sums[sl][j]);
-        else atomicAdd(cnt + (unsigned)rk[q], counts[sl]);
+      } else {   // (the same rows keyed by the rank: one line for NS = 4, two for NS = 10 — vi_row_stride)
+        atomicAdd((unsigned long long *)acc + (size_t)(unsigned)rk[q] * vi_row_stride(NS) + j, j < NS ? sums[sl][j < NS ? j : 0] : (unsigned long long)(unsigned)counts[sl]);
       }
     }
   }
@@ -924,12 +920,7 @@ __global__ __launch_bounds__(kBlock) void k_cleanup(const DevParams *__restrict_
   const int cell = cell_of_rank[r];
   bits[cell >> 5] = 0u;
   const size_t key = by_cell ? (size_t)cell : r;
-  if (ns == 4) {
-    for (int j = 0; j <= ns; j++) acc[key * kByCellStride + j] = 0;
-  } else {
-    for (int j = 0; j < ns; j++) acc[key * ns + j] = 0;
-    cnt[key] = 0;
-  }
+  for (int j = 0; j <= ns; j++) acc[key * vi_row_stride(ns) + j] = 0;
 }
 
 inline unsigned stream_grid(lsa_context *ctx, size_t n) {
