@@ -165,6 +165,8 @@ struct lsa_front_end {
   bool incremental = getenv("LSA_FE_INCREMENTAL") ? atoi(getenv("LSA_FE_INCREMENTAL")) != 0 : true;
   bool lm_off = false;       // fell back to the full build for good (window / table limits, coordinates out of range)
   bool lm_adopted = false;   // the NDT handle currently runs on the local map's table
+  // a single Update defers its ScanMatch's final pass over the key-frame's first launches (fe_update_filtered); LSA_FE_DEFER=0: waits for it first
+  bool defer_single = getenv("LSA_FE_DEFER") ? atoi(getenv("LSA_FE_DEFER")) != 0 : true;
   unsigned long long scale_n = 0;
   unsigned long long n_full_builds = 0;
 };
@@ -309,6 +311,10 @@ int fe_rebuild_map(lsa_front_end *fe, KeyFrame *added, bool evicted, const float
   // transformed points into the slot and swaps it for the evicted key-frame in the persistent sums
   const bool steady = fe->incremental && !fe->lm_off && !relayout && fe->lm.valid && want_filtered == fe->lm.filtered;
   const bool own_stream = fe_map_ctx(fe) == fe->ctx_m;
+  // A single Update may reach this point with its ScanMatch's final derivative pass still in flight (deferred: its sums only complete
+  // the statistics, fe_update_filtered).  The steady update takes its rows between its two halves — nothing the pass reads is written
+  // before (lm_finish_begin); every other way of building the target starts by taking them.
+  if (!steady && (rc = ndt_collect_deferred(fe->ndt))) return rc;
   if (fe->incremental && !fe->lm_off) {
     // an update still in flight on the OTHER stream (the caller alternates between single Updates and batches) comes first
     if (!own_stream && (rc = fe_map_join(fe))) return rc;
@@ -366,7 +372,11 @@ int fe_rebuild_map(lsa_front_end *fe, KeyFrame *added, bool evicted, const float
     LSA_HIP(ctx, hipEventRecord(fe->ev_cloud, fe->ctx_m->stream));
     LSA_HIP(ctx, hipStreamWaitEvent(ctx->stream, fe->ev_cloud, 0));
   }
-  if ((rc = lm_finish(fe->lm))) return rc;
+  if ((rc = lm_finish_begin(fe->lm))) return rc;
+  // (the host has been launching for ~10 us: the deferred pass's rows are there, or as good as; should the pass have to be redone, the
+  // redo still finds the records and the probe table it was posted for)
+  if ((rc = ndt_collect_deferred(fe->ndt))) return rc;
+  if ((rc = lm_finish_end(fe->lm))) return rc;
   if (own_stream) {
     LSA_HIP(ctx, hipEventRecord(fe->ev_map, fe->ctx_m->stream));
     fe->map_inflight = true;
@@ -424,7 +434,19 @@ int fe_update_filtered(lsa_front_end *fe, const float4 *d_cloud, size_t n, const
   } else {
     float cur[16];
     if (fe->incremental && !fe->lm_off && (rc = fe_lm_settle(fe))) return rc;
-    if ((rc = lsa_ndt_scan_match_device(fe->ndt, (const float *)src, n_src, fe->predict_pose, cur, &st->ndt))) return rc;
+    // A single Update defers its ScanMatch's final derivative pass as a batch does (the pose is known before that pass has run: its sums
+    // only complete score / probability / pairs of st->ndt) — for the length of this function: if the scan becomes a key-frame, the
+    // local-map update's first launches go out while the pass is on its way (fe_rebuild_map takes its rows before anything the pass
+    // reads is rewritten); otherwise the rows are taken right below.  Either way st->ndt is complete when this returns.
+    const bool single_defer = !batch && fe->defer_single;
+    const bool prev_defer = single_defer ? ndt_defer_scope(fe->ndt, true) : false;
+    rc = lsa_ndt_scan_match_device(fe->ndt, (const float *)src, n_src, fe->predict_pose, cur, &st->ndt);
+    if (single_defer) (void)ndt_defer_scope(fe->ndt, prev_defer);
+    if (rc) { if (single_defer) (void)ndt_collect_deferred(fe->ndt); return rc; }
+    struct CollectAtExit {   // (every way out of this branch: st is the caller's record, the deferred pass writes into it)
+      lsa_ndt *h; bool on;
+      ~CollectAtExit() { if (on) (void)ndt_collect_deferred(h); }
+    } collect_at_exit{fe->ndt, single_defer};
     memcpy(pose_out, cur, sizeof(cur));
     float inv_last[16];
     if (mat4_inverse(fe->last_pose, inv_last)) mat4_mul(inv_last, cur, fe->step_pose);  // :238
@@ -448,6 +470,7 @@ int fe_update_filtered(lsa_front_end *fe, const float4 *d_cloud, size_t n, const
       if (batch && (rc = fe_map_join(fe))) return rc;
       if (batch && fe->lm_adopted) ndt_prearm(fe->ndt);
     }
+    if (single_defer && (rc = ndt_collect_deferred(fe->ndt))) return rc;   // (not a key-frame: the rows are taken here)
   }
   fe->frames_seen++;
   st->local_map_frames = (int32_t)fe->frames.size();

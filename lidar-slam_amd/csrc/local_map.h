@@ -122,6 +122,10 @@ int lm_swap(LocalMap &lm, float4 *d_slot, size_t slot_cap, bool evict, const flo
 // After lm_swap: move the touched level-F cells' changes into level N, re-finalise the touched level-N cells, publish the
 // status.  Enqueue only; the owner reads lm.h_status once later stream work has completed.
 int lm_finish(LocalMap &lm);
+// the same in two halves (lm_finish = begin + end): everything that writes what a registration pass reads — records, probe table —
+// is in the second
+int lm_finish_begin(LocalMap &lm);
+int lm_finish_end(LocalMap &lm);
 // Everything from scratch from `nranges` ranges of the local-map buffer (first key-frame, the switch to the filtered map,
 // a table that filled up, a re-laid-out buffer): clears, re-adds, finalises every cell, fits the window.  Waits for the stream.
 // leave_in_flight: the window's last two kernels (clear + fill of the dense table) are not waited for — the caller orders the table's

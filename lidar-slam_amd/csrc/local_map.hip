@@ -861,6 +861,14 @@ int lm_swap(LocalMap &lm, float4 *d_slot, size_t slot_cap, bool evict, const flo
 }
 
 int lm_finish(LocalMap &lm) {
+  int rc = lm_finish_begin(lm);
+  return rc ? rc : lm_finish_end(lm);
+}
+
+// first half of an update's tail: the dirty cells of the filter level carried into the sums of level N (filtered map only).  Nothing a
+// registration pass reads is written yet — the records and the probe table are lm_finish_end's — so a pass still in flight on another
+// stream is not disturbed by anything up to here
+int lm_finish_begin(LocalMap &lm) {
   lsa_context *ctx = lm.ctx;
   int rc;
   if (lm.filtered) {
@@ -871,7 +879,14 @@ int lm_finish(LocalMap &lm) {
     const unsigned g = lm.dirty_f.regions + kFdOverWg;
     if ((rc = dirty_shape(ctx, lm.dirty_n, g, kFdRegion, lm.cap_n))) return rc;
     hipLaunchKernelGGL(k_lm_filter_dirty, dim3(g), dim3(kBlock), 0, ctx->stream, view_f(lm), view(lm.dirty_f), view_n(lm), view(lm.dirty_n), A, lm.d_status.p, lm_stamps(lm, 1));
+    LSA_HIP(ctx, hipGetLastError());
   }
+  return LSA_OK;
+}
+
+// second half: the records and the probe-table entries of the dirty level-N cells, the status to the host
+int lm_finish_end(LocalMap &lm) {
+  lsa_context *ctx = lm.ctx;
   lm.epoch++;
   // (a small grid: a key-frame touches ~6 k level-N cells, one per lane of 24 workgroups, and every ACTIVE workgroup ends with one
   // same-address atomic — ~20 ns each at the memory side)

@@ -187,3 +187,59 @@ def test_filter_intensities_outside_the_fixed_point_range(scene, oracle):
     assert np.all(np.isfinite(got))
     err = np.abs(got - ref.astype(np.float64)) / np.maximum(np.abs(ref.astype(np.float64)), 1.0)
     assert err.max() < 4e-6, err.max()
+
+
+def test_single_update_defers_its_final_pass_without_changing_a_bit(scene, monkeypatch):
+    """FrontEnd::Update (one scan per call) posts its ScanMatch's final derivative pass and takes its rows only after the key-frame's
+    first launches (front_end.hip: fe_update_filtered / fe_rebuild_map).  Three drives over the same 26 scans — local map switching to
+    the filtered form at the tenth key-frame — must agree in every pose, every statistic the final pass completes (score, probability,
+    pairs per pass) and the map: (a) LSA_FE_DEFER=0, the pass waited for first; (b) the default; (c) the default with an armed patience
+    of a few microseconds, so that armed kernels — deferred ones among them — leave before their mail comes and their passes are redone
+    the ordinary way BETWEEN the two halves of the map update, where the redo must still find the table the pass was posted for."""
+    import ctypes as C
+    import torch
+    N = 26
+    poses = synth.trajectory(N, step=1.1)
+    d = [torch.from_numpy(np.ascontiguousarray(synth.gen_scan(scene, poses[i], seed=7100 + i))).cuda() for i in range(N)]
+    torch.cuda.synchronize()
+
+    def flat(st):
+        nd = st["ndt"]
+        return (st["key_frame"], st["filtered_points"], st["local_map_points"], st["target_points"], nd["iterations"], nd["passes"], nd["score"],
+                nd["trans_probability"], nd["pairs_per_pass"], nd["converged"])
+
+    def drive(defer, patience_us):
+        monkeypatch.setenv("LSA_FE_DEFER", "1" if defer else "0")
+        ctx = capi.Context(0)
+        fe = front_end.FrontEndHip(ctx)
+        L = capi.lib()
+        L.lsa_front_end_registration.restype = C.c_void_p
+        L.lsa_front_end_registration.argtypes = [C.c_void_p]
+        ndt = C.c_void_p(L.lsa_front_end_registration(fe.h))
+        if patience_us is not None:
+            L.lsa_ndt_set_armed_patience.argtypes = [C.c_void_p, C.c_double]
+            ctx.check(L.lsa_ndt_set_armed_patience(ndt, float(patience_us)))
+        Ts, sts = [], []
+        for c in d:
+            _, T = fe.Update(c)
+            Ts.append(T); sts.append(flat(fe.last_stats))
+        st = capi.NdtArmedStats()
+        L.lsa_ndt_armed_stats.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
+        ctx.check(L.lsa_ndt_armed_stats(ndt, C.byref(st), 0))
+        m = fe.map_verify()
+        fe.close(); ctx.close()
+        return np.stack(Ts), sts, m, st.as_dict()
+
+    T0, s0, m0, a0 = drive(False, None)
+    T1, s1, m1, a1 = drive(True, None)
+    stalled = [drive(True, p) for p in (3.0, 6.0, 10.0)]   # around the link's round trip: some mails come in time, some do not
+    monkeypatch.delenv("LSA_FE_DEFER", raising=False)
+    assert sum(s[0] for s in s0) >= 12 and m0["mismatches"] == 0          # the filtered map is reached and verified against a full build
+    assert a0["deferred"] == 0 and a1["deferred"] >= N // 2, (a0, a1)       # (b) really deferred final passes
+    lost = sum(a["fallbacks"] + a["expired"] for _, _, _, a in stalled)
+    print("deferred %d of %d ScanMatches; stalled drives: %s" % (a1["deferred"], N - 1, [(a["deferred"], a["fallbacks"], a["expired"]) for _, _, _, a in stalled]))
+    assert lost >= 5, [a for _, _, _, a in stalled]                        # (c) really lost armed kernels
+    for T, s, m, _ in [(T1, s1, m1, a1)] + stalled:
+        assert np.array_equal(T, T0)
+        assert s == s0
+        assert m == m0
