@@ -44,24 +44,35 @@ __global__ __launch_bounds__(kBlock) void k_ndt_finalize(long long *__restrict__
 
 // {occupancy, valid, prefix} per 32 cells in one 16-byte word; the index's own bitmap word is cleared on the way (the
 // packed copy is what every later reader uses), which completes the clean-up started in k_ndt_finalize
-__global__ __launch_bounds__(kBlock) void k_pack_words(uint32_t *__restrict__ bits, const uint32_t *__restrict__ vbits,
+__global__ __launch_bounds__(kBlock) void k_pack_words(uint32_t *__restrict__ bits, uint32_t *__restrict__ vbits,
                                                        const uint32_t *__restrict__ prefix, size_t W, uint4 *__restrict__ words) {
   size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= W) return;
   words[i] = make_uint4(bits[i], vbits[i], prefix[i], 0u);
   bits[i] = 0u;
+  vbits[i] = 0u;   // (the valid bitmap is zero again, too: the next build needs no fill launch in front of k_ndt_finalize)
 }
 
-// dense probe table of the pass kernel: one 16-B entry per CELL of the box (not per occupied cell): the centroid relative
-// to the cell's low corner in f32 and the record rank; cells without a usable voxel keep the 0xFF fill (rank -1)
-__global__ __launch_bounds__(kBlock) void k_dense_fill(const double *__restrict__ rec, const int32_t *__restrict__ state, const int32_t *__restrict__ cell_of_rank,
-                                                       size_t nocc, CellMap m, float4 *__restrict__ dense) {
-  size_t r = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (r >= nocc || state[r] != 1) return;
-  int cell = cell_of_rank[r];
-  int ijk[3];
-  lsa_cell_unravel(m, cell, ijk);
-  dense[cell] = ndt_dense_entry(rec + r * kRecDoubles, ijk, m.leaf, (int)r);
+// dense probe table of the pass kernel in ONE sweep over the cells of the box: the entry of a valid voxel (its rank among the occupied
+// cells from the packed words: prefix + occupied bits below), all-ones (rank -1) for every other cell and for the two pad entries a
+// row load may touch.  (Was a 0xFF fill of the whole table and a scatter over the occupied cells behind it: one launch more.)
+__global__ __launch_bounds__(kBlock) void k_dense_build(const uint4 *__restrict__ words, const double *__restrict__ rec, CellMap m, size_t ncells, size_t nc,
+                                                        float4 *__restrict__ dense) {
+  for (size_t c = (size_t)blockIdx.x * blockDim.x + threadIdx.x; c < nc; c += (size_t)gridDim.x * blockDim.x) {
+    const unsigned all = 0xFFFFFFFFu;
+    float4 e = make_float4(__uint_as_float(all), __uint_as_float(all), __uint_as_float(all), __uint_as_float(all));
+    if (c < ncells) {
+      const uint4 w = words[c >> 5];
+      const unsigned bit = (unsigned)(c & 31);
+      if ((w.y >> bit) & 1u) {   // valid (k_ndt_finalize: state == 1)
+        const unsigned r = w.z + (unsigned)__popc(w.x & ((1u << bit) - 1u));
+        int ijk[3];
+        lsa_cell_unravel(m, (int)c, ijk);
+        e = ndt_dense_entry(rec + (size_t)r * kRecDoubles, ijk, m.leaf, (int)r);
+      }
+    }
+    dense[c] = e;
+  }
 }
 
 __global__ __launch_bounds__(kBlock) void k_count_valid(const int32_t *__restrict__ state, size_t nocc, unsigned *__restrict__ out) {
@@ -172,18 +183,25 @@ int ndt_build_grid(lsa_ndt *h, const float4 *d_pts, size_t n) {
   if ((rc = h->words.reserve(ctx, vi.W, 1.25))) return rc;
   if ((rc = h->d_small.reserve(ctx, 64))) return rc;
   if ((rc = h->counts.reserve(ctx, V + 1, 1.25))) return rc;
-  fill16(ctx, h->vbits.p, vi.W * sizeof(uint32_t), 0u);
+  // the valid bitmap: zeroed once when it is (re)allocated — over its whole capacity —, left zero by every build's k_pack_words
+  if (!h->vbits_zero || h->vbits.cap != h->vbits_zero_cap) {
+    fill16(ctx, h->vbits.p, (h->vbits.cap & ~(size_t)3) * sizeof(uint32_t), 0u);   // (cap >= W + 4: every word a build touches lies below cap & ~3)
+    h->vbits_zero_cap = h->vbits.cap;
+  }
+  h->vbits_zero = false;   // (until this build's k_pack_words is enqueued)
   hipLaunchKernelGGL(k_ndt_finalize, dim3(lsa_div_up(V, kBlock)), dim3(kBlock), 0, ctx->stream, vi.acc.p, vi.cnt.p, vi.cell_of_rank.p, V, vi.map, vi.fs,
                      h->rec.p, h->state.p, h->counts.p, h->vbits.p, h->mode == LSA_NDT_MODE_PCL ? 1 : 0);
   hipLaunchKernelGGL(k_pack_words, dim3(lsa_div_up(vi.W, kBlock)), dim3(kBlock), 0, ctx->stream, vi.bits.p, h->vbits.p, vi.prefix.p, vi.W, h->words.p);
+  if (hipGetLastError() == hipSuccess) h->vbits_zero = true;
   vi.clean = true;  // sums, counts and bitmap words of this build are zero again
   // dense probe table when the cell box is small enough (16 B per cell; default limit 16 Mi cells = 256 MiB)
   h->use_dense = vi.map.ncells <= h->dense_max_cells;
   if (h->use_dense) {
     size_t nc = (size_t)vi.map.ncells + 2;  // a row load reads 3 entries from any in-box cell
     if ((rc = h->dense.reserve(ctx, nc, 1.1))) return rc;
-    fill16(ctx, h->dense.p, nc * sizeof(float4), 0xFFFFFFFFu);
-    hipLaunchKernelGGL(k_dense_fill, dim3(lsa_div_up(V, kBlock)), dim3(kBlock), 0, ctx->stream, h->rec.p, h->state.p, vi.cell_of_rank.p, V, vi.map, h->dense.p);
+    size_t g = (nc + kBlock - 1) / kBlock;
+    if (g > 4096) g = 4096;
+    hipLaunchKernelGGL(k_dense_build, dim3((unsigned)g), dim3(kBlock), 0, ctx->stream, h->words.p, h->rec.p, vi.map, (size_t)vi.map.ncells, nc, h->dense.p);
   }
   LSA_HIP(ctx, hipGetLastError());
   // Nothing after the bounding-box / count round trip above needs the host, so the call returns with the table still being

@@ -28,6 +28,8 @@ struct lsa_ndt {
   DevBuf<double> rec;           // [nocc][kRecDoubles]
   DevBuf<int32_t> state;        // [nocc] 0 / 1 / -1
   DevBuf<uint32_t> vbits;       // valid bitmap
+  bool vbits_zero = false;      // ... known to be all zero (left so by the last build's k_pack_words) over vbits_zero_cap words
+  size_t vbits_zero_cap = 0;
   DevBuf<uint4> words;          // {occ bits, valid bits, prefix, 0} per 32 cells
   DevBuf<float4> dense;         // dense probe table {centroid - cell corner (f32 x3), record rank or -1} per cell (+2 pad)
   bool use_dense = false;       // built when the cell box has <= dense_max_cells cells
