@@ -56,13 +56,27 @@ __global__ __launch_bounds__(kBlock) void k_pack_words(uint32_t *__restrict__ bi
 // dense probe table of the pass kernel in ONE sweep over the cells of the box: the entry of a valid voxel (its rank among the occupied
 // cells from the packed words: prefix + occupied bits below), all-ones (rank -1) for every other cell and for the two pad entries a
 // row load may touch.  (Was a 0xFF fill of the whole table and a scatter over the occupied cells behind it: one launch more.)
-__global__ __launch_bounds__(kBlock) void k_dense_build(const uint4 *__restrict__ words, const double *__restrict__ rec, CellMap m, size_t ncells, size_t nc,
-                                                        float4 *__restrict__ dense) {
+// PACK: the sweep also does k_pack_words' work — a word's 32 cells sit in 32 adjacent lanes of ONE wave (a wave takes 64 consecutive
+// cells per step), which read the three bitmaps' words and then, by the lane of the word's first cell, write the packed word and
+// clear the two bitmaps: a third launch less behind the scan.  (Every word has a cell below ncells, so every word is packed.)
+template <bool PACK>
+__global__ __launch_bounds__(kBlock) void k_dense_build(uint4 *__restrict__ words, const double *__restrict__ rec, CellMap m, size_t ncells, size_t nc,
+                                                        float4 *__restrict__ dense, uint32_t *__restrict__ bits, uint32_t *__restrict__ vbits,
+                                                        const uint32_t *__restrict__ prefix) {
   for (size_t c = (size_t)blockIdx.x * blockDim.x + threadIdx.x; c < nc; c += (size_t)gridDim.x * blockDim.x) {
     const unsigned all = 0xFFFFFFFFu;
     float4 e = make_float4(__uint_as_float(all), __uint_as_float(all), __uint_as_float(all), __uint_as_float(all));
     if (c < ncells) {
-      const uint4 w = words[c >> 5];
+      uint4 w;
+      if (PACK) {
+        const size_t i = c >> 5;
+        w = make_uint4(bits[i], vbits[i], prefix[i], 0u);
+        // (all 32 lanes of the word have issued their reads in this very instruction; the stores below come later in program order of
+        // the same wave)
+        if ((c & 31) == 0) { words[i] = w; bits[i] = 0u; vbits[i] = 0u; }
+      } else {
+        w = words[c >> 5];
+      }
       const unsigned bit = (unsigned)(c & 31);
       if ((w.y >> bit) & 1u) {   // valid (k_ndt_finalize: state == 1)
         const unsigned r = w.z + (unsigned)__popc(w.x & ((1u << bit) - 1u));
@@ -191,18 +205,21 @@ int ndt_build_grid(lsa_ndt *h, const float4 *d_pts, size_t n) {
   h->vbits_zero = false;   // (until this build's k_pack_words is enqueued)
   hipLaunchKernelGGL(k_ndt_finalize, dim3(lsa_div_up(V, kBlock)), dim3(kBlock), 0, ctx->stream, vi.acc.p, vi.cnt.p, vi.cell_of_rank.p, V, vi.map, vi.fs,
                      h->rec.p, h->state.p, h->counts.p, h->vbits.p, h->mode == LSA_NDT_MODE_PCL ? 1 : 0);
-  hipLaunchKernelGGL(k_pack_words, dim3(lsa_div_up(vi.W, kBlock)), dim3(kBlock), 0, ctx->stream, vi.bits.p, h->vbits.p, vi.prefix.p, vi.W, h->words.p);
-  if (hipGetLastError() == hipSuccess) h->vbits_zero = true;
-  vi.clean = true;  // sums, counts and bitmap words of this build are zero again
-  // dense probe table when the cell box is small enough (16 B per cell; default limit 16 Mi cells = 256 MiB)
+  // dense probe table when the cell box is small enough (16 B per cell; default limit 16 Mi cells = 256 MiB); its sweep over the cells
+  // packs the words on the way, a box too large for it gets the pack kernel alone
   h->use_dense = vi.map.ncells <= h->dense_max_cells;
   if (h->use_dense) {
     size_t nc = (size_t)vi.map.ncells + 2;  // a row load reads 3 entries from any in-box cell
     if ((rc = h->dense.reserve(ctx, nc, 1.1))) return rc;
     size_t g = (nc + kBlock - 1) / kBlock;
     if (g > 4096) g = 4096;
-    hipLaunchKernelGGL(k_dense_build, dim3((unsigned)g), dim3(kBlock), 0, ctx->stream, h->words.p, h->rec.p, vi.map, (size_t)vi.map.ncells, nc, h->dense.p);
+    hipLaunchKernelGGL(k_dense_build<true>, dim3((unsigned)g), dim3(kBlock), 0, ctx->stream, h->words.p, h->rec.p, vi.map, (size_t)vi.map.ncells, nc, h->dense.p,
+                       vi.bits.p, h->vbits.p, vi.prefix.p);
+  } else {
+    hipLaunchKernelGGL(k_pack_words, dim3(lsa_div_up(vi.W, kBlock)), dim3(kBlock), 0, ctx->stream, vi.bits.p, h->vbits.p, vi.prefix.p, vi.W, h->words.p);
   }
+  if (hipGetLastError() == hipSuccess) h->vbits_zero = true;
+  vi.clean = true;  // sums, counts and bitmap words of this build are zero again
   LSA_HIP(ctx, hipGetLastError());
   // Nothing after the bounding-box / count round trip above needs the host, so the call returns with the table still being
   // finished on the stream (everything that uses it is ordered behind); the number of valid voxels is counted only when
