@@ -332,7 +332,9 @@ int fe_rebuild_map(lsa_front_end *fe, KeyFrame *added, bool evicted, const float
     hipLaunchKernelGGL(k_copy_w, dim3(lsa_div_up(added->n, kBlock)), dim3(kBlock), 0, fe_map_stream(fe), d_cloud, added->n, added->pts.p, reset_w ? 1 : 0);
   if (relayout) {  // first frame, or a cloud larger than any before: lay the buffer out anew
     fe->slot_cap = biggest + biggest / 8 + 1;
-    if ((rc = fe_map_drain(fe))) return rc;   // (the reserve may free the buffer an update in flight still writes)
+    // (the reserve may free the buffer an update in flight still writes: drained first — unless the buffer is large enough already, as
+    // after lsa_front_end_reserve: the new layout is written on the stream the old one was)
+    if (fe->d_map.cap < fe->slot_cap * (size_t)fe->cfg.local_frame_num && (rc = fe_map_drain(fe))) return rc;
     if ((rc = fe->d_map.reserve(ctx, fe->slot_cap * (size_t)fe->cfg.local_frame_num))) return rc;
     int k = 0;
     for (KeyFrame *f : fe->frames) { f->slot = k++; fe_transform_into_slot(fe, f); }
